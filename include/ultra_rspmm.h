@@ -1,0 +1,194 @@
+/*
+ * ultra_rspmm.h -- C ABI of the MI355X-native relational SpMM engine (libultra_amd.so).
+ *
+ * This is the drop-in boundary for ULTRA's one native component:
+ *   /root/reference/ultra/rspmm/source/rspmm.h:63-105   (the 12 rspmm_<sum>_<mul>_{forward,backward}_cuda exports)
+ *   /root/reference/ultra/rspmm/source/rspmm.cpp:270-282 (their pybind registration)
+ *   /root/reference/ultra/rspmm/rspmm.py:168-179         (generalized_rspmm, the Python dispatcher above them)
+ *
+ * Semantics (rspmm.cpp:50-75, operator.cuh:13-80):
+ *   out[row, d] = NARY_{e : edge_index[0][e] == row}  w[e] * BINARY(rel[edge_type[e], d], in[edge_index[1][e], d])
+ *   NARY in {add, min, max} with identity 0 / +MAX / -MAX (empty rows keep the identity),
+ *   BINARY in {mul (DistMult), add (TransE)};  dtype float32 or float64.
+ *
+ * Plain pointers and sizes only -- no torch types.  All `*_dev` pointers are device (HBM) addresses
+ * on the current HIP device, `*_host` pointers are host addresses.  Every function returns 0 on
+ * success and a non-zero ultra_status otherwise; ultra_last_error() returns the message of the last
+ * failure on the calling thread.  Kernels are enqueued on `stream` (a hipStream_t passed as void*,
+ * NULL = the default stream) and never synchronise it.
+ *
+ * Two layers:
+ *   1. plan API (fast path).  The graph is static across the 12 rspmm calls of an Ultra.forward and
+ *      across batches, so the per-call argsort + ind2ptr of the reference (rspmm.py:175-177,
+ *      rspmm.cpp:40-48) is hoisted into a plan built once per graph.
+ *   2. reference-shaped stateless entry points ultra_rspmm_<sum>_<mul>_{forward,backward}_cuda with
+ *      exactly the reference exports' operands (they build a throw-away plan per call).
+ */
+#ifndef ULTRA_RSPMM_H
+#define ULTRA_RSPMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ULTRA_ABI_VERSION 1
+
+typedef enum {
+    ULTRA_OK = 0,
+    ULTRA_ERR_INVALID = 1,      /* bad argument (the reference's TORCH_CHECK / c10::Error cases, rspmm.cpp:15-38) */
+    ULTRA_ERR_UNSORTED = 2,     /* stateless entry got unsorted edge_index (rspmm.py:18 AssertionError) */
+    ULTRA_ERR_HIP = 3,          /* a HIP runtime call failed (no GPU, OOM, launch failure) */
+    ULTRA_ERR_UNSUPPORTED = 4
+} ultra_status;
+
+typedef enum { ULTRA_SUM_ADD = 0, ULTRA_SUM_MIN = 1, ULTRA_SUM_MAX = 2 } ultra_sum;   /* operator.cuh:43-80 */
+typedef enum { ULTRA_MUL_MUL = 0, ULTRA_MUL_ADD = 1 } ultra_mul;                     /* operator.cuh:13-41 */
+typedef enum { ULTRA_F32 = 0, ULTRA_F64 = 1 } ultra_dtype;                           /* AT_DISPATCH_FLOATING_TYPES, rspmm.cpp:148 */
+
+/*
+ * Dense operand: logically [n_outer][n_row][row_len], element (o, r, d) at
+ * ptr[o * stride_outer + r * stride_row + d] (strides in ELEMENTS, innermost contiguous).
+ *   reference layout  (N, D) row-major, D = batch * dim  (layers.py:190-192):  n_outer = 1, row_len = D
+ *   batch-major layout (batch, N, dim), the module-level layout (models.py:139) : n_outer = batch, row_len = dim
+ * A matrix shared by every outer slice (RelNBFNet's relation.weight.expand, layers.py:76) has
+ * stride_outer = 0.  All operands of one call must agree on n_outer and row_len.
+ */
+typedef struct {
+    void *ptr;
+    int64_t n_outer;
+    int64_t stride_outer;
+    int64_t n_row;
+    int64_t stride_row;
+    int64_t row_len;
+} ultra_mat;
+
+/* Plan build options; zero-initialise for defaults. */
+typedef struct {
+    int32_t seg_len;   /* rows with more edges are split into segments of this many edges (0 -> 256) */
+    int32_t g_max;     /* rows with <= g_max edges are walked by one 16-lane group, longer ones by a whole wave (0 -> 16) */
+    int32_t flags;     /* ULTRA_PLAN_* */
+    int32_t reserved;
+} ultra_plan_opts;
+
+#define ULTRA_PLAN_EXACT_ORDER 1   /* no splitting, every row walked sequentially in (row, col) order: bit-reproduces the oracle's summation order */
+
+typedef struct ultra_plan ultra_plan;
+
+typedef struct {
+    int64_t num_edge, num_node, num_relation;
+    int64_t n_item, n_wave_item, n_group_item, n_unit;
+    int64_t n_split_row, n_partial_slot;
+    int32_t seg_len, g_max, flags, packed;   /* packed: col/type share one 32-bit word */
+    int32_t on_device;
+    int32_t has_transpose;
+} ultra_plan_info;
+
+int32_t ultra_abi_version(void);
+const char *ultra_last_error(void);
+
+/* Number of GPUs the HIP runtime sees (0 without a GPU; never fails). */
+int32_t ultra_device_count(void);
+
+/*
+ * Build the aggregation plan of a graph on the host (no HIP calls).
+ *   edge_index_host: (2, num_edge) int64 row-major, [0] = aggregation target, [1] = gathered source (rspmm.cpp:143-145)
+ *   edge_type_host : (num_edge) int64 in [0, num_relation)
+ * Edges may come in any order (generalized_rspmm accepts unsorted input, rspmm.py:175-179).
+ * num_out_row rows are produced, sources index [0, num_in_row); the reference always has
+ * num_out_row == num_in_row == input.size(0) (rspmm.cpp:139).
+ */
+int32_t ultra_plan_create(ultra_plan **plan, const int64_t *edge_index_host, const int64_t *edge_type_host,
+                          int64_t num_edge, int64_t num_out_row, int64_t num_in_row, int64_t num_relation,
+                          const ultra_plan_opts *opts);
+/* Copy the plan arrays to the current HIP device (idempotent). */
+int32_t ultra_plan_upload(ultra_plan *plan);
+int32_t ultra_plan_destroy(ultra_plan *plan);
+int32_t ultra_plan_get_info(const ultra_plan *plan, ultra_plan_info *info);
+
+/* Host-side introspection (tests, tooling): copies array `which` into dst, returns element count via *count. */
+typedef enum {
+    ULTRA_ARR_ROW_PTR = 0,   /* int32 [num_out_row + 1] */
+    ULTRA_ARR_COL = 1,       /* int32 [num_edge] sorted order */
+    ULTRA_ARR_TYPE = 2,      /* int32 [num_edge] */
+    ULTRA_ARR_PERM = 3,      /* int32 [num_edge]  sorted position -> original edge id */
+    ULTRA_ARR_ITEM = 4,      /* int32 [n_item][4] = {row, begin, len, slot}  (slot < 0: writes the output row directly) */
+    ULTRA_ARR_SPLIT_ROW = 5, /* int32 [n_split_row] */
+    ULTRA_ARR_SPLIT_PTR = 6  /* int32 [n_split_row + 1] partial-slot ranges */
+} ultra_plan_array;
+int32_t ultra_plan_export(const ultra_plan *plan, int32_t which, void *dst_host, int64_t capacity_elems, int64_t *count);
+
+/*
+ * Forward.  output = NARY-aggregate (+ fused boundary when boundary != NULL):
+ *   boundary fused with the same NARY op -- layers.py:199-207: sum -> update + boundary, max -> max(update, boundary).
+ * edge_weight_dev: num_edge values of `dtype` in ORIGINAL edge order, or NULL for all-ones
+ * (the fused path of the reference always passes ones, models.py:143).
+ */
+int32_t ultra_rspmm_forward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype,
+                            const void *edge_weight_dev, const ultra_mat *relation, const ultra_mat *input,
+                            const ultra_mat *boundary, const ultra_mat *output, void *stream);
+
+/*
+ * Backward (rspmm.cpp:77-119 / 164-219): gradients w.r.t. edge_weight (original edge order, may be
+ * NULL to skip), relation and input, given the forward output and its gradient.  min/max give the
+ * full gradient to every tying edge (operator.cuh:62-64,75-77).
+ * relation_grad / input_grad are overwritten (the reference returns fresh zeros_like + accumulation).
+ */
+int32_t ultra_rspmm_backward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype,
+                             const void *edge_weight_dev, const ultra_mat *relation, const ultra_mat *input,
+                             const ultra_mat *output, const ultra_mat *output_grad,
+                             void *weight_grad_dev, const ultra_mat *relation_grad, const ultra_mat *input_grad,
+                             void *stream);
+
+/*
+ * Reference-shaped stateless entry points (one per export of rspmm.h:63-105).  Operands are the
+ * reference's: SORTED edge_index (2, E) int64, edge_type (E) int64, edge_weight (E), relation (R, D),
+ * input (N, D), all contiguous device arrays; output (N, D) is written.  Unsorted edge_index ->
+ * ULTRA_ERR_UNSORTED (rspmm.py:18).  They copy the edge list to the host to build a throw-away plan,
+ * i.e. they synchronise -- like the reference wrapper does (rspmm.py:17-18,176).
+ */
+#define ULTRA_DECLARE_REFERENCE_ENTRY(SUM, MUL)                                                                     \
+    int32_t ultra_rspmm_##SUM##_##MUL##_forward_cuda(                                                               \
+        const int64_t *edge_index_dev, const int64_t *edge_type_dev, const void *edge_weight_dev,                   \
+        const void *relation_dev, const void *input_dev, void *output_dev, int64_t num_edge, int64_t num_node,      \
+        int64_t num_relation, int64_t dim, int32_t dtype, void *stream);                                            \
+    int32_t ultra_rspmm_##SUM##_##MUL##_backward_cuda(                                                              \
+        const int64_t *edge_index_dev, const int64_t *edge_type_dev, const void *edge_weight_dev,                   \
+        const void *relation_dev, const void *input_dev, const void *output_dev, const void *output_grad_dev,       \
+        void *weight_grad_dev, void *relation_grad_dev, void *input_grad_dev, int64_t num_edge, int64_t num_node,   \
+        int64_t num_relation, int64_t dim, int32_t dtype, void *stream);
+
+ULTRA_DECLARE_REFERENCE_ENTRY(add, mul) /* rspmm.h:63-68  */
+ULTRA_DECLARE_REFERENCE_ENTRY(min, mul) /* rspmm.h:70-75  */
+ULTRA_DECLARE_REFERENCE_ENTRY(max, mul) /* rspmm.h:77-82  */
+ULTRA_DECLARE_REFERENCE_ENTRY(add, add) /* rspmm.h:84-89  */
+ULTRA_DECLARE_REFERENCE_ENTRY(min, add) /* rspmm.h:91-96  */
+ULTRA_DECLARE_REFERENCE_ENTRY(max, add) /* rspmm.h:98-103 */
+
+/* Tuning / measurement hooks. */
+typedef struct {
+    int32_t threads;      /* workgroup size of the main kernel (0 -> default 1024) */
+    int32_t grid;         /* workgroups (0 -> one per CU) */
+    int32_t rel_lds;      /* -1 auto, 0 never stage the relation slice in LDS, 1 force when it fits */
+    int32_t x_lds;        /* -1 auto, 0 never stage the input slice in LDS, 1 force when it fits */
+    int32_t unroll;       /* edges in flight per lane group (0 -> default) */
+    int32_t reserved[3];
+} ultra_tuning;
+int32_t ultra_set_tuning(const ultra_tuning *t);   /* NULL restores defaults */
+int32_t ultra_get_tuning(ultra_tuning *t);
+
+/*
+ * Time `iters` back-to-back launches of the forward kernel(s) with HIP events on `stream`
+ * (after `warmup` untimed launches); *ms_per_call receives the mean.  Synchronises the stream.
+ * This is the measurement bench.py's roofline block uses.
+ */
+int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype,
+                                  const void *edge_weight_dev, const ultra_mat *relation, const ultra_mat *input,
+                                  const ultra_mat *boundary, const ultra_mat *output, void *stream,
+                                  int32_t warmup, int32_t iters, float *ms_per_call);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ULTRA_RSPMM_H */

@@ -1,0 +1,106 @@
+"""Host logic of the plan builder (no GPU): structure invariants + emulated walk vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rspmm_oracle
+from tests import helpers
+from ultra_amd import _lib
+from ultra_amd.rspmm import Plan
+
+CASES = [
+    dict(num_node=50, num_edge=400, num_relation=5, seed=0),
+    dict(num_node=64, num_edge=300, num_relation=3, seed=1, hub=(7, 700)),           # hub row -> split + wave items
+    dict(num_node=40, num_edge=100, num_relation=4, seed=2, empty_rows=10),          # empty rows keep the identity
+    dict(num_node=30, num_edge=200, num_relation=1, seed=3, duplicates=50),          # single relation, duplicate edges
+    dict(num_node=5, num_edge=0, num_relation=2, seed=4),                             # no edges at all
+    dict(num_node=1, num_edge=17, num_relation=2, seed=5),                            # one node, self loops
+]
+
+
+def _plan_arrays(plan):
+    return {k: plan.export(v).numpy() for k, v in
+            dict(row_ptr=_lib.ARR_ROW_PTR, col=_lib.ARR_COL, type=_lib.ARR_TYPE, perm=_lib.ARR_PERM,
+                 item=_lib.ARR_ITEM, split_row=_lib.ARR_SPLIT_ROW, split_ptr=_lib.ARR_SPLIT_PTR).items()}
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("opts", [dict(), dict(seg_len=16, g_max=4), dict(seg_len=64, g_max=64), dict(exact_order=True)])
+def test_plan_structure(case, opts):
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    plan = Plan(ei, et, N, R, **opts)
+    info = plan.info()
+    a = _plan_arrays(plan)
+    assert info["num_edge"] == E and info["num_node"] == N
+    # CSR: sorted by (row, col), stable in the original edge id; perm is a permutation
+    perm = a["perm"]
+    assert sorted(perm.tolist()) == list(range(E))
+    rows = ei[0].numpy()[perm]
+    cols = ei[1].numpy()[perm]
+    key = rows.astype(np.int64) * (N + 1) + cols
+    assert (np.diff(key) >= 0).all()
+    same = np.diff(key) == 0
+    assert (np.diff(perm)[same] > 0).all(), "ties must keep the original order"
+    assert (a["col"] == cols).all() and (a["type"] == et.numpy()[perm]).all()
+    assert a["row_ptr"][0] == 0 and a["row_ptr"][-1] == E
+    assert (np.bincount(rows, minlength=N) == np.diff(a["row_ptr"])).all()
+    # items: cover every edge exactly once, stay inside their row, honour seg_len / g_max classes
+    items = a["item"].reshape(-1, 4)
+    covered = np.zeros(E, dtype=np.int64)
+    for idx, (row, begin, length, slot) in enumerate(items):
+        assert a["row_ptr"][row] <= begin and begin + length <= a["row_ptr"][row + 1]
+        covered[begin:begin + length] += 1
+        if not opts.get("exact_order"):
+            assert length <= info["seg_len"]
+            assert (length > info["g_max"]) == (idx < info["n_wave_item"])
+    assert (covered == 1).all()
+    assert set(items[:, 0].tolist()) == set(range(N)), "rows without edges still own an (empty) item"
+    nw = info["n_wave_item"]
+    assert (np.diff(items[:nw, 2]) <= 0).all() and (np.diff(items[nw:, 2]) <= 0).all(), "descending length per class"
+    # split rows: slots are contiguous per row and ordered by edge position
+    slots = items[items[:, 3] >= 0]
+    assert len(slots) == info["n_partial_slot"]
+    for k, row in enumerate(a["split_row"]):
+        mine = slots[slots[:, 0] == row]
+        mine = mine[np.argsort(mine[:, 3])]
+        assert mine[:, 3].tolist() == list(range(a["split_ptr"][k], a["split_ptr"][k + 1]))
+        assert (np.diff(mine[:, 1]) > 0).all()
+        assert mine[:, 2].sum() == a["row_ptr"][row + 1] - a["row_ptr"][row]
+    if opts.get("exact_order"):
+        assert info["n_wave_item"] == 0 and info["n_partial_slot"] == 0
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("sum", ["add", "min", "max"])
+@pytest.mark.parametrize("mul", ["mul", "add"])
+def test_emulated_walk_matches_oracle(case, sum, mul):
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    rel, x, w = helpers.features(N, R, 24, E, seed=case["seed"])
+    want = rspmm_oracle.generalized_rspmm(ei, et, w, rel, x, sum=sum, mul=mul)
+    for opts in (dict(seg_len=16, g_max=4), dict()):
+        plan = Plan(ei, et, N, R, **opts)
+        got = helpers.emulate_plan_forward(plan, rel, x, edge_weight=w, sum=sum, mul=mul)
+        if sum == "add":
+            helpers.assert_sum_close(got, want, ei, et, w, rel, x, mul=mul)
+        else:
+            assert torch.equal(got, want), "min/max are order independent: must be bit exact"
+    # exact-order plan: sequential walk in (row, col) order == the oracle's order, bit for bit
+    plan = Plan(ei, et, N, R, exact_order=True)
+    got = helpers.emulate_plan_forward(plan, rel, x, edge_weight=w, sum=sum, mul=mul)
+    assert torch.equal(got, want)
+
+
+def test_plan_rejects_bad_input():
+    ei, et = helpers.random_graph(10, 20, 3)
+    with pytest.raises(RuntimeError):
+        Plan(ei, et, 5, 3)          # node id out of range
+    with pytest.raises(RuntimeError):
+        Plan(ei, et, 10, 2)         # relation id out of range
+    with pytest.raises(RuntimeError):
+        Plan(ei[0], et, 10, 3)      # edge_index must be (2, E)
+    with pytest.raises(RuntimeError):
+        Plan(ei, et[:-1], 10, 3)
+    with pytest.raises(RuntimeError):
+        Plan(ei, et.int(), 10, 3)   # checkSameType(edge_index, edge_type)

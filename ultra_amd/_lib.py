@@ -1,0 +1,97 @@
+"""ctypes binding of libultra_amd.so (include/ultra_rspmm.h).
+
+PyTorch only supplies device memory (tensor.data_ptr()) and the current HIP stream; every kernel is
+ours.  There is NO fallback: if the shared library is missing or fails to load, importing this
+module raises, and CPU tensors are rejected by the callers.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libultra_amd.so")
+
+ULTRA_OK = 0
+ULTRA_ERR_INVALID = 1
+ULTRA_ERR_UNSORTED = 2
+ULTRA_ERR_HIP = 3
+ULTRA_ERR_UNSUPPORTED = 4
+
+SUM_CODES = {"add": 0, "min": 1, "max": 2}
+MUL_CODES = {"mul": 0, "add": 1}
+F32, F64 = 0, 1
+
+ARR_ROW_PTR, ARR_COL, ARR_TYPE, ARR_PERM, ARR_ITEM, ARR_SPLIT_ROW, ARR_SPLIT_PTR = range(7)
+PLAN_EXACT_ORDER = 1
+
+
+class UltraMat(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("n_outer", ctypes.c_int64), ("stride_outer", ctypes.c_int64),
+                ("n_row", ctypes.c_int64), ("stride_row", ctypes.c_int64), ("row_len", ctypes.c_int64)]
+
+
+class PlanOpts(ctypes.Structure):
+    _fields_ = [("seg_len", ctypes.c_int32), ("g_max", ctypes.c_int32), ("flags", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+class PlanInfo(ctypes.Structure):
+    _fields_ = [("num_edge", ctypes.c_int64), ("num_node", ctypes.c_int64), ("num_relation", ctypes.c_int64),
+                ("n_item", ctypes.c_int64), ("n_wave_item", ctypes.c_int64), ("n_group_item", ctypes.c_int64),
+                ("n_unit", ctypes.c_int64), ("n_split_row", ctypes.c_int64), ("n_partial_slot", ctypes.c_int64),
+                ("seg_len", ctypes.c_int32), ("g_max", ctypes.c_int32), ("flags", ctypes.c_int32),
+                ("packed", ctypes.c_int32), ("on_device", ctypes.c_int32), ("has_transpose", ctypes.c_int32)]
+
+
+class Tuning(ctypes.Structure):
+    _fields_ = [("threads", ctypes.c_int32), ("grid", ctypes.c_int32), ("rel_lds", ctypes.c_int32),
+                ("x_lds", ctypes.c_int32), ("unroll", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "ultra_amd: %s is missing. Build it with `python -m ultra_amd.build` (needs hipcc); "
+            "there is no CPU or PyTorch fallback for the rspmm engine." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.ultra_last_error.restype = ctypes.c_char_p
+    lib.ultra_abi_version.restype = ctypes.c_int32
+    lib.ultra_device_count.restype = ctypes.c_int32
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    matp = ctypes.POINTER(UltraMat)
+    lib.ultra_plan_create.argtypes = [ctypes.POINTER(vp), vp, vp, i64, i64, i64, i64, ctypes.POINTER(PlanOpts)]
+    lib.ultra_plan_upload.argtypes = [vp]
+    lib.ultra_plan_destroy.argtypes = [vp]
+    lib.ultra_plan_get_info.argtypes = [vp, ctypes.POINTER(PlanInfo)]
+    lib.ultra_plan_export.argtypes = [vp, i32, vp, i64, ctypes.POINTER(i64)]
+    lib.ultra_rspmm_forward.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp]
+    lib.ultra_rspmm_backward.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp, matp, matp, vp]
+    lib.ultra_rspmm_forward_timed.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp, i32, i32,
+                                              ctypes.POINTER(ctypes.c_float)]
+    lib.ultra_set_tuning.argtypes = [ctypes.POINTER(Tuning)]
+    lib.ultra_get_tuning.argtypes = [ctypes.POINTER(Tuning)]
+    for s in ("add", "min", "max"):
+        for m in ("mul", "add"):
+            f = getattr(lib, "ultra_rspmm_%s_%s_forward_cuda" % (s, m))
+            f.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp]
+            b = getattr(lib, "ultra_rspmm_%s_%s_backward_cuda" % (s, m))
+            b.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp]
+    return lib
+
+
+lib = _load()
+if lib.ultra_abi_version() != 1:
+    raise ImportError("ultra_amd: libultra_amd.so ABI version mismatch")
+
+
+class UltraError(RuntimeError):
+    pass
+
+
+def check(rc):
+    """Map ultra_status to the exceptions the reference raises for the same condition."""
+    if rc == ULTRA_OK:
+        return
+    msg = lib.ultra_last_error().decode("utf-8", "replace")
+    if rc == ULTRA_ERR_UNSORTED:
+        raise AssertionError(msg)           # rspmm.py:18
+    raise UltraError(msg)                    # c10::Error -> RuntimeError in the reference

@@ -1,0 +1,221 @@
+// Host-side plan builder: CSR + load-balanced work list.  No HIP calls in this file.
+// Replaces ultra/rspmm/rspmm.py:175-177 (per-call argsort) and rspmm.cpp:40-48 (per-call ind2ptr).
+#include "plan.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+namespace ultra {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+static int bits_for(int64_t n) {  // bits needed to store values in [0, n)
+    int b = 0;
+    while ((int64_t(1) << b) < n) ++b;
+    return b;
+}
+
+// Stable counting sort of `order` by key[order[i]] in [0, nkey).
+static void counting_pass(std::vector<int32_t> &order, const int32_t *key, int64_t nkey) {
+    const int64_t n = (int64_t)order.size();
+    std::vector<int64_t> start((size_t)nkey + 1, 0);
+    for (int64_t i = 0; i < n; ++i) start[(size_t)key[order[i]] + 1]++;
+    for (int64_t k = 0; k < nkey; ++k) start[k + 1] += start[k];
+    std::vector<int32_t> out((size_t)n);
+    for (int64_t i = 0; i < n; ++i) out[(size_t)start[key[order[i]]]++] = order[i];
+    order.swap(out);
+}
+
+ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *type, int64_t E, int64_t num_out,
+                       int64_t num_in, int64_t num_rel, const ultra_plan_opts *opts, bool keep_edges) {
+    ultra_plan *p = new ultra_plan();
+    p->num_edge = E;
+    p->num_out = num_out;
+    p->num_in = num_in;
+    p->num_rel = num_rel;
+    if (opts) {
+        if (opts->seg_len > 0) p->seg_len = opts->seg_len;
+        if (opts->g_max > 0) p->g_max = opts->g_max;
+        p->flags = opts->flags;
+    }
+    const bool exact = (p->flags & ULTRA_PLAN_EXACT_ORDER) != 0;
+    if (p->g_max > p->seg_len) p->g_max = p->seg_len;
+
+    // ---- sort by (row, col), stable in the original edge id: two LSD counting passes ----
+    std::vector<int32_t> order((size_t)E);
+    std::iota(order.begin(), order.end(), 0);
+    if (E > 0) {
+        counting_pass(order, col, num_in);
+        counting_pass(order, row, num_out);
+    }
+    p->perm = order;
+    p->col.resize((size_t)E);
+    p->type.resize((size_t)E);
+    p->erow.resize((size_t)E);
+    p->row_ptr.assign((size_t)num_out + 1, 0);
+    for (int64_t k = 0; k < E; ++k) {
+        const int32_t e = order[(size_t)k];
+        p->col[(size_t)k] = col[e];
+        p->type[(size_t)k] = type[e];
+        p->erow[(size_t)k] = row[e];
+        p->row_ptr[(size_t)row[e] + 1]++;
+    }
+    for (int64_t r = 0; r < num_out; ++r) p->row_ptr[(size_t)r + 1] += p->row_ptr[(size_t)r];
+
+    // ---- packed (col, type) word when both fit into 32 bits ----
+    p->type_bits = bits_for(std::max<int64_t>(num_rel, 1));
+    const int col_bits = bits_for(std::max<int64_t>(num_in, 1));
+    p->packed_ok = (p->type_bits + col_bits) <= 32;
+    if (p->packed_ok) {
+        p->packed.resize((size_t)E);
+        for (int64_t k = 0; k < E; ++k)
+            p->packed[(size_t)k] = ((uint32_t)p->col[(size_t)k] << p->type_bits) | (uint32_t)p->type[(size_t)k];
+    }
+
+    // ---- items ----
+    std::vector<Item> witems, gitems;
+    int32_t next_slot = 0;
+    p->split_ptr.push_back(0);
+    for (int64_t r = 0; r < num_out; ++r) {
+        const int32_t b = p->row_ptr[(size_t)r], e = p->row_ptr[(size_t)r + 1];
+        const int32_t deg = e - b;
+        if (exact || deg <= p->seg_len) {
+            Item it{(int32_t)r, b, deg, -1};
+            if (exact || deg <= p->g_max)
+                gitems.push_back(it);
+            else
+                witems.push_back(it);
+        } else {
+            // balanced segments of at most seg_len edges
+            const int32_t nseg = (deg + p->seg_len - 1) / p->seg_len;
+            const int32_t base = deg / nseg, extra = deg % nseg;
+            int32_t pos = b;
+            for (int32_t s = 0; s < nseg; ++s) {
+                const int32_t len = base + (s < extra ? 1 : 0);
+                Item it{(int32_t)r, pos, len, next_slot++};
+                pos += len;
+                if (len <= p->g_max)
+                    gitems.push_back(it);
+                else
+                    witems.push_back(it);
+            }
+            p->split_row.push_back((int32_t)r);
+            p->split_ptr.push_back(next_slot);
+        }
+    }
+    p->n_slot = next_slot;
+    auto by_len_desc = [](const Item &a, const Item &b) { return a.len > b.len; };
+    std::stable_sort(witems.begin(), witems.end(), by_len_desc);
+    std::stable_sort(gitems.begin(), gitems.end(), by_len_desc);
+    p->n_w = (int64_t)witems.size();
+    p->n_g = (int64_t)gitems.size();
+    p->n_unit = p->n_w + (p->n_g + 3) / 4;
+    p->items.reserve(witems.size() + gitems.size());
+    p->items.insert(p->items.end(), witems.begin(), witems.end());
+    p->items.insert(p->items.end(), gitems.begin(), gitems.end());
+
+    if (keep_edges) {
+        p->h_row.assign(row, row + E);
+        p->h_col.assign(col, col + E);
+        p->h_type.assign(type, type + E);
+    }
+    return p;
+}
+
+}  // namespace ultra
+
+using ultra::set_error;
+
+extern "C" {
+
+int32_t ultra_abi_version(void) { return ULTRA_ABI_VERSION; }
+
+const char *ultra_last_error(void) { return ultra::g_last_error.c_str(); }
+
+int32_t ultra_plan_create(ultra_plan **plan, const int64_t *edge_index, const int64_t *edge_type, int64_t E,
+                          int64_t num_out, int64_t num_in, int64_t num_rel, const ultra_plan_opts *opts) {
+    if (!plan) {
+        set_error("ultra_plan_create: plan is NULL");
+        return ULTRA_ERR_INVALID;
+    }
+    *plan = nullptr;
+    if (E < 0 || num_out < 0 || num_in < 0 || num_rel < 0 || (E > 0 && (!edge_index || !edge_type))) {
+        set_error("ultra_plan_create: negative size or NULL edge arrays");
+        return ULTRA_ERR_INVALID;
+    }
+    if (E >= (int64_t(1) << 31) || num_out >= (int64_t(1) << 31) || num_in >= (int64_t(1) << 31) ||
+        num_rel >= (int64_t(1) << 31)) {
+        set_error("ultra_plan_create: sizes beyond int32 are not supported");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    std::vector<int32_t> row((size_t)E), col((size_t)E), type((size_t)E);
+    for (int64_t e = 0; e < E; ++e) {
+        const int64_t r = edge_index[e], c = edge_index[E + e], t = edge_type[e];
+        if (r < 0 || r >= num_out || c < 0 || c >= num_in || t < 0 || t >= num_rel) {
+            set_error("ultra_plan_create: edge " + std::to_string(e) + " out of range (row " + std::to_string(r) +
+                      ", col " + std::to_string(c) + ", type " + std::to_string(t) + ")");
+            return ULTRA_ERR_INVALID;
+        }
+        row[(size_t)e] = (int32_t)r;
+        col[(size_t)e] = (int32_t)c;
+        type[(size_t)e] = (int32_t)t;
+    }
+    *plan = ultra::build_plan(row.data(), col.data(), type.data(), E, num_out, num_in, num_rel, opts, true);
+    return ULTRA_OK;
+}
+
+int32_t ultra_plan_get_info(const ultra_plan *p, ultra_plan_info *info) {
+    if (!p || !info) {
+        set_error("ultra_plan_get_info: NULL argument");
+        return ULTRA_ERR_INVALID;
+    }
+    info->num_edge = p->num_edge;
+    info->num_node = p->num_out;
+    info->num_relation = p->num_rel;
+    info->n_item = (int64_t)p->items.size();
+    info->n_wave_item = p->n_w;
+    info->n_group_item = p->n_g;
+    info->n_unit = p->n_unit;
+    info->n_split_row = (int64_t)p->split_row.size();
+    info->n_partial_slot = p->n_slot;
+    info->seg_len = p->seg_len;
+    info->g_max = p->g_max;
+    info->flags = p->flags;
+    info->packed = p->packed_ok ? 1 : 0;
+    info->on_device = p->on_device ? 1 : 0;
+    info->has_transpose = (p->tplan && p->rplan) ? 1 : 0;
+    return ULTRA_OK;
+}
+
+int32_t ultra_plan_export(const ultra_plan *p, int32_t which, void *dst, int64_t capacity, int64_t *count) {
+    if (!p || !count) {
+        set_error("ultra_plan_export: NULL argument");
+        return ULTRA_ERR_INVALID;
+    }
+    const void *src = nullptr;
+    int64_t n = 0;
+    switch (which) {
+        case ULTRA_ARR_ROW_PTR: src = p->row_ptr.data(); n = (int64_t)p->row_ptr.size(); break;
+        case ULTRA_ARR_COL: src = p->col.data(); n = (int64_t)p->col.size(); break;
+        case ULTRA_ARR_TYPE: src = p->type.data(); n = (int64_t)p->type.size(); break;
+        case ULTRA_ARR_PERM: src = p->perm.data(); n = (int64_t)p->perm.size(); break;
+        case ULTRA_ARR_ITEM: src = p->items.data(); n = (int64_t)p->items.size() * 4; break;
+        case ULTRA_ARR_SPLIT_ROW: src = p->split_row.data(); n = (int64_t)p->split_row.size(); break;
+        case ULTRA_ARR_SPLIT_PTR: src = p->split_ptr.data(); n = (int64_t)p->split_ptr.size(); break;
+        default: set_error("ultra_plan_export: unknown array id"); return ULTRA_ERR_INVALID;
+    }
+    *count = n;
+    if (dst) {
+        if (capacity < n) {
+            set_error("ultra_plan_export: destination too small");
+            return ULTRA_ERR_INVALID;
+        }
+        if (n) std::memcpy(dst, src, (size_t)n * sizeof(int32_t));
+    }
+    return ULTRA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// Internal definition of the aggregation plan (host side).  See include/ultra_rspmm.h.
+//
+// The plan replaces the per-call work of the reference: the (row, col) argsort of
+// ultra/rspmm/rspmm.py:175-177 and ind2ptr of ultra/rspmm/source/rspmm.cpp:40-48.  On top of the
+// CSR it carries a static, load-balanced work list for the wave64 kernel:
+//
+//   item  = {row, begin, len, slot}: a run of `len` sorted edges of one output row.  Rows longer
+//           than seg_len are cut into several items whose partial results go to scratch slots and
+//           are combined in slot order by a fix-up kernel (deterministic, no atomics).
+//   unit  = the work of one wavefront: either ONE "wave item" (len > g_max; the four 16-lane
+//           groups stride its edges and reduce across groups at the end) or FOUR "group items"
+//           (len <= g_max; each 16-lane group walks one item sequentially, in sorted order).
+//   Items of each class are ordered by descending length so that the four items of a unit have
+//   similar trip counts and the cyclic unit -> wave assignment is longest-first.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ultra_rspmm.h"
+
+namespace ultra {
+
+struct Item {
+    int32_t row, begin, len, slot;
+};
+
+struct DevicePlan {
+    int32_t *row_ptr = nullptr, *col = nullptr, *type = nullptr, *perm = nullptr, *erow = nullptr;
+    uint32_t *packed = nullptr;
+    Item *items = nullptr;
+    int32_t *split_row = nullptr, *split_ptr = nullptr;
+    void *w_sorted = nullptr;
+    size_t w_sorted_bytes = 0;
+    void *partial = nullptr;
+    size_t partial_bytes = 0;
+    int device = -1;
+};
+
+void set_error(const std::string &msg);
+
+}  // namespace ultra
+
+struct ultra_plan {
+    int64_t num_edge = 0, num_out = 0, num_in = 0, num_rel = 0;
+    int32_t seg_len = 256, g_max = 32, flags = 0;
+    int32_t type_bits = 0;
+    bool packed_ok = false;
+
+    std::vector<int32_t> row_ptr, col, type, perm, erow;  // erow: output row of each sorted edge
+    std::vector<uint32_t> packed;
+    std::vector<ultra::Item> items;
+    int64_t n_w = 0, n_g = 0, n_unit = 0;
+    std::vector<int32_t> split_row, split_ptr;
+    int64_t n_slot = 0;
+
+    // original (unsorted) edges, kept to derive the backward plans lazily
+    std::vector<int32_t> h_row, h_col, h_type;
+
+    bool on_device = false;
+    ultra::DevicePlan d;
+
+    // backward plans (built on first use):
+    //   tplan: rows = edge_index[1], sources = edge_index[0]  -> input_grad
+    //   rplan: rows = edge_type, "relation" index = edge_index[0], sources = edge_index[1] -> relation_grad
+    ultra_plan *tplan = nullptr;
+    ultra_plan *rplan = nullptr;
+};
+
+namespace ultra {
+
+// Build a plan from int32 (row, col, type) triples.  Pure host code.
+ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *type, int64_t num_edge,
+                       int64_t num_out, int64_t num_in, int64_t num_rel, const ultra_plan_opts *opts,
+                       bool keep_edges);
+
+}  // namespace ultra

@@ -1,0 +1,528 @@
+// C-ABI entry points of libultra_amd.so (include/ultra_rspmm.h): plan upload, forward, backward,
+// the reference-shaped stateless exports and the measurement hooks.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rspmm_bwd_kernels.hpp"
+#include "rspmm_kernels.hpp"
+
+namespace ultra {
+
+// explicit instantiations live in rspmm_variant_*.hip
+#define ULTRA_EXTERN_VARIANT(T_, VEC_, MODE_) \
+    template <>                               \
+    hipError_t launch_fwd_variant<T_, VEC_, MODE_>(int, int, const FwdParams &, int, int, size_t, hipStream_t);
+ULTRA_EXTERN_VARIANT(float, 4, 0)
+ULTRA_EXTERN_VARIANT(float, 1, 0)
+ULTRA_EXTERN_VARIANT(float, 4, 1)
+ULTRA_EXTERN_VARIANT(float, 4, 2)
+ULTRA_EXTERN_VARIANT(double, 4, 0)
+ULTRA_EXTERN_VARIANT(double, 1, 0)
+ULTRA_EXTERN_VARIANT(double, 4, 1)
+ULTRA_EXTERN_VARIANT(double, 4, 2)
+
+static ultra_tuning g_tuning = {0, 0, -1, -1, 0, {0, 0, 0}};
+
+static int hip_fail(hipError_t e, const char *what) {
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return ULTRA_ERR_HIP;
+}
+#define HIP_TRY(expr)                                      \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);  \
+    } while (0)
+
+static int invalid(const std::string &msg) {
+    set_error(msg);
+    return ULTRA_ERR_INVALID;
+}
+
+template <typename V>
+static int upload_array(V **dst, const std::vector<V> &src) {
+    *dst = nullptr;
+    const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(V);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(dst), bytes));
+    if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(V), hipMemcpyHostToDevice));
+    return ULTRA_OK;
+}
+
+static int upload_plan(ultra_plan *p) {
+    if (p->on_device) return ULTRA_OK;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    int rc;
+    if ((rc = upload_array(&p->d.row_ptr, p->row_ptr))) return rc;
+    if ((rc = upload_array(&p->d.col, p->col))) return rc;
+    if ((rc = upload_array(&p->d.type, p->type))) return rc;
+    if ((rc = upload_array(&p->d.perm, p->perm))) return rc;
+    if ((rc = upload_array(&p->d.erow, p->erow))) return rc;
+    if ((rc = upload_array(&p->d.packed, p->packed))) return rc;
+    if ((rc = upload_array(&p->d.items, p->items))) return rc;
+    if ((rc = upload_array(&p->d.split_row, p->split_row))) return rc;
+    if ((rc = upload_array(&p->d.split_ptr, p->split_ptr))) return rc;
+    p->d.device = dev;
+    p->on_device = true;
+    return ULTRA_OK;
+}
+
+static void free_device(ultra_plan *p) {
+    if (!p->on_device) return;
+    (void)hipFree(p->d.row_ptr);
+    (void)hipFree(p->d.col);
+    (void)hipFree(p->d.type);
+    (void)hipFree(p->d.perm);
+    (void)hipFree(p->d.erow);
+    (void)hipFree(p->d.packed);
+    (void)hipFree(p->d.items);
+    (void)hipFree(p->d.split_row);
+    (void)hipFree(p->d.split_ptr);
+    if (p->d.w_sorted) (void)hipFree(p->d.w_sorted);
+    if (p->d.partial) (void)hipFree(p->d.partial);
+    p->d = DevicePlan();
+    p->on_device = false;
+}
+
+static int ensure_scratch(void **buf, size_t *have, size_t need) {
+    if (need <= *have) return ULTRA_OK;
+    if (*buf) HIP_TRY(hipFree(*buf));  // implicit device sync: no in-flight kernel still reads it
+    *buf = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc(buf, need));
+    *have = need;
+    return ULTRA_OK;
+}
+
+struct DevInfo {
+    int cu = 0;
+    size_t lds_optin = 0;
+};
+static int device_info(DevInfo *out) {
+    static DevInfo cache[64];
+    static bool have[64] = {false};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return invalid("device id out of range");
+    if (!have[dev]) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        cache[dev].cu = prop.multiProcessorCount;
+        // gfx950: 160 KiB per workgroup (MI355X_MICROARCH: a single workgroup may use all of it)
+        size_t lds = prop.sharedMemPerBlock;
+        if (prop.maxSharedMemoryPerMultiProcessor > lds) lds = prop.maxSharedMemoryPerMultiProcessor;
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) == 0 && lds < 160 * 1024) lds = 160 * 1024;
+        cache[dev].lds_optin = lds;
+        have[dev] = true;
+    }
+    *out = cache[dev];
+    return ULTRA_OK;
+}
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static int check_mat(const ultra_mat *m, const char *name, int64_t min_rows, int64_t n_outer, int64_t row_len) {
+    if (!m || !m->ptr) return invalid(std::string(name) + " is NULL");
+    if (m->n_outer != n_outer) return invalid(std::string(name) + ": n_outer mismatch");
+    if (m->row_len != row_len) return invalid(std::string(name) + ": row_len mismatch (the reference's checkSize on dim 1)");
+    if (m->n_row < min_rows) return invalid(std::string(name) + ": too few rows");
+    if (m->stride_row < row_len && m->n_row > 1) return invalid(std::string(name) + ": stride_row < row_len");
+    return ULTRA_OK;
+}
+
+static bool mat_vec_ok(const ultra_mat *m, int64_t step) {
+    return aligned16(m->ptr) && (m->stride_row % step == 0) && (m->stride_outer % step == 0);
+}
+
+// Generic forward on a plan (internal: accepts the BIN_LHS / BIN_RHS variants used by backward).
+static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *w, const ultra_mat *rel,
+                        const ultra_mat *x, const ultra_mat *bnd, const ultra_mat *out, hipStream_t stream) {
+    if (!p) return invalid("plan is NULL");
+    if (sum < 0 || sum > 2 || mul < 0 || mul > 3) return invalid("unknown sum/mul code");
+    if (dtype != ULTRA_F32 && dtype != ULTRA_F64) return invalid("dtype must be ULTRA_F32 or ULTRA_F64");
+    if (!out || !out->ptr) return invalid("output is NULL");
+    const int64_t n_outer = out->n_outer, row_len = out->row_len;
+    if (n_outer <= 0 || row_len <= 0) return invalid("output: empty n_outer / row_len");
+    int rc;
+    if ((rc = check_mat(out, "output", p->num_out, n_outer, row_len))) return rc;
+    if (mul != BIN_RHS && (rc = check_mat(rel, "relation", p->num_rel, n_outer, row_len))) return rc;
+    if (mul != BIN_LHS && (rc = check_mat(x, "input", p->num_in, n_outer, row_len))) return rc;
+    if (bnd && (rc = check_mat(bnd, "boundary", p->num_out, n_outer, row_len))) return rc;
+    if (p->num_out == 0) return ULTRA_OK;
+    if ((rc = upload_plan(p))) return rc;
+    DevInfo di;
+    if ((rc = device_info(&di))) return rc;
+
+    const size_t esz = dtype == ULTRA_F32 ? 4 : 8;
+    const int64_t step = dtype == ULTRA_F32 ? 4 : 2;  // elements per 16 bytes
+    bool vec4 = (row_len % 4 == 0) && mat_vec_ok(out, step);
+    if (mul != BIN_RHS) vec4 = vec4 && mat_vec_ok(rel, step);
+    if (mul != BIN_LHS) vec4 = vec4 && mat_vec_ok(x, step);
+    if (bnd) vec4 = vec4 && mat_vec_ok(bnd, step);
+    const int VEC = vec4 ? 4 : 1;
+    const int SPAN = 16 * VEC;
+
+    FwdParams fp;
+    std::memset(&fp, 0, sizeof(fp));
+    fp.col = p->d.col;
+    fp.type = p->d.type;
+    fp.packed = p->d.packed;
+    fp.items = p->d.items;
+    fp.n_w = (int32_t)p->n_w;
+    fp.n_item = (int32_t)p->items.size();
+    fp.n_unit = (int32_t)p->n_unit;
+    if (mul != BIN_RHS) fp.rel = MatArg{rel->ptr, rel->stride_outer, rel->stride_row};
+    if (mul != BIN_LHS) fp.x = MatArg{x->ptr, x->stride_outer, x->stride_row};
+    if (bnd) fp.bnd = MatArg{bnd->ptr, bnd->stride_outer, bnd->stride_row};
+    fp.out = out->ptr;
+    fp.out_stride_outer = out->stride_outer;
+    fp.out_stride_row = out->stride_row;
+    fp.n_outer = (int32_t)n_outer;
+    fp.row_len = (int32_t)row_len;
+    fp.spans_per_outer = (int32_t)((row_len + SPAN - 1) / SPAN);
+    fp.n_span = fp.spans_per_outer * fp.n_outer;
+    fp.num_rel = (int32_t)p->num_rel;
+    fp.num_in = (int32_t)p->num_in;
+    fp.type_bits = p->type_bits;
+    fp.unit_w = w ? 0 : 1;
+    fp.packed_on = p->packed_ok ? 1 : 0;
+    fp.has_bnd = bnd ? 1 : 0;
+
+    // per-call edge weights -> sorted order
+    if (w && p->num_edge > 0) {
+        if ((rc = ensure_scratch(&p->d.w_sorted, &p->d.w_sorted_bytes, (size_t)p->num_edge * esz))) return rc;
+        const int blocks = (int)std::min<int64_t>((p->num_edge + 255) / 256, 4096);
+        if (dtype == ULTRA_F32)
+            hipLaunchKernelGGL(permute_weight_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float *)w,
+                               p->d.perm, (float *)p->d.w_sorted, p->num_edge);
+        else
+            hipLaunchKernelGGL(permute_weight_kernel<double>, dim3(blocks), dim3(256), 0, stream, (const double *)w,
+                               p->d.perm, (double *)p->d.w_sorted, p->num_edge);
+        HIP_TRY(hipGetLastError());
+        fp.w_sorted = p->d.w_sorted;
+    }
+    if (p->n_slot > 0) {
+        if ((rc = ensure_scratch(&p->d.partial, &p->d.partial_bytes, (size_t)p->n_slot * n_outer * row_len * esz)))
+            return rc;
+        fp.partial = p->d.partial;
+    }
+
+    // variant selection
+    const size_t budget = di.lds_optin;
+    const size_t rel_bytes = (mul != BIN_RHS) ? (size_t)p->num_rel * SPAN * esz : 0;
+    const size_t x_bytes = (mul != BIN_LHS) ? (size_t)p->num_in * SPAN * esz : 0;
+    int mode = MODE_GLOBAL;
+    if (VEC == 4) {
+        if (g_tuning.x_lds != 0 && g_tuning.rel_lds != 0 && rel_bytes + x_bytes <= budget && x_bytes > 0)
+            mode = MODE_ALL_LDS;
+        else if (g_tuning.rel_lds != 0 && rel_bytes <= budget && rel_bytes > 0)
+            mode = MODE_REL_LDS;
+    }
+    const size_t lds = mode == MODE_ALL_LDS ? rel_bytes + x_bytes : (mode == MODE_REL_LDS ? rel_bytes : 0);
+    const int threads = g_tuning.threads > 0 ? g_tuning.threads : 1024;
+    int grid = g_tuning.grid > 0 ? g_tuning.grid : di.cu;
+    if (grid < 1) grid = 1;
+    fp.smod = std::min<int32_t>(fp.n_span, grid);
+    fp.nparts = grid / fp.smod;
+
+    hipError_t e = hipErrorInvalidValue;
+    if (dtype == ULTRA_F32) {
+        if (VEC == 1) e = launch_fwd_variant<float, 1, 0>(sum, mul, fp, grid, threads, lds, stream);
+        else if (mode == 0) e = launch_fwd_variant<float, 4, 0>(sum, mul, fp, grid, threads, lds, stream);
+        else if (mode == 1) e = launch_fwd_variant<float, 4, 1>(sum, mul, fp, grid, threads, lds, stream);
+        else e = launch_fwd_variant<float, 4, 2>(sum, mul, fp, grid, threads, lds, stream);
+    } else {
+        if (VEC == 1) e = launch_fwd_variant<double, 1, 0>(sum, mul, fp, grid, threads, lds, stream);
+        else if (mode == 0) e = launch_fwd_variant<double, 4, 0>(sum, mul, fp, grid, threads, lds, stream);
+        else if (mode == 1) e = launch_fwd_variant<double, 4, 1>(sum, mul, fp, grid, threads, lds, stream);
+        else e = launch_fwd_variant<double, 4, 2>(sum, mul, fp, grid, threads, lds, stream);
+    }
+    if (e != hipSuccess) return hip_fail(e, "rspmm_fwd_kernel launch");
+
+    if (!p->split_row.empty()) {
+        FixupParams xp;
+        std::memset(&xp, 0, sizeof(xp));
+        xp.split_row = p->d.split_row;
+        xp.split_ptr = p->d.split_ptr;
+        xp.n_split = (int32_t)p->split_row.size();
+        xp.partial = p->d.partial;
+        if (bnd) xp.bnd = fp.bnd;
+        xp.out = out->ptr;
+        xp.out_stride_outer = out->stride_outer;
+        xp.out_stride_row = out->stride_row;
+        xp.n_outer = fp.n_outer;
+        xp.row_len = fp.row_len;
+        xp.has_bnd = fp.has_bnd;
+        const long long total = (long long)xp.n_split * n_outer * (row_len / VEC);
+        const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+#define ULTRA_FIX(T_, V_)                                                                                          \
+    switch (sum) {                                                                                                \
+        case 0: hipLaunchKernelGGL((rspmm_fixup_kernel<T_, V_, 0>), dim3(blocks), dim3(256), 0, stream, xp); break; \
+        case 1: hipLaunchKernelGGL((rspmm_fixup_kernel<T_, V_, 1>), dim3(blocks), dim3(256), 0, stream, xp); break; \
+        default: hipLaunchKernelGGL((rspmm_fixup_kernel<T_, V_, 2>), dim3(blocks), dim3(256), 0, stream, xp); break; \
+    }
+        if (dtype == ULTRA_F32) {
+            if (VEC == 4) { ULTRA_FIX(float, 4) } else { ULTRA_FIX(float, 1) }
+        } else {
+            if (VEC == 4) { ULTRA_FIX(double, 4) } else { ULTRA_FIX(double, 1) }
+        }
+#undef ULTRA_FIX
+        HIP_TRY(hipGetLastError());
+    }
+    return ULTRA_OK;
+}
+
+static int ensure_backward_plans(ultra_plan *p) {
+    if (p->tplan && p->rplan) return ULTRA_OK;
+    if ((int64_t)p->h_row.size() != p->num_edge) return invalid("plan was built without its edge list; backward unavailable");
+    ultra_plan_opts o;
+    std::memset(&o, 0, sizeof(o));
+    o.seg_len = p->seg_len;
+    o.g_max = p->g_max;
+    o.flags = p->flags;
+    if (!p->tplan)
+        p->tplan = build_plan(p->h_col.data(), p->h_row.data(), p->h_type.data(), p->num_edge, p->num_in, p->num_out,
+                              p->num_rel, &o, false);
+    if (!p->rplan)
+        p->rplan = build_plan(p->h_type.data(), p->h_col.data(), p->h_row.data(), p->num_edge, p->num_rel, p->num_in,
+                              p->num_out, &o, false);
+    return ULTRA_OK;
+}
+
+static int backward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *w, const ultra_mat *rel,
+                         const ultra_mat *x, const ultra_mat *outm, const ultra_mat *og, void *wgrad,
+                         const ultra_mat *rgrad, const ultra_mat *xgrad, hipStream_t stream) {
+    if (!p) return invalid("plan is NULL");
+    if (sum < 0 || sum > 2 || mul < 0 || mul > 1) return invalid("unknown sum/mul code");
+    if (dtype != ULTRA_F32 && dtype != ULTRA_F64) return invalid("dtype must be ULTRA_F32 or ULTRA_F64");
+    if (!og || !og->ptr) return invalid("output_grad is NULL");
+    const int64_t n_outer = og->n_outer, row_len = og->row_len;
+    int rc;
+    if ((rc = check_mat(rel, "relation", p->num_rel, n_outer, row_len))) return rc;
+    if ((rc = check_mat(x, "input", p->num_in, n_outer, row_len))) return rc;
+    if ((rc = check_mat(outm, "output", p->num_out, n_outer, row_len))) return rc;
+    if ((rc = check_mat(og, "output_grad", p->num_out, n_outer, row_len))) return rc;
+    if ((rc = check_mat(rgrad, "relation_grad", p->num_rel, n_outer, row_len))) return rc;
+    if ((rc = check_mat(xgrad, "input_grad", p->num_in, n_outer, row_len))) return rc;
+    if ((rc = upload_plan(p))) return rc;
+
+    const size_t esz = dtype == ULTRA_F32 ? 4 : 8;
+    const int64_t step = dtype == ULTRA_F32 ? 4 : 2;
+    const bool vec4 = (row_len % 4 == 0) && mat_vec_ok(rel, step) && mat_vec_ok(x, step) && mat_vec_ok(outm, step) &&
+                      mat_vec_ok(og, step) && mat_vec_ok(rgrad, step) && mat_vec_ok(xgrad, step);
+
+    EdgeParams ep;
+    std::memset(&ep, 0, sizeof(ep));
+    ep.erow = p->d.erow;
+    ep.col = p->d.col;
+    ep.type = p->d.type;
+    ep.perm = p->d.perm;
+    ep.w = w;
+    ep.num_edge = p->num_edge;
+    ep.num_out = (int32_t)p->num_out;
+    ep.rel = MatArg{rel->ptr, rel->stride_outer, rel->stride_row};
+    ep.x = MatArg{x->ptr, x->stride_outer, x->stride_row};
+    ep.out = MatArg{outm->ptr, outm->stride_outer, outm->stride_row};
+    ep.og = MatArg{og->ptr, og->stride_outer, og->stride_row};
+    ep.rgrad = rgrad->ptr;
+    ep.rgrad_so = rgrad->stride_outer;
+    ep.rgrad_sr = rgrad->stride_row;
+    ep.xgrad = xgrad->ptr;
+    ep.xgrad_so = xgrad->stride_outer;
+    ep.xgrad_sr = xgrad->stride_row;
+    ep.wgrad = wgrad;
+    ep.n_outer = (int32_t)n_outer;
+    ep.row_len = (int32_t)row_len;
+
+    if (sum == ULTRA_SUM_ADD) {
+        if ((rc = ensure_backward_plans(p))) return rc;
+        // input_grad[col] = sum_e w * d(rel (x) in)/d in * out_grad[row]   (rspmm.cpp:110-112)
+        if ((rc = forward_impl(p->tplan, ULTRA_SUM_ADD, mul == ULTRA_MUL_MUL ? BIN_MUL : BIN_RHS, dtype, w, rel, og,
+                               nullptr, xgrad, stream)))
+            return rc;
+        // relation_grad[type] = sum_e w * d(rel (x) in)/d rel * out_grad[row]   (rspmm.cpp:106-108)
+        if ((rc = forward_impl(p->rplan, ULTRA_SUM_ADD, mul == ULTRA_MUL_MUL ? BIN_MUL : BIN_LHS, dtype, w, og, x,
+                               nullptr, rgrad, stream)))
+            return rc;
+        if (wgrad && p->num_edge > 0) {
+            if ((rc = launch_edge_kernel(dtype, vec4 ? 4 : 1, sum, mul, /*want_ri=*/false, ep, stream))) return rc;
+        }
+        return ULTRA_OK;
+    }
+    // min / max: gradient flows to every edge whose message equals the output (operator.cuh:62-64,75-77)
+    if ((rc = launch_fill_zero(dtype, rgrad, p->num_rel, stream))) return rc;
+    if ((rc = launch_fill_zero(dtype, xgrad, p->num_in, stream))) return rc;
+    if (p->num_edge > 0) {
+        if ((rc = launch_edge_kernel(dtype, vec4 ? 4 : 1, sum, mul, /*want_ri=*/true, ep, stream))) return rc;
+    }
+    (void)esz;
+    return ULTRA_OK;
+}
+
+static ultra_mat dense2d(const void *ptr, int64_t rows, int64_t dim) {
+    ultra_mat m;
+    m.ptr = const_cast<void *>(ptr);
+    m.n_outer = 1;
+    m.stride_outer = 0;
+    m.n_row = rows;
+    m.stride_row = dim;
+    m.row_len = dim;
+    return m;
+}
+
+// The reference-shaped stateless exports: copy the edge list to the host, check sortedness
+// (rspmm.py:16-18), build a throw-away plan, run, free.
+static int stateless_plan(ultra_plan **plan, const int64_t *ei_dev, const int64_t *et_dev, int64_t E, int64_t N,
+                          int64_t R, hipStream_t stream) {
+    *plan = nullptr;
+    if (E < 0 || N < 0 || R < 0) return invalid("negative size");
+    std::vector<int64_t> ei((size_t)2 * E), et((size_t)E);
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (E > 0) {
+        HIP_TRY(hipMemcpy(ei.data(), ei_dev, sizeof(int64_t) * 2 * E, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(et.data(), et_dev, sizeof(int64_t) * E, hipMemcpyDeviceToHost));
+        int64_t maxc = 0;
+        for (int64_t e = 0; e < E; ++e) maxc = std::max(maxc, ei[(size_t)(E + e)]);
+        for (int64_t e = 1; e < E; ++e) {
+            const int64_t k0 = ei[(size_t)e - 1] * (maxc + 1) + ei[(size_t)(E + e - 1)];
+            const int64_t k1 = ei[(size_t)e] * (maxc + 1) + ei[(size_t)(E + e)];
+            if (k1 < k0) {
+                set_error("Expect sorted `edge_index`");
+                return ULTRA_ERR_UNSORTED;
+            }
+        }
+    }
+    return ultra_plan_create(plan, ei.data(), et.data(), E, N, N, R, nullptr);
+}
+
+}  // namespace ultra
+
+using namespace ultra;
+
+extern "C" {
+
+int32_t ultra_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t ultra_plan_upload(ultra_plan *plan) {
+    if (!plan) return invalid("plan is NULL");
+    return upload_plan(plan);
+}
+
+int32_t ultra_plan_destroy(ultra_plan *plan) {
+    if (!plan) return ULTRA_OK;
+    if (plan->tplan) ultra_plan_destroy(plan->tplan);
+    if (plan->rplan) ultra_plan_destroy(plan->rplan);
+    free_device(plan);
+    delete plan;
+    return ULTRA_OK;
+}
+
+int32_t ultra_rspmm_forward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype, const void *edge_weight_dev,
+                            const ultra_mat *relation, const ultra_mat *input, const ultra_mat *boundary,
+                            const ultra_mat *output, void *stream) {
+    if (mul < 0 || mul > 1) return invalid("unknown mul code");
+    return forward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, boundary, output,
+                        reinterpret_cast<hipStream_t>(stream));
+}
+
+int32_t ultra_rspmm_backward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype, const void *edge_weight_dev,
+                             const ultra_mat *relation, const ultra_mat *input, const ultra_mat *output,
+                             const ultra_mat *output_grad, void *weight_grad_dev, const ultra_mat *relation_grad,
+                             const ultra_mat *input_grad, void *stream) {
+    return backward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, output, output_grad, weight_grad_dev,
+                         relation_grad, input_grad, reinterpret_cast<hipStream_t>(stream));
+}
+
+int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype,
+                                  const void *edge_weight_dev, const ultra_mat *relation, const ultra_mat *input,
+                                  const ultra_mat *boundary, const ultra_mat *output, void *stream, int32_t warmup,
+                                  int32_t iters, float *ms_per_call) {
+    if (!ms_per_call || iters <= 0) return invalid("ultra_rspmm_forward_timed: bad iters / ms_per_call");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+    for (int i = 0; i < warmup; ++i)
+        if ((rc = ultra_rspmm_forward(plan, sum, mul, dtype, edge_weight_dev, relation, input, boundary, output, stream)))
+            return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        if ((rc = ultra_rspmm_forward(plan, sum, mul, dtype, edge_weight_dev, relation, input, boundary, output, stream)))
+            return rc;
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_call = ms / (float)iters;
+    return ULTRA_OK;
+}
+
+int32_t ultra_set_tuning(const ultra_tuning *t) {
+    if (!t) {
+        g_tuning = ultra_tuning{0, 0, -1, -1, 0, {0, 0, 0}};
+        return ULTRA_OK;
+    }
+    if (t->threads < 0 || t->threads > 1024 || (t->threads % 64) != 0) return invalid("threads must be a multiple of 64 <= 1024");
+    g_tuning = *t;
+    return ULTRA_OK;
+}
+
+int32_t ultra_get_tuning(ultra_tuning *t) {
+    if (!t) return invalid("NULL");
+    *t = g_tuning;
+    return ULTRA_OK;
+}
+
+#define ULTRA_DEFINE_REFERENCE_ENTRY(SUM, MUL, SUMC, MULC)                                                           \
+    int32_t ultra_rspmm_##SUM##_##MUL##_forward_cuda(                                                                \
+        const int64_t *edge_index_dev, const int64_t *edge_type_dev, const void *edge_weight_dev,                    \
+        const void *relation_dev, const void *input_dev, void *output_dev, int64_t num_edge, int64_t num_node,       \
+        int64_t num_relation, int64_t dim, int32_t dtype, void *stream) {                                            \
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);                                                       \
+        ultra_plan *plan = nullptr;                                                                                  \
+        int rc = stateless_plan(&plan, edge_index_dev, edge_type_dev, num_edge, num_node, num_relation, s);         \
+        if (rc) return rc;                                                                                           \
+        ultra_mat rel = dense2d(relation_dev, num_relation, dim), in = dense2d(input_dev, num_node, dim),            \
+                  out = dense2d(output_dev, num_node, dim);                                                          \
+        rc = ultra_rspmm_forward(plan, SUMC, MULC, dtype, edge_weight_dev, &rel, &in, nullptr, &out, stream);        \
+        if (rc == ULTRA_OK && hipStreamSynchronize(s) != hipSuccess) rc = ULTRA_ERR_HIP;                             \
+        ultra_plan_destroy(plan);                                                                                    \
+        return rc;                                                                                                   \
+    }                                                                                                                \
+    int32_t ultra_rspmm_##SUM##_##MUL##_backward_cuda(                                                               \
+        const int64_t *edge_index_dev, const int64_t *edge_type_dev, const void *edge_weight_dev,                    \
+        const void *relation_dev, const void *input_dev, const void *output_dev, const void *output_grad_dev,        \
+        void *weight_grad_dev, void *relation_grad_dev, void *input_grad_dev, int64_t num_edge, int64_t num_node,    \
+        int64_t num_relation, int64_t dim, int32_t dtype, void *stream) {                                            \
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);                                                       \
+        ultra_plan *plan = nullptr;                                                                                  \
+        int rc = stateless_plan(&plan, edge_index_dev, edge_type_dev, num_edge, num_node, num_relation, s);         \
+        if (rc) return rc;                                                                                           \
+        ultra_mat rel = dense2d(relation_dev, num_relation, dim), in = dense2d(input_dev, num_node, dim),            \
+                  out = dense2d(output_dev, num_node, dim), og = dense2d(output_grad_dev, num_node, dim),            \
+                  rg = dense2d(relation_grad_dev, num_relation, dim), xg = dense2d(input_grad_dev, num_node, dim);   \
+        rc = ultra_rspmm_backward(plan, SUMC, MULC, dtype, edge_weight_dev, &rel, &in, &out, &og, weight_grad_dev,   \
+                                  &rg, &xg, stream);                                                                 \
+        if (rc == ULTRA_OK && hipStreamSynchronize(s) != hipSuccess) rc = ULTRA_ERR_HIP;                             \
+        ultra_plan_destroy(plan);                                                                                    \
+        return rc;                                                                                                   \
+    }
+
+ULTRA_DEFINE_REFERENCE_ENTRY(add, mul, ULTRA_SUM_ADD, ULTRA_MUL_MUL)
+ULTRA_DEFINE_REFERENCE_ENTRY(min, mul, ULTRA_SUM_MIN, ULTRA_MUL_MUL)
+ULTRA_DEFINE_REFERENCE_ENTRY(max, mul, ULTRA_SUM_MAX, ULTRA_MUL_MUL)
+ULTRA_DEFINE_REFERENCE_ENTRY(add, add, ULTRA_SUM_ADD, ULTRA_MUL_ADD)
+ULTRA_DEFINE_REFERENCE_ENTRY(min, add, ULTRA_SUM_MIN, ULTRA_MUL_ADD)
+ULTRA_DEFINE_REFERENCE_ENTRY(max, add, ULTRA_SUM_MAX, ULTRA_MUL_ADD)
+
+}  // extern "C"

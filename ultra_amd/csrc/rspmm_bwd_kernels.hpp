@@ -1,0 +1,156 @@
+// Edge-parallel backward kernels (rspmm.cpp:77-119 restated for wave64).
+//
+// sum == add needs only weight_grad from here: input_grad and relation_grad are atomics-free
+// re-runs of the forward kernel on the transposed / relation-major plans (rspmm_api.hip).
+// sum == min / max routes everything through this kernel: the gradient reaches every edge whose
+// message equals the forward output (operator.cuh:62-64, 75-77), accumulated with hardware
+// float atomics like the reference's CUDA path (rspmm.cu:142-147, 208-209).
+//
+// One 16-lane group owns one sorted edge and sweeps its feature spans; weight_grad is reduced
+// inside the group with four xor-shuffles and stored once (no atomics) in ORIGINAL edge order.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rspmm_kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace ultra {
+
+struct EdgeParams {
+    const int32_t *erow;
+    const int32_t *col;
+    const int32_t *type;
+    const int32_t *perm;
+    const void *w;  // original edge order, may be NULL (= ones)
+    int64_t num_edge;
+    int32_t num_out;
+    MatArg rel, x, out, og;
+    void *rgrad;
+    long long rgrad_so, rgrad_sr;
+    void *xgrad;
+    long long xgrad_so, xgrad_sr;
+    void *wgrad;  // original edge order, may be NULL
+    int32_t n_outer, row_len;
+};
+
+template <typename T, int VEC, int SUM, int MUL, bool WANT_RI>
+__global__ void __launch_bounds__(256) rspmm_edge_bwd_kernel(const EdgeParams p) {
+    constexpr int SPAN = 16 * VEC;
+    using P = Pack<T, VEC>;
+    const int l16 = threadIdx.x & 15;
+    const long long g0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 4;
+    const long long ng = ((long long)gridDim.x * blockDim.x) >> 4;
+    const int spans_per_outer = (p.row_len + SPAN - 1) / SPAN;
+    for (long long k = g0; k < p.num_edge; k += ng) {
+        const int row = p.erow[k], col = p.col[k], type = p.type[k];
+        const int eid = p.perm[k];
+        const T w = p.w ? reinterpret_cast<const T *>(p.w)[eid] : T(1);
+        T wg = T(0);
+        for (int outer = 0; outer < p.n_outer; ++outer) {
+            for (int inner = 0; inner < spans_per_outer; ++inner) {
+                const int d0 = inner * SPAN + l16 * VEC;
+                if (d0 >= p.row_len) continue;
+                const P r = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.rel.ptr) +
+                                                         outer * p.rel.stride_outer + (long long)type * p.rel.stride_row + d0);
+                const P xi = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.x.ptr) + outer * p.x.stride_outer +
+                                                          (long long)col * p.x.stride_row + d0);
+                const P g = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.og.ptr) + outer * p.og.stride_outer +
+                                                         (long long)row * p.og.stride_row + d0);
+                P o;
+                if (SUM != ULTRA_SUM_ADD)
+                    o = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.out.ptr) + outer * p.out.stride_outer +
+                                                     (long long)row * p.out.stride_row + d0);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const T xb = binary<T, MUL>(r.v[e], xi.v[e]);
+                    const T y = w * xb;
+                    const T dout_dy = (SUM == ULTRA_SUM_ADD) ? T(1) : (o.v[e] == y ? T(1) : T(0));
+                    const T t = g.v[e] * dout_dy;
+                    wg += t * xb;
+                    if (WANT_RI) {
+                        const T tw = t * w;
+                        const T dx_drel = (MUL == BIN_MUL) ? xi.v[e] : T(1);
+                        const T dx_din = (MUL == BIN_MUL) ? r.v[e] : T(1);
+                        T *rg = reinterpret_cast<T *>(p.rgrad) + outer * p.rgrad_so + (long long)type * p.rgrad_sr + d0 + e;
+                        T *xg = reinterpret_cast<T *>(p.xgrad) + outer * p.xgrad_so + (long long)col * p.xgrad_sr + d0 + e;
+                        if (tw != T(0)) {
+                            unsafeAtomicAdd(rg, tw * dx_drel);
+                            unsafeAtomicAdd(xg, tw * dx_din);
+                        }
+                    }
+                }
+            }
+        }
+        if (p.wgrad) {
+            wg += __shfl_xor(wg, 8);
+            wg += __shfl_xor(wg, 4);
+            wg += __shfl_xor(wg, 2);
+            wg += __shfl_xor(wg, 1);
+            if (l16 == 0) reinterpret_cast<T *>(p.wgrad)[eid] = wg;
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) fill_zero_kernel(T *ptr, int n_outer, long long so, long long n_row, long long sr,
+                                                        int row_len) {
+    const long long total = (long long)n_outer * n_row * row_len;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % row_len);
+        const long long r2 = i / row_len;
+        const long long r = r2 % n_row;
+        const int o = (int)(r2 / n_row);
+        ptr[o * so + r * sr + d] = T(0);
+    }
+}
+
+inline int launch_fill_zero(int dtype, const ultra_mat *m, int64_t rows, hipStream_t stream) {
+    const long long total = (long long)m->n_outer * rows * m->row_len;
+    if (total == 0) return ULTRA_OK;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+    if (dtype == ULTRA_F32)
+        hipLaunchKernelGGL(fill_zero_kernel<float>, dim3(blocks), dim3(256), 0, stream, (float *)m->ptr, (int)m->n_outer,
+                           (long long)m->stride_outer, (long long)rows, (long long)m->stride_row, (int)m->row_len);
+    else
+        hipLaunchKernelGGL(fill_zero_kernel<double>, dim3(blocks), dim3(256), 0, stream, (double *)m->ptr, (int)m->n_outer,
+                           (long long)m->stride_outer, (long long)rows, (long long)m->stride_row, (int)m->row_len);
+    if (hipGetLastError() != hipSuccess) {
+        set_error("fill_zero_kernel launch failed");
+        return ULTRA_ERR_HIP;
+    }
+    return ULTRA_OK;
+}
+
+template <typename T, int VEC>
+inline hipError_t launch_edge_t(int sum, int mul, bool want_ri, const EdgeParams &p, hipStream_t s) {
+    const long long groups = p.num_edge;
+    const int blocks = (int)std::min<long long>((groups * 16 + 255) / 256, 16384);
+#define ULTRA_EDGE(S, M)                                                                                              \
+    if (sum == S && mul == M) {                                                                                       \
+        if (want_ri)                                                                                                  \
+            hipLaunchKernelGGL((rspmm_edge_bwd_kernel<T, VEC, S, M, true>), dim3(blocks), dim3(256), 0, s, p);        \
+        else                                                                                                          \
+            hipLaunchKernelGGL((rspmm_edge_bwd_kernel<T, VEC, S, M, false>), dim3(blocks), dim3(256), 0, s, p);       \
+        return hipGetLastError();                                                                                     \
+    }
+    ULTRA_EDGE(0, 0) ULTRA_EDGE(0, 1) ULTRA_EDGE(1, 0) ULTRA_EDGE(1, 1) ULTRA_EDGE(2, 0) ULTRA_EDGE(2, 1)
+#undef ULTRA_EDGE
+    return hipErrorInvalidValue;
+}
+
+inline int launch_edge_kernel(int dtype, int vec, int sum, int mul, bool want_ri, const EdgeParams &p, hipStream_t s) {
+    hipError_t e;
+    if (dtype == ULTRA_F32)
+        e = vec == 4 ? launch_edge_t<float, 4>(sum, mul, want_ri, p, s) : launch_edge_t<float, 1>(sum, mul, want_ri, p, s);
+    else
+        e = vec == 4 ? launch_edge_t<double, 4>(sum, mul, want_ri, p, s) : launch_edge_t<double, 1>(sum, mul, want_ri, p, s);
+    if (e != hipSuccess) {
+        set_error(std::string("rspmm_edge_bwd_kernel launch: ") + hipGetErrorString(e));
+        return ULTRA_ERR_HIP;
+    }
+    return ULTRA_OK;
+}
+
+}  // namespace ultra

@@ -1,0 +1,420 @@
+// CDNA4 (gfx950, wave64) relational-SpMM kernels.  Device code + per-variant launchers.
+//
+//   out[row, :] = NARY_{e in row} w_e * BINARY(rel[type_e, :], x[col_e, :])      (rspmm.cpp:50-75)
+//
+// Mapping to the hardware
+//   * The feature axis is cut into SPANs of 16*VEC elements (64 fp32 = 256 B = two 128-B lines).
+//     A 16-lane group covers one span with one VEC-wide (16-B) load per lane, so every gather of a
+//     source row is a fully coalesced 256-B segment; a wave64 carries four such groups.
+//   * One workgroup (16 waves) works on ONE span at a time and stages that span's slice of the
+//     relation table (R x 256 B) in LDS (MODE_REL_LDS); when the source matrix slice also fits
+//     (N x 256 B <= LDS, the relation-graph regime: few hundred nodes, thousands of edges each) it
+//     is staged too (MODE_ALL_LDS) and the whole gather runs out of LDS.  ds_read_b128 of 256-B
+//     rows by 16-lane groups is bank-conflict free.
+//   * span -> workgroup mapping is blockIdx % n_span, i.e. with 8 spans (batch 8 x dim 64) span s
+//     runs on XCD s (block b is dispatched to XCD b % 8): each XCD's private 4-MiB L2 only ever
+//     sees its own 1/8 slice of x / out.
+//   * Work inside a span is the plan's static unit list (plan.hpp): a wave takes units
+//     u = worker, worker + n_workers, ...  Group items are walked sequentially in sorted edge order
+//     (bit-reproducible, oracle order); wave items stride their edges over the four groups and
+//     combine with two cross-group shuffles.  Rows longer than seg_len were split by the plan and
+//     are combined in slot order by rspmm_fixup_kernel: no atomics anywhere, run-to-run
+//     deterministic.
+//   * Edge records are fetched 16 per group with one coalesced load (next batch prefetched) and
+//     broadcast inside the group with ds_bpermute; UNROLL source-row loads are in flight per lane.
+//   * Arithmetic is compiled with fp-contract off: products and sums round separately exactly like
+//     the reference's scalar CPU loop, so sequential (group) items match the oracle bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <limits>
+
+#include "plan.hpp"
+
+#pragma clang fp contract(off)
+
+namespace ultra {
+
+enum { MODE_GLOBAL = 0, MODE_REL_LDS = 1, MODE_ALL_LDS = 2 };
+// BINARY variants: MUL/ADD are the reference's (operator.cuh:13-41); LHS/RHS pass one operand
+// through and serve the backward passes (d/d input of rel+in is 1, etc.).
+enum { BIN_MUL = 0, BIN_ADD = 1, BIN_LHS = 2, BIN_RHS = 3 };
+
+#ifndef ULTRA_UNROLL
+#define ULTRA_UNROLL 4
+#endif
+
+struct MatArg {
+    const void *ptr;
+    long long stride_outer;
+    long long stride_row;
+};
+
+struct FwdParams {
+    const int32_t *col;
+    const int32_t *type;
+    const uint32_t *packed;
+    const void *w_sorted;
+    const Item *items;
+    int32_t n_w, n_item, n_unit;
+    MatArg rel, x, bnd;
+    void *out;
+    long long out_stride_outer, out_stride_row;
+    void *partial;
+    int32_t n_outer, row_len, spans_per_outer, n_span;
+    int32_t num_rel, num_in;
+    int32_t type_bits;
+    int32_t unit_w, packed_on, has_bnd;
+    int32_t smod, nparts;
+};
+
+struct FixupParams {
+    const int32_t *split_row;
+    const int32_t *split_ptr;
+    int32_t n_split;
+    const void *partial;
+    MatArg bnd;
+    void *out;
+    long long out_stride_outer, out_stride_row;
+    int32_t n_outer, row_len, has_bnd;
+};
+
+template <typename T, int VEC>
+struct alignas(sizeof(T) * VEC > 16 ? 16 : sizeof(T) * VEC) Pack {
+    T v[VEC];
+};
+
+template <typename T, int SUM>
+__device__ __forceinline__ T nary_zero() {
+    if (SUM == ULTRA_SUM_ADD) return T(0);
+    if (SUM == ULTRA_SUM_MIN) return std::numeric_limits<T>::max();
+    return std::numeric_limits<T>::lowest();
+}
+
+template <typename T, int SUM>
+__device__ __forceinline__ T nary(T result, T x) {  // operator.cuh:45,58,71
+    if (SUM == ULTRA_SUM_ADD) return result + x;
+    if (SUM == ULTRA_SUM_MIN) return result < x ? result : x;
+    return result > x ? result : x;
+}
+
+template <typename T, int MUL>
+__device__ __forceinline__ T binary(T rel, T x) {  // operator.cuh:15,29
+    if (MUL == BIN_MUL) return rel * x;
+    if (MUL == BIN_ADD) return rel + x;
+    if (MUL == BIN_LHS) return rel;
+    return x;
+}
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+
+// Walks one group's edge stream {begin + k * stride : k < cnt} for nsteps (wave-uniform) steps and
+// returns the group's accumulator.  PACKED: col/type share one word; UNITW: all edge weights are 1.
+template <typename T, int VEC, int SUM, int MUL, int MODE, bool PACKED, bool UNITW>
+__device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int begin, const int cnt, const int stride,
+                                                   const int nsteps, const int lane, const int l16, const T *xb,
+                                                   const T *relb, const T *lds_x, const T *lds_rel) {
+    constexpr int SPAN = 16 * VEC;
+    using P = Pack<T, VEC>;
+    P acc;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc.v[e] = nary_zero<T, SUM>();
+
+    // record registers: this lane holds record (k0 + l16) of its group's stream
+    uint32_t cur_c = 0, cur_t = 0;
+    T cur_w = T(1);
+    if (l16 < cnt) {
+        const int idx = begin + l16 * stride;
+        if (PACKED) {
+            cur_c = p.packed[idx];
+        } else {
+            cur_c = (uint32_t)p.col[idx];
+            cur_t = (uint32_t)p.type[idx];
+        }
+        if (!UNITW) cur_w = reinterpret_cast<const T *>(p.w_sorted)[idx];
+    }
+    const uint32_t tmask = (1u << p.type_bits) - 1u;
+    for (int k0 = 0; k0 < nsteps; k0 += 16) {
+        uint32_t nxt_c = 0, nxt_t = 0;
+        T nxt_w = T(1);
+        if (k0 + 16 < nsteps) {  // prefetch the next 16 records of this group
+            const int k = k0 + 16 + l16;
+            if (k < cnt) {
+                const int idx = begin + k * stride;
+                if (PACKED) {
+                    nxt_c = p.packed[idx];
+                } else {
+                    nxt_c = (uint32_t)p.col[idx];
+                    nxt_t = (uint32_t)p.type[idx];
+                }
+                if (!UNITW) nxt_w = reinterpret_cast<const T *>(p.w_sorted)[idx];
+            }
+        }
+        const int nb = min(16, nsteps - k0);
+        for (int j = 0; j < nb; j += ULTRA_UNROLL) {
+            uint32_t c[ULTRA_UNROLL], t[ULTRA_UNROLL];
+            T w[ULTRA_UNROLL];
+            bool ok[ULTRA_UNROLL];
+            P xv[ULTRA_UNROLL], rv[ULTRA_UNROLL];
+#pragma unroll
+            for (int q = 0; q < ULTRA_UNROLL; ++q) {
+                const int jj = j + q;
+                const int src = (lane & 48) | (jj & 15);
+                const uint32_t cc = (uint32_t)__shfl((int)cur_c, src);
+                if (PACKED) {
+                    t[q] = cc & tmask;
+                    c[q] = cc >> p.type_bits;
+                } else {
+                    c[q] = cc;
+                    t[q] = (uint32_t)__shfl((int)cur_t, src);
+                }
+                w[q] = UNITW ? T(1) : __shfl(cur_w, src);
+                ok[q] = (jj < 16) && (k0 + jj < cnt);
+            }
+#pragma unroll
+            for (int q = 0; q < ULTRA_UNROLL; ++q) {
+                if (MUL != BIN_LHS) {
+                    if (MODE == MODE_ALL_LDS)
+                        xv[q] = *reinterpret_cast<const P *>(lds_x + c[q] * SPAN + l16 * VEC);
+                    else
+                        xv[q] = *reinterpret_cast<const P *>(xb + (long long)c[q] * p.x.stride_row);
+                }
+                if (MUL != BIN_RHS) {
+                    if (MODE >= MODE_REL_LDS)
+                        rv[q] = *reinterpret_cast<const P *>(lds_rel + t[q] * SPAN + l16 * VEC);
+                    else
+                        rv[q] = *reinterpret_cast<const P *>(relb + (long long)t[q] * p.rel.stride_row);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < ULTRA_UNROLL; ++q) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const T rr = (MUL != BIN_RHS) ? rv[q].v[e] : T(0);
+                    const T xx = (MUL != BIN_LHS) ? xv[q].v[e] : T(0);
+                    T y = binary<T, MUL>(rr, xx);
+                    if (!UNITW) y = w[q] * y;
+                    const T cand = nary<T, SUM>(acc.v[e], y);
+                    acc.v[e] = ok[q] ? cand : acc.v[e];
+                }
+            }
+        }
+        cur_c = nxt_c;
+        cur_t = nxt_t;
+        cur_w = nxt_w;
+    }
+    return acc;
+}
+
+template <typename T, int VEC, int SUM, int MUL, int MODE>
+__global__ void __launch_bounds__(1024) rspmm_fwd_kernel(const FwdParams p) {
+    constexpr int SPAN = 16 * VEC;
+    using P = Pack<T, VEC>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *lds_rel = reinterpret_cast<T *>(smem);
+    T *lds_x = lds_rel + (MUL == BIN_RHS ? 0 : (size_t)p.num_rel * SPAN);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = rfl(tid >> 6);
+    const int nwave = blockDim.x >> 6;
+    const int grp = lane >> 4;
+    const int l16 = lane & 15;
+    const int part = blockIdx.x / p.smod;
+    if (part >= p.nparts) return;
+    const int4 *items4 = reinterpret_cast<const int4 *>(p.items);
+
+    for (int span = blockIdx.x % p.smod; span < p.n_span; span += p.smod) {
+        const int outer = span / p.spans_per_outer;
+        const int inner = span - outer * p.spans_per_outer;
+        const int d0 = inner * SPAN + l16 * VEC;
+        const bool dvalid = d0 < p.row_len;
+        const int d0c = dvalid ? d0 : 0;
+        const T *xb = reinterpret_cast<const T *>(p.x.ptr) + outer * p.x.stride_outer + d0c;
+        const T *relb = reinterpret_cast<const T *>(p.rel.ptr) + outer * p.rel.stride_outer + d0c;
+
+        if (MODE >= MODE_REL_LDS) {
+            __syncthreads();  // readers of the previous span are done with the LDS image
+            if (MUL != BIN_RHS) {
+                const T *src = reinterpret_cast<const T *>(p.rel.ptr) + outer * p.rel.stride_outer;
+                for (int i = tid; i < p.num_rel * 16; i += blockDim.x) {
+                    const int r = i >> 4, l = i & 15;
+                    const int d = inner * SPAN + l * VEC;
+                    P v;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v.v[e] = T(0);
+                    if (d < p.row_len) v = *reinterpret_cast<const P *>(src + (long long)r * p.rel.stride_row + d);
+                    *reinterpret_cast<P *>(lds_rel + r * SPAN + l * VEC) = v;
+                }
+            }
+            if (MODE == MODE_ALL_LDS && MUL != BIN_LHS) {
+                const T *src = reinterpret_cast<const T *>(p.x.ptr) + outer * p.x.stride_outer;
+                for (int i = tid; i < p.num_in * 16; i += blockDim.x) {
+                    const int r = i >> 4, l = i & 15;
+                    const int d = inner * SPAN + l * VEC;
+                    P v;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v.v[e] = T(0);
+                    if (d < p.row_len) v = *reinterpret_cast<const P *>(src + (long long)r * p.x.stride_row + d);
+                    *reinterpret_cast<P *>(lds_x + r * SPAN + l * VEC) = v;
+                }
+            }
+            __syncthreads();
+        }
+
+        for (int u = part * nwave + wave; u < p.n_unit; u += p.nparts * nwave) {
+            const bool wmode = u < p.n_w;  // wave-uniform
+            int begin, cnt, stride, row, slot, nsteps;
+            if (wmode) {
+                const int4 it = items4[u];
+                row = rfl(it.x);
+                const int ibegin = rfl(it.y), ilen = rfl(it.z);
+                slot = rfl(it.w);
+                begin = ibegin + grp;
+                stride = 4;
+                cnt = (ilen - grp + 3) >> 2;
+                nsteps = (ilen + 3) >> 2;
+            } else {
+                const int q = p.n_w + 4 * (u - p.n_w) + grp;
+                if (q < p.n_item) {
+                    const int4 it = items4[q];
+                    row = it.x;
+                    begin = it.y;
+                    cnt = it.z;
+                    slot = it.w;
+                } else {
+                    row = -1;
+                    begin = 0;
+                    cnt = 0;
+                    slot = -1;
+                }
+                stride = 1;
+                const int m01 = max(__shfl(cnt, 0), __shfl(cnt, 16));
+                const int m23 = max(__shfl(cnt, 32), __shfl(cnt, 48));
+                nsteps = rfl(max(m01, m23));
+            }
+
+            P acc;
+            if (p.packed_on) {
+                if (p.unit_w)
+                    acc = walk_edges<T, VEC, SUM, MUL, MODE, true, true>(p, begin, cnt, stride, nsteps, lane, l16, xb, relb, lds_x, lds_rel);
+                else
+                    acc = walk_edges<T, VEC, SUM, MUL, MODE, true, false>(p, begin, cnt, stride, nsteps, lane, l16, xb, relb, lds_x, lds_rel);
+            } else {
+                if (p.unit_w)
+                    acc = walk_edges<T, VEC, SUM, MUL, MODE, false, true>(p, begin, cnt, stride, nsteps, lane, l16, xb, relb, lds_x, lds_rel);
+                else
+                    acc = walk_edges<T, VEC, SUM, MUL, MODE, false, false>(p, begin, cnt, stride, nsteps, lane, l16, xb, relb, lds_x, lds_rel);
+            }
+
+            if (wmode) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    T v = acc.v[e];
+                    v = nary<T, SUM>(v, __shfl_xor(v, 16));
+                    v = nary<T, SUM>(v, __shfl_xor(v, 32));
+                    acc.v[e] = v;
+                }
+            }
+            const bool writer = wmode ? (grp == 0) : (row >= 0);
+            if (writer && dvalid) {
+                if (slot >= 0) {
+                    T *dst = reinterpret_cast<T *>(p.partial) + ((long long)slot * p.n_outer + outer) * p.row_len + d0;
+                    *reinterpret_cast<P *>(dst) = acc;
+                } else {
+                    if (p.has_bnd) {
+                        const P b = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.bnd.ptr) +
+                                                                 outer * p.bnd.stride_outer +
+                                                                 (long long)row * p.bnd.stride_row + d0);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc.v[e] = nary<T, SUM>(acc.v[e], b.v[e]);
+                    }
+                    T *dst = reinterpret_cast<T *>(p.out) + outer * p.out_stride_outer +
+                             (long long)row * p.out_stride_row + d0;
+                    *reinterpret_cast<P *>(dst) = acc;
+                }
+            }
+        }
+    }
+}
+
+// Combines the partial results of split rows in slot order and applies the boundary epilogue.
+template <typename T, int VEC, int SUM>
+__global__ void __launch_bounds__(256) rspmm_fixup_kernel(const FixupParams p) {
+    using P = Pack<T, VEC>;
+    const int vec_per_row = p.row_len / VEC;
+    const long long total = (long long)p.n_split * p.n_outer * vec_per_row;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int dv = (int)(i % vec_per_row);
+        const long long r2 = i / vec_per_row;
+        const int outer = (int)(r2 % p.n_outer);
+        const int k = (int)(r2 / p.n_outer);
+        const int row = p.split_row[k];
+        const int s0 = p.split_ptr[k], s1 = p.split_ptr[k + 1];
+        const int d0 = dv * VEC;
+        P acc;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc.v[e] = nary_zero<T, SUM>();
+        for (int s = s0; s < s1; ++s) {
+            const P v = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.partial) +
+                                                     ((long long)s * p.n_outer + outer) * p.row_len + d0);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc.v[e] = nary<T, SUM>(acc.v[e], v.v[e]);
+        }
+        if (p.has_bnd) {
+            const P b = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.bnd.ptr) +
+                                                     outer * p.bnd.stride_outer + (long long)row * p.bnd.stride_row + d0);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc.v[e] = nary<T, SUM>(acc.v[e], b.v[e]);
+        }
+        T *dst = reinterpret_cast<T *>(p.out) + outer * p.out_stride_outer + (long long)row * p.out_stride_row + d0;
+        *reinterpret_cast<P *>(dst) = acc;
+    }
+}
+
+// w_sorted[k] = w[perm[k]]: per-call edge weights arrive in original edge order.
+template <typename T>
+__global__ void __launch_bounds__(256) permute_weight_kernel(const T *w, const int32_t *perm, T *w_sorted, int64_t n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        w_sorted[i] = w[perm[i]];
+}
+
+// ---- per-variant launchers (explicitly instantiated in rspmm_variant_*.hip) ----
+template <typename T, int VEC, int SUM, int MUL, int MODE>
+inline hipError_t launch_one(const FwdParams &p, int grid, int threads, size_t lds, hipStream_t s) {
+    auto kern = rspmm_fwd_kernel<T, VEC, SUM, MUL, MODE>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, p);
+    return hipGetLastError();
+}
+
+template <typename T, int VEC, int MODE>
+hipError_t launch_fwd_variant(int sum, int mul, const FwdParams &p, int grid, int threads, size_t lds, hipStream_t s);
+
+#define ULTRA_CASE(S, M)                                                        \
+    case (S) * 4 + (M):                                                         \
+        return launch_one<T, VEC, S, M, MODE>(p, grid, threads, lds, s);
+
+#define ULTRA_DEFINE_VARIANT(T_, VEC_, MODE_)                                                                     \
+    template <>                                                                                                   \
+    hipError_t launch_fwd_variant<T_, VEC_, MODE_>(int sum, int mul, const FwdParams &p, int grid, int threads,  \
+                                                   size_t lds, hipStream_t s) {                                   \
+        using T = T_;                                                                                             \
+        constexpr int VEC = VEC_;                                                                                 \
+        constexpr int MODE = MODE_;                                                                               \
+        switch (sum * 4 + mul) {                                                                                  \
+            ULTRA_CASE(0, 0) ULTRA_CASE(0, 1) ULTRA_CASE(0, 2) ULTRA_CASE(0, 3)                                   \
+            ULTRA_CASE(1, 0) ULTRA_CASE(1, 1) ULTRA_CASE(1, 2) ULTRA_CASE(1, 3)                                   \
+            ULTRA_CASE(2, 0) ULTRA_CASE(2, 1) ULTRA_CASE(2, 2) ULTRA_CASE(2, 3)                                   \
+        }                                                                                                         \
+        return hipErrorInvalidValue;                                                                              \
+    }
+
+}  // namespace ultra

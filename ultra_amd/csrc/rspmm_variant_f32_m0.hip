@@ -1,0 +1,6 @@
+// Explicit instantiation: float, relation/input read through L2 (MODE_GLOBAL); VEC 4 and the VEC 1 fallback.
+#include "rspmm_kernels.hpp"
+namespace ultra {
+ULTRA_DEFINE_VARIANT(float, 4, 0)
+ULTRA_DEFINE_VARIANT(float, 1, 0)
+}  // namespace ultra

@@ -1,0 +1,357 @@
+"""Drop-in operator boundary: generalized_rspmm and the six RSPMM*Function classes.
+
+Mirrors /root/reference/ultra/rspmm/rspmm.py (names, argument meaning, error behaviour):
+  * generalized_rspmm(edge_index, edge_type, edge_weight, relation, input, sum="add", mul="mul")
+    (rspmm.py:168-179) -- accepts unsorted edges, ValueError for unknown (sum, mul) pairs;
+  * RSPMM{Add,Min,Max}{Mul,Add}Function (rspmm.py:12-165) -- require sorted `edge_index`
+    (AssertionError "Expect sorted `edge_index`"), differentiable w.r.t. edge_weight, relation, input;
+  * `rspmm` -- a namespace exporting the reference extension's function names
+    rspmm_<sum>_<mul>_{forward,backward}_cuda (rspmm.cpp:270-282), bound to the stateless C entry points.
+
+What changes underneath: the per-call argsort / ind2ptr / host syncs of the reference are replaced by a
+cached `Plan` (built once per graph) and the HIP kernels of libultra_amd.so.  CPU tensors raise: this
+engine has no CPU path (the reference's `rspmm_*_cpu` names exist only to say so).
+"""
+import ctypes
+import sys
+from collections import OrderedDict
+
+import torch
+from torch import autograd
+
+from . import _lib
+from ._lib import UltraMat, check, lib
+
+module = sys.modules[__name__]
+
+_DTYPES = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and t.device.type != "cuda":
+            raise RuntimeError("ultra_amd.rspmm: expected a GPU (ROCm `cuda`) tensor, got device `%s`; "
+                               "the MI355X engine has no CPU path" % t.device)
+
+
+def _dtype_code(*tensors):
+    dt = tensors[0].dtype
+    for t in tensors:
+        if t.dtype != dt:
+            raise RuntimeError("Expected tensors of the same floating type (edge_weight, relation, input), got %s and %s"
+                               % (dt, t.dtype))  # checkAllSameType, rspmm.cpp:23
+    if dt not in _DTYPES:
+        raise RuntimeError("rspmm supports float32 / float64, got %s" % dt)  # AT_DISPATCH_FLOATING_TYPES
+    return _DTYPES[dt]
+
+
+def as_mat(t):
+    """Describe a 2-D (rows, D) or batch-major 3-D (batch, rows, d) tensor to the C ABI without copying."""
+    if t.dim() == 2:
+        if t.stride(1) != 1 and t.shape[1] > 1:
+            t = t.contiguous()
+        return t, UltraMat(t.data_ptr(), 1, 0, t.shape[0], t.stride(0), t.shape[1])
+    if t.dim() == 3:
+        if t.stride(2) != 1 and t.shape[2] > 1:
+            t = t.contiguous()
+        return t, UltraMat(t.data_ptr(), t.shape[0], t.stride(0), t.shape[1], t.stride(1), t.shape[2])
+    raise RuntimeError("Expected a 2-dimensional (or batch-major 3-dimensional) tensor, got %d dims" % t.dim())
+
+
+class Plan(object):
+    """Aggregation plan of one graph (sorted CSR + balanced work list), resident in HBM."""
+
+    def __init__(self, edge_index, edge_type, num_node, num_relation, seg_len=0, g_max=0, exact_order=False,
+                 num_in=None):
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise RuntimeError("Expected `edge_index` of shape (2, num_edge)")          # checkDim/checkSize
+        if edge_type.dim() != 1 or edge_type.shape[0] != edge_index.shape[1]:
+            raise RuntimeError("Expected `edge_type` of shape (num_edge,)")
+        if edge_index.dtype != edge_type.dtype:
+            raise RuntimeError("Expected `edge_index` and `edge_type` of the same type")  # checkSameType, rspmm.cpp:22
+        ei = edge_index.detach().to("cpu", torch.int64).contiguous()
+        et = edge_type.detach().to("cpu", torch.int64).contiguous()
+        opts = _lib.PlanOpts(int(seg_len), int(g_max), _lib.PLAN_EXACT_ORDER if exact_order else 0, 0)
+        handle = ctypes.c_void_p()
+        self.num_edge = ei.shape[1]
+        self.num_node = int(num_node)
+        self.num_in = int(num_node if num_in is None else num_in)
+        self.num_relation = int(num_relation)
+        check(lib.ultra_plan_create(ctypes.byref(handle), ei.data_ptr(), et.data_ptr(), self.num_edge, self.num_node,
+                                    self.num_in, self.num_relation, ctypes.byref(opts)))
+        self._h = handle
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+            except Exception:
+                pass
+            lib.ultra_plan_destroy(h)
+            self._h = None
+
+    def info(self):
+        info = _lib.PlanInfo()
+        check(lib.ultra_plan_get_info(self._h, ctypes.byref(info)))
+        return {name: getattr(info, name) for name, _ in _lib.PlanInfo._fields_}
+
+    def export(self, which):
+        n = ctypes.c_int64()
+        check(lib.ultra_plan_export(self._h, which, None, 0, ctypes.byref(n)))
+        out = torch.empty(n.value, dtype=torch.int32)
+        check(lib.ultra_plan_export(self._h, which, out.data_ptr(), n.value, ctypes.byref(n)))
+        return out
+
+    # ---- kernels ----
+    def forward(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", out=None):
+        _require_gpu(relation, input, edge_weight, boundary)
+        dt = _dtype_code(*([relation, input] + ([edge_weight] if edge_weight is not None else [])
+                           + ([boundary] if boundary is not None else [])))
+        relation, mrel = as_mat(relation)
+        input, mx = as_mat(input)
+        if relation.dim() != input.dim():
+            raise RuntimeError("relation and input must both be 2-D or both batch-major 3-D")
+        if out is None:
+            shape = list(input.shape)
+            shape[-2] = self.num_node
+            out = torch.empty(shape, dtype=input.dtype, device=input.device)
+        out, mout = as_mat(out)
+        mb = None
+        if boundary is not None:
+            boundary, mbv = as_mat(boundary)
+            mb = ctypes.byref(mbv)
+        w = None
+        if edge_weight is not None:
+            if edge_weight.dim() != 1 or edge_weight.shape[0] != self.num_edge:
+                raise RuntimeError("Expected `edge_weight` of shape (num_edge,)")
+            edge_weight = edge_weight.contiguous()
+            w = edge_weight.data_ptr()
+        check(lib.ultra_rspmm_forward(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
+                                      ctypes.byref(mx), mb, ctypes.byref(mout), _stream()))
+        return out
+
+    def backward(self, relation, input, output, output_grad, edge_weight=None, need_weight_grad=False, sum="add",
+                 mul="mul"):
+        _require_gpu(relation, input, output, output_grad, edge_weight)
+        dt = _dtype_code(relation, input, output, output_grad)
+        relation, mrel = as_mat(relation)
+        input, mx = as_mat(input)
+        output, mo = as_mat(output)
+        output_grad, mog = as_mat(output_grad)
+        rgrad = torch.empty(relation.shape, dtype=relation.dtype, device=relation.device)
+        xgrad = torch.empty(input.shape, dtype=input.dtype, device=input.device)
+        _, mrg = as_mat(rgrad)
+        _, mxg = as_mat(xgrad)
+        w = None
+        if edge_weight is not None:
+            edge_weight = edge_weight.contiguous()
+            w = edge_weight.data_ptr()
+        wgrad = None
+        wg = None
+        if need_weight_grad:
+            wgrad = torch.zeros(self.num_edge, dtype=input.dtype, device=input.device)
+            wg = wgrad.data_ptr()
+        check(lib.ultra_rspmm_backward(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
+                                       ctypes.byref(mx), ctypes.byref(mo), ctypes.byref(mog), wg, ctypes.byref(mrg),
+                                       ctypes.byref(mxg), _stream()))
+        return wgrad, rgrad, xgrad
+
+    def forward_timed(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", warmup=3, iters=20):
+        """Mean HIP-event time (ms) of the forward launch sequence on the current stream."""
+        dt = _dtype_code(relation, input)
+        relation, mrel = as_mat(relation)
+        input, mx = as_mat(input)
+        shape = list(input.shape)
+        shape[-2] = self.num_node
+        out = torch.empty(shape, dtype=input.dtype, device=input.device)
+        out, mout = as_mat(out)
+        mb = None
+        if boundary is not None:
+            boundary, mbv = as_mat(boundary)
+            mb = ctypes.byref(mbv)
+        w = edge_weight.contiguous().data_ptr() if edge_weight is not None else None
+        ms = ctypes.c_float()
+        check(lib.ultra_rspmm_forward_timed(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
+                                            ctypes.byref(mx), mb, ctypes.byref(mout), _stream(), warmup, iters,
+                                            ctypes.byref(ms)))
+        return ms.value, out
+
+
+# ---- plan cache: the graph is static across the 12 rspmm calls of a forward and across batches ----
+_PLAN_CACHE = OrderedDict()
+_PLAN_CACHE_SIZE = 16
+_plan_defaults = {"seg_len": 0, "g_max": 0, "exact_order": False}
+
+
+def set_plan_defaults(seg_len=0, g_max=0, exact_order=False):
+    """Tuning hook: defaults for newly built plans (clears the cache)."""
+    _plan_defaults.update(seg_len=seg_len, g_max=g_max, exact_order=exact_order)
+    _PLAN_CACHE.clear()
+
+
+def get_plan(edge_index, edge_type, num_node, num_relation):
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), tuple(edge_index.stride()),
+           edge_type.data_ptr(), edge_type._version, tuple(edge_type.shape), str(edge_index.device),
+           int(num_node), int(num_relation))
+    hit = _PLAN_CACHE.get(key)
+    if hit is not None:
+        plan, ei_ref, et_ref = hit
+        _PLAN_CACHE.move_to_end(key)
+        return plan
+    plan = Plan(edge_index, edge_type, num_node, num_relation, **_plan_defaults)
+    # the tensors are kept alive with the plan so a recycled data_ptr can never alias a stale entry
+    _PLAN_CACHE[key] = (plan, edge_index, edge_type)
+    while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
+        _PLAN_CACHE.popitem(last=False)
+    return plan
+
+
+def clear_plan_cache():
+    _PLAN_CACHE.clear()
+
+
+class _PlanRSPMM(autograd.Function):
+    """autograd node shared by every (sum, mul) pair; the graph plan rides along as a non-tensor arg."""
+
+    @staticmethod
+    def forward(ctx, plan, sum, mul, edge_weight, relation, input):
+        output = plan.forward(relation, input, edge_weight=edge_weight, sum=sum, mul=mul)
+        ctx.plan, ctx.sum, ctx.mul = plan, sum, mul
+        ctx.save_for_backward(edge_weight, relation, input, output)   # rspmm.py:25
+        return output
+
+    @staticmethod
+    def backward(ctx, output_grad):
+        edge_weight, relation, input, output = ctx.saved_tensors
+        need_w = ctx.needs_input_grad[3]
+        weight_grad, relation_grad, input_grad = ctx.plan.backward(
+            relation, input, output, output_grad.contiguous(), edge_weight=edge_weight, need_weight_grad=need_w,
+            sum=ctx.sum, mul=ctx.mul)
+        return None, None, None, weight_grad, relation_grad, input_grad   # rspmm.py:35
+
+
+def _check_args(edge_index, edge_type, edge_weight, relation, input):
+    # rspmm_forward_check, rspmm.cpp:15-27
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise RuntimeError("Expected 2-dimensional `edge_index` of size (2, num_edge)")
+    if edge_type.dim() != 1 or edge_weight.dim() != 1 or relation.dim() != 2 or input.dim() != 2:
+        raise RuntimeError("Expected 1-dimensional edge_type / edge_weight and 2-dimensional relation / input")
+    E = edge_index.shape[1]
+    if edge_type.shape[0] != E or edge_weight.shape[0] != E:
+        raise RuntimeError("Expected edge_type and edge_weight of size (%d,)" % E)
+    if relation.shape[1] != input.shape[1]:
+        raise RuntimeError("Expected relation.size(1) == input.size(1), got %d and %d"
+                           % (relation.shape[1], input.shape[1]))
+    _require_gpu(edge_index, edge_type, edge_weight, relation, input)
+    _dtype_code(edge_weight, relation, input)
+
+
+def _sorted_assert(edge_index):
+    node_in, node_out = edge_index
+    if node_in.numel():
+        key = node_in * (node_out.max() + 1) + node_out
+        assert (key.diff() >= 0).all(), "Expect sorted `edge_index`"   # rspmm.py:16-18
+
+
+def _make_function(sum, mul):
+    class _Function(autograd.Function):
+        @staticmethod
+        def forward(ctx, edge_index, edge_type, edge_weight, relation, input):
+            _check_args(edge_index, edge_type, edge_weight, relation, input)
+            _sorted_assert(edge_index)
+            plan = get_plan(edge_index, edge_type, input.shape[0], relation.shape[0])
+            output = plan.forward(relation, input, edge_weight=edge_weight, sum=sum, mul=mul)
+            ctx.plan = plan
+            ctx.save_for_backward(edge_index, edge_type, edge_weight, relation, input, output)
+            return output
+
+        @staticmethod
+        def backward(ctx, output_grad):
+            edge_index, edge_type, edge_weight, relation, input, output = ctx.saved_tensors
+            weight_grad, relation_grad, input_grad = ctx.plan.backward(
+                relation, input, output, output_grad.contiguous(), edge_weight=edge_weight,
+                need_weight_grad=True, sum=sum, mul=mul)
+            return None, None, weight_grad, relation_grad, input_grad
+
+    _Function.__name__ = _Function.__qualname__ = "RSPMM%s%sFunction" % (sum.capitalize(), mul.capitalize())
+    return _Function
+
+
+RSPMMAddMulFunction = _make_function("add", "mul")   # rspmm.py:12
+RSPMMMinMulFunction = _make_function("min", "mul")   # rspmm.py:38
+RSPMMMaxMulFunction = _make_function("max", "mul")   # rspmm.py:64
+RSPMMAddAddFunction = _make_function("add", "add")   # rspmm.py:90
+RSPMMMinAddFunction = _make_function("min", "add")   # rspmm.py:116
+RSPMMMaxAddFunction = _make_function("max", "add")   # rspmm.py:142
+
+
+def generalized_rspmm(edge_index, edge_type, edge_weight, relation, input, sum="add", mul="mul"):
+    """rspmm.py:168-179.  Unsorted edges are fine: the cached plan carries the sort."""
+    name = "RSPMM%s%sFunction" % (sum.capitalize(), mul.capitalize())
+    if not hasattr(module, name):
+        raise ValueError("No generalized rspmm implementation found for summation `%s` and multiplication `%s`"
+                         % (sum, mul))
+    _check_args(edge_index, edge_type, edge_weight, relation, input)
+    plan = get_plan(edge_index, edge_type, input.shape[0], relation.shape[0])
+    return _PlanRSPMM.apply(plan, sum, mul, edge_weight, relation, input)
+
+
+def plan_rspmm(plan, relation, input, edge_weight=None, sum="add", mul="mul"):
+    """Differentiable rspmm on an explicit plan; accepts batch-major (batch, N, d) operands."""
+    return _PlanRSPMM.apply(plan, sum, mul, edge_weight, relation, input)
+
+
+class _ReferenceExports(object):
+    """The reference extension's pybind surface (rspmm.cpp:256-283) over the stateless C entry points."""
+
+    def __getattr__(self, name):
+        parts = name.split("_")
+        if len(parts) == 5 and parts[0] == "rspmm" and parts[1] in _lib.SUM_CODES and parts[2] in _lib.MUL_CODES \
+                and parts[3] in ("forward", "backward") and parts[4] in ("cuda", "cpu"):
+            if parts[4] == "cpu":
+                def no_cpu(*args, **kwargs):
+                    raise RuntimeError("ultra_amd: `%s` -- this engine is MI355X-only and has no CPU path" % name)
+                return no_cpu
+            return self._forward(parts[1], parts[2]) if parts[3] == "forward" else self._backward(parts[1], parts[2])
+        raise AttributeError(name)
+
+    @staticmethod
+    def _forward(sum, mul):
+        fn = getattr(lib, "ultra_rspmm_%s_%s_forward_cuda" % (sum, mul))
+
+        def forward(edge_index, edge_type, edge_weight, relation, input):
+            _check_args(edge_index, edge_type, edge_weight, relation, input)
+            dt = _dtype_code(edge_weight, relation, input)
+            ei, et, ew = edge_index.contiguous(), edge_type.contiguous(), edge_weight.contiguous()
+            rel, x = relation.contiguous(), input.contiguous()
+            out = torch.empty_like(x)
+            check(fn(ei.data_ptr(), et.data_ptr(), ew.data_ptr(), rel.data_ptr(), x.data_ptr(), out.data_ptr(),
+                     ei.shape[1], x.shape[0], rel.shape[0], x.shape[1], dt, _stream()))
+            return out
+        return forward
+
+    @staticmethod
+    def _backward(sum, mul):
+        fn = getattr(lib, "ultra_rspmm_%s_%s_backward_cuda" % (sum, mul))
+
+        def backward(edge_index, edge_type, edge_weight, relation, input, output, output_grad):
+            _check_args(edge_index, edge_type, edge_weight, relation, input)
+            dt = _dtype_code(edge_weight, relation, input, output, output_grad)
+            ei, et, ew = edge_index.contiguous(), edge_type.contiguous(), edge_weight.contiguous()
+            rel, x = relation.contiguous(), input.contiguous()
+            o, og = output.contiguous(), output_grad.contiguous()
+            wg, rg, xg = torch.zeros_like(ew), torch.zeros_like(rel), torch.zeros_like(x)
+            check(fn(ei.data_ptr(), et.data_ptr(), ew.data_ptr(), rel.data_ptr(), x.data_ptr(), o.data_ptr(),
+                     og.data_ptr(), wg.data_ptr(), rg.data_ptr(), xg.data_ptr(), ei.shape[1], x.shape[0],
+                     rel.shape[0], x.shape[1], dt, _stream()))
+            return wg, rg, xg
+        return backward
+
+
+rspmm = _ReferenceExports()
