@@ -1,0 +1,248 @@
+"""Parity tests proper: HIP kernels (through the C ABI) vs the oracle on the same seeded inputs."""
+import itertools
+
+import pytest
+import torch
+
+from oracle import rspmm_oracle
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+SUMS = ["add", "min", "max"]
+MULS = ["mul", "add"]
+CASES = [
+    dict(num_node=50, num_edge=400, num_relation=5, seed=0),
+    dict(num_node=64, num_edge=300, num_relation=3, seed=1, hub=(7, 700)),
+    dict(num_node=40, num_edge=100, num_relation=4, seed=2, empty_rows=10),
+    dict(num_node=30, num_edge=200, num_relation=1, seed=3, duplicates=50),
+    dict(num_node=5, num_edge=0, num_relation=2, seed=4),
+    dict(num_node=1, num_edge=17, num_relation=2, seed=5),
+    dict(num_node=700, num_edge=9000, num_relation=600, seed=6, hub=(3, 1500)),   # relation slice > x slice
+]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _reset():
+    from ultra_amd import rspmm
+    rspmm.set_tuning()
+    rspmm.set_plan_defaults()
+    yield
+    rspmm.set_tuning()
+    rspmm.set_plan_defaults()
+
+
+def _check(got, want, sum, ei, et, w, rel, x, mul, boundary=None):
+    if sum == "add":
+        helpers.assert_sum_close(got, want, ei, et, w, rel, x, mul=mul, boundary=boundary)
+    else:
+        assert torch.equal(got, want), "min/max must be bit exact (max |d| = %g)" % (got - want).abs().max().item()
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("sum,mul", list(itertools.product(SUMS, MULS)))
+@pytest.mark.parametrize("dtype,dim", [(torch.float32, 64), (torch.float32, 200), (torch.float32, 30), (torch.float64, 72)])
+def test_forward_matches_oracle(dev, case, sum, mul, dtype, dim):
+    from ultra_amd.rspmm import generalized_rspmm
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    rel, x, w = helpers.features(N, R, dim, E, dtype=dtype, seed=case["seed"])
+    want = rspmm_oracle.generalized_rspmm(ei, et, w, rel, x, sum=sum, mul=mul)
+    got = generalized_rspmm(ei.to(dev), et.to(dev), w.to(dev), rel.to(dev), x.to(dev), sum=sum, mul=mul).cpu()
+    _check(got, want, sum, ei, et, w, rel, x, mul)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("mul", MULS)
+def test_exact_order_plan_is_bit_exact(dev, case, mul):
+    """Sequential walk in (row, col) order with separately rounded products == the oracle's loop."""
+    from ultra_amd.rspmm import Plan
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    rel, x, w = helpers.features(N, R, 64, E, seed=case["seed"])
+    want = rspmm_oracle.generalized_rspmm(ei, et, w, rel, x, sum="add", mul=mul)
+    plan = Plan(ei, et, N, R, exact_order=True)
+    got = plan.forward(rel.to(dev), x.to(dev), edge_weight=w.to(dev), sum="add", mul=mul).cpu()
+    assert torch.equal(got, want)
+    got1 = plan.forward(rel.to(dev), x.to(dev), edge_weight=None, sum="add", mul=mul).cpu()
+    want1 = rspmm_oracle.generalized_rspmm(ei, et, torch.ones(E), rel, x, sum="add", mul=mul)
+    assert torch.equal(got1, want1)
+
+
+@pytest.mark.parametrize("case", CASES[:4])
+@pytest.mark.parametrize("opts", [dict(), dict(seg_len=16, g_max=4), dict(seg_len=64, g_max=64)])
+def test_fast_order_matches_host_emulation_bitwise(dev, case, opts):
+    """The kernel's grouping / reduction order is fully specified by the plan: a numpy walk of the
+    exported plan reproduces the GPU result bit for bit (determinism, no atomics)."""
+    from ultra_amd.rspmm import Plan
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    rel, x, w = helpers.features(N, R, 64, E, seed=case["seed"])
+    plan = Plan(ei, et, N, R, **opts)
+    emu = helpers.emulate_plan_forward(plan, rel, x, edge_weight=w, sum="add", mul="mul")
+    got = plan.forward(rel.to(dev), x.to(dev), edge_weight=w.to(dev), sum="add", mul="mul").cpu()
+    assert torch.equal(got, emu)
+    again = plan.forward(rel.to(dev), x.to(dev), edge_weight=w.to(dev), sum="add", mul="mul").cpu()
+    assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[6]])
+@pytest.mark.parametrize("sum", SUMS)
+def test_variants_agree(dev, case, sum):
+    """LDS-staged and L2-read variants, workgroup sizes and grids compute the same thing."""
+    from ultra_amd import rspmm
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    rel, x, w = helpers.features(N, R, 128, E, seed=case["seed"])
+    plan = rspmm.Plan(ei, et, N, R, seg_len=32, g_max=8)
+    args = (rel.to(dev), x.to(dev))
+    base = plan.forward(*args, edge_weight=w.to(dev), sum=sum).cpu()
+    for kw in (dict(rel_lds=0, x_lds=0), dict(x_lds=0), dict(threads=256), dict(threads=512, grid=7),
+               dict(grid=1), dict(grid=1000)):
+        rspmm.set_tuning(**kw)
+        got = plan.forward(*args, edge_weight=w.to(dev), sum=sum).cpu()
+        assert torch.equal(got, base), kw
+    rspmm.set_tuning()
+
+
+@pytest.mark.parametrize("sum", SUMS)
+@pytest.mark.parametrize("layout", ["node_major", "batch_major", "shared_relation"])
+def test_layouts_and_fused_boundary(dev, sum, layout):
+    """Batch-major (batch, N, d) operands and the fused boundary epilogue (layers.py:199-207)."""
+    from ultra_amd.rspmm import Plan
+    case = CASES[1]
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    bs, d = 3, 64
+    rel, x, w = helpers.features(N, R, bs * d, E, seed=11)
+    g = torch.Generator().manual_seed(12)
+    bnd = torch.randn(N, bs * d, generator=g)
+    if layout == "shared_relation":   # RelNBFNet: relation.weight.expand(bs, -1, -1) (layers.py:76)
+        rel = rel[:, :d].repeat(1, bs)
+    want = rspmm_oracle.generalized_rspmm(ei, et, w, rel, x, sum=sum, mul="mul")
+    want = want + bnd if sum == "add" else (torch.max(want, bnd) if sum == "max" else torch.min(want, bnd))
+    plan = Plan(ei, et, N, R)
+    if layout == "node_major":
+        got = plan.forward(rel.to(dev), x.to(dev), edge_weight=w.to(dev), boundary=bnd.to(dev), sum=sum).cpu()
+    else:
+        to_b = lambda t: t.view(t.shape[0], bs, d).transpose(0, 1).contiguous().to(dev)   # (bs, rows, d)
+        relb = to_b(rel)
+        if layout == "shared_relation":
+            relb = relb[0].unsqueeze(0).expand(bs, -1, -1)     # stride_outer == 0, never materialised
+        got = plan.forward(relb, to_b(x), edge_weight=w.to(dev), boundary=to_b(bnd), sum=sum)
+        got = got.transpose(0, 1).reshape(N, bs * d).cpu()
+    _check(got, want, sum, ei, et, w, rel, x, "mul", boundary=bnd)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[6]])
+@pytest.mark.parametrize("sum,mul", list(itertools.product(SUMS, MULS)))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_backward_matches_oracle(dev, case, sum, mul, dtype):
+    from ultra_amd.rspmm import generalized_rspmm
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    dim = 64
+    rel, x, w = helpers.features(N, R, dim, E, dtype=dtype, seed=case["seed"])
+    g = torch.Generator().manual_seed(5)
+    og = torch.randn(N, dim, generator=g, dtype=torch.float64).to(dtype)
+    sei, set_, sw, order = rspmm_oracle.sort_edges(ei, et, w)
+    out = rspmm_oracle.rspmm_forward(sei, set_, sw, rel, x, sum=sum, mul=mul)
+    wg_s, rg, xg = rspmm_oracle.rspmm_backward(sei, set_, sw, rel, x, out, og, sum=sum, mul=mul)
+    wg = torch.empty_like(wg_s)
+    wg[order] = wg_s
+    dw, drel, dx = (t.to(dev).requires_grad_() for t in (w, rel, x))
+    res = generalized_rspmm(ei.to(dev), et.to(dev), dw, drel, dx, sum=sum, mul=mul)
+    res.backward(og.to(dev))
+    tol = dict(rtol=3e-4, atol=3e-4) if dtype == torch.float32 else dict(rtol=1e-10, atol=1e-10)
+    if sum != "add" and dtype == torch.float32:
+        # ties are decided on the forward values: compare against the oracle's own forward
+        assert torch.equal(res.detach().cpu(), out)
+    torch.testing.assert_close(dx.grad.cpu(), xg, **tol)
+    torch.testing.assert_close(drel.grad.cpu(), rg, **tol)
+    torch.testing.assert_close(dw.grad.cpu(), wg, **tol)
+
+
+def test_function_classes_and_reference_exports(dev):
+    """RSPMM*Function need sorted edges (rspmm.py:18); the `rspmm` namespace mirrors rspmm.cpp:270-282."""
+    from ultra_amd import rspmm as R_
+    case = CASES[0]
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    rel, x, w = helpers.features(N, R, 64, E)
+    sei, set_, sw, _ = rspmm_oracle.sort_edges(ei, et, w)
+    want = rspmm_oracle.rspmm_forward(sei, set_, sw, rel, x, sum="add", mul="mul")
+    d = lambda t: t.to(dev)
+    got = R_.RSPMMAddMulFunction.apply(d(sei), d(set_), d(sw), d(rel), d(x)).cpu()
+    helpers.assert_sum_close(got, want, sei, set_, sw, rel, x)
+    with pytest.raises(AssertionError, match="Expect sorted"):
+        R_.RSPMMAddMulFunction.apply(d(ei), d(et), d(w), d(rel), d(x))
+    got2 = R_.rspmm.rspmm_add_mul_forward_cuda(d(sei), d(set_), d(sw), d(rel), d(x)).cpu()
+    helpers.assert_sum_close(got2, want, sei, set_, sw, rel, x)
+    with pytest.raises(AssertionError, match="Expect sorted"):
+        R_.rspmm.rspmm_add_mul_forward_cuda(d(ei), d(et), d(w), d(rel), d(x))
+    out = rspmm_oracle.rspmm_forward(sei, set_, sw, rel, x, sum="max", mul="add")
+    og = torch.ones_like(out)
+    wg, rg, xg = rspmm_oracle.rspmm_backward(sei, set_, sw, rel, x, out, og, sum="max", mul="add")
+    gwg, grg, gxg = R_.rspmm.rspmm_max_add_backward_cuda(d(sei), d(set_), d(sw), d(rel), d(x), d(out), d(og))
+    torch.testing.assert_close(gxg.cpu(), xg, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(grg.cpu(), rg, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gwg.cpu(), wg, rtol=1e-4, atol=1e-4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        R_.rspmm.rspmm_add_mul_forward_cpu(sei, set_, sw, rel, x)
+
+
+def test_error_behaviour(dev):
+    from ultra_amd.rspmm import generalized_rspmm
+    ei, et = helpers.random_graph(10, 30, 3)
+    rel, x, w = helpers.features(10, 3, 64, 30)
+    d = lambda t: t.to(dev)
+    with pytest.raises(ValueError, match="No generalized rspmm implementation"):
+        generalized_rspmm(d(ei), d(et), d(w), d(rel), d(x), sum="mean")
+    with pytest.raises(RuntimeError):
+        generalized_rspmm(d(ei), d(et), d(w), d(rel[:, :32]), d(x))            # relation.size(1) != input.size(1)
+    with pytest.raises(RuntimeError):
+        generalized_rspmm(d(ei), d(et), d(w).double(), d(rel), d(x))           # checkAllSameType
+    with pytest.raises(RuntimeError):
+        generalized_rspmm(d(ei), d(et[:-1]), d(w), d(rel), d(x))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        generalized_rspmm(ei, et, w, rel, x)                                   # no silent CPU fallback
+
+
+def test_full_size_properties(dev):
+    """FB15k237-shaped synthetic graph at the benchmark width (D = 8 * 64): too big for the scalar
+    oracle to be quick, so use size-independent properties + an independent torch fp32 restatement."""
+    from ultra_amd import synthetic
+    from ultra_amd.rspmm import Plan
+    data = synthetic.make_kg(**synthetic.SHAPES["fb15k237"], seed=1234, relation_graph=False)
+    ei, et = data.edge_index.to(dev), data.edge_type.to(dev)
+    N, R, D = data.num_nodes, data.num_relations, 512
+    g = torch.Generator().manual_seed(3)
+    x1 = torch.randn(N, D, generator=g).to(dev)
+    x2 = torch.randn(N, D, generator=g).to(dev)
+    rel = torch.randn(R, D, generator=g).to(dev)
+    plan = Plan(data.edge_index, data.edge_type, N, R)
+    y1 = plan.forward(rel, x1)
+    y2 = plan.forward(rel, x2)
+    y12 = plan.forward(rel, x1 + x2)
+    scale = plan.forward(rel.abs(), x1.abs() + x2.abs())
+    assert ((y12 - (y1 + y2)).abs() <= 1e-5 * scale + 1e-6).all(), "linearity in the input"
+    # independent restatement with torch index ops (fp32): out.index_add_(0, row, rel[type] * x[col])
+    ref = torch.zeros_like(y1).index_add_(0, ei[0], rel[et] * x1[ei[1]])
+    assert ((y1 - ref).abs() <= 1e-5 * scale + 1e-6).all()
+    # max: idempotent under edge duplication, and equals torch's scatter amax
+    ymax = plan.forward(rel, x1, sum="max")
+    ref_max = torch.full_like(y1, torch.finfo(torch.float32).min).scatter_reduce_(
+        0, ei[0].unsqueeze(-1).expand(-1, D), rel[et] * x1[ei[1]], reduce="amax", include_self=True)
+    assert torch.equal(ymax, ref_max)
+    plan2 = Plan(torch.cat([data.edge_index, data.edge_index], 1), torch.cat([data.edge_type, data.edge_type]), N, R)
+    assert torch.equal(plan2.forward(rel, x1, sum="max"), ymax)
+    # checksum of checksums: column sums of the output == sum over edges of the messages
+    lhs = y1.double().sum(0)
+    rhs = (rel[et].double() * x1[ei[1]].double()).sum(0)
+    assert ((lhs - rhs).abs() <= 1e-6 * (rel[et].double() * x1[ei[1]].double()).abs().sum(0)).all()

@@ -87,13 +87,13 @@ class Plan(object):
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:   # (module globals are gone at interpreter shutdown)
             try:
                 if torch.cuda.is_available():
                     torch.cuda.synchronize()
+                lib.ultra_plan_destroy(h)
             except Exception:
                 pass
-            lib.ultra_plan_destroy(h)
             self._h = None
 
     def info(self):
@@ -355,3 +355,9 @@ class _ReferenceExports(object):
 
 
 rspmm = _ReferenceExports()
+
+
+def set_tuning(threads=0, grid=0, rel_lds=-1, x_lds=-1, unroll=0):
+    """Kernel-launch tuning knobs (measurement / tests).  set_tuning() restores the defaults."""
+    t = _lib.Tuning(int(threads), int(grid), int(rel_lds), int(x_lds), int(unroll), (ctypes.c_int32 * 3)(0, 0, 0))
+    check(lib.ultra_set_tuning(ctypes.byref(t)))

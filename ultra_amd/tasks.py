@@ -1,0 +1,142 @@
+"""Evaluation / sampling glue around the hot path (the reference's ultra/tasks.py), pure torch on
+whatever device the graph lives on.  Same names, arguments and results as the reference:
+
+  edge_match             tasks.py:7-39     all graph edges matching each query key, via mixed-radix keys + searchsorted
+  negative_sampling      tasks.py:42-76
+  all_negative           tasks.py:79-91    (bs, 3) positives -> (bs, N, 3) tail- and head-candidate batches
+  strict_negative_mask   tasks.py:94-130   filtered-ranking masks
+  compute_ranking        tasks.py:133-141  rank = #(masked candidates scoring >= positive) + 1
+  build_relation_graph   tasks.py:144-199  relation-relation graph with the 4 fundamental interactions
+"""
+import torch
+
+from .data import Data
+
+
+def _mixed_radix_scale(edge_index):
+    # one radix per row: (max + 1); key = sum_i index[i] * prod_{j>i} radix[j]
+    radix = edge_index.max(dim=1)[0] + 1
+    total = 1
+    for r in radix.tolist():
+        total *= int(r)
+    assert total < torch.iinfo(torch.long).max, "edge key overflows int64"
+    scale = torch.ones_like(radix)
+    for i in range(len(radix) - 2, -1, -1):
+        scale[i] = scale[i + 1] * radix[i + 1]
+    return scale
+
+
+def edge_match(edge_index, query_index):
+    """For every query column, the ids of all graph edges with the same key.
+    Returns (edge ids concatenated query by query, matches per query)."""
+    scale = _mixed_radix_scale(edge_index).unsqueeze(-1)
+    edge_key, order = (edge_index * scale).sum(dim=0).sort()
+    query_key = (query_index * scale).sum(dim=0)
+    lo = torch.searchsorted(edge_key, query_key, right=False)
+    hi = torch.searchsorted(edge_key, query_key, right=True)
+    num_match = hi - lo
+    # ranges [lo, hi) flattened: position p of query q is lo[q] + (p - first position of q)
+    first = num_match.cumsum(0) - num_match
+    total = int(num_match.sum())
+    pos = torch.arange(total, device=edge_index.device)
+    pos = pos + (lo - first).repeat_interleave(num_match)
+    return order[pos], num_match
+
+
+def strict_negative_mask(data, batch):
+    """(t_mask, h_mask): True where a candidate entity is a valid negative (not a known true answer)."""
+    pos_h, pos_t, pos_r = batch.t()
+    masks = []
+    # tails of every (h, r) in the graph, then heads of every (t, r)
+    for known, anchor, answer_row, positive in ((0, pos_h, 1, pos_t), (1, pos_t, 0, pos_h)):
+        keyed = torch.stack([data.edge_index[known], data.edge_type])
+        query = torch.stack([anchor, pos_r])
+        edge_id, count = edge_match(keyed, query)
+        truth = data.edge_index[answer_row, edge_id]
+        sample = torch.arange(len(count), device=batch.device).repeat_interleave(count)
+        mask = torch.ones(len(count), data.num_nodes, dtype=torch.bool, device=batch.device)
+        mask[sample, truth] = False
+        mask.scatter_(1, positive.unsqueeze(-1), False)
+        masks.append(mask)
+    return masks[0], masks[1]
+
+
+def negative_sampling(data, batch, num_negative, strict=True):
+    batch_size = len(batch)
+    pos_h, pos_t, pos_r = batch.t()
+    half = batch_size // 2
+    if strict:
+        t_mask, h_mask = strict_negative_mask(data, batch)
+
+        def draw(mask):
+            candidate = mask.nonzero()[:, 1]
+            count = mask.sum(dim=-1)
+            rand = torch.rand(len(mask), num_negative, device=batch.device)
+            index = (rand * count.unsqueeze(-1)).long() + (count.cumsum(0) - count).unsqueeze(-1)
+            return candidate[index]
+
+        neg_t = draw(t_mask[:half])
+        neg_h = draw(h_mask[half:])
+    else:
+        neg = torch.randint(data.num_nodes, (batch_size, num_negative), device=batch.device)
+        neg_t, neg_h = neg[:half], neg[half:]
+    h_index = pos_h.unsqueeze(-1).repeat(1, num_negative + 1)
+    t_index = pos_t.unsqueeze(-1).repeat(1, num_negative + 1)
+    r_index = pos_r.unsqueeze(-1).repeat(1, num_negative + 1)
+    t_index[:half, 1:] = neg_t
+    h_index[half:, 1:] = neg_h
+    return torch.stack([h_index, t_index, r_index], dim=-1)
+
+
+def all_negative(data, batch):
+    pos_h, pos_t, pos_r = batch.t()
+    n = data.num_nodes
+    every = torch.arange(n, device=batch.device).unsqueeze(0).expand(len(batch), -1)
+    r = pos_r.unsqueeze(-1).expand(-1, n)
+    t_batch = torch.stack([pos_h.unsqueeze(-1).expand(-1, n), every, r], dim=-1)
+    h_batch = torch.stack([every, pos_t.unsqueeze(-1).expand(-1, n), r], dim=-1)
+    return t_batch, h_batch
+
+
+def compute_ranking(pred, target, mask=None):
+    pos_pred = pred.gather(-1, target.unsqueeze(-1))
+    worse_or_equal = pos_pred <= pred      # ties count against the positive (tasks.py:137)
+    if mask is not None:
+        worse_or_equal = worse_or_equal & mask
+    return worse_or_equal.sum(dim=-1) + 1
+
+
+def build_relation_graph(graph, node_chunk=1 << 16):
+    """Relation graph of a KG that already contains inverse edges: nodes are relation ids, an edge
+    (r1, r2) of type hh / tt / ht / th exists iff some entity is a head (h) or tail (t) of r1 and of
+    r2 respectively.  The reference forms four sparse products E^T E (tasks.py:152-189) and keeps
+    only their sparsity pattern; here the pattern is accumulated from dense per-chunk incidence
+    GEMMs.  Edge order matches the reference: hh, tt, ht, th blocks, each row-major sorted."""
+    edge_index, edge_type = graph.edge_index, graph.edge_type
+    num_nodes, num_rels = graph.num_nodes, graph.num_relations
+    device = edge_index.device
+    counts = [torch.zeros(num_rels, num_rels, device=device) for _ in range(4)]
+    key_h = torch.unique(edge_index[0] * num_rels + edge_type)
+    key_t = torch.unique(edge_index[1] * num_rels + edge_type)
+    for lo in range(0, num_nodes, node_chunk):
+        hi = min(num_nodes, lo + node_chunk)
+        inc = []
+        for key in (key_h, key_t):
+            sel = key[(key >= lo * num_rels) & (key < hi * num_rels)] - lo * num_rels
+            m = torch.zeros((hi - lo) * num_rels, device=device)
+            m[sel] = 1.0
+            inc.append(m.view(hi - lo, num_rels))
+        bh, bt = inc
+        counts[0] += bh.t() @ bh
+        counts[1] += bt.t() @ bt
+        counts[2] += bh.t() @ bt
+        counts[3] += bt.t() @ bh
+    blocks, types = [], []
+    for k, c in enumerate(counts):
+        idx = (c > 0).nonzero().t()
+        blocks.append(idx)
+        types.append(torch.full((idx.shape[1],), k, dtype=torch.long, device=device))
+    rel_graph = Data(edge_index=torch.cat(blocks, dim=1), edge_type=torch.cat(types), num_nodes=num_rels,
+                     num_relations=4)
+    graph.relation_graph = rel_graph
+    return graph
