@@ -1,0 +1,97 @@
+"""Generate the committed golden vectors by RUNNING THE REFERENCE in this container.
+
+    python tests/golden/gen_golden.py
+
+Needs /root/reference (so it only runs in the build container, never on the GPU box).  The unchanged
+reference modules (ultra.rspmm, ultra.layers, ultra.models, ultra.tasks) are imported under the
+test-only torch_geometric / torch_scatter shim in tests/golden/pyg_shim/ and executed on CPU with
+the shipped checkpoints.  Outputs (small, committed):
+
+  rspmm_<sum>_<mul>.pt      inputs, output and gradients of the reference generalized_rspmm (rspmm.py:168)
+  ultra_3g_model.pt         ckpts/ultra_3g.pth["model"]  (the state dict only, 168,705 fp32 values)
+  ultra_50g_model.pt        ckpts/ultra_50g.pth["model"]
+  model_<ckpt>_<aggr>.pt    a seeded small KG, its reference relation graph, all-negative batches, reference
+                            scores for tail and head batches, filter masks and rankings
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+os.environ.setdefault("TORCH_EXTENSIONS_DIR", "/tmp/torch_ext_ref")
+sys.path.insert(0, os.path.join(HERE, "pyg_shim"))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def gen_rspmm():
+    from ultra.rspmm import generalized_rspmm  # JIT-builds the reference rspmm.cpp (CPU only here)
+    from tests import helpers
+    for sum in ("add", "min", "max"):
+        for mul in ("mul", "add"):
+            ei, et = helpers.random_graph(num_node=48, num_edge=300, num_relation=5, seed=17, hub=(3, 90),
+                                          empty_rows=4, duplicates=20)
+            rel, x, w = helpers.features(48, 5, 40, ei.shape[1], seed=18)
+            g = torch.Generator().manual_seed(19)
+            og = torch.randn(48, 40, generator=g)
+            w_, rel_, x_ = (t.clone().requires_grad_() for t in (w, rel, x))
+            out = generalized_rspmm(ei, et, w_, rel_, x_, sum=sum, mul=mul)
+            out.backward(og)
+            torch.save(dict(sum=sum, mul=mul, edge_index=ei, edge_type=et, edge_weight=w, relation=rel, input=x,
+                            output=out.detach(), output_grad=og, weight_grad=w_.grad, relation_grad=rel_.grad,
+                            input_grad=x_.grad),
+                       os.path.join(HERE, "rspmm_%s_%s.pt" % (sum, mul)))
+            print("rspmm", sum, mul, "ok")
+
+
+def gen_models():
+    from torch_geometric.data import Data
+    from ultra import tasks as ref_tasks
+    from ultra.models import Ultra
+    from ultra_amd import synthetic
+
+    for ckpt_name, aggr in (("ultra_3g", "sum"), ("ultra_50g", "max")):
+        ckpt = torch.load(os.path.join(REF, "ckpts", ckpt_name + ".pth"), map_location="cpu")
+        state = {k: v.clone() for k, v in ckpt["model"].items()}
+        torch.save(state, os.path.join(HERE, ckpt_name + "_model.pt"))
+
+        kg = synthetic.make_kg(num_node=200, num_triple=1500, num_relation_base=6, num_test=16, seed=7,
+                               relation_graph=False)
+        data = Data(edge_index=kg.edge_index, edge_type=kg.edge_type, num_nodes=kg.num_nodes,
+                    num_relations=kg.num_relations, target_edge_index=kg.target_edge_index,
+                    target_edge_type=kg.target_edge_type)
+        data = ref_tasks.build_relation_graph(data)
+        cfg = synthetic.default_model_cfg(aggregate_func=aggr)
+        model = Ultra(rel_model_cfg=dict(cfg["rel_model_cfg"]), entity_model_cfg=dict(cfg["entity_model_cfg"]))
+        model.load_state_dict(state)
+        model.eval()
+        batch = kg.target_triples[:4]
+        with torch.no_grad():
+            t_batch, h_batch = ref_tasks.all_negative(data, batch)
+            t_pred = model(data, t_batch)
+            h_pred = model(data, h_batch)
+            t_mask, h_mask = ref_tasks.strict_negative_mask(data, batch)
+            pos_h, pos_t, pos_r = batch.t()
+            t_rank = ref_tasks.compute_ranking(t_pred, pos_t, t_mask)
+            h_rank = ref_tasks.compute_ranking(h_pred, pos_h, h_mask)
+            # a (bs, 1 + num_neg, 3) training-style batch through the same forward
+            neg_batch = ref_tasks.negative_sampling(data, batch, 8, strict=True)
+            neg_pred = model(data, neg_batch)
+        torch.save(dict(ckpt=ckpt_name, aggregate_func=aggr,
+                        edge_index=data.edge_index, edge_type=data.edge_type, num_nodes=data.num_nodes,
+                        num_relations=data.num_relations,
+                        rel_edge_index=data.relation_graph.edge_index, rel_edge_type=data.relation_graph.edge_type,
+                        batch=batch, t_batch=t_batch, h_batch=h_batch, t_pred=t_pred, h_pred=h_pred,
+                        t_mask=t_mask, h_mask=h_mask, t_rank=t_rank, h_rank=h_rank,
+                        neg_batch=neg_batch, neg_pred=neg_pred),
+                   os.path.join(HERE, "model_%s_%s.pt" % (ckpt_name, aggr)))
+        print("model", ckpt_name, aggr, "scores", tuple(t_pred.shape), "ranks", t_rank.tolist(), h_rank.tolist())
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "golden generation needs the reference checkout at /root/reference"
+    gen_rspmm()
+    gen_models()

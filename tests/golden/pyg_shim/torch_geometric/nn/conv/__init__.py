@@ -11,6 +11,8 @@ class _Inspector(object):
 
     def collect_param_data(self, name, data):
         params = list(inspect.signature(getattr(self.module, name)).parameters)
+        if name in ("aggregate", "update", "message_and_aggregate"):
+            params = params[1:]   # PyG inspects these with exclude=[0]: the first argument is passed positionally
         return {k: data[k] for k in params if k in data}
 
     distribute = collect_param_data
@@ -47,9 +49,5 @@ class MessagePassing(torch.nn.Module):
         size = self._check_input(edge_index, size)
         coll = self._collect(None, edge_index, size, kwargs)
         msg = self.message(**self.inspector.collect_param_data("message", coll))
-        aggr_kwargs = self.inspector.collect_param_data("aggregate", coll)
-        aggr_kwargs.pop("input", None)
-        out = self.aggregate(msg, **aggr_kwargs)
-        upd_kwargs = self.inspector.collect_param_data("update", coll)
-        upd_kwargs.pop("update", None)
-        return self.update(out, **upd_kwargs)
+        out = self.aggregate(msg, **self.inspector.collect_param_data("aggregate", coll))
+        return self.update(out, **self.inspector.collect_param_data("update", coll))

@@ -1,0 +1,135 @@
+"""Model-level parity on the GPU: Ultra.forward through the HIP engine vs (a) golden scores recorded
+from the reference and (b) the CPU oracle model on a larger seeded graph.  Tolerance: fp32 scores
+within 1e-4 (BASELINE north_star), rankings / metrics identical."""
+import pytest
+import torch
+
+from oracle import ultra_oracle_model
+from tests.test_oracle_model import MODELS, load_golden
+from ultra_amd import models, synthetic, tasks
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def build(state, cfg, dev):
+    model = models.Ultra(**cfg)
+    model.load_state_dict(state)
+    return model.to(dev).eval()
+
+
+@pytest.mark.parametrize("ckpt,aggr", MODELS)
+def test_scores_match_reference_golden(dev, ckpt, aggr):
+    g, state, data, cfg = load_golden(ckpt, aggr)
+    model = build(state, cfg, dev)
+    gdata = data.to(dev)
+    batch = g["batch"].to(dev)
+    pos_h, pos_t, _ = batch.t()
+    with torch.no_grad():
+        t_pred = model(gdata, g["t_batch"].to(dev))
+        h_pred = model(gdata, g["h_batch"].to(dev))
+        neg_pred = model(gdata, g["neg_batch"].to(dev))
+        t_mask, h_mask = tasks.strict_negative_mask(gdata, batch)
+        t_rank = tasks.compute_ranking(t_pred, pos_t, t_mask)
+        h_rank = tasks.compute_ranking(h_pred, pos_h, h_mask)
+    for got, want in ((t_pred, g["t_pred"]), (h_pred, g["h_pred"]), (neg_pred, g["neg_pred"])):
+        err = (got.cpu() - want).abs().max().item()
+        assert err <= TOL, "max |gpu - reference| = %g" % err
+    assert torch.equal(t_rank.cpu(), g["t_rank"]) and torch.equal(h_rank.cpu(), g["h_rank"])
+
+
+@pytest.mark.parametrize("ckpt,aggr", MODELS)
+def test_scores_and_rankings_match_oracle_on_larger_graph(dev, ckpt, aggr):
+    _, state, _, cfg = load_golden(ckpt, aggr)
+    data = synthetic.make_kg(num_node=3000, num_triple=24000, num_relation_base=20, num_test=64, seed=11)
+    batch = data.target_triples[:8]
+    t_batch, h_batch = tasks.all_negative(data, batch)
+    fn = ultra_oracle_model.reference_rspmm_fn()
+    want_t = ultra_oracle_model.ultra_forward(state, cfg, data, t_batch, rspmm_fn=fn)
+    want_h = ultra_oracle_model.ultra_forward(state, cfg, data, h_batch, rspmm_fn=fn)
+    model = build(state, cfg, dev)
+    gdata = data.to(dev)
+    with torch.no_grad():
+        got_t = model(gdata, t_batch.to(dev)).cpu()
+        got_h = model(gdata, h_batch.to(dev)).cpu()
+    assert (got_t - want_t).abs().max().item() <= TOL
+    assert (got_h - want_h).abs().max().item() <= TOL
+    t_mask, h_mask = tasks.strict_negative_mask(data, batch)
+    pos_h, pos_t, _ = batch.t()
+    for got, want, pos, mask in ((got_t, want_t, pos_t, t_mask), (got_h, want_h, pos_h, h_mask)):
+        r_got = tasks.compute_ranking(got, pos, mask)
+        r_want = tasks.compute_ranking(want, pos, mask)
+        assert torch.equal(r_got, r_want), "rank mismatches: %d" % (r_got != r_want).sum().item()
+
+
+def test_mean_and_transe_paths_run_and_match_oracle(dev):
+    _, state, _, _ = load_golden("ultra_3g", "sum")
+    data = synthetic.make_kg(num_node=400, num_triple=3000, num_relation_base=5, num_test=16, seed=2)
+    batch = data.target_triples[:3]
+    t_batch, _ = tasks.all_negative(data, batch)
+    for aggr, msg in (("mean", "distmult"), ("sum", "transe"), ("max", "transe")):
+        cfg = synthetic.default_model_cfg(aggregate_func=aggr, message_func=msg)
+        want = ultra_oracle_model.ultra_forward(state, cfg, data, t_batch)
+        model = build(state, cfg, dev)
+        with torch.no_grad():
+            got = model(data.to(dev), t_batch.to(dev)).cpu()
+        assert (got - want).abs().max().item() <= TOL, (aggr, msg)
+
+
+def test_training_step_gradients_match_cpu_autograd(dev):
+    """fwd + bwd through the HIP autograd path vs torch autograd over the oracle model with a
+    differentiable index_add restatement of rspmm (CPU, fp32)."""
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    data = synthetic.make_kg(num_node=300, num_triple=2400, num_relation_base=5, num_test=16, seed=4)
+    batch = data.target_triples[:4]
+    torch.manual_seed(0)
+    neg = tasks.negative_sampling(data, batch, 8, strict=True)
+
+    def torch_rspmm(edge_index, edge_type, edge_weight, relation, input, sum="add", mul="mul"):
+        msg = relation[edge_type] * input[edge_index[1]] if mul == "mul" else relation[edge_type] + input[edge_index[1]]
+        return torch.zeros_like(input).index_add(0, edge_index[0], msg * edge_weight.unsqueeze(-1))
+
+    sd = {k: v.clone().requires_grad_() for k, v in state.items()}
+    with torch.enable_grad():
+        rel = ultra_oracle_model.rel_nbfnet(sd, data.relation_graph, neg[:, 0, 2], cfg["rel_model_cfg"], torch_rspmm)
+        want = ultra_oracle_model.entity_nbfnet(sd, data, rel, neg, cfg["entity_model_cfg"], torch_rspmm)
+        target = torch.zeros_like(want)
+        target[:, 0] = 1
+        loss_want = torch.nn.functional.binary_cross_entropy_with_logits(want, target)
+        loss_want.backward()
+
+    model = models.Ultra(**cfg)
+    model.load_state_dict(state)
+    model = model.to(dev).eval()     # eval: keep the edge set fixed (remove_easy_edges is training-only)
+    got = model(data.to(dev), neg.to(dev))
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(got, target.to(dev))
+    loss.backward()
+    assert abs(loss.item() - loss_want.item()) <= 1e-5
+    for name, p in model.named_parameters():
+        want_g = sd[name].grad
+        assert p.grad is not None, name
+        scale = max(want_g.abs().max().item(), 1e-6)
+        err = (p.grad.cpu() - want_g).abs().max().item()
+        assert err <= 2e-4 * scale + 1e-6, "%s: grad err %g (scale %g)" % (name, err, scale)
+
+
+def test_training_mode_removes_easy_edges(dev):
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    data = synthetic.make_kg(num_node=200, num_triple=1500, num_relation_base=4, num_test=16, seed=6)
+    # use graph edges as the batch so that remove_easy_edges has something to remove
+    batch = torch.stack([data.edge_index[0, :4], data.edge_index[1, :4], data.edge_type[:4]], dim=-1)
+    torch.manual_seed(0)
+    neg = tasks.negative_sampling(data, batch, 4, strict=True)
+    model = build(state, cfg, dev).train()
+    out_train = model(data.to(dev), neg.to(dev))
+    model.eval()
+    with torch.no_grad():
+        out_eval = model(data.to(dev), neg.to(dev))
+    assert out_train.shape == out_eval.shape == (4, 5)
+    assert not torch.allclose(out_train.detach(), out_eval)      # the direct edges were dropped in training mode

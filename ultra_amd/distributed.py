@@ -1,0 +1,56 @@
+"""Query sharding over the GPUs of a node.
+
+Every query row (h, r, ?) is an independent Bellman-Ford propagation over a replicated graph, so the
+path shards by queries with no data-path collective inside the forward; the reference does the same
+with DistributedSampler (script/run.py:127) and then emulates an all-gather with six zero-padded
+all_reduce(SUM) calls (script/run.py:166-186).  Here: one all-gather (RCCL over xGMI on GPUs, gloo on
+CPU for the tests) of the per-rank score rows, or of the per-rank rankings.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def shard_range(num_items, rank_=None, world=None):
+    """Contiguous, balanced [lo, hi) share of `num_items` for a rank (no padding, no duplicates,
+    unlike DistributedSampler which repeats samples to equalise shard sizes)."""
+    world = world_size() if world is None else world
+    rank_ = rank() if rank_ is None else rank_
+    base, extra = divmod(num_items, world)
+    lo = rank_ * base + min(rank_, extra)
+    return lo, lo + base + (1 if rank_ < extra else 0)
+
+
+def all_gather_scores(score):
+    """(b, N) per-rank score rows -> (world * b, N), rank-major.  One collective."""
+    world = world_size()
+    if world == 1:
+        return score
+    score = score.contiguous()
+    out = torch.empty((world * score.shape[0],) + tuple(score.shape[1:]), dtype=score.dtype, device=score.device)
+    dist.all_gather_into_tensor(out, score)
+    return out
+
+
+def all_gather_variable(t):
+    """Concatenate 1-D tensors of different lengths from every rank (rank order).  Two collectives:
+    lengths, then padded payloads."""
+    world = world_size()
+    if world == 1:
+        return t
+    n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.long)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s) for s in sizes]
+    pad = torch.zeros(max(sizes), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)])

@@ -1,0 +1,218 @@
+"""GeneralizedRelationalConv -- the relational message-passing layer (reference: ultra/layers.py).
+
+Same constructor, forward signature, parameter names and numerics as the reference layer, without
+PyG: the fused path (layers.py:183-231) calls the HIP rspmm engine directly on the module-level
+batch-major layout (batch, N, dim), so the three `transpose(0, 1).flatten(1)` copies of the
+reference (layers.py:190-192) and the per-call edge sort disappear, and under no_grad the boundary
+epilogue (layers.py:199-207) is fused into the kernel.  The unfused message/aggregate path
+(layers.py:135-181; `rotate`, or differentiable edge weights) is kept as plain torch index ops.
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import rspmm
+
+
+def _scatter(src, index, dim_size, reduce):
+    # src (batch, M, d) scattered along dim 1 (what torch_scatter.scatter does at layers.py:165-179)
+    shape = (src.shape[0], dim_size, src.shape[2])
+    idx = index.view(1, -1, 1).expand_as(src)
+    if reduce in ("sum", "add"):
+        return torch.zeros(shape, dtype=src.dtype, device=src.device).scatter_add_(1, idx, src)
+    if reduce == "mean":
+        total = torch.zeros(shape, dtype=src.dtype, device=src.device).scatter_add_(1, idx, src)
+        count = torch.zeros(shape, dtype=src.dtype, device=src.device).scatter_add_(1, idx, torch.ones_like(src))
+        return total / count.clamp(min=1)
+    if reduce in ("max", "min"):
+        out = torch.zeros(shape, dtype=src.dtype, device=src.device)
+        return out.scatter_reduce(1, idx, src, reduce="amax" if reduce == "max" else "amin", include_self=False)
+    raise ValueError("Unknown aggregation function `%s`" % reduce)
+
+
+class GeneralizedRelationalConv(nn.Module):
+
+    eps = 1e-6
+
+    message2mul = {
+        "transe": "add",
+        "distmult": "mul",
+    }
+
+    def __init__(self, input_dim, output_dim, num_relation, query_input_dim, message_func="distmult",
+                 aggregate_func="pna", layer_norm=False, activation="relu", dependent=False, project_relations=False):
+        super(GeneralizedRelationalConv, self).__init__()
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        self.num_relation = num_relation
+        self.query_input_dim = query_input_dim
+        self.message_func = message_func
+        self.aggregate_func = aggregate_func
+        self.dependent = dependent
+        self.project_relations = project_relations
+        self.node_dim = -2
+
+        if layer_norm:
+            self.layer_norm = nn.LayerNorm(output_dim)
+        else:
+            self.layer_norm = None
+        if isinstance(activation, str):
+            self.activation = getattr(F, activation)
+        else:
+            self.activation = activation
+
+        if self.aggregate_func == "pna":
+            self.linear = nn.Linear(input_dim * 13, output_dim)
+        else:
+            self.linear = nn.Linear(input_dim * 2, output_dim)
+
+        if dependent:
+            self.relation_linear = nn.Linear(query_input_dim, num_relation * input_dim)
+        else:
+            if not self.project_relations:
+                self.relation = nn.Embedding(num_relation, input_dim)
+            else:
+                # set by EntityNBFNet.forward from the relation-graph pass (models.py:184-185)
+                self.relation = None
+                self.relation_projection = nn.Sequential(
+                    nn.Linear(input_dim, input_dim),
+                    nn.ReLU(),
+                    nn.Linear(input_dim, input_dim)
+                )
+
+    def forward(self, input, query, boundary, edge_index, edge_type, size, edge_weight=None):
+        batch_size = len(query)
+
+        if self.dependent:
+            relation = self.relation_linear(query).view(batch_size, self.num_relation, self.input_dim)
+        else:
+            if not self.project_relations:
+                relation = self.relation.weight.expand(batch_size, -1, -1)   # stride-0 view, never materialised
+            else:
+                relation = self.relation_projection(self.relation)
+        # edge_weight=None means "all ones" (what every caller on the fused path passes, models.py:143):
+        # the kernel then skips the weight stream instead of multiplying by 1.
+        return self.propagate(input=input, relation=relation, boundary=boundary, edge_index=edge_index,
+                              edge_type=edge_type, size=size, edge_weight=edge_weight)
+
+    def propagate(self, edge_index, size=None, **kwargs):
+        edge_weight = kwargs["edge_weight"]
+        if (edge_weight is not None and edge_weight.requires_grad) or self.message_func == "rotate":
+            # layers.py:91-94: the fused kernel covers TransE / DistMult with constant edge weights only
+            return self._propagate_unfused(edge_index, size, **kwargs)
+        num_node = size[0] if size is not None else kwargs["input"].shape[1]
+        out = self.message_and_aggregate(edge_index, kwargs["input"], kwargs["relation"], kwargs["boundary"],
+                                         kwargs["edge_type"], edge_weight, edge_index[1], num_node)
+        return self.update(out, kwargs["input"])
+
+    # ---- unfused path: PyG semantics (gather edge_index[0], scatter to edge_index[1]; layers.py:135-181) ----
+    def _propagate_unfused(self, edge_index, size, input, relation, boundary, edge_type, edge_weight):
+        dim_size = size[1] if size is not None else input.shape[1]
+        if edge_weight is None:
+            edge_weight = torch.ones(edge_index.shape[1], device=input.device, dtype=input.dtype)
+        input_j = input.index_select(self.node_dim, edge_index[0])
+        message = self.message(input_j, relation, boundary, edge_type)
+        out = self.aggregate(message, edge_weight, edge_index[1], dim_size)
+        return self.update(out, input)
+
+    def message(self, input_j, relation, boundary, edge_type):
+        relation_j = relation.index_select(self.node_dim, edge_type)
+
+        if self.message_func == "transe":
+            message = input_j + relation_j
+        elif self.message_func == "distmult":
+            message = input_j * relation_j
+        elif self.message_func == "rotate":
+            x_j_re, x_j_im = input_j.chunk(2, dim=-1)
+            r_j_re, r_j_im = relation_j.chunk(2, dim=-1)
+            message_re = x_j_re * r_j_re - x_j_im * r_j_im
+            message_im = x_j_re * r_j_im + x_j_im * r_j_re
+            message = torch.cat([message_re, message_im], dim=-1)
+        else:
+            raise ValueError("Unknown message function `%s`" % self.message_func)
+
+        # boundary condition as self-loop messages
+        return torch.cat([message, boundary], dim=self.node_dim)
+
+    def aggregate(self, input, edge_weight, index, dim_size):
+        index = torch.cat([index, torch.arange(dim_size, device=input.device)])
+        edge_weight = torch.cat([edge_weight, torch.ones(dim_size, device=input.device, dtype=edge_weight.dtype)])
+        edge_weight = edge_weight.view(1, -1, 1)
+
+        if self.aggregate_func == "pna":
+            mean = _scatter(input * edge_weight, index, dim_size, "mean")
+            sq_mean = _scatter(input ** 2 * edge_weight, index, dim_size, "mean")
+            max = _scatter(input * edge_weight, index, dim_size, "max")
+            min = _scatter(input * edge_weight, index, dim_size, "min")
+            std = (sq_mean - mean ** 2).clamp(min=self.eps).sqrt()
+            features = torch.cat([mean.unsqueeze(-1), max.unsqueeze(-1), min.unsqueeze(-1), std.unsqueeze(-1)], dim=-1)
+            features = features.flatten(-2)
+            degree_out = torch.bincount(index, minlength=dim_size).to(input.dtype).unsqueeze(0).unsqueeze(-1)
+            scale = degree_out.log()
+            scale = scale / scale.mean()
+            scales = torch.cat([torch.ones_like(scale), scale, 1 / scale.clamp(min=1e-2)], dim=-1)
+            output = (features.unsqueeze(-1) * scales.unsqueeze(-2)).flatten(-2)
+        else:
+            output = _scatter(input * edge_weight, index, dim_size, self.aggregate_func)
+        return output
+
+    # ---- fused path ----
+    def message_and_aggregate(self, edge_index, input, relation, boundary, edge_type, edge_weight, index, dim_size):
+        """(batch, N, d) in, (batch, N, d') out.  Aggregates into edge_index[0] from edge_index[1]
+        (the fused kernel's direction, rspmm.cpp:143-145) -- not the unfused path's direction."""
+        batch_size, num_node = input.shape[:2]
+        if self.message_func in self.message2mul:
+            mul = self.message2mul[self.message_func]
+        else:
+            raise ValueError("Unknown message function `%s`" % self.message_func)
+        plan = rspmm.get_plan(edge_index, edge_type, num_node, relation.shape[1])
+        if edge_weight is not None and not torch.is_floating_point(edge_weight):
+            edge_weight = edge_weight.to(input.dtype)
+        needs_grad = torch.is_grad_enabled() and (input.requires_grad or relation.requires_grad or
+                                                   boundary.requires_grad)
+
+        def agg(sum, rel=relation, x=input, fuse_boundary=None):
+            if needs_grad:
+                out = rspmm.plan_rspmm(plan, rel, x, edge_weight, sum=sum, mul=mul)
+                if fuse_boundary is None:
+                    return out
+                if sum == "add":
+                    return out + fuse_boundary
+                return torch.max(out, fuse_boundary) if sum == "max" else torch.min(out, fuse_boundary)
+            return plan.forward(rel, x, edge_weight=edge_weight, boundary=fuse_boundary, sum=sum, mul=mul)
+
+        if self.aggregate_func in ("mean", "pna"):
+            # layers.py:193 -- PyG's `index` is edge_index[1]
+            degree_out = (torch.bincount(index, minlength=dim_size).to(input.dtype) + 1).view(1, -1, 1)
+
+        if self.aggregate_func == "sum":
+            update = agg("add", fuse_boundary=boundary)
+        elif self.aggregate_func == "mean":
+            update = agg("add", fuse_boundary=boundary) / degree_out
+        elif self.aggregate_func == "max":
+            update = agg("max", fuse_boundary=boundary)
+        elif self.aggregate_func == "pna":
+            sum = agg("add")
+            sq_sum = agg("add", rel=relation ** 2, x=input ** 2)
+            max = agg("max", fuse_boundary=boundary)
+            min = agg("min", fuse_boundary=boundary)
+            mean = (sum + boundary) / degree_out
+            sq_mean = (sq_sum + boundary ** 2) / degree_out
+            std = (sq_mean - mean ** 2).clamp(min=self.eps).sqrt()
+            features = torch.cat([mean.unsqueeze(-1), max.unsqueeze(-1), min.unsqueeze(-1), std.unsqueeze(-1)], dim=-1)
+            features = features.flatten(-2)   # (batch, node, dim * 4)
+            scale = degree_out.log()
+            scale = scale / scale.mean()
+            scales = torch.cat([torch.ones_like(scale), scale, 1 / scale.clamp(min=1e-2)], dim=-1)   # (1, node, 3)
+            update = (features.unsqueeze(-1) * scales.unsqueeze(-2)).flatten(-2)
+        else:
+            raise ValueError("Unknown aggregation function `%s`" % self.aggregate_func)
+        return update
+
+    def update(self, update, input):
+        output = self.linear(torch.cat([input, update], dim=-1))
+        if self.layer_norm:
+            output = self.layer_norm(output)
+        if self.activation:
+            output = self.activation(output)
+        return output

@@ -1,0 +1,246 @@
+"""Ultra / RelNBFNet / EntityNBFNet / QueryNBFNet on the MI355X engine.
+
+Drop-in for the reference's ultra/models.py + ultra/base_nbfnet.py (hot-path part): same class
+names, constructor arguments, forward signatures and state-dict keys, so
+`model.load_state_dict(torch.load(ckpt)["model"])` works unchanged (script/run.py:257-258).
+`data` is duck-typed: .edge_index, .edge_type, .num_nodes, .num_relations, .relation_graph.
+Interpretability tooling of BaseNBFNet (visualize / beam search, base_nbfnet.py:156-336) is out of scope.
+"""
+import copy
+from collections.abc import Sequence
+
+import torch
+from torch import nn
+
+from . import layers, tasks
+
+
+def index_to_mask(index, size):
+    mask = torch.zeros(size, dtype=torch.bool, device=index.device)
+    mask[index] = True
+    return mask
+
+
+class BaseNBFNet(nn.Module):
+    """base_nbfnet.py:11-52 (constructor) and 54-86 (edge removal, head->tail conversion)."""
+
+    def __init__(self, input_dim, hidden_dims, num_relation, message_func="distmult", aggregate_func="sum",
+                 short_cut=False, layer_norm=False, activation="relu", concat_hidden=False, num_mlp_layer=2,
+                 dependent=False, remove_one_hop=False, num_beam=10, path_topk=10, **kwargs):
+        super(BaseNBFNet, self).__init__()
+
+        if not isinstance(hidden_dims, Sequence):
+            hidden_dims = [hidden_dims]
+
+        self.dims = [input_dim] + list(hidden_dims)
+        self.num_relation = num_relation
+        self.short_cut = short_cut
+        self.concat_hidden = concat_hidden
+        self.remove_one_hop = remove_one_hop
+        self.num_beam = num_beam
+        self.path_topk = path_topk
+
+        self.message_func = message_func
+        self.aggregate_func = aggregate_func
+        self.layer_norm = layer_norm
+        self.activation = activation
+        self.num_mlp_layers = num_mlp_layer
+
+    def remove_easy_edges(self, data, h_index, t_index, r_index=None):
+        # dynamic edge dropout of the training triples and their inverses (base_nbfnet.py:54-77)
+        h_index_ext = torch.cat([h_index, t_index], dim=-1)
+        t_index_ext = torch.cat([t_index, h_index], dim=-1)
+        r_index_ext = torch.cat([r_index, r_index + data.num_relations // 2], dim=-1)
+        if self.remove_one_hop:
+            edge_index = data.edge_index
+            easy_edge = torch.stack([h_index_ext, t_index_ext]).flatten(1)
+        else:
+            edge_index = torch.cat([data.edge_index, data.edge_type.unsqueeze(0)])
+            easy_edge = torch.stack([h_index_ext, t_index_ext, r_index_ext]).flatten(1)
+        index = tasks.edge_match(edge_index, easy_edge)[0]
+        mask = ~index_to_mask(index, data.num_edges)
+
+        data = copy.copy(data)
+        data.edge_index = data.edge_index[:, mask]
+        data.edge_type = data.edge_type[mask]
+        return data
+
+    def negative_sample_to_tail(self, h_index, t_index, r_index, num_direct_rel):
+        # p(h | t, r) -> p(t' | h', r'): h' = t, r' = r^-1, t' = h (base_nbfnet.py:79-86)
+        is_t_neg = (h_index == h_index[:, [0]]).all(dim=-1, keepdim=True)
+        new_h_index = torch.where(is_t_neg, h_index, t_index)
+        new_t_index = torch.where(is_t_neg, t_index, h_index)
+        new_r_index = torch.where(is_t_neg, r_index, r_index + num_direct_rel)
+        return new_h_index, new_t_index, new_r_index
+
+    def _propagate_layers(self, data, layer_input, query, boundary, separate_grad=False):
+        """The Bellman-Ford loop shared by every model (models.py:72-80, 150-163, 233-246)."""
+        size = (data.num_nodes, data.num_nodes)
+        edge_weight = None   # all ones; only materialised when its gradient is asked for
+        hiddens, edge_weights = [], []
+        for layer in self.layers:
+            if separate_grad:
+                edge_weight = torch.ones(data.num_edges, device=layer_input.device).requires_grad_()
+            hidden = layer(layer_input, query, boundary, data.edge_index, data.edge_type, size, edge_weight)
+            if self.short_cut and hidden.shape == layer_input.shape:
+                hidden = hidden + layer_input
+            hiddens.append(hidden)
+            edge_weights.append(edge_weight)
+            layer_input = hidden
+        return hiddens, edge_weights
+
+
+class RelNBFNet(BaseNBFNet):
+    """NBFNet over the relation graph (4 interaction types); returns (batch, num_rel, hidden). models.py:32-102."""
+
+    def __init__(self, input_dim, hidden_dims, num_relation=4, **kwargs):
+        super().__init__(input_dim, hidden_dims, num_relation, **kwargs)
+
+        self.layers = nn.ModuleList()
+        for i in range(len(self.dims) - 1):
+            self.layers.append(
+                layers.GeneralizedRelationalConv(
+                    self.dims[i], self.dims[i + 1], num_relation,
+                    self.dims[0], self.message_func, self.aggregate_func, self.layer_norm,
+                    self.activation, dependent=False)
+            )
+
+        if self.concat_hidden:
+            feature_dim = sum(hidden_dims) + input_dim
+            self.mlp = nn.Sequential(
+                nn.Linear(feature_dim, feature_dim),
+                nn.ReLU(),
+                nn.Linear(feature_dim, input_dim)
+            )
+
+    def bellmanford(self, data, h_index, separate_grad=False):
+        batch_size = len(h_index)
+        query = torch.ones(batch_size, self.dims[0], device=h_index.device, dtype=torch.float)
+        index = h_index.unsqueeze(-1).expand_as(query)
+        # boundary: ones at the query relation's node, zeros elsewhere (models.py:59-66)
+        boundary = torch.zeros(batch_size, data.num_nodes, self.dims[0], device=h_index.device)
+        boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
+
+        hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad=False)
+
+        node_query = query.unsqueeze(1).expand(-1, data.num_nodes, -1)
+        if self.concat_hidden:
+            output = torch.cat(hiddens + [node_query], dim=-1)
+            output = self.mlp(output)
+        else:
+            output = hiddens[-1]
+        return {
+            "node_feature": output,
+            "edge_weights": edge_weights,
+        }
+
+    def forward(self, rel_graph, query):
+        return self.bellmanford(rel_graph, h_index=query)["node_feature"]
+
+
+class EntityNBFNet(BaseNBFNet):
+    """NBFNet over the entity graph conditioned on relation representations. models.py:105-209."""
+
+    def __init__(self, input_dim, hidden_dims, num_relation=1, **kwargs):
+        # num_relation is a dummy: layers take their relation features from the relation model
+        super().__init__(input_dim, hidden_dims, num_relation, **kwargs)
+
+        self.layers = nn.ModuleList()
+        for i in range(len(self.dims) - 1):
+            self.layers.append(
+                layers.GeneralizedRelationalConv(
+                    self.dims[i], self.dims[i + 1], num_relation,
+                    self.dims[0], self.message_func, self.aggregate_func, self.layer_norm,
+                    self.activation, dependent=False, project_relations=True)
+            )
+
+        feature_dim = (sum(hidden_dims) if self.concat_hidden else hidden_dims[-1]) + input_dim
+        mlp = []
+        for i in range(self.num_mlp_layers - 1):
+            mlp.append(nn.Linear(feature_dim, feature_dim))
+            mlp.append(nn.ReLU())
+        mlp.append(nn.Linear(feature_dim, 1))
+        self.mlp = nn.Sequential(*mlp)
+
+    def bellmanford(self, data, h_index, r_index, separate_grad=False):
+        batch_size = len(r_index)
+        # query = representation of each sample's query relation, scattered to its head node
+        query = self.query[torch.arange(batch_size, device=r_index.device), r_index]
+        index = h_index.unsqueeze(-1).expand_as(query)
+        boundary = torch.zeros(batch_size, data.num_nodes, self.dims[0], device=h_index.device, dtype=query.dtype)
+        boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
+
+        hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad)
+
+        node_query = query.unsqueeze(1).expand(-1, data.num_nodes, -1)
+        if self.concat_hidden:
+            output = torch.cat(hiddens + [node_query], dim=-1)
+        else:
+            output = torch.cat([hiddens[-1], node_query], dim=-1)
+        return {
+            "node_feature": output,
+            "edge_weights": edge_weights,
+        }
+
+    def forward(self, data, relation_representations, batch):
+        h_index, t_index, r_index = batch.unbind(-1)
+
+        self.query = relation_representations
+        for layer in self.layers:
+            layer.relation = relation_representations
+
+        if self.training:
+            data = self.remove_easy_edges(data, h_index, t_index, r_index)
+
+        shape = h_index.shape
+        h_index, t_index, r_index = self.negative_sample_to_tail(h_index, t_index, r_index,
+                                                                 num_direct_rel=data.num_relations // 2)
+        assert (h_index[:, [0]] == h_index).all()
+        assert (r_index[:, [0]] == r_index).all()
+
+        output = self.bellmanford(data, h_index[:, 0], r_index[:, 0])
+        feature = output["node_feature"]
+        index = t_index.unsqueeze(-1).expand(-1, -1, feature.shape[-1])
+        feature = feature.gather(1, index)   # (batch, 1 + num_negative, feature_dim)
+        score = self.mlp(feature).squeeze(-1)
+        return score.view(shape)
+
+
+class QueryNBFNet(EntityNBFNet):
+    """Entity-level reasoner of UltraQuery: initial node features and queries come from outside,
+    scores every node (models.py:212-275)."""
+
+    def bellmanford(self, data, node_features, query, separate_grad=False):
+        hiddens, edge_weights = self._propagate_layers(data, node_features, query, node_features, separate_grad)
+        node_query = query.unsqueeze(1).expand(-1, data.num_nodes, -1)
+        if self.concat_hidden:
+            output = torch.cat(hiddens + [node_query], dim=-1)
+        else:
+            output = torch.cat([hiddens[-1], node_query], dim=-1)
+        return {
+            "node_feature": output,
+            "edge_weights": edge_weights,
+        }
+
+    def forward(self, data, node_features, relation_representations, query):
+        for layer in self.layers:
+            layer.relation = relation_representations
+        output = self.bellmanford(data, node_features, query)
+        return self.mlp(output["node_feature"]).squeeze(-1)   # (batch, num_nodes)
+
+
+class Ultra(nn.Module):
+    """models.py:7-26: relation model over data.relation_graph, then the entity model."""
+
+    def __init__(self, rel_model_cfg, entity_model_cfg):
+        super(Ultra, self).__init__()
+        rel_model_cfg, entity_model_cfg = dict(rel_model_cfg), dict(entity_model_cfg)
+        self.relation_model = globals()[rel_model_cfg.pop('class')](**rel_model_cfg)
+        self.entity_model = globals()[entity_model_cfg.pop('class')](**entity_model_cfg)
+
+    def forward(self, data, batch):
+        # batch: (bs, 1 + num_negs, 3); the relation is shared by every triple of a row
+        query_rels = batch[:, 0, 2]
+        relation_representations = self.relation_model(data.relation_graph, query=query_rels)
+        score = self.entity_model(data, relation_representations, batch)
+        return score
