@@ -31,6 +31,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
+def available_cores():
+    """Host cores this process may actually use: min(cpu_count, affinity mask, cgroup CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return n
+
+
 def b_gather(E, N, R, D, boundary):
     # SURVEY.md section 8d: every edge reads its source row, output written once, relation table once,
     # CSR (col, type, weight = 12 B/edge) once, row pointers once; + the boundary read when fused.
@@ -168,7 +184,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import ultra_oracle_model
             fn = ultra_oracle_model.reference_rspmm_fn()
-            ncores = os.cpu_count()
+            ncores = available_cores()
             torch.set_num_threads(ncores)
             batch = data_cpu.target_triples[:bs]
             t_batch_cpu, _ = tasks.all_negative(data_cpu, batch)

@@ -1,0 +1,49 @@
+/*
+ * ultra_nbfnet.h -- C ABI of the dense layer epilogues around rspmm (libultra_amd.so).
+ *
+ * These replace the torch op chains of the reference layer on the hot path; operands are plain fp32
+ * device pointers, kernels are enqueued on `stream` (hipStream_t as void*), status codes as in
+ * ultra_rspmm.h.  Built for the shapes of the shipped ULTRA checkpoints (hidden dim 64); other shapes
+ * return ULTRA_ERR_UNSUPPORTED and the host layer keeps using its generic path.
+ */
+#ifndef ULTRA_NBFNET_H
+#define ULTRA_NBFNET_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ULTRA_CONV_LAYER_NORM 1
+#define ULTRA_CONV_RELU 2
+#define ULTRA_CONV_RESIDUAL 4
+
+/*
+ * GeneralizedRelationalConv.update (/root/reference/ultra/layers.py:233-240) fused with the residual
+ * of the Bellman-Ford loop (/root/reference/ultra/models.py:158-160):
+ *     out = [x +] relu( LayerNorm_eps( W . cat[x, agg] + b ) )
+ * x, agg, out: (rows, 64) contiguous; weight (64, 128) row-major = linear.weight; bias (64) may be NULL;
+ * ln_weight / ln_bias (64) required with ULTRA_CONV_LAYER_NORM.  out may not alias x or agg.
+ */
+int32_t ultra_conv_update(const void *x, const void *agg, const void *weight, const void *bias, const void *ln_weight,
+                          const void *ln_bias, void *out, int64_t rows, int32_t input_dim, int32_t output_dim, float eps,
+                          int32_t flags, void *stream);
+
+/*
+ * Readout of EntityNBFNet.forward (/root/reference/ultra/models.py:166-170, 202-209):
+ *     feature = cat[hidden, query]; score = mlp.2( relu( mlp.0( feature.gather(t_index) ) ) )
+ * The query half of mlp.0 is constant per sample and arrives pre-folded:
+ *     qbias[b] = mlp.0.weight[:, 64:] . query[b] + mlp.0.bias            (batch, 128)
+ * hidden (batch, num_node, 64) contiguous; t_index (batch, n_cand) int64 node ids or NULL for
+ * all-tail (n_cand == num_node, identity); w1 = mlp.0.weight (128, 128) row-major; w2 = mlp.2.weight (128); b2 = mlp.2.bias (1);
+ * score (batch, n_cand).
+ */
+int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1, const void *qbias, const void *w2,
+                      const void *b2, void *score, int64_t batch, int64_t num_node, int64_t n_cand, int32_t hidden_dim,
+                      int32_t feature_dim, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ULTRA_NBFNET_H */

@@ -1,0 +1,316 @@
+// Dense epilogues of the NBFNet layer on the MI355X matrix cores (f32-in / f32-accumulate MFMA).
+//
+//   ultra_conv_update : out = [+x] relu( LayerNorm( W . [x ; agg] + b ) )        layers.py:233-240 (+ models.py:158-160)
+//   ultra_readout     : score = w2 . relu( W1[:, :d] . h[t] + qb[sample] ) + b2  models.py:202-209 with the query half of
+//                       the concatenated feature folded into a per-sample bias qb = W1[:, d:] . query + b1
+//
+// Both are skinny GEMMs (K = 128 / 64, N = 64 / 128) over M = batch * num_node rows, i.e. HBM/L2-bound
+// epilogues: one wave owns 32 data rows and computes the TRANSPOSED product D[feature][row] with
+// v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains, MI355X_MICROARCH.md), so that a data row's features
+// land in one lane pair (lane, lane ^ 32): LayerNorm / the final dot product need one cross-lane
+// shuffle instead of a 32-lane reduction.  A-operand = weights, staged once per workgroup in LDS in
+// MFMA fragment order (ds_read_b128, conflict free); B-operand = the data rows, loaded straight from
+// global memory as 16-byte chunks in a K-permuted order (lane half h takes chunks 2i + h), which also
+// leaves the residual input already in registers for the epilogue.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "../../include/ultra_rspmm.h"
+#include "plan.hpp"
+
+namespace ultra {
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+
+struct ConvParams {
+    const float *x;
+    const float *agg;
+    const float *weight;  // (64, 128) row-major
+    const float *bias, *ln_w, *ln_b;
+    float *out;
+    long long rows;
+    float eps;
+    int flags;
+};
+
+enum { CONV_LN = 1, CONV_RELU = 2, CONV_RESIDUAL = 4 };
+
+// feature owned by accumulator register r of feature tile m in lane half h (32x32 C/D layout)
+__device__ __forceinline__ int feat_of(int m, int r, int h) { return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__global__ void __launch_bounds__(256) conv_update_kernel(const ConvParams p) {
+    // [tile m][i][lane][q] : W[32 m + (lane & 31)][8 i + 4 (lane >> 5) + q]
+    __shared__ __attribute__((aligned(16))) float lds_w[2 * 16 * 64 * 4];
+    __shared__ float lds_vec[3 * 64];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 2 * 16 * 64 * 4; idx += 256) {
+        const int q = idx & 3, l = (idx >> 2) & 63, i = (idx >> 8) & 15, m = idx >> 12;
+        lds_w[idx] = p.weight[(32 * m + (l & 31)) * 128 + 8 * i + 4 * (l >> 5) + q];
+    }
+    if (tid < 64) {
+        lds_vec[tid] = p.bias ? p.bias[tid] : 0.f;
+        lds_vec[64 + tid] = (p.flags & CONV_LN) ? p.ln_w[tid] : 1.f;
+        lds_vec[128 + tid] = (p.flags & CONV_LN) ? p.ln_b[tid] : 0.f;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const float4 *w4 = reinterpret_cast<const float4 *>(lds_w);
+    const long long ntile = (p.rows + 31) / 32;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
+        const long long row = tile * 32 + j;
+        const bool valid = row < p.rows;
+        const long long rowc = valid ? row : p.rows - 1;
+        const float4 *xr = reinterpret_cast<const float4 *>(p.x + rowc * 64);
+        const float4 *ar = reinterpret_cast<const float4 *>(p.agg + rowc * 64);
+        float4 bx[8], ba[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bx[i] = xr[2 * i + h];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ba[i] = ar[2 * i + h];
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc0[r] = 0.f;
+            acc1[r] = 0.f;
+        }
+        // weights for step i + 1 are fetched from LDS while the 8 MFMAs of step i run; the scheduling
+        // barrier keeps the compiler from hoisting all 32 fragment reads (128 VGPRs) to the top
+        float4 a0 = w4[(0 * 16 + 0) * 64 + lane];
+        float4 a1 = w4[(1 * 16 + 0) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 b = i < 8 ? bx[i] : ba[i - 8];
+            float4 a0n = a0, a1n = a1;
+            if (i + 1 < 16) {
+                a0n = w4[(0 * 16 + i + 1) * 64 + lane];
+                a1n = w4[(1 * 16 + i + 1) * 64 + lane];
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
+            a0 = a0n;
+            a1 = a1n;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue: bias, LayerNorm over the row's 64 features (32 here + 32 in lane ^ 32), ReLU, residual ----
+        float v[2][16];
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            v[0][r] = acc0[r] + lds_vec[feat_of(0, r, h)];
+            v[1][r] = acc1[r] + lds_vec[feat_of(1, r, h)];
+            s += v[0][r] + v[1][r];
+        }
+        if (p.flags & CONV_LN) {
+            s += __shfl_xor(s, 32);
+            const float mean = s * (1.f / 64.f);
+            float q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d0 = v[0][r] - mean, d1 = v[1][r] - mean;
+                q += d0 * d0 + d1 * d1;
+            }
+            q += __shfl_xor(q, 32);
+            const float rstd = 1.f / sqrtf(q * (1.f / 64.f) + p.eps);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = feat_of(m, r, h);
+                    v[m][r] = (v[m][r] - mean) * rstd * lds_vec[64 + f] + lds_vec[128 + f];
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 y = make_float4(v[m][4 * g + 0], v[m][4 * g + 1], v[m][4 * g + 2], v[m][4 * g + 3]);
+                if (p.flags & CONV_RELU) {
+                    y.x = fmaxf(y.x, 0.f);
+                    y.y = fmaxf(y.y, 0.f);
+                    y.z = fmaxf(y.z, 0.f);
+                    y.w = fmaxf(y.w, 0.f);
+                }
+                if (p.flags & CONV_RESIDUAL) {
+                    const float4 xi = bx[4 * m + g];  // x[row][32 m + 8 g + 4 h ..]: the chunk this lane already holds
+                    y.x += xi.x;
+                    y.y += xi.y;
+                    y.z += xi.z;
+                    y.w += xi.w;
+                }
+                if (valid) *reinterpret_cast<float4 *>(p.out + row * 64 + 32 * m + 8 * g + 4 * h) = y;
+            }
+    }
+}
+
+struct ReadoutParams {
+    const float *hidden;     // (batch, num_node, 64) contiguous
+    const int64_t *t_index;  // (batch, n_cand) node ids, or NULL = identity (all-tail)
+    const float *w1;         // (128, 128) row-major; only the first 64 input columns are used here
+    const float *qbias;      // (batch, 128) = W1[:, 64:] . query + b1
+    const float *w2;         // (128)
+    const float *b2;         // (1) = mlp.2.bias
+    float *score;            // (batch, n_cand)
+    long long batch, num_node, n_cand;
+};
+
+__global__ void __launch_bounds__(256) readout_kernel(const ReadoutParams p) {
+    // [tile m (4)][i (8)][lane][q] : W1[32 m + (lane & 31)][8 i + 4 (lane >> 5) + q]
+    __shared__ __attribute__((aligned(16))) float lds_w[4 * 8 * 64 * 4];
+    __shared__ float lds_w2[128];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 4 * 8 * 64 * 4; idx += 256) {
+        const int q = idx & 3, l = (idx >> 2) & 63, i = (idx >> 8) & 7, m = idx >> 11;
+        lds_w[idx] = p.w1[(32 * m + (l & 31)) * 128 + 8 * i + 4 * (l >> 5) + q];
+    }
+    if (tid < 128) lds_w2[tid] = p.w2[tid];
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const float4 *w4 = reinterpret_cast<const float4 *>(lds_w);
+    const long long total = p.batch * p.n_cand;
+    const long long ntile = (total + 31) / 32;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
+        const long long row = tile * 32 + j;
+        const bool valid = row < total;
+        const long long rowc = valid ? row : total - 1;
+        const long long b = rowc / p.n_cand;
+        const long long c = rowc - b * p.n_cand;
+        const long long node = p.t_index ? p.t_index[rowc] : c;
+        const float4 *hr = reinterpret_cast<const float4 *>(p.hidden + (b * p.num_node + node) * 64);
+        float4 bh[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bh[i] = hr[2 * i + h];
+        f32x16 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        float4 a[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = w4[(m * 8 + 0) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float4 an[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) an[m] = (i + 1 < 8) ? w4[(m * 8 + i + 1) * 64 + lane] : a[m];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, bh[i].x, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, bh[i].y, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, bh[i].z, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, bh[i].w, acc[m], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = an[m];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float *qb = p.qbias + b * 128;
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = feat_of(m, r, h);
+                const float hid = fmaxf(acc[m][r] + qb[f], 0.f);
+                s += hid * lds_w2[f];
+            }
+        s += __shfl_xor(s, 32);
+        if (valid && h == 0) p.score[row] = s + p.b2[0];
+    }
+}
+
+static int grid_for(long long ntile, int waves_per_block) {
+    int dev = 0, cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cu = v;
+    }
+    long long blocks = (ntile + waves_per_block - 1) / waves_per_block;
+    const long long cap = (long long)cu * 4;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+}  // namespace ultra
+
+using namespace ultra;
+
+extern "C" {
+
+int32_t ultra_conv_update(const void *x, const void *agg, const void *weight, const void *bias, const void *ln_weight,
+                          const void *ln_bias, void *out, int64_t rows, int32_t input_dim, int32_t output_dim, float eps,
+                          int32_t flags, void *stream) {
+    if (input_dim != 64 || output_dim != 64) {
+        set_error("ultra_conv_update: only input_dim = output_dim = 64 is built (the ULTRA checkpoints' shape)");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    if (!x || !agg || !weight || !out || rows < 0 || ((flags & CONV_LN) && (!ln_weight || !ln_bias))) {
+        set_error("ultra_conv_update: NULL operand");
+        return ULTRA_ERR_INVALID;
+    }
+    if (rows == 0) return ULTRA_OK;
+    ConvParams p;
+    p.x = (const float *)x;
+    p.agg = (const float *)agg;
+    p.weight = (const float *)weight;
+    p.bias = (const float *)bias;
+    p.ln_w = (const float *)ln_weight;
+    p.ln_b = (const float *)ln_bias;
+    p.out = (float *)out;
+    p.rows = rows;
+    p.eps = eps;
+    p.flags = flags;
+    const int grid = grid_for((rows + 31) / 32, 4);
+    hipLaunchKernelGGL(conv_update_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error(std::string("conv_update_kernel launch: ") + hipGetErrorString(e));
+        return ULTRA_ERR_HIP;
+    }
+    return ULTRA_OK;
+}
+
+int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1, const void *qbias, const void *w2,
+                      const void *b2, void *score, int64_t batch, int64_t num_node, int64_t n_cand, int32_t hidden_dim,
+                      int32_t feature_dim, void *stream) {
+    if (hidden_dim != 64 || feature_dim != 128) {
+        set_error("ultra_readout: only hidden_dim = 64, feature_dim = 128 is built (the ULTRA checkpoints' shape)");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    if (!hidden || !w1 || !qbias || !w2 || !b2 || !score || batch < 0 || n_cand < 0) {
+        set_error("ultra_readout: NULL operand");
+        return ULTRA_ERR_INVALID;
+    }
+    if (batch * n_cand == 0) return ULTRA_OK;
+    ReadoutParams p;
+    p.hidden = (const float *)hidden;
+    p.t_index = t_index;
+    p.w1 = (const float *)w1;
+    p.qbias = (const float *)qbias;
+    p.w2 = (const float *)w2;
+    p.b2 = (const float *)b2;
+    p.score = (float *)score;
+    p.batch = batch;
+    p.num_node = num_node;
+    p.n_cand = n_cand;
+    const int grid = grid_for((batch * n_cand + 31) / 32, 4);
+    hipLaunchKernelGGL(readout_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error(std::string("readout_kernel launch: ") + hipGetErrorString(e));
+        return ULTRA_ERR_HIP;
+    }
+    return ULTRA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+"""Host side of the fused dense epilogues (include/ultra_nbfnet.h): the MFMA kernels that replace the
+torch op chains `cat -> Linear -> LayerNorm -> ReLU (-> + residual)` (layers.py:233-240, models.py:158-160)
+and `cat -> gather -> Linear -> ReLU -> Linear` (models.py:166-170, 202-209) on the inference path."""
+import ctypes
+
+import torch
+from torch.nn import functional as F
+
+from ._lib import check, lib
+
+CONV_LAYER_NORM, CONV_RELU, CONV_RESIDUAL = 1, 2, 4
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def conv_update_supported(layer, input, update):
+    return (input.is_cuda and input.dtype == torch.float32 and update.dtype == torch.float32
+            and layer.input_dim == 64 and layer.output_dim == 64 and layer.linear.in_features == 128
+            and update.shape[-1] == 64 and (layer.activation is None or layer.activation is F.relu)
+            and not (torch.is_grad_enabled() and (input.requires_grad or update.requires_grad
+                                                  or layer.linear.weight.requires_grad)))
+
+
+def conv_update(layer, input, update, residual):
+    """out = [input +] relu(layer_norm(linear(cat[input, update]))) for (..., 64) fp32 GPU tensors."""
+    x = input.contiguous()
+    agg = update.contiguous()
+    out = torch.empty_like(x)
+    rows = x.numel() // 64
+    flags = (CONV_LAYER_NORM if layer.layer_norm is not None else 0) | (CONV_RELU if layer.activation is not None else 0) \
+        | (CONV_RESIDUAL if residual else 0)
+    ln = layer.layer_norm
+    bias = layer.linear.bias
+    check(lib.ultra_conv_update(x.data_ptr(), agg.data_ptr(), layer.linear.weight.data_ptr(),
+                                bias.data_ptr() if bias is not None else None,
+                                ln.weight.data_ptr() if ln is not None else None,
+                                ln.bias.data_ptr() if ln is not None else None,
+                                out.data_ptr(), rows, 64, 64, float(ln.eps) if ln is not None else 1e-5, flags, _stream()))
+    return out
+
+
+def readout_supported(model, hidden):
+    mlp = model.mlp
+    return (hidden.is_cuda and hidden.dtype == torch.float32 and hidden.shape[-1] == 64 and not model.concat_hidden
+            and len(mlp) == 3 and isinstance(mlp[0], torch.nn.Linear) and isinstance(mlp[1], torch.nn.ReLU)
+            and isinstance(mlp[2], torch.nn.Linear) and mlp[0].in_features == 128 and mlp[0].out_features == 128
+            and mlp[2].out_features == 1 and mlp[0].bias is not None and mlp[2].bias is not None
+            and not (torch.is_grad_enabled() and (hidden.requires_grad or mlp[0].weight.requires_grad)))
+
+
+def readout(model, hidden, query, t_index):
+    """score[b, i] = mlp(cat[hidden[b, t_index[b, i]], query[b]]) without materialising the concatenation."""
+    mlp = model.mlp
+    w1 = mlp[0].weight
+    qbias = F.linear(query, w1[:, 64:], mlp[0].bias).contiguous()      # (batch, 128): the query half of mlp.0
+    hidden = hidden.contiguous()
+    batch, num_node = hidden.shape[:2]
+    t_index = t_index.contiguous()
+    n_cand = t_index.shape[1]
+    score = torch.empty(batch, n_cand, dtype=hidden.dtype, device=hidden.device)
+    check(lib.ultra_readout(hidden.data_ptr(), t_index.data_ptr(), w1.data_ptr(), qbias.data_ptr(),
+                            mlp[2].weight.data_ptr(), mlp[2].bias.data_ptr(), score.data_ptr(), batch, num_node, n_cand,
+                            64, 128, _stream()))
+    return score

@@ -11,7 +11,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from . import rspmm
+from . import dense, rspmm
 
 
 def _scatter(src, index, dim_size, reduce):
@@ -81,6 +81,10 @@ class GeneralizedRelationalConv(nn.Module):
                 )
 
     def forward(self, input, query, boundary, edge_index, edge_type, size, edge_weight=None):
+        return self._forward_impl(input, query, boundary, edge_index, edge_type, size, edge_weight, residual=False)
+
+    def _forward_impl(self, input, query, boundary, edge_index, edge_type, size, edge_weight=None, residual=False):
+        """forward() plus the option to fuse the caller's residual `hidden + layer_input` (models.py:158-160)."""
         batch_size = len(query)
 
         if self.dependent:
@@ -93,17 +97,18 @@ class GeneralizedRelationalConv(nn.Module):
         # edge_weight=None means "all ones" (what every caller on the fused path passes, models.py:143):
         # the kernel then skips the weight stream instead of multiplying by 1.
         return self.propagate(input=input, relation=relation, boundary=boundary, edge_index=edge_index,
-                              edge_type=edge_type, size=size, edge_weight=edge_weight)
+                              edge_type=edge_type, size=size, edge_weight=edge_weight, residual=residual)
 
-    def propagate(self, edge_index, size=None, **kwargs):
+    def propagate(self, edge_index, size=None, residual=False, **kwargs):
         edge_weight = kwargs["edge_weight"]
         if (edge_weight is not None and edge_weight.requires_grad) or self.message_func == "rotate":
             # layers.py:91-94: the fused kernel covers TransE / DistMult with constant edge weights only
-            return self._propagate_unfused(edge_index, size, **kwargs)
+            out = self._propagate_unfused(edge_index, size, **kwargs)
+            return out + kwargs["input"] if residual else out
         num_node = size[0] if size is not None else kwargs["input"].shape[1]
         out = self.message_and_aggregate(edge_index, kwargs["input"], kwargs["relation"], kwargs["boundary"],
                                          kwargs["edge_type"], edge_weight, edge_index[1], num_node)
-        return self.update(out, kwargs["input"])
+        return self.update(out, kwargs["input"], residual=residual)
 
     # ---- unfused path: PyG semantics (gather edge_index[0], scatter to edge_index[1]; layers.py:135-181) ----
     def _propagate_unfused(self, edge_index, size, input, relation, boundary, edge_type, edge_weight):
@@ -209,10 +214,15 @@ class GeneralizedRelationalConv(nn.Module):
             raise ValueError("Unknown aggregation function `%s`" % self.aggregate_func)
         return update
 
-    def update(self, update, input):
+    def update(self, update, input, residual=False):
+        if dense.conv_update_supported(self, input, update):
+            # one MFMA kernel: Linear(cat[input, update]) -> LayerNorm -> ReLU (-> + input)
+            return dense.conv_update(self, input, update, residual)
         output = self.linear(torch.cat([input, update], dim=-1))
         if self.layer_norm:
             output = self.layer_norm(output)
         if self.activation:
             output = self.activation(output)
+        if residual:
+            output = output + input
         return output

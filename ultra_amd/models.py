@@ -12,7 +12,7 @@ from collections.abc import Sequence
 import torch
 from torch import nn
 
-from . import layers, tasks
+from . import dense, layers, tasks
 
 
 def index_to_mask(index, size):
@@ -81,9 +81,10 @@ class BaseNBFNet(nn.Module):
         for layer in self.layers:
             if separate_grad:
                 edge_weight = torch.ones(data.num_edges, device=layer_input.device).requires_grad_()
-            hidden = layer(layer_input, query, boundary, data.edge_index, data.edge_type, size, edge_weight)
-            if self.short_cut and hidden.shape == layer_input.shape:
-                hidden = hidden + layer_input
+            # residual connection (models.py:158-160) is fused into the layer's update kernel
+            residual = self.short_cut and layer.output_dim == layer_input.shape[-1]
+            hidden = layer._forward_impl(layer_input, query, boundary, data.edge_index, data.edge_type, size,
+                                         edge_weight, residual=residual)
             hiddens.append(hidden)
             edge_weights.append(edge_weight)
             layer_input = hidden
@@ -162,16 +163,18 @@ class EntityNBFNet(BaseNBFNet):
         mlp.append(nn.Linear(feature_dim, 1))
         self.mlp = nn.Sequential(*mlp)
 
-    def bellmanford(self, data, h_index, r_index, separate_grad=False):
+    def _bellmanford_hidden(self, data, h_index, r_index, separate_grad=False):
         batch_size = len(r_index)
         # query = representation of each sample's query relation, scattered to its head node
         query = self.query[torch.arange(batch_size, device=r_index.device), r_index]
         index = h_index.unsqueeze(-1).expand_as(query)
         boundary = torch.zeros(batch_size, data.num_nodes, self.dims[0], device=h_index.device, dtype=query.dtype)
         boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
-
         hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad)
+        return hiddens, edge_weights, query
 
+    def bellmanford(self, data, h_index, r_index, separate_grad=False):
+        hiddens, edge_weights, query = self._bellmanford_hidden(data, h_index, r_index, separate_grad)
         node_query = query.unsqueeze(1).expand(-1, data.num_nodes, -1)
         if self.concat_hidden:
             output = torch.cat(hiddens + [node_query], dim=-1)
@@ -198,8 +201,15 @@ class EntityNBFNet(BaseNBFNet):
         assert (h_index[:, [0]] == h_index).all()
         assert (r_index[:, [0]] == r_index).all()
 
-        output = self.bellmanford(data, h_index[:, 0], r_index[:, 0])
-        feature = output["node_feature"]
+        hiddens, _, query = self._bellmanford_hidden(data, h_index[:, 0], r_index[:, 0])
+        if dense.readout_supported(self, hiddens[-1]):
+            # gather + cat[hidden, query] + MLP in one MFMA kernel (nothing of size (bs, N, 128) is materialised)
+            return dense.readout(self, hiddens[-1], query, t_index).view(shape)
+        node_query = query.unsqueeze(1).expand(-1, data.num_nodes, -1)
+        if self.concat_hidden:
+            feature = torch.cat(hiddens + [node_query], dim=-1)
+        else:
+            feature = torch.cat([hiddens[-1], node_query], dim=-1)
         index = t_index.unsqueeze(-1).expand(-1, -1, feature.shape[-1])
         feature = feature.gather(1, index)   # (batch, 1 + num_negative, feature_dim)
         score = self.mlp(feature).squeeze(-1)
