@@ -188,6 +188,10 @@ int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, in
                                   const ultra_mat *boundary, const ultra_mat *output, void *stream,
                                   int32_t warmup, int32_t iters, float *ms_per_call);
 
+/* Measurement helper: streaming 16-B/lane copy of `bytes` (multiple of 16) device bytes.  Used for the
+ * achievable-HBM-copy ceiling and to calibrate the FETCH_SIZE / WRITE_SIZE counters on a known byte count. */
+int32_t ultra_stream_copy(void *dst_dev, const void *src_dev, int64_t bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,7 +34,7 @@ def conv_layer(sd, prefix, input, relation, boundary, edge_index, edge_type, num
                layer_norm=True, rspmm_fn=None):
     """One GeneralizedRelationalConv.forward on (batch, N, d) tensors; `relation` is (batch, R, d)."""
     batch_size = input.shape[0]
-    edge_weight = torch.ones(edge_index.shape[1])                     # layers.py:81-82
+    edge_weight = torch.ones(edge_index.shape[1], dtype=input.dtype)  # layers.py:81-82
     # message_and_aggregate, layers.py:189-230
     x = input.transpose(0, 1).flatten(1)
     rel = relation.transpose(0, 1).flatten(1)
@@ -43,7 +43,7 @@ def conv_layer(sd, prefix, input, relation, boundary, edge_index, edge_type, num
     if aggregate_func == "sum":
         update = _rspmm(rspmm_fn, edge_index, edge_type, edge_weight, rel, x, "add", mul) + bnd
     elif aggregate_func == "mean":
-        degree_out = torch.bincount(edge_index[1], minlength=num_node).float().unsqueeze(-1) + 1   # layers.py:193
+        degree_out = torch.bincount(edge_index[1], minlength=num_node).to(input.dtype).unsqueeze(-1) + 1   # layers.py:193
         update = (_rspmm(rspmm_fn, edge_index, edge_type, edge_weight, rel, x, "add", mul) + bnd) / degree_out
     elif aggregate_func == "max":
         update = torch.max(_rspmm(rspmm_fn, edge_index, edge_type, edge_weight, rel, x, "max", mul), bnd)
@@ -71,9 +71,9 @@ def rel_nbfnet(sd, rel_graph, query_rels, cfg, rspmm_fn=None):
     dim = sd[prefix + "layers.0.relation.weight"].shape[1]
     batch_size = len(query_rels)
     num_node = rel_graph.num_nodes
-    query = torch.ones(batch_size, dim)
+    query = torch.ones(batch_size, dim, dtype=sd[prefix + "layers.0.relation.weight"].dtype)
     index = query_rels.unsqueeze(-1).expand_as(query)
-    boundary = torch.zeros(batch_size, num_node, dim)
+    boundary = torch.zeros(batch_size, num_node, dim, dtype=query.dtype)
     boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
     layer_input = boundary
     for i in range(_num_layers(sd, prefix)):
@@ -107,7 +107,7 @@ def entity_nbfnet(sd, data, relation_representations, batch, cfg, rspmm_fn=None)
     num_node = data.num_nodes
     query = relation_representations[torch.arange(batch_size), r0]
     index = h0.unsqueeze(-1).expand_as(query)
-    boundary = torch.zeros(batch_size, num_node, query.shape[-1])
+    boundary = torch.zeros(batch_size, num_node, query.shape[-1], dtype=query.dtype)
     boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
     layer_input = boundary
     for i in range(_num_layers(sd, prefix)):

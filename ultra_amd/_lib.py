@@ -69,6 +69,7 @@ def _load():
                                               ctypes.POINTER(ctypes.c_float)]
     lib.ultra_conv_update.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, ctypes.c_float, i32, vp]
     lib.ultra_readout.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
+    lib.ultra_stream_copy.argtypes = [vp, vp, i64, vp]
     lib.ultra_set_tuning.argtypes = [ctypes.POINTER(Tuning)]
     lib.ultra_get_tuning.argtypes = [ctypes.POINTER(Tuning)]
     for s in ("add", "min", "max"):
