@@ -190,6 +190,15 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
     fp.unit_w = w ? 0 : 1;
     fp.packed_on = p->packed_ok ? 1 : 0;
     fp.has_bnd = bnd ? 1 : 0;
+    // 32-bit byte offsets inside one operand slice (uniform 64-bit base + 32-bit voffset loads)
+    const auto slice_bytes = [&](const ultra_mat *m, int64_t rows) { return (uint64_t)rows * (uint64_t)m->stride_row * esz; };
+    if ((mul != BIN_LHS && slice_bytes(x, p->num_in) >= (1ull << 32)) ||
+        (mul != BIN_RHS && slice_bytes(rel, p->num_rel) >= (1ull << 32))) {
+        set_error("rspmm: an operand slice (rows * stride_row) exceeds 4 GiB; use the batch-major layout");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    if (mul != BIN_LHS) fp.x_row_bytes = (uint32_t)(x->stride_row * (int64_t)esz);
+    if (mul != BIN_RHS) fp.rel_row_bytes = (uint32_t)(rel->stride_row * (int64_t)esz);
 
     // per-call edge weights -> sorted order
     if (w && p->num_edge > 0) {

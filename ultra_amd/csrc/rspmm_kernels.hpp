@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <limits>
+#include <type_traits>
 
 #include "plan.hpp"
 
@@ -67,6 +68,7 @@ struct FwdParams {
     int32_t type_bits;
     int32_t unit_w, packed_on, has_bnd;
     int32_t smod, nparts;
+    uint32_t x_row_bytes, rel_row_bytes;   // row strides in bytes (each operand slice is < 4 GiB)
 };
 
 struct FixupParams {
@@ -95,6 +97,7 @@ __device__ __forceinline__ T nary_zero() {
 template <typename T, int SUM>
 __device__ __forceinline__ T nary(T result, T x) {  // operator.cuh:45,58,71
     if (SUM == ULTRA_SUM_ADD) return result + x;
+    // v_min / v_max: identical to the reference's `result < x ? result : x` for every non-NaN input
     if (SUM == ULTRA_SUM_MIN) return result < x ? result : x;
     return result > x ? result : x;
 }
@@ -109,18 +112,96 @@ __device__ __forceinline__ T binary(T rel, T x) {  // operator.cuh:15,29
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Register-side view of a Pack: an ext vector, so that the elementwise math maps onto the packed
+// fp32 VALU (v_pk_mul_f32 / v_pk_add_f32 on adjacent register pairs) without shuffling moves.
+template <typename T, int VEC>
+struct VecOf {
+    using type = T __attribute__((ext_vector_type(VEC)));
+};
+template <typename T>
+struct VecOf<T, 1> {
+    using type = T;
+};
+
+template <typename T, int VEC>
+__device__ __forceinline__ typename VecOf<T, VEC>::type to_vec(const Pack<T, VEC> &p) {
+    typename VecOf<T, VEC>::type v;
+    if constexpr (VEC == 1) {
+        v = p.v[0];
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = p.v[e];
+    }
+    return v;
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> to_pack(const typename VecOf<T, VEC>::type &v) {
+    Pack<T, VEC> p;
+    if constexpr (VEC == 1) {
+        p.v[0] = v;
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) p.v[e] = v[e];
+    }
+    return p;
+}
+
+template <typename V, int SUM>
+__device__ __forceinline__ V nary_vec(V result, V x) {
+    if constexpr (SUM == ULTRA_SUM_ADD) return result + x;
+    else if constexpr (SUM == ULTRA_SUM_MIN) return __builtin_elementwise_min(result, x);
+    else return __builtin_elementwise_max(result, x);
+}
+
+template <typename V, int MUL>
+__device__ __forceinline__ V binary_vec(V rel, V x) {
+    if constexpr (MUL == BIN_MUL) return rel * x;
+    else if constexpr (MUL == BIN_ADD) return rel + x;
+    else if constexpr (MUL == BIN_LHS) return rel;
+    else return x;
+}
+
+
+// Copies the span-wide column slice [inner * SPAN, +SPAN) of `rows` rows into LDS (row-major, SPAN
+// elements per row).  Four 16-byte loads are in flight per thread before the first LDS write.
+template <typename T, int VEC>
+__device__ __forceinline__ void stage_slice(T *lds, const T *src, long long stride_row, int rows, int inner, int row_len,
+                                            int tid, int nthreads) {
+    constexpr int SPAN = 16 * VEC;
+    using P = Pack<T, VEC>;
+    const int total = rows * 16;
+    for (int i0 = tid; i0 < total; i0 += 4 * nthreads) {
+        P v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * nthreads;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[u].v[e] = T(0);
+            const int r = i >> 4, d = inner * SPAN + (i & 15) * VEC;
+            if (i < total && d < row_len) v[u] = *reinterpret_cast<const P *>(src + (long long)r * stride_row + d);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * nthreads;
+            if (i < total) *reinterpret_cast<P *>(lds + (i >> 4) * SPAN + (i & 15) * VEC) = v[u];
+        }
+    }
+}
 
 // Walks one group's edge stream {begin + k * stride : k < cnt} for nsteps (wave-uniform) steps and
 // returns the group's accumulator.  PACKED: col/type share one word; UNITW: all edge weights are 1.
+// Steps below nfull (wave-uniform) are valid for all four groups and run without per-lane predicates.
+// Source rows are addressed as uniform base + 32-bit byte offset (one v_mad per edge, saddr loads).
 template <typename T, int VEC, int SUM, int MUL, int MODE, bool PACKED, bool UNITW>
 __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int begin, const int cnt, const int stride,
-                                                   const int nsteps, const int lane, const int l16, const T *xb,
-                                                   const T *relb, const T *lds_x, const T *lds_rel) {
+                                                   const int nsteps, const int nfull, const int lane, const int l16,
+                                                   const char *xbase, const char *relbase, const uint32_t lane_bytes,
+                                                   const T *lds_x, const T *lds_rel) {
     constexpr int SPAN = 16 * VEC;
     using P = Pack<T, VEC>;
-    P acc;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) acc.v[e] = nary_zero<T, SUM>();
+    using V = typename VecOf<T, VEC>::type;
+    V acc = V(nary_zero<T, SUM>());
 
     // record registers: this lane holds record (k0 + l16) of its group's stream
     uint32_t cur_c = 0, cur_t = 0;
@@ -136,6 +217,56 @@ __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int
         if (!UNITW) cur_w = reinterpret_cast<const T *>(p.w_sorted)[idx];
     }
     const uint32_t tmask = (1u << p.type_bits) - 1u;
+    const T *lds_x_lane = lds_x + l16 * VEC;
+    const T *lds_rel_lane = lds_rel + l16 * VEC;
+
+    auto chunk = [&](auto pred_tag, const int k0, const int j) {
+        constexpr bool PRED = decltype(pred_tag)::value;
+        uint32_t c[ULTRA_UNROLL], t[ULTRA_UNROLL];
+        T w[ULTRA_UNROLL];
+        P xv[ULTRA_UNROLL], rv[ULTRA_UNROLL];
+#pragma unroll
+        for (int q = 0; q < ULTRA_UNROLL; ++q) {
+            const int src = (lane & 48) | ((j + q) & 15);
+            const uint32_t cc = (uint32_t)__shfl((int)cur_c, src);
+            if (PACKED) {
+                t[q] = cc & tmask;
+                c[q] = cc >> p.type_bits;
+            } else {
+                c[q] = cc;
+                t[q] = (uint32_t)__shfl((int)cur_t, src);
+            }
+            w[q] = UNITW ? T(1) : __shfl(cur_w, src);
+        }
+#pragma unroll
+        for (int q = 0; q < ULTRA_UNROLL; ++q) {
+            if (MUL != BIN_LHS) {
+                if (MODE == MODE_ALL_LDS)
+                    xv[q] = *reinterpret_cast<const P *>(lds_x_lane + c[q] * SPAN);
+                else
+                    xv[q] = *reinterpret_cast<const P *>(xbase + (c[q] * p.x_row_bytes + lane_bytes));
+            }
+            if (MUL != BIN_RHS) {
+                if (MODE >= MODE_REL_LDS)
+                    rv[q] = *reinterpret_cast<const P *>(lds_rel_lane + t[q] * SPAN);
+                else
+                    rv[q] = *reinterpret_cast<const P *>(relbase + (t[q] * p.rel_row_bytes + lane_bytes));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < ULTRA_UNROLL; ++q) {
+            const V rr = (MUL != BIN_RHS) ? to_vec<T, VEC>(rv[q]) : V(T(0));
+            const V xx = (MUL != BIN_LHS) ? to_vec<T, VEC>(xv[q]) : V(T(0));
+            V y = binary_vec<V, MUL>(rr, xx);
+            if (!UNITW) y = y * V(w[q]);
+            const V cand = nary_vec<V, SUM>(acc, y);
+            if (PRED)
+                acc = (k0 + j + q < cnt) ? cand : acc;
+            else
+                acc = cand;
+        }
+    };
+
     for (int k0 = 0; k0 < nsteps; k0 += 16) {
         uint32_t nxt_c = 0, nxt_t = 0;
         T nxt_w = T(1);
@@ -154,58 +285,16 @@ __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int
         }
         const int nb = min(16, nsteps - k0);
         for (int j = 0; j < nb; j += ULTRA_UNROLL) {
-            uint32_t c[ULTRA_UNROLL], t[ULTRA_UNROLL];
-            T w[ULTRA_UNROLL];
-            bool ok[ULTRA_UNROLL];
-            P xv[ULTRA_UNROLL], rv[ULTRA_UNROLL];
-#pragma unroll
-            for (int q = 0; q < ULTRA_UNROLL; ++q) {
-                const int jj = j + q;
-                const int src = (lane & 48) | (jj & 15);
-                const uint32_t cc = (uint32_t)__shfl((int)cur_c, src);
-                if (PACKED) {
-                    t[q] = cc & tmask;
-                    c[q] = cc >> p.type_bits;
-                } else {
-                    c[q] = cc;
-                    t[q] = (uint32_t)__shfl((int)cur_t, src);
-                }
-                w[q] = UNITW ? T(1) : __shfl(cur_w, src);
-                ok[q] = (jj < 16) && (k0 + jj < cnt);
-            }
-#pragma unroll
-            for (int q = 0; q < ULTRA_UNROLL; ++q) {
-                if (MUL != BIN_LHS) {
-                    if (MODE == MODE_ALL_LDS)
-                        xv[q] = *reinterpret_cast<const P *>(lds_x + c[q] * SPAN + l16 * VEC);
-                    else
-                        xv[q] = *reinterpret_cast<const P *>(xb + (long long)c[q] * p.x.stride_row);
-                }
-                if (MUL != BIN_RHS) {
-                    if (MODE >= MODE_REL_LDS)
-                        rv[q] = *reinterpret_cast<const P *>(lds_rel + t[q] * SPAN + l16 * VEC);
-                    else
-                        rv[q] = *reinterpret_cast<const P *>(relb + (long long)t[q] * p.rel.stride_row);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < ULTRA_UNROLL; ++q) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const T rr = (MUL != BIN_RHS) ? rv[q].v[e] : T(0);
-                    const T xx = (MUL != BIN_LHS) ? xv[q].v[e] : T(0);
-                    T y = binary<T, MUL>(rr, xx);
-                    if (!UNITW) y = w[q] * y;
-                    const T cand = nary<T, SUM>(acc.v[e], y);
-                    acc.v[e] = ok[q] ? cand : acc.v[e];
-                }
-            }
+            if (k0 + j + ULTRA_UNROLL <= nfull)
+                chunk(std::false_type{}, k0, j);
+            else
+                chunk(std::true_type{}, k0, j);
         }
         cur_c = nxt_c;
         cur_t = nxt_t;
         cur_w = nxt_w;
     }
-    return acc;
+    return to_pack<T, VEC>(acc);
 }
 
 template <typename T, int VEC, int SUM, int MUL, int MODE>
@@ -232,41 +321,25 @@ __global__ void __launch_bounds__(1024) rspmm_fwd_kernel(const FwdParams p) {
         const int d0 = inner * SPAN + l16 * VEC;
         const bool dvalid = d0 < p.row_len;
         const int d0c = dvalid ? d0 : 0;
-        const T *xb = reinterpret_cast<const T *>(p.x.ptr) + outer * p.x.stride_outer + d0c;
-        const T *relb = reinterpret_cast<const T *>(p.rel.ptr) + outer * p.rel.stride_outer + d0c;
+        const char *xbase = reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.x.ptr) + outer * p.x.stride_outer);
+        const char *relbase =
+            reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.rel.ptr) + outer * p.rel.stride_outer);
+        const uint32_t lane_bytes = (uint32_t)d0c * (uint32_t)sizeof(T);
 
         if (MODE >= MODE_REL_LDS) {
             __syncthreads();  // readers of the previous span are done with the LDS image
-            if (MUL != BIN_RHS) {
-                const T *src = reinterpret_cast<const T *>(p.rel.ptr) + outer * p.rel.stride_outer;
-                for (int i = tid; i < p.num_rel * 16; i += blockDim.x) {
-                    const int r = i >> 4, l = i & 15;
-                    const int d = inner * SPAN + l * VEC;
-                    P v;
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) v.v[e] = T(0);
-                    if (d < p.row_len) v = *reinterpret_cast<const P *>(src + (long long)r * p.rel.stride_row + d);
-                    *reinterpret_cast<P *>(lds_rel + r * SPAN + l * VEC) = v;
-                }
-            }
-            if (MODE == MODE_ALL_LDS && MUL != BIN_LHS) {
-                const T *src = reinterpret_cast<const T *>(p.x.ptr) + outer * p.x.stride_outer;
-                for (int i = tid; i < p.num_in * 16; i += blockDim.x) {
-                    const int r = i >> 4, l = i & 15;
-                    const int d = inner * SPAN + l * VEC;
-                    P v;
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) v.v[e] = T(0);
-                    if (d < p.row_len) v = *reinterpret_cast<const P *>(src + (long long)r * p.x.stride_row + d);
-                    *reinterpret_cast<P *>(lds_x + r * SPAN + l * VEC) = v;
-                }
-            }
+            if (MUL != BIN_RHS)
+                stage_slice<T, VEC>(lds_rel, reinterpret_cast<const T *>(p.rel.ptr) + outer * p.rel.stride_outer,
+                                    p.rel.stride_row, p.num_rel, inner, p.row_len, tid, blockDim.x);
+            if (MODE == MODE_ALL_LDS && MUL != BIN_LHS)
+                stage_slice<T, VEC>(lds_x, reinterpret_cast<const T *>(p.x.ptr) + outer * p.x.stride_outer,
+                                    p.x.stride_row, p.num_in, inner, p.row_len, tid, blockDim.x);
             __syncthreads();
         }
 
         for (int u = part * nwave + wave; u < p.n_unit; u += p.nparts * nwave) {
             const bool wmode = u < p.n_w;  // wave-uniform
-            int begin, cnt, stride, row, slot, nsteps;
+            int begin, cnt, stride, row, slot, nsteps, nfull;
             if (wmode) {
                 const int4 it = items4[u];
                 row = rfl(it.x);
@@ -276,6 +349,7 @@ __global__ void __launch_bounds__(1024) rspmm_fwd_kernel(const FwdParams p) {
                 stride = 4;
                 cnt = (ilen - grp + 3) >> 2;
                 nsteps = (ilen + 3) >> 2;
+                nfull = ilen >> 2;
             } else {
                 const int q = p.n_w + 4 * (u - p.n_w) + grp;
                 if (q < p.n_item) {
@@ -294,19 +368,22 @@ __global__ void __launch_bounds__(1024) rspmm_fwd_kernel(const FwdParams p) {
                 const int m01 = max(__shfl(cnt, 0), __shfl(cnt, 16));
                 const int m23 = max(__shfl(cnt, 32), __shfl(cnt, 48));
                 nsteps = rfl(max(m01, m23));
+                const int n01 = min(__shfl(cnt, 0), __shfl(cnt, 16));
+                const int n23 = min(__shfl(cnt, 32), __shfl(cnt, 48));
+                nfull = rfl(min(n01, n23));
             }
 
             P acc;
             if (p.packed_on) {
                 if (p.unit_w)
-                    acc = walk_edges<T, VEC, SUM, MUL, MODE, true, true>(p, begin, cnt, stride, nsteps, lane, l16, xb, relb, lds_x, lds_rel);
+                    acc = walk_edges<T, VEC, SUM, MUL, MODE, true, true>(p, begin, cnt, stride, nsteps, nfull, lane, l16, xbase, relbase, lane_bytes, lds_x, lds_rel);
                 else
-                    acc = walk_edges<T, VEC, SUM, MUL, MODE, true, false>(p, begin, cnt, stride, nsteps, lane, l16, xb, relb, lds_x, lds_rel);
+                    acc = walk_edges<T, VEC, SUM, MUL, MODE, true, false>(p, begin, cnt, stride, nsteps, nfull, lane, l16, xbase, relbase, lane_bytes, lds_x, lds_rel);
             } else {
                 if (p.unit_w)
-                    acc = walk_edges<T, VEC, SUM, MUL, MODE, false, true>(p, begin, cnt, stride, nsteps, lane, l16, xb, relb, lds_x, lds_rel);
+                    acc = walk_edges<T, VEC, SUM, MUL, MODE, false, true>(p, begin, cnt, stride, nsteps, nfull, lane, l16, xbase, relbase, lane_bytes, lds_x, lds_rel);
                 else
-                    acc = walk_edges<T, VEC, SUM, MUL, MODE, false, false>(p, begin, cnt, stride, nsteps, lane, l16, xb, relb, lds_x, lds_rel);
+                    acc = walk_edges<T, VEC, SUM, MUL, MODE, false, false>(p, begin, cnt, stride, nsteps, nfull, lane, l16, xbase, relbase, lane_bytes, lds_x, lds_rel);
             }
 
             if (wmode) {
