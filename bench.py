@@ -213,12 +213,19 @@ def main():
                                    "cpu": cpu_model, "ms_per_forward": 1e3 * t_cpu / n_fwd}
             with torch.no_grad():
                 got = model(data, t_batch_cpu.to(dev)).cpu()
+            # fp64 run of the same oracle: the value both fp32 implementations approximate
+            truth = ultra_oracle_model.ultra_forward({k: v.double() for k, v in state.items()}, cfg, data_cpu, t_batch_cpu)
             t_mask, _ = tasks.strict_negative_mask(data_cpu, batch)
             pos_t = batch[:, 1]
             r_gpu = tasks.compute_ranking(got, pos_t, t_mask)
             r_cpu = tasks.compute_ranking(ref_score, pos_t, t_mask)
+            r_true = tasks.compute_ranking(truth.float(), pos_t, t_mask)
             out["parity"] = {"max_abs_score_diff": (got - ref_score).abs().max().item(), "tolerance": 1e-4,
-                             "rank_mismatches": int((r_gpu != r_cpu).sum()), "queries": bs}
+                             "rank_mismatches": int((r_gpu != r_cpu).sum()), "queries": bs,
+                             "max_abs_err_gpu_vs_fp64": (got.double() - truth).abs().max().item(),
+                             "max_abs_err_reference_fp32_vs_fp64": (ref_score.double() - truth).abs().max().item(),
+                             "rank_mismatches_gpu_vs_fp64": int((r_gpu != r_true).sum()),
+                             "rank_mismatches_reference_fp32_vs_fp64": int((r_cpu != r_true).sum())}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

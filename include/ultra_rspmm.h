@@ -67,7 +67,7 @@ typedef struct {
 /* Plan build options; zero-initialise for defaults. */
 typedef struct {
     int32_t seg_len;   /* rows with more edges are split into segments of this many edges (0 -> 256) */
-    int32_t g_max;     /* rows with <= g_max edges are walked by one 16-lane group, longer ones by a whole wave (0 -> 16) */
+    int32_t g_max;     /* rows with <= g_max edges are walked by one 16-lane group, longer ones by a whole wave (0 -> 64) */
     int32_t flags;     /* ULTRA_PLAN_* */
     int32_t reserved;
 } ultra_plan_opts;

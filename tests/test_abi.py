@@ -1,0 +1,77 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol the headers declare.
+No compute calls here (those are the -m gpu tests); only host-side entry points are exercised."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INCLUDE = os.path.join(ROOT, "include")
+
+
+def declared_symbols():
+    names = set()
+    for fn in sorted(os.listdir(INCLUDE)):
+        text = open(os.path.join(INCLUDE, fn)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names.update(re.findall(r"\b(ultra_[a-z0-9_]+)\s*\(", text))
+        for s, m in re.findall(r"ULTRA_DECLARE_REFERENCE_ENTRY\((\w+),\s*(\w+)\)", text):
+            if s != "SUM":
+                names.add("ultra_rspmm_%s_%s_forward_cuda" % (s, m))
+                names.add("ultra_rspmm_%s_%s_backward_cuda" % (s, m))
+    names.discard("ultra_rspmm_")
+    return sorted(n for n in names if not n.endswith("_"))
+
+
+def test_library_exports_every_declared_symbol():
+    from ultra_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 28, names
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, "declared in include/*.h but not exported: %s" % missing
+    for s in ("add", "min", "max"):
+        for m in ("mul", "add"):
+            for d in ("forward", "backward"):
+                assert "ultra_rspmm_%s_%s_%s_cuda" % (s, m, d) in names      # rspmm.h:63-105, one per reference export
+
+
+def test_host_entry_points_without_gpu():
+    from ultra_amd import _lib
+    lib = _lib.lib
+    assert lib.ultra_abi_version() == 1
+    assert lib.ultra_device_count() >= 0
+    t = _lib.Tuning()
+    assert lib.ultra_get_tuning(ctypes.byref(t)) == 0
+    bad = _lib.Tuning(100, 0, -1, -1, 0, (ctypes.c_int32 * 3)(0, 0, 0))      # threads not a multiple of 64
+    assert lib.ultra_set_tuning(ctypes.byref(bad)) == _lib.ULTRA_ERR_INVALID
+    assert b"multiple of 64" in lib.ultra_last_error()
+    assert lib.ultra_set_tuning(None) == 0
+    # plan creation is pure host code; error paths report through ultra_last_error()
+    h = ctypes.c_void_p()
+    assert lib.ultra_plan_create(ctypes.byref(h), None, None, -1, 1, 1, 1, None) == _lib.ULTRA_ERR_INVALID
+    assert lib.ultra_plan_create(ctypes.byref(h), None, None, 0, 3, 3, 1, None) == 0
+    info = _lib.PlanInfo()
+    assert lib.ultra_plan_get_info(h, ctypes.byref(info)) == 0
+    assert info.num_node == 3 and info.n_item == 3 and info.on_device == 0
+    assert lib.ultra_plan_destroy(h) == 0
+
+
+def test_dense_entry_points_validate_shapes():
+    from ultra_amd import _lib
+    lib = _lib.lib
+    rc = lib.ultra_conv_update(None, None, None, None, None, None, None, 10, 32, 64, 1e-5, 0, None)
+    assert rc == _lib.ULTRA_ERR_UNSUPPORTED
+    rc = lib.ultra_readout(None, None, None, None, None, None, None, 1, 10, 10, 32, 64, None)
+    assert rc == _lib.ULTRA_ERR_UNSUPPORTED
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    """No silent fallback: without the .so the binding module refuses to import."""
+    import importlib
+    from ultra_amd import _lib
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libultra_amd.so"))
+    with pytest.raises(ImportError, match="no CPU or PyTorch fallback"):
+        _lib._load()
+    importlib.reload(_lib)

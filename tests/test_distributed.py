@@ -1,0 +1,102 @@
+"""The N > 1 path without a cluster: world_size-2 gloo processes on CPU.  The scorer is a small
+deterministic stand-in module (the real Ultra needs a GPU); what is under test is the sharding, the
+single all-gather, and that metrics equal the single-process result (script/run.py:121-226 protocol)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class StubScorer(torch.nn.Module):
+    """score(h, t, r) = <emb[h] * rel[r], emb[t]>: any deterministic function of the batch works here."""
+
+    def __init__(self, num_node, num_rel):
+        super().__init__()
+        g = torch.Generator().manual_seed(7)
+        self.emb = torch.nn.Parameter(torch.randn(num_node, 8, generator=g))
+        self.rel = torch.nn.Parameter(torch.randn(num_rel, 8, generator=g))
+
+    def forward(self, data, batch):
+        h, t, r = batch.unbind(-1)
+        return (self.emb[h] * self.rel[r] * self.emb[t]).sum(-1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ultra_amd import distributed as udist
+    from ultra_amd import eval as ueval
+    from ultra_amd import synthetic
+    data = synthetic.make_kg(num_node=60, num_triple=400, num_relation_base=3, num_test=37, seed=5, relation_graph=False)
+    model = StubScorer(data.num_nodes, data.num_relations)
+    res = ueval.evaluate(model, data, batch_size=4, metrics=("mr", "mrr", "hits@1", "hits@10", "hits@10_50", "mrr-tail"))
+    # score-row all-gather (the per-step collective of the benchmark)
+    score = torch.full((3, 5), float(rank))
+    gathered = udist.all_gather_scores(score)
+    var = udist.all_gather_variable(torch.arange(rank + 2) + 10 * rank)
+    torch.save(dict(res=res, gathered=gathered, var=var, shard=udist.shard_range(37)), os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_query_sharded_evaluation_matches_single_process(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    from ultra_amd import eval as ueval
+    from ultra_amd import synthetic
+    data = synthetic.make_kg(num_node=60, num_triple=400, num_relation_base=3, num_test=37, seed=5, relation_graph=False)
+    model = StubScorer(data.num_nodes, data.num_relations)
+    want = ueval.evaluate(model, data, batch_size=4, metrics=("mr", "mrr", "hits@1", "hits@10", "hits@10_50", "mrr-tail"))
+    outs = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(world)]
+    assert want["_num_rankings"] == 2 * 37
+    for o in outs:
+        assert o["res"]["_num_rankings"] == want["_num_rankings"]           # no padding, no duplicated samples
+        for k, v in want.items():
+            assert o["res"][k] == pytest.approx(v, rel=1e-6), k
+        assert o["gathered"].shape == (6, 5)
+        assert o["gathered"][:3].eq(0).all() and o["gathered"][3:].eq(1).all()   # rank-major
+        assert o["var"].tolist() == [0, 1, 10, 11, 12]
+    assert outs[0]["shard"] == (0, 19) and outs[1]["shard"] == (19, 37)
+
+
+def test_shard_range_is_a_partition():
+    from ultra_amd import distributed as udist
+    for n in (0, 1, 7, 8, 20466):
+        for world in (1, 2, 3, 8):
+            parts = [udist.shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_metrics_formulas():
+    from ultra_amd import eval as ueval
+    ranking = torch.tensor([1, 2, 4, 10, 100])
+    neg = torch.tensor([100, 100, 100, 100, 100])
+    m = ueval.metrics_from_rankings(ranking, neg, ["mr", "mrr", "hits@1", "hits@3", "hits@10", "hits@1_50"])
+    assert m["mr"] == pytest.approx(23.4)
+    assert m["mrr"] == pytest.approx((1 + 0.5 + 0.25 + 0.1 + 0.01) / 5)
+    assert m["hits@1"] == pytest.approx(0.2) and m["hits@3"] == pytest.approx(0.4) and m["hits@10"] == pytest.approx(0.8)
+    fp = (ranking - 1).float() / neg
+    assert m["hits@1_50"] == pytest.approx(float(((1 - fp) ** 49).mean()))
+    with pytest.raises(ValueError):
+        ueval.metrics_from_rankings(ranking, neg, ["auroc"])

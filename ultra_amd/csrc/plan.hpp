@@ -44,7 +44,7 @@ void set_error(const std::string &msg);
 
 struct ultra_plan {
     int64_t num_edge = 0, num_out = 0, num_in = 0, num_rel = 0;
-    int32_t seg_len = 256, g_max = 32, flags = 0;
+    int32_t seg_len = 256, g_max = 64, flags = 0;
     int32_t type_bits = 0;
     bool packed_ok = false;
 

@@ -220,79 +220,126 @@ __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int
     const T *lds_x_lane = lds_x + l16 * VEC;
     const T *lds_rel_lane = lds_rel + l16 * VEC;
 
-    auto chunk = [&](auto pred_tag, const int k0, const int j) {
-        constexpr bool PRED = decltype(pred_tag)::value;
-        uint32_t c[ULTRA_UNROLL], t[ULTRA_UNROLL];
+    // One chunk = ULTRA_UNROLL consecutive steps.  fetch() broadcasts the chunk's records inside each
+    // group and issues its source-row loads; compute() consumes them.  The loop below keeps the loads
+    // of chunk i + 1 in flight while chunk i is reduced (software pipelining: the compiler's vmcnt
+    // bookkeeping only waits for the older chunk).
+    struct Fetched {
+        uint32_t t[ULTRA_UNROLL];
         T w[ULTRA_UNROLL];
-        P xv[ULTRA_UNROLL], rv[ULTRA_UNROLL];
+        P xv[ULTRA_UNROLL];
+    };
+    auto fetch = [&](Fetched &f, const uint32_t rec_c, const uint32_t rec_t, const T rec_w, const int j) {
+        uint32_t c[ULTRA_UNROLL];
 #pragma unroll
         for (int q = 0; q < ULTRA_UNROLL; ++q) {
             const int src = (lane & 48) | ((j + q) & 15);
-            const uint32_t cc = (uint32_t)__shfl((int)cur_c, src);
+            const uint32_t cc = (uint32_t)__shfl((int)rec_c, src);
             if (PACKED) {
-                t[q] = cc & tmask;
+                f.t[q] = cc & tmask;
                 c[q] = cc >> p.type_bits;
             } else {
                 c[q] = cc;
-                t[q] = (uint32_t)__shfl((int)cur_t, src);
+                f.t[q] = (uint32_t)__shfl((int)rec_t, src);
             }
-            w[q] = UNITW ? T(1) : __shfl(cur_w, src);
+            f.w[q] = UNITW ? T(1) : __shfl(rec_w, src);
         }
 #pragma unroll
         for (int q = 0; q < ULTRA_UNROLL; ++q) {
             if (MUL != BIN_LHS) {
                 if (MODE == MODE_ALL_LDS)
-                    xv[q] = *reinterpret_cast<const P *>(lds_x_lane + c[q] * SPAN);
+                    f.xv[q] = *reinterpret_cast<const P *>(lds_x_lane + c[q] * SPAN);
                 else
-                    xv[q] = *reinterpret_cast<const P *>(xbase + (c[q] * p.x_row_bytes + lane_bytes));
+                    f.xv[q] = *reinterpret_cast<const P *>(xbase + (c[q] * p.x_row_bytes + lane_bytes));
             }
+        }
+    };
+    auto compute = [&](auto pred_tag, const Fetched &f, const int kbase) {
+        constexpr bool PRED = decltype(pred_tag)::value;
+        P rv[ULTRA_UNROLL];
+#pragma unroll
+        for (int q = 0; q < ULTRA_UNROLL; ++q) {
             if (MUL != BIN_RHS) {
                 if (MODE >= MODE_REL_LDS)
-                    rv[q] = *reinterpret_cast<const P *>(lds_rel_lane + t[q] * SPAN);
+                    rv[q] = *reinterpret_cast<const P *>(lds_rel_lane + f.t[q] * SPAN);
                 else
-                    rv[q] = *reinterpret_cast<const P *>(relbase + (t[q] * p.rel_row_bytes + lane_bytes));
+                    rv[q] = *reinterpret_cast<const P *>(relbase + (f.t[q] * p.rel_row_bytes + lane_bytes));
             }
         }
 #pragma unroll
         for (int q = 0; q < ULTRA_UNROLL; ++q) {
             const V rr = (MUL != BIN_RHS) ? to_vec<T, VEC>(rv[q]) : V(T(0));
-            const V xx = (MUL != BIN_LHS) ? to_vec<T, VEC>(xv[q]) : V(T(0));
+            const V xx = (MUL != BIN_LHS) ? to_vec<T, VEC>(f.xv[q]) : V(T(0));
             V y = binary_vec<V, MUL>(rr, xx);
-            if (!UNITW) y = y * V(w[q]);
+            if (!UNITW) y = y * V(f.w[q]);
             const V cand = nary_vec<V, SUM>(acc, y);
             if (PRED)
-                acc = (k0 + j + q < cnt) ? cand : acc;
+                acc = (kbase + q < cnt) ? cand : acc;
             else
                 acc = cand;
         }
     };
+    auto load_records = [&](uint32_t &rc, uint32_t &rt, T &rw, const int k0) {
+        rc = 0;
+        rt = 0;
+        rw = T(1);
+        const int k = k0 + l16;
+        if (k0 < nsteps && k < cnt) {
+            const int idx = begin + k * stride;
+            if (PACKED) {
+                rc = p.packed[idx];
+            } else {
+                rc = (uint32_t)p.col[idx];
+                rt = (uint32_t)p.type[idx];
+            }
+            if (!UNITW) rw = reinterpret_cast<const T *>(p.w_sorted)[idx];
+        }
+    };
 
-    for (int k0 = 0; k0 < nsteps; k0 += 16) {
-        uint32_t nxt_c = 0, nxt_t = 0;
-        T nxt_w = T(1);
-        if (k0 + 16 < nsteps) {  // prefetch the next 16 records of this group
-            const int k = k0 + 16 + l16;
-            if (k < cnt) {
-                const int idx = begin + k * stride;
-                if (PACKED) {
-                    nxt_c = p.packed[idx];
-                } else {
-                    nxt_c = (uint32_t)p.col[idx];
-                    nxt_t = (uint32_t)p.type[idx];
+    constexpr int CHUNKS_PER_BATCH = 16 / ULTRA_UNROLL;
+    const int nchunks = (nsteps + ULTRA_UNROLL - 1) / ULTRA_UNROLL;
+    if (nchunks > 0) {
+        uint32_t nxt_c, nxt_t;
+        T nxt_w;
+        load_records(nxt_c, nxt_t, nxt_w, 16);   // records of batch 1, needed CHUNKS_PER_BATCH chunks from now
+        Fetched fa, fb;
+        fetch(fa, cur_c, cur_t, cur_w, 0);
+        for (int ci = 0; ci < nchunks; ci += 2) {
+            // ---- even chunk: in fa; prefetch ci + 1 into fb ----
+            {
+                const int cn = ci + 1;
+                if (cn < nchunks) {
+                    if ((cn % CHUNKS_PER_BATCH) == 0) {
+                        cur_c = nxt_c;
+                        cur_t = nxt_t;
+                        cur_w = nxt_w;
+                        load_records(nxt_c, nxt_t, nxt_w, (cn / CHUNKS_PER_BATCH + 1) * 16);
+                    }
+                    fetch(fb, cur_c, cur_t, cur_w, (cn % CHUNKS_PER_BATCH) * ULTRA_UNROLL);
                 }
-                if (!UNITW) nxt_w = reinterpret_cast<const T *>(p.w_sorted)[idx];
+                if ((ci + 1) * ULTRA_UNROLL <= nfull)
+                    compute(std::false_type{}, fa, ci * ULTRA_UNROLL);
+                else
+                    compute(std::true_type{}, fa, ci * ULTRA_UNROLL);
+            }
+            // ---- odd chunk: in fb; prefetch ci + 2 into fa ----
+            if (ci + 1 < nchunks) {
+                const int cn = ci + 2;
+                if (cn < nchunks) {
+                    if ((cn % CHUNKS_PER_BATCH) == 0) {
+                        cur_c = nxt_c;
+                        cur_t = nxt_t;
+                        cur_w = nxt_w;
+                        load_records(nxt_c, nxt_t, nxt_w, (cn / CHUNKS_PER_BATCH + 1) * 16);
+                    }
+                    fetch(fa, cur_c, cur_t, cur_w, (cn % CHUNKS_PER_BATCH) * ULTRA_UNROLL);
+                }
+                if ((ci + 2) * ULTRA_UNROLL <= nfull)
+                    compute(std::false_type{}, fb, (ci + 1) * ULTRA_UNROLL);
+                else
+                    compute(std::true_type{}, fb, (ci + 1) * ULTRA_UNROLL);
             }
         }
-        const int nb = min(16, nsteps - k0);
-        for (int j = 0; j < nb; j += ULTRA_UNROLL) {
-            if (k0 + j + ULTRA_UNROLL <= nfull)
-                chunk(std::false_type{}, k0, j);
-            else
-                chunk(std::true_type{}, k0, j);
-        }
-        cur_c = nxt_c;
-        cur_t = nxt_t;
-        cur_w = nxt_w;
     }
     return to_pack<T, VEC>(acc);
 }

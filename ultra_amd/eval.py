@@ -1,0 +1,93 @@
+"""Filtered-ranking evaluation, query-sharded over the GPUs of a node (reference: script/run.py:121-226).
+
+Same protocol as the reference's test(): for every test triple score all tails and all heads
+(tasks.all_negative), mask known true answers (tasks.strict_negative_mask), rank the positive
+(tasks.compute_ranking), then mr / mrr / hits@k (+ the unbiased hits@k_N estimator) over both
+directions, plus the tail-only variants ("mrr-tail", ...).
+
+What differs from the reference:
+  * sharding: contiguous balanced shards of the test triples (distributed.shard_range) instead of
+    DistributedSampler (which pads by repeating samples and therefore double-counts a few of them);
+  * collectives: ONE all-gather of (ranking, num_negative, is_tail) rows per evaluation instead of six
+    zero-padded all_reduce(SUM) calls (run.py:166-186) -- RCCL over xGMI on GPUs, gloo in the CPU tests.
+"""
+import math
+
+import torch
+
+from . import distributed as udist
+from . import tasks
+
+
+def metrics_from_rankings(ranking, num_negative, metric_names):
+    out = {}
+    for metric in metric_names:
+        name = metric
+        if name == "mr":
+            score = ranking.float().mean()
+        elif name == "mrr":
+            score = (1 / ranking.float()).mean()
+        elif name.startswith("hits@"):
+            values = name[5:].split("_")
+            threshold = int(values[0])
+            if len(values) > 1:
+                num_sample = int(values[1])
+                fp_rate = (ranking - 1).float() / num_negative      # unbiased estimation, run.py:208-217
+                score = 0
+                for i in range(threshold):
+                    num_comb = math.factorial(num_sample - 1) / math.factorial(i) / math.factorial(num_sample - i - 1)
+                    score = score + num_comb * (fp_rate ** i) * ((1 - fp_rate) ** (num_sample - i - 1))
+                score = score.mean()
+            else:
+                score = (ranking <= threshold).float().mean()
+        else:
+            raise ValueError("Unknown metric `%s`" % metric)
+        out[metric] = float(score)
+    return out
+
+
+@torch.no_grad()
+def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", "mrr", "hits@1", "hits@3", "hits@10"),
+             max_triples=None):
+    """Returns {metric: value} on every rank (the reference only fills it on rank 0)."""
+    world, rank = udist.world_size(), udist.rank()
+    triples = torch.cat([test_data.target_edge_index, test_data.target_edge_type.unsqueeze(0)]).t()
+    if max_triples is not None:
+        triples = triples[:max_triples]
+    lo, hi = udist.shard_range(len(triples), rank, world)
+    mine = triples[lo:hi]
+    filt = test_data if filtered_data is None else filtered_data
+
+    was_training = model.training
+    model.eval()
+    rows = []
+    for start in range(0, len(mine), batch_size):
+        batch = mine[start:start + batch_size]
+        t_batch, h_batch = tasks.all_negative(test_data, batch)
+        t_pred = model(test_data, t_batch)
+        h_pred = model(test_data, h_batch)
+        t_mask, h_mask = tasks.strict_negative_mask(filt, batch)
+        pos_h, pos_t, _ = batch.t()
+        t_rank = tasks.compute_ranking(t_pred, pos_t, t_mask)
+        h_rank = tasks.compute_ranking(h_pred, pos_h, h_mask)
+        is_tail = torch.ones_like(t_rank)
+        rows.append(torch.stack([t_rank, t_mask.sum(dim=-1), is_tail], dim=-1))
+        rows.append(torch.stack([h_rank, h_mask.sum(dim=-1), torch.zeros_like(is_tail)], dim=-1))
+    if rows:
+        local = torch.cat(rows).long()
+    else:
+        local = torch.zeros(0, 3, dtype=torch.long, device=triples.device)
+    flat = udist.all_gather_variable(local.reshape(-1)).view(-1, 3)     # the single gather of the evaluation
+    model.train(was_training)
+
+    ranking, num_neg, is_tail = flat[:, 0], flat[:, 1], flat[:, 2].bool()
+    plain = [m for m in metrics if "-tail" not in m]
+    tail = [m for m in metrics if "-tail" in m]
+    out = metrics_from_rankings(ranking, num_neg, plain)
+    for m in tail:
+        base, direction = m.split("-")
+        if direction != "tail":
+            raise ValueError("Only tail metric is supported in this mode")
+        out[m] = metrics_from_rankings(ranking[is_tail], num_neg[is_tail], [base])[base]
+    out["_num_rankings"] = int(ranking.numel())
+    return out
