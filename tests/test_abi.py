@@ -69,9 +69,7 @@ def test_dense_entry_points_validate_shapes():
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     """No silent fallback: without the .so the binding module refuses to import."""
-    import importlib
     from ultra_amd import _lib
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libultra_amd.so"))
     with pytest.raises(ImportError, match="no CPU or PyTorch fallback"):
         _lib._load()
-    importlib.reload(_lib)

@@ -141,3 +141,28 @@ def test_training_mode_removes_easy_edges(dev):
         out_eval = model(data.to(dev), neg.to(dev))
     assert out_train.shape == out_eval.shape == (4, 5)
     assert not torch.allclose(out_train.detach(), out_eval)      # the direct edges were dropped in training mode
+
+
+def test_graph_capture_replays_the_same_scores(dev):
+    """hipGraph capture of the inference forward (ultra_amd/graph.py): replay == eager, for new batches too."""
+    from ultra_amd.graph import GraphedForward
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    data = synthetic.make_kg(num_node=500, num_triple=4000, num_relation_base=6, num_test=64, seed=8).to(dev)
+    model = build(state, cfg, dev)
+    batches = [tasks.all_negative(data, data.target_triples[i * 4:(i + 1) * 4])[0] for i in range(3)]
+    graphed = GraphedForward(model, data, batches[0])
+    for b in batches:
+        with torch.no_grad():
+            want = model(data, b).clone()
+        got = graphed(b, check=True).clone()
+        assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        graphed(batches[0][:2])
+    # the deferred input check still fires: rows must share head and relation
+    bad = batches[0].clone()
+    bad[0, 5, 0] += 1
+    with pytest.raises(AssertionError):
+        with torch.no_grad():
+            model(data, bad)
+    with pytest.raises(AssertionError):
+        graphed(bad, check=True)

@@ -229,10 +229,13 @@ __global__ void __launch_bounds__(256) readout_kernel(const ReadoutParams p) {
 }
 
 static int grid_for(long long ntile, int waves_per_block) {
-    int dev = 0, cu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cu = v;
+    static int cu = 0;   // queried once (kept out of hipGraph capture)
+    if (cu == 0) {
+        int dev = 0, v = 0;
+        cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cu = v;
     }
     long long blocks = (ntile + waves_per_block - 1) / waves_per_block;
     const long long cap = (long long)cu * 4;

@@ -510,10 +510,14 @@ __global__ void __launch_bounds__(256) permute_weight_kernel(const T *w, const i
 template <typename T, int VEC, int SUM, int MUL, int MODE>
 inline hipError_t launch_one(const FwdParams &p, int grid, int threads, size_t lds, hipStream_t s) {
     auto kern = rspmm_fwd_kernel<T, VEC, SUM, MUL, MODE>;
-    if (lds > 48 * 1024) {
+    // LDS opt-in above 48 KiB: raised once per kernel to the largest size seen (not a stream operation,
+    // and kept out of hipGraph capture: warm-up launches have already done it)
+    static size_t lds_opted_in = 0;
+    if (lds > 48 * 1024 && lds > lds_opted_in) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        lds_opted_in = lds;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, p);
     return hipGetLastError();

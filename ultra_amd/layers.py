@@ -83,11 +83,15 @@ class GeneralizedRelationalConv(nn.Module):
     def forward(self, input, query, boundary, edge_index, edge_type, size, edge_weight=None):
         return self._forward_impl(input, query, boundary, edge_index, edge_type, size, edge_weight, residual=False)
 
-    def _forward_impl(self, input, query, boundary, edge_index, edge_type, size, edge_weight=None, residual=False):
-        """forward() plus the option to fuse the caller's residual `hidden + layer_input` (models.py:158-160)."""
+    def _forward_impl(self, input, query, boundary, edge_index, edge_type, size, edge_weight=None, residual=False,
+                      relation=None):
+        """forward() plus the option to fuse the caller's residual `hidden + layer_input` (models.py:158-160)
+        and to take this layer's relation features precomputed by the caller."""
         batch_size = len(query)
 
-        if self.dependent:
+        if relation is not None:
+            pass
+        elif self.dependent:
             relation = self.relation_linear(query).view(batch_size, self.num_relation, self.input_dim)
         else:
             if not self.project_relations:

@@ -67,24 +67,27 @@ class BaseNBFNet(nn.Module):
 
     def negative_sample_to_tail(self, h_index, t_index, r_index, num_direct_rel):
         # p(h | t, r) -> p(t' | h', r'): h' = t, r' = r^-1, t' = h (base_nbfnet.py:79-86)
-        is_t_neg = (h_index == h_index[:, [0]]).all(dim=-1, keepdim=True)
+        is_t_neg = (h_index == h_index[:, :1]).all(dim=-1, keepdim=True)
         new_h_index = torch.where(is_t_neg, h_index, t_index)
         new_t_index = torch.where(is_t_neg, t_index, h_index)
         new_r_index = torch.where(is_t_neg, r_index, r_index + num_direct_rel)
         return new_h_index, new_t_index, new_r_index
 
-    def _propagate_layers(self, data, layer_input, query, boundary, separate_grad=False):
-        """The Bellman-Ford loop shared by every model (models.py:72-80, 150-163, 233-246)."""
+    def _propagate_layers(self, data, layer_input, query, boundary, separate_grad=False, relations=None):
+        """The Bellman-Ford loop shared by every model (models.py:72-80, 150-163, 233-246).
+        `relations`: optional per-layer relation features computed up front (EntityNBFNet batches the six
+        relation_projection MLPs, which all read the same relation representations)."""
         size = (data.num_nodes, data.num_nodes)
         edge_weight = None   # all ones; only materialised when its gradient is asked for
         hiddens, edge_weights = [], []
-        for layer in self.layers:
+        for i, layer in enumerate(self.layers):
             if separate_grad:
                 edge_weight = torch.ones(data.num_edges, device=layer_input.device).requires_grad_()
             # residual connection (models.py:158-160) is fused into the layer's update kernel
             residual = self.short_cut and layer.output_dim == layer_input.shape[-1]
             hidden = layer._forward_impl(layer_input, query, boundary, data.edge_index, data.edge_type, size,
-                                         edge_weight, residual=residual)
+                                         edge_weight, residual=residual,
+                                         relation=None if relations is None else relations[i])
             hiddens.append(hidden)
             edge_weights.append(edge_weight)
             layer_input = hidden
@@ -170,8 +173,30 @@ class EntityNBFNet(BaseNBFNet):
         index = h_index.unsqueeze(-1).expand_as(query)
         boundary = torch.zeros(batch_size, data.num_nodes, self.dims[0], device=h_index.device, dtype=query.dtype)
         boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
-        hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad)
+        hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad,
+                                                       relations=self._project_relations_batched())
         return hiddens, edge_weights, query
+
+    def _project_relations_batched(self):
+        """All layers' relation_projection MLPs (layers.py:80) read the same input: run them as two batched
+        GEMMs instead of 12 small ones.  Inference only; training keeps the per-layer modules."""
+        rel = self.query
+        if torch.is_grad_enabled() or rel is None or not rel.is_cuda or not all(
+                getattr(l, "project_relations", False) and not l.dependent for l in self.layers):
+            return None
+        params = [p for l in self.layers for p in l.relation_projection.parameters()]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if getattr(self, "_proj_key", None) != key:
+            self._proj_w0 = torch.stack([l.relation_projection[0].weight for l in self.layers]).transpose(1, 2).contiguous()
+            self._proj_b0 = torch.stack([l.relation_projection[0].bias for l in self.layers]).unsqueeze(1)
+            self._proj_w2 = torch.stack([l.relation_projection[2].weight for l in self.layers]).transpose(1, 2).contiguous()
+            self._proj_b2 = torch.stack([l.relation_projection[2].bias for l in self.layers]).unsqueeze(1)
+            self._proj_key = key
+        n = len(self.layers)
+        x = rel.reshape(1, -1, rel.shape[-1]).expand(n, -1, -1)
+        h = torch.baddbmm(self._proj_b0, x, self._proj_w0).relu_()
+        out = torch.baddbmm(self._proj_b2, h, self._proj_w2)
+        return list(out.view(n, *rel.shape[:-1], out.shape[-1]).unbind(0))
 
     def bellmanford(self, data, h_index, r_index, separate_grad=False):
         hiddens, edge_weights, query = self._bellmanford_hidden(data, h_index, r_index, separate_grad)
@@ -198,13 +223,16 @@ class EntityNBFNet(BaseNBFNet):
         shape = h_index.shape
         h_index, t_index, r_index = self.negative_sample_to_tail(h_index, t_index, r_index,
                                                                  num_direct_rel=data.num_relations // 2)
-        assert (h_index[:, [0]] == h_index).all()
-        assert (r_index[:, [0]] == r_index).all()
+        # models.py:196-197 asserts these on the spot (two host syncs in the middle of the forward); here the
+        # flag is computed on the GPU now and checked after the whole forward has been enqueued.
+        valid = (h_index[:, :1] == h_index).all() & (r_index[:, :1] == r_index).all()
 
         hiddens, _, query = self._bellmanford_hidden(data, h_index[:, 0], r_index[:, 0])
         if dense.readout_supported(self, hiddens[-1]):
             # gather + cat[hidden, query] + MLP in one MFMA kernel (nothing of size (bs, N, 128) is materialised)
-            return dense.readout(self, hiddens[-1], query, t_index).view(shape)
+            score = dense.readout(self, hiddens[-1], query, t_index).view(shape)
+            self._check_valid(valid)
+            return score
         node_query = query.unsqueeze(1).expand(-1, data.num_nodes, -1)
         if self.concat_hidden:
             feature = torch.cat(hiddens + [node_query], dim=-1)
@@ -213,7 +241,14 @@ class EntityNBFNet(BaseNBFNet):
         index = t_index.unsqueeze(-1).expand(-1, -1, feature.shape[-1])
         feature = feature.gather(1, index)   # (batch, 1 + num_negative, feature_dim)
         score = self.mlp(feature).squeeze(-1)
+        self._check_valid(valid)
         return score.view(shape)
+
+    def _check_valid(self, valid):
+        if valid.is_cuda and torch.cuda.is_current_stream_capturing():
+            self._pending_valid = valid      # checked by the graph wrapper after replay (graph.py)
+            return
+        assert valid, "every row of `batch` must share its head (or tail) and its relation (models.py:196-197)"
 
 
 class QueryNBFNet(EntityNBFNet):
