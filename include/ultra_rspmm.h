@@ -73,6 +73,9 @@ typedef struct {
 } ultra_plan_opts;
 
 #define ULTRA_PLAN_EXACT_ORDER 1   /* no splitting, every row walked sequentially in (row, col) order: bit-reproduces the oracle's summation order */
+#define ULTRA_PLAN_TYPE_RUNS 2     /* edges sorted by (row, type, col) and cut at type changes: every item holds ONE relation, so
+                                      add_mul sums the sources first and multiplies by rel[type] once per item.  Pays off when runs are
+                                      long (dense graphs with few relation types, e.g. ULTRA's relation graph); add_mul only. */
 
 typedef struct ultra_plan ultra_plan;
 
@@ -83,6 +86,7 @@ typedef struct {
     int32_t seg_len, g_max, flags, packed;   /* packed: col/type share one 32-bit word */
     int32_t on_device;
     int32_t has_transpose;
+    int64_t n_type_run;   /* number of distinct (row, type) pairs: num_edge / n_type_run = mean run length */
 } ultra_plan_info;
 
 int32_t ultra_abi_version(void);

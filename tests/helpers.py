@@ -53,6 +53,9 @@ def _zero(sum, dtype):
 def emulate_plan_forward(plan, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul"):
     """Walk the exported plan exactly like rspmm_fwd_kernel does (same grouping, same operation
     order, separately rounded products and sums) with numpy.  Slow: small graphs only."""
+    typed = getattr(plan, "typed", None) is not None and sum == "add" and mul == "mul"
+    if typed:
+        plan = plan.typed       # the type-run twin serves add_mul: items hold one relation each
     info = plan.info()
     col = plan.export(_lib.ARR_COL).numpy()
     typ = plan.export(_lib.ARR_TYPE).numpy()
@@ -71,7 +74,7 @@ def emulate_plan_forward(plan, relation, input, edge_weight=None, boundary=None,
 
     def msg(k):
         r, xi = rel[typ[k]], x[col[k]]
-        y = r * xi if mul == "mul" else r + xi
+        y = xi if typed else (r * xi if mul == "mul" else r + xi)
         if w_sorted is not None:
             y = w_sorted[k] * y
         return y.astype(dtype)
@@ -97,6 +100,10 @@ def emulate_plan_forward(plan, relation, input, edge_weight=None, boundary=None,
             acc = _nary(sum, _nary(sum, g[0], g[1]).astype(dtype), _nary(sum, g[2], g[3]).astype(dtype)).astype(dtype)
         else:
             acc = walk(begin, length, 1)
+        if typed and length > 0:        # rel[type] (x) sum of the run, applied once
+            acc = (rel[typ[begin]] * acc).astype(dtype)
+        elif typed:
+            acc = (rel[0] * acc).astype(dtype)
         emit(row, slot, acc)
         seen_rows.add(int(row))
     for k, row in enumerate(split_row):

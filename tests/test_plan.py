@@ -104,3 +104,61 @@ def test_plan_rejects_bad_input():
         Plan(ei, et[:-1], 10, 3)
     with pytest.raises(RuntimeError):
         Plan(ei, et.int(), 10, 3)   # checkSameType(edge_index, edge_type)
+
+
+DENSE = dict(num_node=40, num_edge=3000, num_relation=4, seed=9)      # relation-graph regime: long (row, type) runs
+
+
+@pytest.mark.parametrize("case", [DENSE, CASES[1], CASES[3], CASES[4]])
+def test_type_run_plan_structure(case):
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    plan = Plan(ei, et, N, R, seg_len=32, g_max=8, type_runs="only")
+    info = plan.info()
+    a = _plan_arrays(plan)
+    assert info["flags"] & _lib.PLAN_TYPE_RUNS
+    perm = a["perm"]
+    rows, cols, types = ei[0].numpy()[perm], ei[1].numpy()[perm], et.numpy()[perm]
+    key = (rows.astype(np.int64) * R + types) * (N + 1) + cols
+    assert (np.diff(key) >= 0).all(), "sorted by (row, type, col)"
+    items = a["item"].reshape(-1, 4)
+    covered = np.zeros(E, dtype=np.int64)
+    per_row = np.zeros(N, dtype=np.int64)
+    for row, begin, length, slot in items:
+        covered[begin:begin + length] += 1
+        per_row[row] += 1
+        assert length <= 32
+        if length:
+            assert len(set(types[begin:begin + length].tolist())) == 1, "one relation per item"
+            assert (rows[begin:begin + length] == row).all()
+    assert (covered == 1).all() and (per_row >= 1).all()
+    for row, begin, length, slot in items:
+        assert (slot >= 0) == (per_row[row] > 1), "rows with several items combine through partial slots"
+    runs = len(set(zip(ei[0].tolist(), et.tolist())))
+    assert info["n_type_run"] == runs
+    assert Plan(ei, et, N, R).info()["n_type_run"] == runs           # the statistic does not depend on the sort order
+
+
+def test_type_run_twin_is_automatic_for_dense_few_relation_graphs():
+    ei, et = helpers.random_graph(**DENSE)
+    assert Plan(ei, et, 40, 4).typed is not None                      # mean run length 3000 / 160 ~ 19
+    ei2, et2 = helpers.random_graph(**CASES[0])
+    assert Plan(ei2, et2, 50, 5).typed is None                        # 400 edges over ~200 runs
+    assert Plan(ei, et, 40, 4, type_runs=False).typed is None
+    assert Plan(ei, et, 40, 4, exact_order=True).typed is None
+
+
+@pytest.mark.parametrize("case", [DENSE, CASES[3]])
+def test_type_run_emulated_walk_matches_oracle(case):
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    rel, x, w = helpers.features(N, R, 24, E, seed=3)
+    plan = Plan(ei, et, N, R, seg_len=32, g_max=8, type_runs=True)
+    assert plan.typed is not None
+    for weight in (w, None):
+        want = rspmm_oracle.generalized_rspmm(ei, et, w if weight is not None else torch.ones(E), rel, x)
+        got = helpers.emulate_plan_forward(plan, rel, x, edge_weight=weight, sum="add", mul="mul")
+        helpers.assert_sum_close(got, want, ei, et, w if weight is not None else torch.ones(E), rel, x)
+    # other semirings keep using the (row, col) plan
+    want = rspmm_oracle.generalized_rspmm(ei, et, w, rel, x, sum="max", mul="mul")
+    assert torch.equal(helpers.emulate_plan_forward(plan, rel, x, edge_weight=w, sum="max", mul="mul"), want)

@@ -19,6 +19,7 @@ CASES = [
     dict(num_node=5, num_edge=0, num_relation=2, seed=4),
     dict(num_node=1, num_edge=17, num_relation=2, seed=5),
     dict(num_node=700, num_edge=9000, num_relation=600, seed=6, hub=(3, 1500)),   # relation slice > x slice
+    dict(num_node=100, num_edge=20000, num_relation=4, seed=7),                  # dense, 4 relations: type-run twin plan
 ]
 
 
@@ -75,8 +76,8 @@ def test_exact_order_plan_is_bit_exact(dev, case, mul):
     assert torch.equal(got1, want1)
 
 
-@pytest.mark.parametrize("case", CASES[:4])
-@pytest.mark.parametrize("opts", [dict(), dict(seg_len=16, g_max=4), dict(seg_len=64, g_max=64)])
+@pytest.mark.parametrize("case", CASES[:4] + [CASES[7]])
+@pytest.mark.parametrize("opts", [dict(), dict(seg_len=16, g_max=4), dict(seg_len=64, g_max=64), dict(type_runs=True)])
 def test_fast_order_matches_host_emulation_bitwise(dev, case, opts):
     """The kernel's grouping / reduction order is fully specified by the plan: a numpy walk of the
     exported plan reproduces the GPU result bit for bit (determinism, no atomics)."""
@@ -92,7 +93,7 @@ def test_fast_order_matches_host_emulation_bitwise(dev, case, opts):
     assert torch.equal(got, again)
 
 
-@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[6]])
+@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[6], CASES[7]])
 @pytest.mark.parametrize("sum", SUMS)
 def test_variants_agree(dev, case, sum):
     """LDS-staged and L2-read variants, workgroup sizes and grids compute the same thing."""
@@ -140,7 +141,7 @@ def test_layouts_and_fused_boundary(dev, sum, layout):
     _check(got, want, sum, ei, et, w, rel, x, "mul", boundary=bnd)
 
 
-@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[6]])
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[6], CASES[7]])
 @pytest.mark.parametrize("sum,mul", list(itertools.product(SUMS, MULS)))
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_backward_matches_oracle(dev, case, sum, mul, dtype):

@@ -22,6 +22,7 @@ F32, F64 = 0, 1
 
 ARR_ROW_PTR, ARR_COL, ARR_TYPE, ARR_PERM, ARR_ITEM, ARR_SPLIT_ROW, ARR_SPLIT_PTR = range(7)
 PLAN_EXACT_ORDER = 1
+PLAN_TYPE_RUNS = 2
 
 
 class UltraMat(ctypes.Structure):
@@ -39,7 +40,8 @@ class PlanInfo(ctypes.Structure):
                 ("n_item", ctypes.c_int64), ("n_wave_item", ctypes.c_int64), ("n_group_item", ctypes.c_int64),
                 ("n_unit", ctypes.c_int64), ("n_split_row", ctypes.c_int64), ("n_partial_slot", ctypes.c_int64),
                 ("seg_len", ctypes.c_int32), ("g_max", ctypes.c_int32), ("flags", ctypes.c_int32),
-                ("packed", ctypes.c_int32), ("on_device", ctypes.c_int32), ("has_transpose", ctypes.c_int32)]
+                ("packed", ctypes.c_int32), ("on_device", ctypes.c_int32), ("has_transpose", ctypes.c_int32),
+                ("n_type_run", ctypes.c_int64)]
 
 
 class Tuning(ctypes.Structure):

@@ -42,13 +42,15 @@ ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *ty
         p->flags = opts->flags;
     }
     const bool exact = (p->flags & ULTRA_PLAN_EXACT_ORDER) != 0;
+    const bool type_runs = !exact && (p->flags & ULTRA_PLAN_TYPE_RUNS) != 0;
     if (p->g_max > p->seg_len) p->g_max = p->seg_len;
 
-    // ---- sort by (row, col), stable in the original edge id: two LSD counting passes ----
+    // ---- sort by (row, [type,] col), stable in the original edge id: LSD counting passes ----
     std::vector<int32_t> order((size_t)E);
     std::iota(order.begin(), order.end(), 0);
     if (E > 0) {
         counting_pass(order, col, num_in);
+        if (type_runs) counting_pass(order, type, num_rel);
         counting_pass(order, row, num_out);
     }
     p->perm = order;
@@ -75,6 +77,20 @@ ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *ty
             p->packed[(size_t)k] = ((uint32_t)p->col[(size_t)k] << p->type_bits) | (uint32_t)p->type[(size_t)k];
     }
 
+    // ---- number of (row, type) runs (a plan statistic: long runs favour ULTRA_PLAN_TYPE_RUNS) ----
+    {
+        std::vector<int32_t> last_row((size_t)std::max<int64_t>(num_rel, 1), -1);
+        int64_t runs = 0;
+        for (int64_t k = 0; k < E; ++k) {
+            const int32_t t = p->type[(size_t)k], r = p->erow[(size_t)k];
+            if (last_row[(size_t)t] != r) {
+                last_row[(size_t)t] = r;
+                ++runs;
+            }
+        }
+        p->n_type_run = runs;
+    }
+
     // ---- items ----
     std::vector<Item> witems, gitems;
     int32_t next_slot = 0;
@@ -82,6 +98,31 @@ ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *ty
     for (int64_t r = 0; r < num_out; ++r) {
         const int32_t b = p->row_ptr[(size_t)r], e = p->row_ptr[(size_t)r + 1];
         const int32_t deg = e - b;
+        if (type_runs) {
+            // one or more items per (row, type) run; a row with a single item writes its output directly
+            std::vector<Item> mine;
+            int32_t pos = b;
+            while (pos < e) {
+                int32_t end = pos + 1;
+                while (end < e && p->type[(size_t)end] == p->type[(size_t)pos]) ++end;
+                const int32_t len_run = end - pos;
+                const int32_t nseg = (len_run + p->seg_len - 1) / p->seg_len;
+                const int32_t base = len_run / nseg, extra = len_run % nseg;
+                for (int32_t s = 0; s < nseg; ++s) {
+                    const int32_t len = base + (s < extra ? 1 : 0);
+                    mine.push_back(Item{(int32_t)r, pos, len, -1});
+                    pos += len;
+                }
+            }
+            if (mine.empty()) mine.push_back(Item{(int32_t)r, b, 0, -1});
+            if (mine.size() > 1) {
+                for (auto &it : mine) it.slot = next_slot++;
+                p->split_row.push_back((int32_t)r);
+                p->split_ptr.push_back(next_slot);
+            }
+            for (auto &it : mine) (it.len <= p->g_max ? gitems : witems).push_back(it);
+            continue;
+        }
         if (exact || deg <= p->seg_len) {
             Item it{(int32_t)r, b, deg, -1};
             if (exact || deg <= p->g_max)
@@ -187,6 +228,7 @@ int32_t ultra_plan_get_info(const ultra_plan *p, ultra_plan_info *info) {
     info->packed = p->packed_ok ? 1 : 0;
     info->on_device = p->on_device ? 1 : 0;
     info->has_transpose = (p->tplan && p->rplan) ? 1 : 0;
+    info->n_type_run = p->n_type_run;
     return ULTRA_OK;
 }
 

@@ -54,6 +54,7 @@ struct ultra_plan {
     int64_t n_w = 0, n_g = 0, n_unit = 0;
     std::vector<int32_t> split_row, split_ptr;
     int64_t n_slot = 0;
+    int64_t n_type_run = 0;
 
     // original (unsorted) edges, kept to derive the backward plans lazily
     std::vector<int32_t> h_row, h_col, h_type;

@@ -69,6 +69,7 @@ struct FwdParams {
     int32_t unit_w, packed_on, has_bnd;
     int32_t smod, nparts;
     uint32_t x_row_bytes, rel_row_bytes;   // row strides in bytes (each operand slice is < 4 GiB)
+    int32_t typed_items;                    // plan built with ULTRA_PLAN_TYPE_RUNS: every item has one relation
 };
 
 struct FixupParams {
@@ -193,7 +194,7 @@ __device__ __forceinline__ void stage_slice(T *lds, const T *src, long long stri
 // returns the group's accumulator.  PACKED: col/type share one word; UNITW: all edge weights are 1.
 // Steps below nfull (wave-uniform) are valid for all four groups and run without per-lane predicates.
 // Source rows are addressed as uniform base + 32-bit byte offset (one v_mad per edge, saddr loads).
-template <typename T, int VEC, int SUM, int MUL, int MODE, bool PACKED, bool UNITW>
+template <typename T, int VEC, int SUM, int MUL, int MODE, bool PACKED, bool UNITW, bool TYPED = false>
 __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int begin, const int cnt, const int stride,
                                                    const int nsteps, const int nfull, const int lane, const int l16,
                                                    const char *xbase, const char *relbase, const uint32_t lane_bytes,
@@ -259,7 +260,7 @@ __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int
         P rv[ULTRA_UNROLL];
 #pragma unroll
         for (int q = 0; q < ULTRA_UNROLL; ++q) {
-            if (MUL != BIN_RHS) {
+            if (MUL != BIN_RHS && !TYPED) {
                 if (MODE >= MODE_REL_LDS)
                     rv[q] = *reinterpret_cast<const P *>(lds_rel_lane + f.t[q] * SPAN);
                 else
@@ -268,9 +269,10 @@ __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int
         }
 #pragma unroll
         for (int q = 0; q < ULTRA_UNROLL; ++q) {
-            const V rr = (MUL != BIN_RHS) ? to_vec<T, VEC>(rv[q]) : V(T(0));
+            const V rr = (MUL != BIN_RHS && !TYPED) ? to_vec<T, VEC>(rv[q]) : V(T(0));
             const V xx = (MUL != BIN_LHS) ? to_vec<T, VEC>(f.xv[q]) : V(T(0));
-            V y = binary_vec<V, MUL>(rr, xx);
+            // TYPED items hold edges of ONE relation: sum the sources, multiply by rel[type] once at the end
+            V y = TYPED ? xx : binary_vec<V, MUL>(rr, xx);
             if (!UNITW) y = y * V(f.w[q]);
             const V cand = nary_vec<V, SUM>(acc, y);
             if (PRED)
@@ -421,17 +423,25 @@ __global__ void __launch_bounds__(1024) rspmm_fwd_kernel(const FwdParams p) {
             }
 
             P acc;
-            if (p.packed_on) {
-                if (p.unit_w)
-                    acc = walk_edges<T, VEC, SUM, MUL, MODE, true, true>(p, begin, cnt, stride, nsteps, nfull, lane, l16, xbase, relbase, lane_bytes, lds_x, lds_rel);
-                else
-                    acc = walk_edges<T, VEC, SUM, MUL, MODE, true, false>(p, begin, cnt, stride, nsteps, nfull, lane, l16, xbase, relbase, lane_bytes, lds_x, lds_rel);
+#define ULTRA_WALK(PK, UW, TY)                                                                                       \
+    acc = walk_edges<T, VEC, SUM, MUL, MODE, PK, UW, TY>(p, begin, cnt, stride, nsteps, nfull, lane, l16, xbase, relbase, \
+                                                         lane_bytes, lds_x, lds_rel)
+            bool typed = false;
+            if constexpr (SUM == ULTRA_SUM_ADD && MUL == BIN_MUL) typed = p.typed_items != 0;
+            if (typed) {
+                if constexpr (SUM == ULTRA_SUM_ADD && MUL == BIN_MUL) {
+                    if (p.packed_on) {
+                        if (p.unit_w) ULTRA_WALK(true, true, true); else ULTRA_WALK(true, false, true);
+                    } else {
+                        if (p.unit_w) ULTRA_WALK(false, true, true); else ULTRA_WALK(false, false, true);
+                    }
+                }
+            } else if (p.packed_on) {
+                if (p.unit_w) ULTRA_WALK(true, true, false); else ULTRA_WALK(true, false, false);
             } else {
-                if (p.unit_w)
-                    acc = walk_edges<T, VEC, SUM, MUL, MODE, false, true>(p, begin, cnt, stride, nsteps, nfull, lane, l16, xbase, relbase, lane_bytes, lds_x, lds_rel);
-                else
-                    acc = walk_edges<T, VEC, SUM, MUL, MODE, false, false>(p, begin, cnt, stride, nsteps, nfull, lane, l16, xbase, relbase, lane_bytes, lds_x, lds_rel);
+                if (p.unit_w) ULTRA_WALK(false, true, false); else ULTRA_WALK(false, false, false);
             }
+#undef ULTRA_WALK
 
             if (wmode) {
 #pragma unroll
@@ -443,6 +453,19 @@ __global__ void __launch_bounds__(1024) rspmm_fwd_kernel(const FwdParams p) {
                 }
             }
             const bool writer = wmode ? (grp == 0) : (row >= 0);
+            if (typed && writer && dvalid) {
+                // one relation per item: y = rel[type] (x) sum_e w_e x_e   (distributivity of mul over add)
+                const int first = wmode ? (begin - grp) : begin;
+                uint32_t t = 0;
+                if (wmode || cnt > 0) t = p.packed_on ? (p.packed[first] & ((1u << p.type_bits) - 1u)) : (uint32_t)p.type[first];
+                P r;
+                if (MODE >= MODE_REL_LDS)
+                    r = *reinterpret_cast<const P *>(lds_rel + t * SPAN + l16 * VEC);
+                else
+                    r = *reinterpret_cast<const P *>(relbase + (t * p.rel_row_bytes + lane_bytes));
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc.v[e] = r.v[e] * acc.v[e];
+            }
             if (writer && dvalid) {
                 if (slot >= 0) {
                     T *dst = reinterpret_cast<T *>(p.partial) + ((long long)slot * p.n_outer + outer) * p.row_len + d0;

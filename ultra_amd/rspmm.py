@@ -65,8 +65,10 @@ def as_mat(t):
 class Plan(object):
     """Aggregation plan of one graph (sorted CSR + balanced work list), resident in HBM."""
 
+    TYPE_RUN_MIN_MEAN_LENGTH = 16   # build the type-run twin when (row, type) runs average at least this many edges
+
     def __init__(self, edge_index, edge_type, num_node, num_relation, seg_len=0, g_max=0, exact_order=False,
-                 num_in=None):
+                 num_in=None, type_runs="auto"):
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise RuntimeError("Expected `edge_index` of shape (2, num_edge)")          # checkDim/checkSize
         if edge_type.dim() != 1 or edge_type.shape[0] != edge_index.shape[1]:
@@ -75,7 +77,8 @@ class Plan(object):
             raise RuntimeError("Expected `edge_index` and `edge_type` of the same type")  # checkSameType, rspmm.cpp:22
         ei = edge_index.detach().to("cpu", torch.int64).contiguous()
         et = edge_type.detach().to("cpu", torch.int64).contiguous()
-        opts = _lib.PlanOpts(int(seg_len), int(g_max), _lib.PLAN_EXACT_ORDER if exact_order else 0, 0)
+        flags = (_lib.PLAN_EXACT_ORDER if exact_order else 0) | (_lib.PLAN_TYPE_RUNS if type_runs == "only" else 0)
+        opts = _lib.PlanOpts(int(seg_len), int(g_max), flags, 0)
         handle = ctypes.c_void_p()
         self.num_edge = ei.shape[1]
         self.num_node = int(num_node)
@@ -84,6 +87,14 @@ class Plan(object):
         check(lib.ultra_plan_create(ctypes.byref(handle), ei.data_ptr(), et.data_ptr(), self.num_edge, self.num_node,
                                     self.num_in, self.num_relation, ctypes.byref(opts)))
         self._h = handle
+        # Dense graphs with few relation types (ULTRA's relation graph: 474 nodes, 4 types, ~470 edges per
+        # (row, type) run) get a twin plan whose items hold one relation each; add_mul forwards use it.
+        self.typed = None
+        if type_runs in ("auto", True) and not exact_order and self.num_edge > 0:
+            runs = max(1, self.info()["n_type_run"])
+            if type_runs is True or self.num_edge / runs >= self.TYPE_RUN_MIN_MEAN_LENGTH:
+                self.typed = Plan(ei, et, num_node, num_relation, seg_len=seg_len, g_max=g_max, num_in=num_in,
+                                  type_runs="only")
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -110,6 +121,8 @@ class Plan(object):
 
     # ---- kernels ----
     def forward(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", out=None):
+        if self.typed is not None and sum == "add" and mul == "mul":
+            return self.typed.forward(relation, input, edge_weight=edge_weight, boundary=boundary, sum=sum, mul=mul, out=out)
         _require_gpu(relation, input, edge_weight, boundary)
         dt = _dtype_code(*([relation, input] + ([edge_weight] if edge_weight is not None else [])
                            + ([boundary] if boundary is not None else [])))
@@ -164,6 +177,9 @@ class Plan(object):
 
     def forward_timed(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", warmup=3, iters=20):
         """Mean HIP-event time (ms) of the forward launch sequence on the current stream."""
+        if self.typed is not None and sum == "add" and mul == "mul":
+            return self.typed.forward_timed(relation, input, edge_weight=edge_weight, boundary=boundary, sum=sum,
+                                            mul=mul, warmup=warmup, iters=iters)
         dt = _dtype_code(relation, input)
         relation, mrel = as_mat(relation)
         input, mx = as_mat(input)
@@ -186,12 +202,12 @@ class Plan(object):
 # ---- plan cache: the graph is static across the 12 rspmm calls of a forward and across batches ----
 _PLAN_CACHE = OrderedDict()
 _PLAN_CACHE_SIZE = 16
-_plan_defaults = {"seg_len": 0, "g_max": 0, "exact_order": False}
+_plan_defaults = {"seg_len": 0, "g_max": 0, "exact_order": False, "type_runs": "auto"}
 
 
-def set_plan_defaults(seg_len=0, g_max=0, exact_order=False):
+def set_plan_defaults(seg_len=0, g_max=0, exact_order=False, type_runs="auto"):
     """Tuning hook: defaults for newly built plans (clears the cache)."""
-    _plan_defaults.update(seg_len=seg_len, g_max=g_max, exact_order=exact_order)
+    _plan_defaults.update(seg_len=seg_len, g_max=g_max, exact_order=exact_order, type_runs=type_runs)
     _PLAN_CACHE.clear()
 
 
