@@ -190,10 +190,12 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
     fp.unit_w = w ? 0 : 1;
     fp.packed_on = p->packed_ok ? 1 : 0;
     fp.has_bnd = bnd ? 1 : 0;
-    fp.typed_items = ((p->flags & ULTRA_PLAN_TYPE_RUNS) && !(p->flags & ULTRA_PLAN_EXACT_ORDER)) ? 1 : 0;
-    if (fp.typed_items && !(sum == ULTRA_SUM_ADD && mul == BIN_MUL)) {
-        set_error("a ULTRA_PLAN_TYPE_RUNS plan serves add_mul only (distributivity)");
-        return ULTRA_ERR_UNSUPPORTED;
+    if ((p->flags & ULTRA_PLAN_TYPE_RUNS) && !(p->flags & ULTRA_PLAN_EXACT_ORDER)) {
+        if (!(sum == ULTRA_SUM_ADD && mul == BIN_MUL)) {
+            set_error("a ULTRA_PLAN_TYPE_RUNS plan serves add_mul only (distributivity)");
+            return ULTRA_ERR_UNSUPPORTED;
+        }
+        mul = BIN_MUL_TYPED;
     }
     // 32-bit byte offsets inside one operand slice (uniform 64-bit base + 32-bit voffset loads)
     const auto slice_bytes = [&](const ultra_mat *m, int64_t rows) { return (uint64_t)rows * (uint64_t)m->stride_row * esz; };

@@ -40,7 +40,9 @@ namespace ultra {
 enum { MODE_GLOBAL = 0, MODE_REL_LDS = 1, MODE_ALL_LDS = 2 };
 // BINARY variants: MUL/ADD are the reference's (operator.cuh:13-41); LHS/RHS pass one operand
 // through and serve the backward passes (d/d input of rel+in is 1, etc.).
-enum { BIN_MUL = 0, BIN_ADD = 1, BIN_LHS = 2, BIN_RHS = 3 };
+// BIN_MUL_TYPED: add_mul over a ULTRA_PLAN_TYPE_RUNS plan -- every item holds one relation, so the walk sums
+// the sources and the relation vector is applied once per item (its own kernel, no extra code in BIN_MUL).
+enum { BIN_MUL = 0, BIN_ADD = 1, BIN_LHS = 2, BIN_RHS = 3, BIN_MUL_TYPED = 4 };
 
 #ifndef ULTRA_UNROLL
 #define ULTRA_UNROLL 4
@@ -69,7 +71,6 @@ struct FwdParams {
     int32_t unit_w, packed_on, has_bnd;
     int32_t smod, nparts;
     uint32_t x_row_bytes, rel_row_bytes;   // row strides in bytes (each operand slice is < 4 GiB)
-    int32_t typed_items;                    // plan built with ULTRA_PLAN_TYPE_RUNS: every item has one relation
 };
 
 struct FixupParams {
@@ -158,6 +159,7 @@ __device__ __forceinline__ V nary_vec(V result, V x) {
 template <typename V, int MUL>
 __device__ __forceinline__ V binary_vec(V rel, V x) {
     if constexpr (MUL == BIN_MUL) return rel * x;
+    else if constexpr (MUL == BIN_MUL_TYPED) return x;
     else if constexpr (MUL == BIN_ADD) return rel + x;
     else if constexpr (MUL == BIN_LHS) return rel;
     else return x;
@@ -194,12 +196,13 @@ __device__ __forceinline__ void stage_slice(T *lds, const T *src, long long stri
 // returns the group's accumulator.  PACKED: col/type share one word; UNITW: all edge weights are 1.
 // Steps below nfull (wave-uniform) are valid for all four groups and run without per-lane predicates.
 // Source rows are addressed as uniform base + 32-bit byte offset (one v_mad per edge, saddr loads).
-template <typename T, int VEC, int SUM, int MUL, int MODE, bool PACKED, bool UNITW, bool TYPED = false>
+template <typename T, int VEC, int SUM, int MUL, int MODE, bool PACKED, bool UNITW>
 __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int begin, const int cnt, const int stride,
                                                    const int nsteps, const int nfull, const int lane, const int l16,
                                                    const char *xbase, const char *relbase, const uint32_t lane_bytes,
                                                    const T *lds_x, const T *lds_rel) {
     constexpr int SPAN = 16 * VEC;
+    constexpr bool TYPED = (MUL == BIN_MUL_TYPED);
     using P = Pack<T, VEC>;
     using V = typename VecOf<T, VEC>::type;
     V acc = V(nary_zero<T, SUM>());
@@ -423,23 +426,14 @@ __global__ void __launch_bounds__(1024) rspmm_fwd_kernel(const FwdParams p) {
             }
 
             P acc;
-#define ULTRA_WALK(PK, UW, TY)                                                                                       \
-    acc = walk_edges<T, VEC, SUM, MUL, MODE, PK, UW, TY>(p, begin, cnt, stride, nsteps, nfull, lane, l16, xbase, relbase, \
-                                                         lane_bytes, lds_x, lds_rel)
-            bool typed = false;
-            if constexpr (SUM == ULTRA_SUM_ADD && MUL == BIN_MUL) typed = p.typed_items != 0;
-            if (typed) {
-                if constexpr (SUM == ULTRA_SUM_ADD && MUL == BIN_MUL) {
-                    if (p.packed_on) {
-                        if (p.unit_w) ULTRA_WALK(true, true, true); else ULTRA_WALK(true, false, true);
-                    } else {
-                        if (p.unit_w) ULTRA_WALK(false, true, true); else ULTRA_WALK(false, false, true);
-                    }
-                }
-            } else if (p.packed_on) {
-                if (p.unit_w) ULTRA_WALK(true, true, false); else ULTRA_WALK(true, false, false);
+#define ULTRA_WALK(PK, UW)                                                                                       \
+    acc = walk_edges<T, VEC, SUM, MUL, MODE, PK, UW>(p, begin, cnt, stride, nsteps, nfull, lane, l16, xbase, relbase, \
+                                                     lane_bytes, lds_x, lds_rel)
+            constexpr bool typed = (MUL == BIN_MUL_TYPED);
+            if (p.packed_on) {
+                if (p.unit_w) ULTRA_WALK(true, true); else ULTRA_WALK(true, false);
             } else {
-                if (p.unit_w) ULTRA_WALK(false, true, false); else ULTRA_WALK(false, false, false);
+                if (p.unit_w) ULTRA_WALK(false, true); else ULTRA_WALK(false, false);
             }
 #undef ULTRA_WALK
 
@@ -560,10 +554,11 @@ hipError_t launch_fwd_variant(int sum, int mul, const FwdParams &p, int grid, in
         using T = T_;                                                                                             \
         constexpr int VEC = VEC_;                                                                                 \
         constexpr int MODE = MODE_;                                                                               \
-        switch (sum * 4 + mul) {                                                                                  \
+        switch (mul == BIN_MUL_TYPED ? 100 : sum * 4 + mul) {                                                     \
             ULTRA_CASE(0, 0) ULTRA_CASE(0, 1) ULTRA_CASE(0, 2) ULTRA_CASE(0, 3)                                   \
             ULTRA_CASE(1, 0) ULTRA_CASE(1, 1) ULTRA_CASE(1, 2) ULTRA_CASE(1, 3)                                   \
             ULTRA_CASE(2, 0) ULTRA_CASE(2, 1) ULTRA_CASE(2, 2) ULTRA_CASE(2, 3)                                   \
+            case 100: return launch_one<T, VEC, 0, BIN_MUL_TYPED, MODE>(p, grid, threads, lds, s);                 \
         }                                                                                                         \
         return hipErrorInvalidValue;                                                                              \
     }
