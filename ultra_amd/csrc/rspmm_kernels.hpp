@@ -47,6 +47,9 @@ enum { BIN_MUL = 0, BIN_ADD = 1, BIN_LHS = 2, BIN_RHS = 3, BIN_MUL_TYPED = 4 };
 #ifndef ULTRA_UNROLL
 #define ULTRA_UNROLL 4
 #endif
+#ifndef ULTRA_UNROLL_LDS
+#define ULTRA_UNROLL_LDS 4
+#endif
 
 struct MatArg {
     const void *ptr;
@@ -203,6 +206,8 @@ __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int
                                                    const T *lds_x, const T *lds_rel) {
     constexpr int SPAN = 16 * VEC;
     constexpr bool TYPED = (MUL == BIN_MUL_TYPED);
+    // edges per group and chunk: LDS-resident gathers have short latency and cheap registers -> deeper chunks
+    constexpr int UNR = (MODE == MODE_ALL_LDS && sizeof(T) == 4) ? ULTRA_UNROLL_LDS : ULTRA_UNROLL;
     using P = Pack<T, VEC>;
     using V = typename VecOf<T, VEC>::type;
     V acc = V(nary_zero<T, SUM>());
@@ -229,14 +234,14 @@ __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int
     // of chunk i + 1 in flight while chunk i is reduced (software pipelining: the compiler's vmcnt
     // bookkeeping only waits for the older chunk).
     struct Fetched {
-        uint32_t t[ULTRA_UNROLL];
-        T w[ULTRA_UNROLL];
-        P xv[ULTRA_UNROLL];
+        uint32_t t[UNR];
+        T w[UNR];
+        P xv[UNR];
     };
     auto fetch = [&](Fetched &f, const uint32_t rec_c, const uint32_t rec_t, const T rec_w, const int j) {
-        uint32_t c[ULTRA_UNROLL];
+        uint32_t c[UNR];
 #pragma unroll
-        for (int q = 0; q < ULTRA_UNROLL; ++q) {
+        for (int q = 0; q < UNR; ++q) {
             const int src = (lane & 48) | ((j + q) & 15);
             const uint32_t cc = (uint32_t)__shfl((int)rec_c, src);
             if (PACKED) {
@@ -249,7 +254,7 @@ __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int
             f.w[q] = UNITW ? T(1) : __shfl(rec_w, src);
         }
 #pragma unroll
-        for (int q = 0; q < ULTRA_UNROLL; ++q) {
+        for (int q = 0; q < UNR; ++q) {
             if (MUL != BIN_LHS) {
                 if (MODE == MODE_ALL_LDS)
                     f.xv[q] = *reinterpret_cast<const P *>(lds_x_lane + c[q] * SPAN);
@@ -260,9 +265,9 @@ __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int
     };
     auto compute = [&](auto pred_tag, const Fetched &f, const int kbase) {
         constexpr bool PRED = decltype(pred_tag)::value;
-        P rv[ULTRA_UNROLL];
+        P rv[UNR];
 #pragma unroll
-        for (int q = 0; q < ULTRA_UNROLL; ++q) {
+        for (int q = 0; q < UNR; ++q) {
             if (MUL != BIN_RHS && !TYPED) {
                 if (MODE >= MODE_REL_LDS)
                     rv[q] = *reinterpret_cast<const P *>(lds_rel_lane + f.t[q] * SPAN);
@@ -271,7 +276,7 @@ __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int
             }
         }
 #pragma unroll
-        for (int q = 0; q < ULTRA_UNROLL; ++q) {
+        for (int q = 0; q < UNR; ++q) {
             const V rr = (MUL != BIN_RHS && !TYPED) ? to_vec<T, VEC>(rv[q]) : V(T(0));
             const V xx = (MUL != BIN_LHS) ? to_vec<T, VEC>(f.xv[q]) : V(T(0));
             // TYPED items hold edges of ONE relation: sum the sources, multiply by rel[type] once at the end
@@ -301,8 +306,8 @@ __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int
         }
     };
 
-    constexpr int CHUNKS_PER_BATCH = 16 / ULTRA_UNROLL;
-    const int nchunks = (nsteps + ULTRA_UNROLL - 1) / ULTRA_UNROLL;
+    constexpr int CHUNKS_PER_BATCH = 16 / UNR;
+    const int nchunks = (nsteps + UNR - 1) / UNR;
     if (nchunks > 0) {
         uint32_t nxt_c, nxt_t;
         T nxt_w;
@@ -320,12 +325,12 @@ __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int
                         cur_w = nxt_w;
                         load_records(nxt_c, nxt_t, nxt_w, (cn / CHUNKS_PER_BATCH + 1) * 16);
                     }
-                    fetch(fb, cur_c, cur_t, cur_w, (cn % CHUNKS_PER_BATCH) * ULTRA_UNROLL);
+                    fetch(fb, cur_c, cur_t, cur_w, (cn % CHUNKS_PER_BATCH) * UNR);
                 }
-                if ((ci + 1) * ULTRA_UNROLL <= nfull)
-                    compute(std::false_type{}, fa, ci * ULTRA_UNROLL);
+                if ((ci + 1) * UNR <= nfull)
+                    compute(std::false_type{}, fa, ci * UNR);
                 else
-                    compute(std::true_type{}, fa, ci * ULTRA_UNROLL);
+                    compute(std::true_type{}, fa, ci * UNR);
             }
             // ---- odd chunk: in fb; prefetch ci + 2 into fa ----
             if (ci + 1 < nchunks) {
@@ -337,12 +342,12 @@ __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int
                         cur_w = nxt_w;
                         load_records(nxt_c, nxt_t, nxt_w, (cn / CHUNKS_PER_BATCH + 1) * 16);
                     }
-                    fetch(fa, cur_c, cur_t, cur_w, (cn % CHUNKS_PER_BATCH) * ULTRA_UNROLL);
+                    fetch(fa, cur_c, cur_t, cur_w, (cn % CHUNKS_PER_BATCH) * UNR);
                 }
-                if ((ci + 2) * ULTRA_UNROLL <= nfull)
-                    compute(std::false_type{}, fb, (ci + 1) * ULTRA_UNROLL);
+                if ((ci + 2) * UNR <= nfull)
+                    compute(std::false_type{}, fb, (ci + 1) * UNR);
                 else
-                    compute(std::true_type{}, fb, (ci + 1) * ULTRA_UNROLL);
+                    compute(std::true_type{}, fb, (ci + 1) * UNR);
             }
         }
     }
