@@ -183,14 +183,17 @@ int32_t ultra_set_tuning(const ultra_tuning *t);   /* NULL restores defaults */
 int32_t ultra_get_tuning(ultra_tuning *t);
 
 /*
- * Time `iters` back-to-back launches of the forward kernel(s) with HIP events on `stream`
- * (after `warmup` untimed launches); *ms_per_call receives the mean.  Synchronises the stream.
- * This is the measurement bench.py's roofline block uses.
+ * Time the forward with HIP events on `stream` after `warmup` untimed calls.  Synchronises the stream.
+ *   *ms_per_call    : mean over `iters` back-to-back calls of the whole launch sequence
+ *                     (weight permute + main kernel + fix-up kernel);
+ *   *ms_main_kernel : (optional) mean duration of the main rspmm_fwd_kernel alone, events recorded right
+ *                     around its launch, one call at a time -- the figure bench.py's roofline block uses
+ *                     and the one comparable with rocprofv3's per-kernel average.
  */
 int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype,
                                   const void *edge_weight_dev, const ultra_mat *relation, const ultra_mat *input,
                                   const ultra_mat *boundary, const ultra_mat *output, void *stream,
-                                  int32_t warmup, int32_t iters, float *ms_per_call);
+                                  int32_t warmup, int32_t iters, float *ms_per_call, float *ms_main_kernel);
 
 /* Measurement helper: streaming 16-B/lane copy of `bytes` (multiple of 16) device bytes.  Used for the
  * achievable-HBM-copy ceiling and to calibrate the FETCH_SIZE / WRITE_SIZE counters on a known byte count. */

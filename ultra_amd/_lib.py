@@ -68,7 +68,7 @@ def _load():
     lib.ultra_rspmm_forward.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp]
     lib.ultra_rspmm_backward.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp, matp, matp, vp]
     lib.ultra_rspmm_forward_timed.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp, i32, i32,
-                                              ctypes.POINTER(ctypes.c_float)]
+                                              ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     lib.ultra_conv_update.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, ctypes.c_float, i32, vp]
     lib.ultra_readout.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
     lib.ultra_stream_copy.argtypes = [vp, vp, i64, vp]

@@ -59,17 +59,36 @@ __global__ void __launch_bounds__(256) conv_update_kernel(const ConvParams p) {
     const int j = lane & 31, h = lane >> 5;
     const float4 *w4 = reinterpret_cast<const float4 *>(lds_w);
     const long long ntile = (p.rows + 31) / 32;
-    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
-        const long long row = tile * 32 + j;
-        const bool valid = row < p.rows;
-        const long long rowc = valid ? row : p.rows - 1;
-        const float4 *xr = reinterpret_cast<const float4 *>(p.x + rowc * 64);
-        const float4 *ar = reinterpret_cast<const float4 *>(p.agg + rowc * 64);
-        float4 bx[8], ba[8];
+    // persistent waves: the rows of the NEXT tile are requested before the 128 MFMAs of the current one, so
+    // their HBM/L2 latency hides under ~8k cycles of matrix work
+    const long long tstride = (long long)gridDim.x * 4;
+    long long tile = (long long)blockIdx.x * 4 + wave;
+    float4 bx[8], ba[8];
+    if (tile < ntile) {
+        const long long r0 = tile * 32 + j;
+        const long long rc0 = r0 < p.rows ? r0 : p.rows - 1;
+        const float4 *xr = reinterpret_cast<const float4 *>(p.x + rc0 * 64);
+        const float4 *ar = reinterpret_cast<const float4 *>(p.agg + rc0 * 64);
 #pragma unroll
         for (int i = 0; i < 8; ++i) bx[i] = xr[2 * i + h];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ba[i] = ar[2 * i + h];
+    }
+    for (; tile < ntile; tile += tstride) {
+        const long long row = tile * 32 + j;
+        const bool valid = row < p.rows;
+        float4 bxn[8], ban[8];
+        {
+            const long long tn = tile + tstride;
+            const long long rn = (tn < ntile ? tn : tile) * 32 + j;
+            const long long rcn = rn < p.rows ? rn : p.rows - 1;
+            const float4 *xr = reinterpret_cast<const float4 *>(p.x + rcn * 64);
+            const float4 *ar = reinterpret_cast<const float4 *>(p.agg + rcn * 64);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bxn[i] = xr[2 * i + h];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ban[i] = ar[2 * i + h];
+        }
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -148,6 +167,11 @@ __global__ void __launch_bounds__(256) conv_update_kernel(const ConvParams p) {
                 }
                 if (valid) *reinterpret_cast<float4 *>(p.out + row * 64 + 32 * m + 8 * g + 4 * h) = y;
             }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bx[i] = bxn[i];
+            ba[i] = ban[i];
+        }
     }
 }
 
@@ -238,7 +262,7 @@ static int grid_for(long long ntile, int waves_per_block) {
             cu = v;
     }
     long long blocks = (ntile + waves_per_block - 1) / waves_per_block;
-    const long long cap = (long long)cu * 4;
+    const long long cap = (long long)cu * 2;   // 8 waves per CU = 2 per SIMD (the kernels' VGPR budget), persistent over tiles
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;

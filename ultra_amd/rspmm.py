@@ -178,8 +178,10 @@ class Plan(object):
     def forward_timed(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", warmup=3, iters=20):
         """Mean HIP-event time (ms) of the forward launch sequence on the current stream."""
         if self.typed is not None and sum == "add" and mul == "mul":
-            return self.typed.forward_timed(relation, input, edge_weight=edge_weight, boundary=boundary, sum=sum,
-                                            mul=mul, warmup=warmup, iters=iters)
+            res = self.typed.forward_timed(relation, input, edge_weight=edge_weight, boundary=boundary, sum=sum,
+                                           mul=mul, warmup=warmup, iters=iters)
+            self.last_main_kernel_ms = self.typed.last_main_kernel_ms
+            return res
         dt = _dtype_code(relation, input)
         relation, mrel = as_mat(relation)
         input, mx = as_mat(input)
@@ -192,10 +194,11 @@ class Plan(object):
             boundary, mbv = as_mat(boundary)
             mb = ctypes.byref(mbv)
         w = edge_weight.contiguous().data_ptr() if edge_weight is not None else None
-        ms = ctypes.c_float()
+        ms, ms_kernel = ctypes.c_float(), ctypes.c_float()
         check(lib.ultra_rspmm_forward_timed(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
                                             ctypes.byref(mx), mb, ctypes.byref(mout), _stream(), warmup, iters,
-                                            ctypes.byref(ms)))
+                                            ctypes.byref(ms), ctypes.byref(ms_kernel)))
+        self.last_main_kernel_ms = ms_kernel.value
         return ms.value, out
 
 
