@@ -504,11 +504,23 @@ __global__ void __launch_bounds__(256) rspmm_fixup_kernel(const FixupParams p) {
         P acc;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc.v[e] = nary_zero<T, SUM>();
-        for (int s = s0; s < s1; ++s) {
-            const P v = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.partial) +
-                                                     ((long long)s * p.n_outer + outer) * p.row_len + d0);
+        // slot order is the summation order (deterministic); eight partials are in flight at a time so a
+        // hub row with dozens of slots does not serialise on memory latency
+        for (int sb = s0; sb < s1; sb += 8) {
+            P v[8];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc.v[e] = nary<T, SUM>(acc.v[e], v.v[e]);
+            for (int u = 0; u < 8; ++u) {
+                const int sl = sb + u < s1 ? sb + u : s1 - 1;
+                v[u] = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.partial) +
+                                                    ((long long)sl * p.n_outer + outer) * p.row_len + d0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (sb + u < s1) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc.v[e] = nary<T, SUM>(acc.v[e], v[u].v[e]);
+                }
+            }
         }
         if (p.has_bnd) {
             const P b = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.bnd.ptr) +
