@@ -72,9 +72,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # started by torch.distributed.run
+    if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=dev)                   # "nccl" is RCCL on ROCm
     assert world == args.gpus or world == 1, "--gpus must match the launcher's world size"
 
     import __graft_entry__ as entry
@@ -117,7 +118,7 @@ def main():
     def one_step(step):
         t_batch, _ = tasks.all_negative(data, batch_for(step))
         score = forward(data, t_batch)                     # (bs, N)
-        if world > 1:
+        if world > 1 or launched:
             score = udist.all_gather_scores(score)         # (world * bs, N): one RCCL all-gather per step
         return score
 
@@ -241,7 +242,7 @@ def main():
                              "rank_mismatches_gpu_vs_fp64": int((r_gpu != r_true).sum()),
                              "rank_mismatches_reference_fp32_vs_fp64": int((r_cpu != r_true).sum())}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or launched:
         dist.barrier()
         dist.destroy_process_group()
 

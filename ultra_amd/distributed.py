@@ -31,7 +31,7 @@ def shard_range(num_items, rank_=None, world=None):
 def all_gather_scores(score):
     """(b, N) per-rank score rows -> (world * b, N), rank-major.  One collective."""
     world = world_size()
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return score
     score = score.contiguous()
     out = torch.empty((world * score.shape[0],) + tuple(score.shape[1:]), dtype=score.dtype, device=score.device)
