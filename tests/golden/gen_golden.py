@@ -91,7 +91,42 @@ def gen_models():
         print("model", ckpt_name, aggr, "scores", tuple(t_pred.shape), "ranks", t_rank.tolist(), h_rank.tolist())
 
 
+def gen_query_nbfnet():
+    """QueryNBFNet (ultra/models.py:212-275), the UltraQuery entity reasoner: same layers as EntityNBFNet but
+    initial node features and queries come from outside.  Weights: the entity_model half of ultra_3g."""
+    from torch_geometric.data import Data
+    from ultra import tasks as ref_tasks
+    from ultra.models import QueryNBFNet, RelNBFNet
+    from ultra_amd import synthetic
+
+    state = torch.load(os.path.join(HERE, "ultra_3g_model.pt"))
+    kg = synthetic.make_kg(num_node=150, num_triple=1000, num_relation_base=5, num_test=8, seed=13, relation_graph=False)
+    data = Data(edge_index=kg.edge_index, edge_type=kg.edge_type, num_nodes=kg.num_nodes, num_relations=kg.num_relations)
+    data = ref_tasks.build_relation_graph(data)
+    cfg = synthetic.default_model_cfg()
+    ent_cfg = {k: v for k, v in cfg["entity_model_cfg"].items() if k != "class"}
+    rel_cfg = {k: v for k, v in cfg["rel_model_cfg"].items() if k != "class"}
+    qnet, rnet = QueryNBFNet(**ent_cfg), RelNBFNet(**rel_cfg)
+    qnet.load_state_dict({k[len("entity_model."):]: v for k, v in state.items() if k.startswith("entity_model.")})
+    rnet.load_state_dict({k[len("relation_model."):]: v for k, v in state.items() if k.startswith("relation_model.")})
+    qnet.eval(), rnet.eval()
+    g = torch.Generator().manual_seed(21)
+    query_rels = torch.tensor([1, 4, 7])
+    node_features = torch.rand(3, kg.num_nodes, 64, generator=g) * (torch.rand(3, kg.num_nodes, 1, generator=g) < 0.1)
+    with torch.no_grad():
+        rel_repr = rnet(data.relation_graph, query=query_rels)
+        query = rel_repr[torch.arange(3), query_rels]
+        score = qnet(data, node_features, rel_repr, query)
+    torch.save(dict(edge_index=data.edge_index, edge_type=data.edge_type, num_nodes=data.num_nodes,
+                    num_relations=data.num_relations, rel_edge_index=data.relation_graph.edge_index,
+                    rel_edge_type=data.relation_graph.edge_type, query_rels=query_rels, node_features=node_features,
+                    rel_repr=rel_repr, query=query, score=score), os.path.join(HERE, "query_nbfnet_ultra_3g.pt"))
+    print("query_nbfnet", tuple(score.shape))
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden generation needs the reference checkout at /root/reference"
+    torch.manual_seed(0)     # negative_sampling draws from the global generator
     gen_rspmm()
     gen_models()
+    gen_query_nbfnet()

@@ -166,3 +166,29 @@ def test_graph_capture_replays_the_same_scores(dev):
             model(data, bad)
     with pytest.raises(AssertionError):
         graphed(bad, check=True)
+
+
+def test_query_nbfnet_matches_reference_golden(dev):
+    """QueryNBFNet (UltraQuery's entity reasoner, models.py:212-275) on the same kernels."""
+    import os
+    from tests.test_oracle_model import GOLDEN
+    from ultra_amd.data import Data
+    g = torch.load(os.path.join(GOLDEN, "query_nbfnet_ultra_3g.pt"))
+    state = torch.load(os.path.join(GOLDEN, "ultra_3g_model.pt"))
+    cfg = synthetic.default_model_cfg()
+    qnet = models.QueryNBFNet(**{k: v for k, v in cfg["entity_model_cfg"].items() if k != "class"})
+    rnet = models.RelNBFNet(**{k: v for k, v in cfg["rel_model_cfg"].items() if k != "class"})
+    qnet.load_state_dict({k[len("entity_model."):]: v for k, v in state.items() if k.startswith("entity_model.")})
+    rnet.load_state_dict({k[len("relation_model."):]: v for k, v in state.items() if k.startswith("relation_model.")})
+    qnet, rnet = qnet.to(dev).eval(), rnet.to(dev).eval()
+    data = Data(edge_index=g["edge_index"], edge_type=g["edge_type"], num_nodes=g["num_nodes"],
+                num_relations=g["num_relations"],
+                relation_graph=Data(edge_index=g["rel_edge_index"], edge_type=g["rel_edge_type"],
+                                    num_nodes=g["num_relations"], num_relations=4)).to(dev)
+    with torch.no_grad():
+        rel_repr = rnet(data.relation_graph, query=g["query_rels"].to(dev))
+        assert (rel_repr.cpu() - g["rel_repr"]).abs().max().item() <= TOL
+        query = rel_repr[torch.arange(3, device=dev), g["query_rels"].to(dev)]
+        score = qnet(data, g["node_features"].to(dev), rel_repr, query)
+    assert score.shape == g["score"].shape
+    assert (score.cpu() - g["score"]).abs().max().item() <= TOL

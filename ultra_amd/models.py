@@ -270,8 +270,15 @@ class QueryNBFNet(EntityNBFNet):
     def forward(self, data, node_features, relation_representations, query):
         for layer in self.layers:
             layer.relation = relation_representations
-        output = self.bellmanford(data, node_features, query)
-        return self.mlp(output["node_feature"]).squeeze(-1)   # (batch, num_nodes)
+        self.query = relation_representations      # input of the batched relation projections
+        hiddens, _ = self._propagate_layers(data, node_features, query, node_features,
+                                            relations=self._project_relations_batched())
+        if dense.readout_supported(self, hiddens[-1]):
+            every = torch.arange(data.num_nodes, device=query.device).unsqueeze(0).expand(len(query), -1)
+            return dense.readout(self, hiddens[-1], query, every)
+        node_query = query.unsqueeze(1).expand(-1, data.num_nodes, -1)
+        feature = torch.cat((hiddens if self.concat_hidden else hiddens[-1:]) + [node_query], dim=-1)
+        return self.mlp(feature).squeeze(-1)   # (batch, num_nodes)
 
 
 class Ultra(nn.Module):
