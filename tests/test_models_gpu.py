@@ -192,3 +192,30 @@ def test_query_nbfnet_matches_reference_golden(dev):
         score = qnet(data, g["node_features"].to(dev), rel_repr, query)
     assert score.shape == g["score"].shape
     assert (score.cpu() - g["score"]).abs().max().item() <= TOL
+
+
+def test_training_edge_dropout_by_weight_equals_edge_removal(dev):
+    """sum aggregation: masking the batch's edges with 0/1 weights on the cached plan == rebuilding the graph
+    without them (base_nbfnet.py:54-77), forward and gradients."""
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    data = synthetic.make_kg(num_node=200, num_triple=1500, num_relation_base=4, num_test=16, seed=6).to(dev)
+    batch = torch.stack([data.edge_index[0, :4], data.edge_index[1, :4], data.edge_type[:4]], dim=-1)
+    torch.manual_seed(0)
+    neg = tasks.negative_sampling(data, batch, 4, strict=True)
+    model = build(state, cfg, dev).train()
+    ent = model.entity_model
+    out_masked = model(data, neg)
+    out_masked.sum().backward()
+    g_masked = {n: p.grad.clone() for n, p in model.named_parameters()}
+    model.zero_grad()
+    h, t, r = neg.unbind(-1)
+    removed = ent.remove_easy_edges(data, h, t, r)
+    assert removed.num_edges < data.num_edges
+    ent.eval()                       # eval mode on the edge-removed graph = the reference's training forward
+    out_removed = model(removed, neg)
+    out_removed.sum().backward()
+    ent.train()
+    assert (out_masked - out_removed).abs().max().item() <= 1e-5
+    for n, p in model.named_parameters():
+        scale = max(p.grad.abs().max().item(), 1e-6)
+        assert (p.grad - g_masked[n]).abs().max().item() <= 1e-4 * scale + 1e-7, n

@@ -46,6 +46,20 @@ class BaseNBFNet(nn.Module):
         self.activation = activation
         self.num_mlp_layers = num_mlp_layer
 
+    def easy_edge_mask(self, data, h_index, t_index, r_index=None):
+        """True for the edges base_nbfnet.py:54-77 keeps, False for the batch's own (h, t[, r]) edges and inverses."""
+        h_index_ext = torch.cat([h_index, t_index], dim=-1)
+        t_index_ext = torch.cat([t_index, h_index], dim=-1)
+        r_index_ext = torch.cat([r_index, r_index + data.num_relations // 2], dim=-1)
+        if self.remove_one_hop:
+            edge_index = data.edge_index
+            easy_edge = torch.stack([h_index_ext, t_index_ext]).flatten(1)
+        else:
+            edge_index = torch.cat([data.edge_index, data.edge_type.unsqueeze(0)])
+            easy_edge = torch.stack([h_index_ext, t_index_ext, r_index_ext]).flatten(1)
+        index = tasks.edge_match(edge_index, easy_edge)[0]
+        return ~index_to_mask(index, data.num_edges)
+
     def remove_easy_edges(self, data, h_index, t_index, r_index=None):
         # dynamic edge dropout of the training triples and their inverses (base_nbfnet.py:54-77)
         h_index_ext = torch.cat([h_index, t_index], dim=-1)
@@ -73,12 +87,13 @@ class BaseNBFNet(nn.Module):
         new_r_index = torch.where(is_t_neg, r_index, r_index + num_direct_rel)
         return new_h_index, new_t_index, new_r_index
 
-    def _propagate_layers(self, data, layer_input, query, boundary, separate_grad=False, relations=None):
+    def _propagate_layers(self, data, layer_input, query, boundary, separate_grad=False, relations=None,
+                          edge_weight=None):
         """The Bellman-Ford loop shared by every model (models.py:72-80, 150-163, 233-246).
         `relations`: optional per-layer relation features computed up front (EntityNBFNet batches the six
         relation_projection MLPs, which all read the same relation representations)."""
         size = (data.num_nodes, data.num_nodes)
-        edge_weight = None   # all ones; only materialised when its gradient is asked for
+        # edge_weight None = all ones (only materialised when its gradient is asked for); a 0/1 vector = edge dropout
         hiddens, edge_weights = [], []
         for i, layer in enumerate(self.layers):
             if separate_grad:
@@ -166,7 +181,7 @@ class EntityNBFNet(BaseNBFNet):
         mlp.append(nn.Linear(feature_dim, 1))
         self.mlp = nn.Sequential(*mlp)
 
-    def _bellmanford_hidden(self, data, h_index, r_index, separate_grad=False):
+    def _bellmanford_hidden(self, data, h_index, r_index, separate_grad=False, edge_weight=None):
         batch_size = len(r_index)
         # query = representation of each sample's query relation, scattered to its head node
         query = self.query[torch.arange(batch_size, device=r_index.device), r_index]
@@ -174,7 +189,8 @@ class EntityNBFNet(BaseNBFNet):
         boundary = torch.zeros(batch_size, data.num_nodes, self.dims[0], device=h_index.device, dtype=query.dtype)
         boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
         hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad,
-                                                       relations=self._project_relations_batched())
+                                                       relations=self._project_relations_batched(),
+                                                       edge_weight=edge_weight)
         return hiddens, edge_weights, query
 
     def _project_relations_batched(self):
@@ -217,8 +233,19 @@ class EntityNBFNet(BaseNBFNet):
         for layer in self.layers:
             layer.relation = relation_representations
 
+        edge_weight = None
         if self.training:
-            data = self.remove_easy_edges(data, h_index, t_index, r_index)
+            if self.aggregate_func in ("sum", "mean") and self.message_func in ("distmult", "transe"):
+                # Edge dropout without touching the graph: a 0/1 edge weight removes the batch's own edges from a
+                # SUM exactly (w * message = 0), so the cached plan of the static graph keeps serving every batch.
+                # (mean divides by the static degree in the reference only after its own edge removal -> keep the
+                # reference behaviour there; max/min need the edges really gone.)
+                if self.aggregate_func == "sum":
+                    edge_weight = self.easy_edge_mask(data, h_index, t_index, r_index).to(relation_representations.dtype)
+                else:
+                    data = self.remove_easy_edges(data, h_index, t_index, r_index)
+            else:
+                data = self.remove_easy_edges(data, h_index, t_index, r_index)
 
         shape = h_index.shape
         h_index, t_index, r_index = self.negative_sample_to_tail(h_index, t_index, r_index,
@@ -227,7 +254,7 @@ class EntityNBFNet(BaseNBFNet):
         # flag is computed on the GPU now and checked after the whole forward has been enqueued.
         valid = (h_index[:, :1] == h_index).all() & (r_index[:, :1] == r_index).all()
 
-        hiddens, _, query = self._bellmanford_hidden(data, h_index[:, 0], r_index[:, 0])
+        hiddens, _, query = self._bellmanford_hidden(data, h_index[:, 0], r_index[:, 0], edge_weight=edge_weight)
         if dense.readout_supported(self, hiddens[-1]):
             # gather + cat[hidden, query] + MLP in one MFMA kernel (nothing of size (bs, N, 128) is materialised)
             score = dense.readout(self, hiddens[-1], query, t_index).view(shape)
