@@ -43,6 +43,18 @@ int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1
                       const void *b2, void *score, int64_t batch, int64_t num_node, int64_t n_cand, int32_t hidden_dim,
                       int32_t feature_dim, void *stream);
 
+/*
+ * Filtered ranking without the (batch, N) mask (/root/reference/ultra/tasks.py:94-141):
+ *     rank[q] = 1 + #{t : t not in known(q) and score[q, pos[q]] <= score[q, t]}
+ *     num_negative[q] = n_cand - |known(q)|
+ * known(q) = known_index[known_ptr[q] : known_ptr[q + 1]]: the de-duplicated ids of the query's known true
+ * answers INCLUDING pos[q] (strict_negative_mask zeroes both, tasks.py:108-111).  score (batch, n_cand) fp32,
+ * everything else int64, all device pointers.  Ties count against the positive exactly like tasks.py:137.
+ */
+int32_t ultra_filtered_rank(const void *score, const int64_t *pos_index, const int64_t *known_ptr,
+                            const int64_t *known_index, int64_t batch, int64_t n_cand, int64_t *rank_out,
+                            int64_t *num_negative_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

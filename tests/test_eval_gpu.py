@@ -1,0 +1,64 @@
+"""Evaluation glue on the GPU: fused filtered-rank kernel == tasks.compute_ranking over strict_negative_mask,
+and the full evaluate() protocol equals a plain restatement of script/run.py:121-226 on the same scores."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("n,bs", [(60, 5), (5000, 8), (14541, 8)])
+def test_filtered_rank_kernel_matches_masked_ranking(dev, n, bs):
+    from ultra_amd import synthetic, tasks
+    data = synthetic.make_kg(num_node=n, num_triple=8 * n, num_relation_base=3, num_test=64, seed=n).to(dev)
+    batch = torch.stack([data.edge_index[0, :bs], data.edge_index[1, :bs], data.edge_type[:bs]], dim=-1)   # true triples
+    g = torch.Generator().manual_seed(1)
+    for quantised in (False, True):
+        pred = torch.randn(bs, n, generator=g)
+        if quantised:
+            pred = (pred * 2).round() / 2          # many exact ties: they count against the positive (tasks.py:137)
+        pred = pred.to(dev)
+        t_mask, h_mask = tasks.strict_negative_mask(data, batch)
+        for mode, mask, pos in (("tail", t_mask, batch[:, 1]), ("head", h_mask, batch[:, 0])):
+            want = tasks.compute_ranking(pred, pos, mask)
+            rank, num_neg = tasks.filtered_ranking(data, batch, pred, mode=mode)
+            assert torch.equal(rank, want)
+            assert torch.equal(num_neg, mask.sum(dim=-1))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        tasks.filtered_ranking(data.to("cpu"), batch.cpu(), pred.cpu())
+
+
+def test_evaluate_matches_reference_protocol(dev):
+    from tests.test_oracle_model import load_golden
+    from ultra_amd import eval as ueval
+    from ultra_amd import models, synthetic, tasks
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    data = synthetic.make_kg(num_node=400, num_triple=3000, num_relation_base=5, num_test=21, seed=3).to(dev)
+    model = models.Ultra(**cfg)
+    model.load_state_dict(state)
+    model = model.to(dev).eval()
+    res = ueval.evaluate(model, data, batch_size=8, metrics=("mr", "mrr", "hits@1", "hits@10", "mrr-tail"))
+    # restatement of script/run.py:131-150 + 188-224 with the mask-based ranking
+    triples = torch.cat([data.target_edge_index, data.target_edge_type.unsqueeze(0)]).t()
+    ranks, tails = [], []
+    with torch.no_grad():
+        for s in range(0, len(triples), 8):
+            batch = triples[s:s + 8]
+            t_batch, h_batch = tasks.all_negative(data, batch)
+            t_mask, h_mask = tasks.strict_negative_mask(data, batch)
+            t_rank = tasks.compute_ranking(model(data, t_batch), batch[:, 1], t_mask)
+            h_rank = tasks.compute_ranking(model(data, h_batch), batch[:, 0], h_mask)
+            ranks += [t_rank, h_rank]
+            tails += [t_rank]
+    ranking, tail = torch.cat(ranks).float(), torch.cat(tails).float()
+    assert res["_num_rankings"] == 42
+    assert res["mr"] == pytest.approx(ranking.mean().item())
+    assert res["mrr"] == pytest.approx((1 / ranking).mean().item())
+    assert res["hits@1"] == pytest.approx((ranking <= 1).float().mean().item())
+    assert res["hits@10"] == pytest.approx((ranking <= 10).float().mean().item())
+    assert res["mrr-tail"] == pytest.approx((1 / tail).mean().item())

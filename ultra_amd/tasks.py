@@ -106,6 +106,43 @@ def compute_ranking(pred, target, mask=None):
     return worse_or_equal.sum(dim=-1) + 1
 
 
+def known_answers(data, batch, mode="tail"):
+    """Ragged list of the known true tails (mode="tail": of every (h, r)) or heads (mode="head": of every
+    (t, r)) per query, de-duplicated and including the positive itself -- what strict_negative_mask
+    (tasks.py:94-130) zeroes, without building the (batch, N) mask.  Returns (ptr (bs + 1), index)."""
+    pos_h, pos_t, pos_r = batch.t()
+    if mode == "tail":
+        keyed, anchor, answer_row, positive = 0, pos_h, 1, pos_t
+    else:
+        keyed, anchor, answer_row, positive = 1, pos_t, 0, pos_h
+    edge_id, count = edge_match(torch.stack([data.edge_index[keyed], data.edge_type]), torch.stack([anchor, pos_r]))
+    truth = data.edge_index[answer_row, edge_id]
+    sample = torch.arange(len(count), device=batch.device).repeat_interleave(count)
+    n = data.num_nodes
+    key = torch.cat([sample * n + truth, torch.arange(len(batch), device=batch.device) * n + positive])
+    key = torch.unique(key)                                    # sorted: grouped by query, ids ascending
+    ptr = torch.searchsorted(key, torch.arange(len(batch) + 1, device=batch.device) * n)
+    return ptr, key % n
+
+
+def filtered_ranking(data, batch, pred, mode="tail"):
+    """(ranking, num_negative) of the positives under the filtered protocol == compute_ranking(pred, pos,
+    strict_negative_mask(...)) and mask.sum(-1), through the fused HIP kernel (no (batch, N) mask)."""
+    import ctypes
+    from ._lib import check, lib
+    if not pred.is_cuda:
+        raise RuntimeError("ultra_amd.tasks.filtered_ranking: expected a GPU tensor; the MI355X engine has no CPU path")
+    pos = (batch[:, 1] if mode == "tail" else batch[:, 0]).contiguous()
+    ptr, index = known_answers(data, batch, mode)
+    pred = pred.float().contiguous()
+    rank = torch.empty(len(batch), dtype=torch.long, device=pred.device)
+    num_neg = torch.empty_like(rank)
+    check(lib.ultra_filtered_rank(pred.data_ptr(), pos.data_ptr(), ptr.contiguous().data_ptr(), index.contiguous().data_ptr(),
+                                  pred.shape[0], pred.shape[1], rank.data_ptr(), num_neg.data_ptr(),
+                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return rank, num_neg
+
+
 def build_relation_graph(graph, node_chunk=1 << 16):
     """Relation graph of a KG that already contains inverse edges: nodes are relation ids, an edge
     (r1, r2) of type hh / tt / ht / th exists iff some entity is a head (h) or tail (t) of r1 and of
