@@ -48,7 +48,7 @@ def metrics_from_rankings(ranking, num_negative, metric_names):
 
 @torch.no_grad()
 def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", "mrr", "hits@1", "hits@3", "hits@10"),
-             max_triples=None):
+             max_triples=None, use_graph=True):
     """Returns {metric: value} on every rank (the reference only fills it on rank 0)."""
     world, rank = udist.world_size(), udist.rank()
     triples = torch.cat([test_data.target_edge_index, test_data.target_edge_type.unsqueeze(0)]).t()
@@ -61,11 +61,20 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
     was_training = model.training
     model.eval()
     rows = []
+    graphed = None
     for start in range(0, len(mine), batch_size):
         batch = mine[start:start + batch_size]
         t_batch, h_batch = tasks.all_negative(test_data, batch)
-        t_pred = model(test_data, t_batch)
-        h_pred = model(test_data, h_batch)
+        if use_graph and t_batch.is_cuda and len(batch) == batch_size and len(mine) >= 4 * batch_size:
+            # full batches replay the captured hipGraph of the forward (ultra_amd/graph.py); the ragged last one runs eagerly
+            if graphed is None:
+                from .graph import GraphedForward
+                graphed = GraphedForward(model, test_data, t_batch)
+            t_pred = graphed(t_batch).clone()
+            h_pred = graphed(h_batch).clone()
+        else:
+            t_pred = model(test_data, t_batch)
+            h_pred = model(test_data, h_batch)
         if t_pred.is_cuda:
             # fused filtered rank: no (bs, N) masks (tasks.py:94-141 in one kernel per direction)
             t_rank, t_neg = tasks.filtered_ranking(filt, batch, t_pred, mode="tail")

@@ -26,11 +26,35 @@ def _mixed_radix_scale(edge_index):
     return scale
 
 
-def edge_match(edge_index, query_index):
+class EdgeKeyIndex(object):
+    """The sorted mixed-radix keys of a static edge list: edge_match sorts the whole graph on every call
+    (tasks.py:25-26); for the evaluation loop that sort is hoisted and reused across batches."""
+
+    def __init__(self, edge_index):
+        self.scale = _mixed_radix_scale(edge_index).unsqueeze(-1)
+        self.edge_key, self.order = (edge_index * self.scale).sum(dim=0).sort()
+
+
+_KEY_INDEX_CACHE = {}
+
+
+def _key_index(tag, tensors, build):
+    key = (tag,) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    hit = _KEY_INDEX_CACHE.get(key)
+    if hit is None:
+        if len(_KEY_INDEX_CACHE) > 16:
+            _KEY_INDEX_CACHE.clear()
+        hit = (build(), tensors)          # keep the tensors alive so a recycled data_ptr cannot alias
+        _KEY_INDEX_CACHE[key] = hit
+    return hit[0]
+
+
+def edge_match(edge_index, query_index, index=None):
     """For every query column, the ids of all graph edges with the same key.
     Returns (edge ids concatenated query by query, matches per query)."""
-    scale = _mixed_radix_scale(edge_index).unsqueeze(-1)
-    edge_key, order = (edge_index * scale).sum(dim=0).sort()
+    if index is None:
+        index = EdgeKeyIndex(edge_index)
+    scale, edge_key, order = index.scale, index.edge_key, index.order
     query_key = (query_index * scale).sum(dim=0)
     lo = torch.searchsorted(edge_key, query_key, right=False)
     hi = torch.searchsorted(edge_key, query_key, right=True)
@@ -38,7 +62,7 @@ def edge_match(edge_index, query_index):
     # ranges [lo, hi) flattened: position p of query q is lo[q] + (p - first position of q)
     first = num_match.cumsum(0) - num_match
     total = int(num_match.sum())
-    pos = torch.arange(total, device=edge_index.device)
+    pos = torch.arange(total, device=query_index.device)
     pos = pos + (lo - first).repeat_interleave(num_match)
     return order[pos], num_match
 
@@ -115,7 +139,9 @@ def known_answers(data, batch, mode="tail"):
         keyed, anchor, answer_row, positive = 0, pos_h, 1, pos_t
     else:
         keyed, anchor, answer_row, positive = 1, pos_t, 0, pos_h
-    edge_id, count = edge_match(torch.stack([data.edge_index[keyed], data.edge_type]), torch.stack([anchor, pos_r]))
+    idx = _key_index(mode, (data.edge_index, data.edge_type),
+                     lambda: EdgeKeyIndex(torch.stack([data.edge_index[keyed], data.edge_type])))
+    edge_id, count = edge_match(None, torch.stack([anchor, pos_r]), index=idx)
     truth = data.edge_index[answer_row, edge_id]
     sample = torch.arange(len(count), device=batch.device).repeat_interleave(count)
     n = data.num_nodes
