@@ -1,0 +1,83 @@
+"""Secondary measurements for the non-headline BASELINE.json configs (single MI355X, synthetic shapes):
+  (3) ultra_50g-style max-aggregate zero-shot forward on the CoDEx-L shape, batch 8, all-tail;
+  (5) fine-tuning step (fwd + bwd + AdamW) on the YAGO3-10 shape, batch 8 x (1 + 256 negatives), sum aggregate;
+  plus the same fine-tuning step on the FB15k237 shape.
+Prints one JSON line per measurement."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ultra_amd import models, synthetic, tasks  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dev = torch.device("cuda:0")
+
+
+def load_model(aggr, ckpt):
+    model = models.Ultra(**synthetic.default_model_cfg(aggregate_func=aggr))
+    model.load_state_dict(torch.load(os.path.join(ROOT, "tests", "golden", ckpt + "_model.pt")))
+    return model.to(dev)
+
+
+def timeit(fn, warmup, iters):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def forward_case(shape, aggr, ckpt, bs=8):
+    data = synthetic.make_kg(**synthetic.SHAPES[shape], seed=1234).to(dev)
+    model = load_model(aggr, ckpt).eval()
+    t_batch, _ = tasks.all_negative(data, data.target_triples[:bs])
+
+    def step():
+        with torch.no_grad():
+            model(data, t_batch)
+    dt = timeit(step, 3, 20)
+    print(json.dumps({"case": "forward all-tail", "shape": shape, "aggregate": aggr, "weights": ckpt, "batch": bs,
+                      "ms_per_forward": 1e3 * dt, "triples_per_s": bs * data.num_nodes / dt, "launch": "eager"}), flush=True)
+
+
+def train_case(shape, bs=8, num_negative=256):
+    data = synthetic.make_kg(**synthetic.SHAPES[shape], seed=1234).to(dev)
+    model = load_model("sum", "ultra_50g").train()
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-4)          # config/transductive/inference.yaml:34-36
+    triples = torch.stack([data.edge_index[0], data.edge_index[1], data.edge_type], dim=-1)[: data.num_edges // 2]
+    state = {"i": 0}
+
+    def step():
+        i = state["i"]
+        state["i"] += 1
+        batch = triples[(i * bs) % 4096:(i * bs) % 4096 + bs]
+        neg = tasks.negative_sampling(data, batch, num_negative, strict=True)
+        pred = model(data, neg)
+        target = torch.zeros_like(pred)
+        target[:, 0] = 1
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(pred, target, reduction="none")
+        neg_w = torch.ones_like(pred)
+        with torch.no_grad():                                   # self-adversarial negative weights, script/run.py:66-77
+            neg_w[:, 1:] = torch.softmax(pred[:, 1:], dim=-1)
+        loss = ((loss * neg_w).sum(dim=-1) / neg_w.sum(dim=-1)).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    dt = timeit(step, 3, 10)
+    print(json.dumps({"case": "fine-tune step fwd+bwd+AdamW", "shape": shape, "batch": bs, "num_negative": num_negative,
+                      "ms_per_step": 1e3 * dt, "samples_per_s": bs / dt}), flush=True)
+
+
+if __name__ == "__main__":
+    forward_case("codex_l", "max", "ultra_50g")
+    forward_case("codex_l", "sum", "ultra_50g")
+    forward_case("wn18rr", "sum", "ultra_3g", bs=4)
+    train_case("fb15k237")
+    train_case("yago310")
