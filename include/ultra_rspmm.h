@@ -134,6 +134,19 @@ int32_t ultra_rspmm_forward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t 
                             const ultra_mat *boundary, const ultra_mat *output, void *stream);
 
 /*
+ * add_mul forward for a ROW-SPARSE input: input[o] is zero outside row src_rows_dev[o] (int64, one per outer
+ * slice) -- the layer-0 input of every NBFNet, whose boundary condition puts the query vector at the head node
+ * and zeros elsewhere (/root/reference/ultra/models.py:59-66, 135-141).  Zero rows contribute exact zeros to a
+ * sum of products, so only the edges gathered from the source row are visited (through the transposed plan, in
+ * edge-id order per target: deterministic); the result equals ultra_rspmm_forward(add, mul) on the same
+ * operands.  output is fully written (zero fill + contributions + boundary at the source row).
+ * The CALLER guarantees the sparsity pattern; square graphs only.
+ */
+int32_t ultra_rspmm_forward_onehot(ultra_plan *plan, int32_t dtype, const void *edge_weight_dev,
+                                   const ultra_mat *relation, const ultra_mat *input, const int64_t *src_rows_dev,
+                                   const ultra_mat *boundary, const ultra_mat *output, void *stream);
+
+/*
  * Backward (rspmm.cpp:77-119 / 164-219): gradients w.r.t. edge_weight (original edge order, may be
  * NULL to skip), relation and input, given the forward output and its gradient.  min/max give the
  * full gradient to every tying edge (operator.cuh:62-64,75-77).

@@ -219,3 +219,22 @@ def test_training_edge_dropout_by_weight_equals_edge_removal(dev):
     for n, p in model.named_parameters():
         scale = max(p.grad.abs().max().item(), 1e-6)
         assert (p.grad - g_masked[n]).abs().max().item() <= 1e-4 * scale + 1e-7, n
+
+
+@pytest.mark.parametrize("ckpt", ["ultra_3g"])
+def test_onehot_layer0_path_matches_dense_path(dev, ckpt):
+    """Layer 0 through the row-sparse forward == layer 0 through the dense forward (scores to fp32 round-off)."""
+    from ultra_amd import layers
+    _, state, _, cfg = load_golden(ckpt, "sum")
+    data = synthetic.make_kg(num_node=1500, num_triple=20000, num_relation_base=6, num_test=16, seed=14).to(dev)
+    model = build(state, cfg, dev)
+    t_batch, h_batch = tasks.all_negative(data, data.target_triples[:6])
+    try:
+        with torch.no_grad():
+            layers.ONEHOT_FAST_PATH = True
+            a_t, a_h = model(data, t_batch).clone(), model(data, h_batch).clone()
+            layers.ONEHOT_FAST_PATH = False
+            b_t, b_h = model(data, t_batch).clone(), model(data, h_batch).clone()
+    finally:
+        layers.ONEHOT_FAST_PATH = True
+    assert (a_t - b_t).abs().max().item() <= 2e-5 and (a_h - b_h).abs().max().item() <= 2e-5

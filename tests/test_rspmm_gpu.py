@@ -247,3 +247,37 @@ def test_full_size_properties(dev):
     lhs = y1.double().sum(0)
     rhs = (rel[et].double() * x1[ei[1]].double()).sum(0)
     assert ((lhs - rhs).abs() <= 1e-6 * (rel[et].double() * x1[ei[1]].double()).abs().sum(0)).all()
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[6], CASES[7]])
+@pytest.mark.parametrize("layout", ["batch_major", "node_major"])
+@pytest.mark.parametrize("weights", [False, True])
+def test_onehot_forward_equals_dense_forward(dev, case, layout, weights):
+    """Row-sparse (one-hot) input path == the dense add_mul forward on the same operands."""
+    from ultra_amd.rspmm import Plan
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    bs, d = 3, 64
+    g = torch.Generator().manual_seed(case["seed"])
+    src = torch.randint(0, N, (bs,), generator=g)
+    src[0] = 7 % N                                             # the hub row of CASES[1]
+    x = torch.zeros(bs, N, d)
+    x[torch.arange(bs), src] = torch.randn(bs, d, generator=g)
+    rel = torch.randn(bs, R, d, generator=g)
+    w = (torch.rand(E, generator=g) + 0.5) if weights else None
+    plan = Plan(ei, et, N, R)
+    dx, drel, dw = x.to(dev), rel.to(dev), (w.to(dev) if weights else None)
+    if layout == "batch_major":
+        want = plan.forward(drel, dx, edge_weight=dw, boundary=dx)
+        got = plan.forward_onehot(drel, dx, src.to(dev), edge_weight=dw, boundary=dx)
+    else:
+        x2, rel2 = dx[0].contiguous(), drel[0].contiguous()
+        want = plan.forward(rel2, x2, edge_weight=dw, boundary=x2)
+        got = plan.forward_onehot(rel2, x2, src[:1].to(dev), edge_weight=dw, boundary=x2)
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+    untouched = (want == 0).all(dim=-1)
+    assert (got[untouched] == 0).all()
+    # and against the oracle
+    ref = rspmm_oracle.generalized_rspmm(ei, et, w if weights else torch.ones(E), rel[0], x[0]) + x[0]
+    helpers.assert_sum_close((got[0] if layout == "batch_major" else got).cpu(), ref, ei, et,
+                             w if weights else torch.ones(E), rel[0], x[0], boundary=x[0])

@@ -66,6 +66,7 @@ def _load():
     lib.ultra_plan_get_info.argtypes = [vp, ctypes.POINTER(PlanInfo)]
     lib.ultra_plan_export.argtypes = [vp, i32, vp, i64, ctypes.POINTER(i64)]
     lib.ultra_rspmm_forward.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp]
+    lib.ultra_rspmm_forward_onehot.argtypes = [vp, i32, vp, matp, matp, vp, matp, matp, vp]
     lib.ultra_rspmm_backward.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp, matp, matp, vp]
     lib.ultra_rspmm_forward_timed.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp, i32, i32,
                                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]

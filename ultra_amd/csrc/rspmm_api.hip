@@ -383,6 +383,59 @@ static int backward_impl(ultra_plan *p, int sum, int mul, int dtype, const void 
     return ULTRA_OK;
 }
 
+// add_mul forward for an input that is zero outside one row per outer slice (NBFNet layer 0: the boundary condition).
+static int forward_onehot_impl(ultra_plan *p, int dtype, const void *w, const ultra_mat *rel, const ultra_mat *x,
+                               const int64_t *src_rows, const ultra_mat *bnd, const ultra_mat *out, hipStream_t stream) {
+    if (!p) return invalid("plan is NULL");
+    if (dtype != ULTRA_F32 && dtype != ULTRA_F64) return invalid("dtype must be ULTRA_F32 or ULTRA_F64");
+    if (!out || !out->ptr || !src_rows) return invalid("output / src_rows is NULL");
+    if (p->flags & ULTRA_PLAN_TYPE_RUNS) return invalid("use the (row, col) plan for the one-hot path");
+    const int64_t n_outer = out->n_outer, row_len = out->row_len;
+    int rc;
+    if ((rc = check_mat(out, "output", p->num_out, n_outer, row_len))) return rc;
+    if ((rc = check_mat(rel, "relation", p->num_rel, n_outer, row_len))) return rc;
+    if ((rc = check_mat(x, "input", p->num_in, n_outer, row_len))) return rc;
+    if (bnd && (rc = check_mat(bnd, "boundary", p->num_out, n_outer, row_len))) return rc;
+    if (p->num_out != p->num_in) return invalid("one-hot path needs a square graph (source rows are output rows)");
+    if ((rc = ensure_backward_plans(p))) return rc;
+    if ((rc = upload_plan(p->tplan))) return rc;
+    const size_t esz = dtype == ULTRA_F32 ? 4 : 8;
+    if (out->stride_row == row_len && (n_outer == 1 || out->stride_outer == out->n_row * row_len) && out->n_row == p->num_out) {
+        HIP_TRY(hipMemsetAsync(out->ptr, 0, (size_t)n_outer * p->num_out * row_len * esz, stream));   // contiguous: plain memset
+    } else if ((rc = launch_fill_zero(dtype, out, p->num_out, stream))) {
+        return rc;
+    }
+    const int64_t step = dtype == ULTRA_F32 ? 4 : 2;
+    const bool vec4 = (row_len % 4 == 0) && mat_vec_ok(out, step) && mat_vec_ok(rel, step) && mat_vec_ok(x, step);
+    OneHotParams op;
+    std::memset(&op, 0, sizeof(op));
+    op.trow_ptr = p->tplan->d.row_ptr;
+    op.tcol = p->tplan->d.col;
+    op.ttype = p->tplan->d.type;
+    op.tperm = p->tplan->d.perm;
+    op.w = w;
+    op.src = src_rows;
+    op.rel = MatArg{rel->ptr, rel->stride_outer, rel->stride_row};
+    op.x = MatArg{x->ptr, x->stride_outer, x->stride_row};
+    if (bnd) op.bnd = MatArg{bnd->ptr, bnd->stride_outer, bnd->stride_row};
+    op.out = out->ptr;
+    op.out_so = out->stride_outer;
+    op.out_sr = out->stride_row;
+    op.n_outer = (int32_t)n_outer;
+    op.row_len = (int32_t)row_len;
+    op.has_bnd = bnd ? 1 : 0;
+    const dim3 grid(64, (unsigned)n_outer), block(256);   // 1024 sixteen-lane groups per outer slice
+    if (dtype == ULTRA_F32) {
+        if (vec4) hipLaunchKernelGGL((rspmm_onehot_kernel<float, 4>), grid, block, 0, stream, op);
+        else hipLaunchKernelGGL((rspmm_onehot_kernel<float, 1>), grid, block, 0, stream, op);
+    } else {
+        if (vec4) hipLaunchKernelGGL((rspmm_onehot_kernel<double, 4>), grid, block, 0, stream, op);
+        else hipLaunchKernelGGL((rspmm_onehot_kernel<double, 1>), grid, block, 0, stream, op);
+    }
+    HIP_TRY(hipGetLastError());
+    return ULTRA_OK;
+}
+
 static ultra_mat dense2d(const void *ptr, int64_t rows, int64_t dim) {
     ultra_mat m;
     m.ptr = const_cast<void *>(ptr);
@@ -451,6 +504,13 @@ int32_t ultra_rspmm_forward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t 
     if (mul < 0 || mul > 1) return invalid("unknown mul code");
     return forward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, boundary, output,
                         reinterpret_cast<hipStream_t>(stream));
+}
+
+int32_t ultra_rspmm_forward_onehot(ultra_plan *plan, int32_t dtype, const void *edge_weight_dev,
+                                   const ultra_mat *relation, const ultra_mat *input, const int64_t *src_rows_dev,
+                                   const ultra_mat *boundary, const ultra_mat *output, void *stream) {
+    return forward_onehot_impl(plan, dtype, edge_weight_dev, relation, input, src_rows_dev, boundary, output,
+                               reinterpret_cast<hipStream_t>(stream));
 }
 
 int32_t ultra_rspmm_backward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype, const void *edge_weight_dev,

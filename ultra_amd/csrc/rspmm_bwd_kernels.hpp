@@ -93,6 +93,85 @@ __global__ void __launch_bounds__(256) rspmm_edge_bwd_kernel(const EdgeParams p)
     }
 }
 
+// One-hot (row-sparse) input, add_mul: x[outer] is zero except row src[outer].  Only the edges gathered FROM that
+// row contribute, i.e. the src[outer]-th row of the TRANSPOSED plan (sorted by target, stable in the edge id):
+//   out[outer, target, :] += w_e * rel[outer, type_e, :] * x[outer, src, :]
+// out was zero-filled by the caller; runs of equal target are summed by one 16-lane group in edge order (no atomics),
+// then boundary[outer, src] is added to the source row (the only non-zero boundary row of an NBFNet layer-0 input).
+struct OneHotParams {
+    const int32_t *trow_ptr;   // transposed plan: row = gathered source
+    const int32_t *tcol;       // = aggregation target
+    const int32_t *ttype;
+    const int32_t *tperm;
+    const void *w;             // original edge order or NULL
+    const int64_t *src;        // [n_outer]
+    MatArg rel, x, bnd;
+    void *out;
+    long long out_so, out_sr;
+    int32_t n_outer, row_len, has_bnd;
+};
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) rspmm_onehot_kernel(const OneHotParams p) {
+    constexpr int SPAN = 16 * VEC;
+    using P = Pack<T, VEC>;
+    const int outer = blockIdx.y;
+    const int l16 = threadIdx.x & 15;
+    const int grp = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    const int ngrp = gridDim.x * (blockDim.x >> 4);
+    const long long s = p.src[outer];
+    const int k0 = p.trow_ptr[s], k1 = p.trow_ptr[s + 1];
+    const int spans = (p.row_len + SPAN - 1) / SPAN;
+    const T *xrow = reinterpret_cast<const T *>(p.x.ptr) + outer * p.x.stride_outer + s * p.x.stride_row;
+    const T *relb = reinterpret_cast<const T *>(p.rel.ptr) + outer * p.rel.stride_outer;
+    const T *bndrow = p.has_bnd ? reinterpret_cast<const T *>(p.bnd.ptr) + outer * p.bnd.stride_outer + s * p.bnd.stride_row
+                                : nullptr;
+    T *outb = reinterpret_cast<T *>(p.out) + outer * p.out_so;
+    // the source row's out-edges are sorted by target: each run of equal targets belongs to the group that owns
+    // its first edge and is summed in edge order
+    for (int k = k0 + grp; k < k1; k += ngrp) {
+        const int target = p.tcol[k];
+        if (k > k0 && p.tcol[k - 1] == target) continue;
+        int kend = k + 1;
+        while (kend < k1 && p.tcol[kend] == target) ++kend;
+        for (int sp = 0; sp < spans; ++sp) {
+            const int d0 = sp * SPAN + l16 * VEC;
+            if (d0 >= p.row_len) continue;
+            const P xv = *reinterpret_cast<const P *>(xrow + d0);
+            P acc;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc.v[e] = T(0);
+            for (int kk = k; kk < kend; ++kk) {
+                const P rv = *reinterpret_cast<const P *>(relb + (long long)p.ttype[kk] * p.rel.stride_row + d0);
+                const T w = p.w ? reinterpret_cast<const T *>(p.w)[p.tperm[kk]] : T(1);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    T y = rv.v[e] * xv.v[e];
+                    if (p.w) y = w * y;
+                    acc.v[e] = acc.v[e] + y;
+                }
+            }
+            if (bndrow && target == s) {   // update + boundary (layers.py:200): after the sum
+                const P b = *reinterpret_cast<const P *>(bndrow + d0);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc.v[e] = acc.v[e] + b.v[e];
+            }
+            *reinterpret_cast<P *>(outb + (long long)target * p.out_sr + d0) = acc;
+        }
+    }
+    // no edge leads back to the source row itself: its output is 0 + boundary
+    if (bndrow && grp == 0) {
+        int lo = k0, hi = k1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (p.tcol[mid] < (int)s) lo = mid + 1; else hi = mid;
+        }
+        if (!(lo < k1 && p.tcol[lo] == (int)s)) {
+            for (int d = l16; d < p.row_len; d += 16) outb[s * p.out_sr + d] = bndrow[d];
+        }
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) fill_zero_kernel(T *ptr, int n_outer, long long so, long long n_row, long long sr,
                                                         int row_len) {

@@ -14,6 +14,12 @@ from torch.nn import functional as F
 from . import dense, rspmm
 
 
+# Layer 0 of every NBFNet reads the boundary condition itself: zero everywhere except the head row of each sample.
+# With sum aggregation and DistMult messages only that row's out-edges contribute (exactly), so the layer can ask
+# the engine for the row-sparse forward instead of the dense one.  Module-level switch for A/B tests.
+ONEHOT_FAST_PATH = True
+
+
 def _scatter(src, index, dim_size, reduce):
     # src (batch, M, d) scattered along dim 1 (what torch_scatter.scatter does at layers.py:165-179)
     shape = (src.shape[0], dim_size, src.shape[2])
@@ -84,9 +90,10 @@ class GeneralizedRelationalConv(nn.Module):
         return self._forward_impl(input, query, boundary, edge_index, edge_type, size, edge_weight, residual=False)
 
     def _forward_impl(self, input, query, boundary, edge_index, edge_type, size, edge_weight=None, residual=False,
-                      relation=None):
-        """forward() plus the option to fuse the caller's residual `hidden + layer_input` (models.py:158-160)
-        and to take this layer's relation features precomputed by the caller."""
+                      relation=None, onehot_rows=None):
+        """forward() plus the option to fuse the caller's residual `hidden + layer_input` (models.py:158-160),
+        to take this layer's relation features precomputed by the caller, and to be told that `input` is zero
+        outside row onehot_rows[b] of every sample (the layer-0 boundary condition, models.py:139-141)."""
         batch_size = len(query)
 
         if relation is not None:
@@ -101,9 +108,10 @@ class GeneralizedRelationalConv(nn.Module):
         # edge_weight=None means "all ones" (what every caller on the fused path passes, models.py:143):
         # the kernel then skips the weight stream instead of multiplying by 1.
         return self.propagate(input=input, relation=relation, boundary=boundary, edge_index=edge_index,
-                              edge_type=edge_type, size=size, edge_weight=edge_weight, residual=residual)
+                              edge_type=edge_type, size=size, edge_weight=edge_weight, residual=residual,
+                              onehot_rows=onehot_rows)
 
-    def propagate(self, edge_index, size=None, residual=False, **kwargs):
+    def propagate(self, edge_index, size=None, residual=False, onehot_rows=None, **kwargs):
         edge_weight = kwargs["edge_weight"]
         if (edge_weight is not None and edge_weight.requires_grad) or self.message_func == "rotate":
             # layers.py:91-94: the fused kernel covers TransE / DistMult with constant edge weights only
@@ -111,7 +119,8 @@ class GeneralizedRelationalConv(nn.Module):
             return out + kwargs["input"] if residual else out
         num_node = size[0] if size is not None else kwargs["input"].shape[1]
         out = self.message_and_aggregate(edge_index, kwargs["input"], kwargs["relation"], kwargs["boundary"],
-                                         kwargs["edge_type"], edge_weight, edge_index[1], num_node)
+                                         kwargs["edge_type"], edge_weight, edge_index[1], num_node,
+                                         onehot_rows=onehot_rows)
         return self.update(out, kwargs["input"], residual=residual)
 
     # ---- unfused path: PyG semantics (gather edge_index[0], scatter to edge_index[1]; layers.py:135-181) ----
@@ -166,7 +175,8 @@ class GeneralizedRelationalConv(nn.Module):
         return output
 
     # ---- fused path ----
-    def message_and_aggregate(self, edge_index, input, relation, boundary, edge_type, edge_weight, index, dim_size):
+    def message_and_aggregate(self, edge_index, input, relation, boundary, edge_type, edge_weight, index, dim_size,
+                              onehot_rows=None):
         """(batch, N, d) in, (batch, N, d') out.  Aggregates into edge_index[0] from edge_index[1]
         (the fused kernel's direction, rspmm.cpp:143-145) -- not the unfused path's direction."""
         batch_size, num_node = input.shape[:2]
@@ -194,7 +204,11 @@ class GeneralizedRelationalConv(nn.Module):
             # layers.py:193 -- PyG's `index` is edge_index[1]
             degree_out = (torch.bincount(index, minlength=dim_size).to(input.dtype) + 1).view(1, -1, 1)
 
-        if self.aggregate_func == "sum":
+        if (ONEHOT_FAST_PATH and onehot_rows is not None and not needs_grad and self.aggregate_func == "sum"
+                and mul == "mul" and input.is_cuda):
+            # row-sparse input (layer 0): only the edges leaving the source rows contribute to a sum of products
+            update = plan.forward_onehot(relation, input, onehot_rows, edge_weight=edge_weight, boundary=boundary)
+        elif self.aggregate_func == "sum":
             update = agg("add", fuse_boundary=boundary)
         elif self.aggregate_func == "mean":
             update = agg("add", fuse_boundary=boundary) / degree_out

@@ -88,7 +88,7 @@ class BaseNBFNet(nn.Module):
         return new_h_index, new_t_index, new_r_index
 
     def _propagate_layers(self, data, layer_input, query, boundary, separate_grad=False, relations=None,
-                          edge_weight=None):
+                          edge_weight=None, onehot_rows=None):
         """The Bellman-Ford loop shared by every model (models.py:72-80, 150-163, 233-246).
         `relations`: optional per-layer relation features computed up front (EntityNBFNet batches the six
         relation_projection MLPs, which all read the same relation representations)."""
@@ -102,7 +102,8 @@ class BaseNBFNet(nn.Module):
             residual = self.short_cut and layer.output_dim == layer_input.shape[-1]
             hidden = layer._forward_impl(layer_input, query, boundary, data.edge_index, data.edge_type, size,
                                          edge_weight, residual=residual,
-                                         relation=None if relations is None else relations[i])
+                                         relation=None if relations is None else relations[i],
+                                         onehot_rows=onehot_rows if i == 0 else None)
             hiddens.append(hidden)
             edge_weights.append(edge_weight)
             layer_input = hidden
@@ -140,7 +141,9 @@ class RelNBFNet(BaseNBFNet):
         boundary = torch.zeros(batch_size, data.num_nodes, self.dims[0], device=h_index.device)
         boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
 
-        hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad=False)
+        # layer 0 reads the one-hot boundary itself: tell the layer which row of each sample is non-zero
+        hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad=False,
+                                                       onehot_rows=h_index)
 
         node_query = query.unsqueeze(1).expand(-1, data.num_nodes, -1)
         if self.concat_hidden:
@@ -190,7 +193,7 @@ class EntityNBFNet(BaseNBFNet):
         boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
         hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad,
                                                        relations=self._project_relations_batched(),
-                                                       edge_weight=edge_weight)
+                                                       edge_weight=edge_weight, onehot_rows=h_index)
         return hiddens, edge_weights, query
 
     def _project_relations_batched(self):

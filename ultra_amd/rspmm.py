@@ -149,6 +149,35 @@ class Plan(object):
                                       ctypes.byref(mx), mb, ctypes.byref(mout), _stream()))
         return out
 
+    def forward_onehot(self, relation, input, src_rows, edge_weight=None, boundary=None):
+        """add_mul forward for an input that is zero outside row src_rows[o] of every outer slice (the NBFNet
+        layer-0 boundary condition).  Same result as forward(sum="add", mul="mul"), visiting only the edges
+        gathered from the source rows."""
+        _require_gpu(relation, input, edge_weight, boundary, src_rows)
+        dt = _dtype_code(*([relation, input] + ([edge_weight] if edge_weight is not None else [])
+                           + ([boundary] if boundary is not None else [])))
+        relation, mrel = as_mat(relation)
+        input, mx = as_mat(input)
+        shape = list(input.shape)
+        shape[-2] = self.num_node
+        out = torch.empty(shape, dtype=input.dtype, device=input.device)
+        out, mout = as_mat(out)
+        n_outer = 1 if input.dim() == 2 else input.shape[0]
+        src_rows = src_rows.to(torch.int64).contiguous()
+        if src_rows.numel() != n_outer:
+            raise RuntimeError("Expected one source row per outer slice (%d), got %d" % (n_outer, src_rows.numel()))
+        mb = None
+        if boundary is not None:
+            boundary, mbv = as_mat(boundary)
+            mb = ctypes.byref(mbv)
+        w = None
+        if edge_weight is not None:
+            edge_weight = edge_weight.contiguous()
+            w = edge_weight.data_ptr()
+        check(lib.ultra_rspmm_forward_onehot(self._h, dt, w, ctypes.byref(mrel), ctypes.byref(mx), src_rows.data_ptr(), mb,
+                                             ctypes.byref(mout), _stream()))
+        return out
+
     def backward(self, relation, input, output, output_grad, edge_weight=None, need_weight_grad=False, sum="add",
                  mul="mul"):
         _require_gpu(relation, input, output, output_grad, edge_weight)
