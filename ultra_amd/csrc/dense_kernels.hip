@@ -45,9 +45,11 @@ __global__ void __launch_bounds__(256) conv_update_kernel(const ConvParams p) {
     __shared__ __attribute__((aligned(16))) float lds_w[2 * 16 * 64 * 4];
     __shared__ float lds_vec[3 * 64];
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < 2 * 16 * 64 * 4; idx += 256) {
-        const int q = idx & 3, l = (idx >> 2) & 63, i = (idx >> 8) & 15, m = idx >> 12;
-        lds_w[idx] = p.weight[(32 * m + (l & 31)) * 128 + 8 * i + 4 * (l >> 5) + q];
+    // 16-byte staging loads: fragment (m, i, lane) = 4 consecutive k of one weight row
+    for (int idx4 = tid; idx4 < 2 * 16 * 64; idx4 += 256) {
+        const int l = idx4 & 63, i = (idx4 >> 6) & 15, m = idx4 >> 10;
+        reinterpret_cast<float4 *>(lds_w)[idx4] =
+            *reinterpret_cast<const float4 *>(p.weight + (32 * m + (l & 31)) * 128 + 8 * i + 4 * (l >> 5));
     }
     if (tid < 64) {
         lds_vec[tid] = p.bias ? p.bias[tid] : 0.f;
@@ -191,9 +193,10 @@ __global__ void __launch_bounds__(256) readout_kernel(const ReadoutParams p) {
     __shared__ __attribute__((aligned(16))) float lds_w[4 * 8 * 64 * 4];
     __shared__ float lds_w2[128];
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < 4 * 8 * 64 * 4; idx += 256) {
-        const int q = idx & 3, l = (idx >> 2) & 63, i = (idx >> 8) & 7, m = idx >> 11;
-        lds_w[idx] = p.w1[(32 * m + (l & 31)) * 128 + 8 * i + 4 * (l >> 5) + q];
+    for (int idx4 = tid; idx4 < 4 * 8 * 64; idx4 += 256) {
+        const int l = idx4 & 63, i = (idx4 >> 6) & 7, m = idx4 >> 9;
+        reinterpret_cast<float4 *>(lds_w)[idx4] =
+            *reinterpret_cast<const float4 *>(p.w1 + (32 * m + (l & 31)) * 128 + 8 * i + 4 * (l >> 5));
     }
     if (tid < 128) lds_w2[tid] = p.w2[tid];
     __syncthreads();
