@@ -251,11 +251,16 @@ class EntityNBFNet(BaseNBFNet):
                 data = self.remove_easy_edges(data, h_index, t_index, r_index)
 
         shape = h_index.shape
-        h_index, t_index, r_index = self.negative_sample_to_tail(h_index, t_index, r_index,
-                                                                 num_direct_rel=data.num_relations // 2)
-        # models.py:196-197 asserts these on the spot (two host syncs in the middle of the forward); here the
-        # flag is computed on the GPU now and checked after the whole forward has been enqueued.
-        valid = (h_index[:, :1] == h_index).all() & (r_index[:, :1] == r_index).all()
+        # One reduction tells, per row, whether heads / tails / relations are constant along the candidates:
+        # it drives the head->tail conversion (base_nbfnet.py:82) AND replaces the two asserts of models.py:196-197
+        # (two host syncs in the middle of the forward there; here the flag is checked after the whole forward has
+        # been enqueued): a converted row has a uniform head iff its heads or its tails were uniform.
+        same = (batch == batch[:, :1]).all(dim=1)                      # (bs, 3): h, t, r uniform?
+        is_t_neg = same[:, :1]
+        num_direct_rel = data.num_relations // 2
+        h_index, t_index, r_index = (torch.where(is_t_neg, h_index, t_index), torch.where(is_t_neg, t_index, h_index),
+                                     torch.where(is_t_neg, r_index, r_index + num_direct_rel))
+        valid = ((same[:, 0] | same[:, 1]) & same[:, 2]).all()
 
         hiddens, _, query = self._bellmanford_hidden(data, h_index[:, 0], r_index[:, 0], edge_weight=edge_weight)
         if dense.readout_supported(self, hiddens[-1]):
