@@ -44,6 +44,21 @@ int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1
                       int32_t feature_dim, void *stream);
 
 /*
+ * Batch prologue of EntityNBFNet.forward (/root/reference/ultra/models.py:190-197 with
+ * /root/reference/ultra/base_nbfnet.py:79-86) in one pass over triples = (batch, n_cand, 3) int64 [h, t, r]:
+ *   side[b] = 1 if row b keeps its head fixed (tail candidates), 0 if it keeps its tail fixed (head candidates, turned
+ *             into a tail query with the inverse relation r + num_direct_rel);
+ *   h0[b], r0[b] = source node / query relation of row b after that conversion;
+ *   *valid = 1 iff every row shares its source node and its relation (the reference's two asserts), else 0.
+ * ultra_readout_batch is ultra_readout reading the candidate node straight from `triples` (column 1 or 0 by side[b]).
+ */
+int32_t ultra_batch_prologue(const int64_t *triples, int64_t batch, int64_t n_cand, int64_t num_direct_rel, int64_t *h0,
+                             int64_t *r0, int32_t *side, int32_t *valid, void *stream);
+int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const int32_t *side, const void *w1,
+                            const void *qbias, const void *w2, const void *b2, void *score, int64_t batch, int64_t num_node,
+                            int64_t n_cand, int32_t hidden_dim, int32_t feature_dim, void *stream);
+
+/*
  * Filtered ranking without the (batch, N) mask (/root/reference/ultra/tasks.py:94-141):
  *     rank[q] = 1 + #{t : t not in known(q) and score[q, pos[q]] <= score[q, t]}
  *     num_negative[q] = n_cand - |known(q)|

@@ -180,6 +180,8 @@ __global__ void __launch_bounds__(256) conv_update_kernel(const ConvParams p) {
 struct ReadoutParams {
     const float *hidden;     // (batch, num_node, 64) contiguous
     const int64_t *t_index;  // (batch, n_cand) node ids, or NULL = identity (all-tail)
+    const int64_t *triples;  // alternative to t_index: the raw (batch, n_cand, 3) [h, t, r] batch ...
+    const int32_t *side;     // ... with side[b] = 1 -> candidates are the tails (column 1), 0 -> the heads (column 0)
     const float *w1;         // (128, 128) row-major; only the first 64 input columns are used here
     const float *qbias;      // (batch, 128) = W1[:, 64:] . query + b1
     const float *w2;         // (128)
@@ -211,7 +213,11 @@ __global__ void __launch_bounds__(256) readout_kernel(const ReadoutParams p) {
         const long long rowc = valid ? row : total - 1;
         const long long b = rowc / p.n_cand;
         const long long c = rowc - b * p.n_cand;
-        const long long node = p.t_index ? p.t_index[rowc] : c;
+        long long node = c;
+        if (p.triples)
+            node = p.triples[rowc * 3 + (p.side[b] ? 1 : 0)];
+        else if (p.t_index)
+            node = p.t_index[rowc];
         const float4 *hr = reinterpret_cast<const float4 *>(p.hidden + (b * p.num_node + node) * 64);
         float4 bh[8];
 #pragma unroll
@@ -325,6 +331,43 @@ int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1
     ReadoutParams p;
     p.hidden = (const float *)hidden;
     p.t_index = t_index;
+    p.triples = nullptr;
+    p.side = nullptr;
+    p.w1 = (const float *)w1;
+    p.qbias = (const float *)qbias;
+    p.w2 = (const float *)w2;
+    p.b2 = (const float *)b2;
+    p.score = (float *)score;
+    p.batch = batch;
+    p.num_node = num_node;
+    p.n_cand = n_cand;
+    const int grid = grid_for((batch * n_cand + 31) / 32, 4);
+    hipLaunchKernelGGL(readout_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error(std::string("readout_kernel launch: ") + hipGetErrorString(e));
+        return ULTRA_ERR_HIP;
+    }
+    return ULTRA_OK;
+}
+
+int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const int32_t *side, const void *w1,
+                            const void *qbias, const void *w2, const void *b2, void *score, int64_t batch, int64_t num_node,
+                            int64_t n_cand, int32_t hidden_dim, int32_t feature_dim, void *stream) {
+    if (hidden_dim != 64 || feature_dim != 128) {
+        set_error("ultra_readout_batch: only hidden_dim = 64, feature_dim = 128 is built (the ULTRA checkpoints' shape)");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    if (!hidden || !triples || !side || !w1 || !qbias || !w2 || !b2 || !score || batch < 0 || n_cand < 0) {
+        set_error("ultra_readout_batch: NULL operand");
+        return ULTRA_ERR_INVALID;
+    }
+    if (batch * n_cand == 0) return ULTRA_OK;
+    ReadoutParams p;
+    p.hidden = (const float *)hidden;
+    p.t_index = nullptr;
+    p.triples = triples;
+    p.side = side;
     p.w1 = (const float *)w1;
     p.qbias = (const float *)qbias;
     p.w2 = (const float *)w2;

@@ -43,7 +43,62 @@ __global__ void __launch_bounds__(256) filtered_rank_kernel(const float *__restr
     if ((threadIdx.x & 63) == 0) atomicAdd(rank + q, (unsigned long long)count);
 }
 
+// Batch prologue of EntityNBFNet.forward (models.py:190-197 + base_nbfnet.py:79-86) in one pass over the
+// (batch, n_cand, 3) int64 triples [h, t, r]:
+//   side[b]  = 1 if every candidate of row b shares the head (a tail-prediction row), else 0 (head-prediction row:
+//              the propagation then starts from the shared TAIL with the inverse relation r + num_direct_rel);
+//   h0[b], r0[b] = source node and query relation of the row after that conversion;
+//   *valid  &= the row really shares its source node and its relation (the reference's two asserts).
+__global__ void __launch_bounds__(256) batch_prologue_kernel(const int64_t *__restrict__ batch, long long n_cand,
+                                                             long long num_direct_rel, int64_t *h0, int64_t *r0,
+                                                             int32_t *side, int32_t *valid) {
+    const int b = blockIdx.x;
+    const int64_t *row = batch + (long long)b * n_cand * 3;
+    const int64_t fh = row[0], ft = row[1], fr = row[2];
+    int same_h = 1, same_t = 1, same_r = 1;
+    for (long long i = threadIdx.x; i < n_cand; i += blockDim.x) {
+        same_h &= (row[3 * i] == fh);
+        same_t &= (row[3 * i + 1] == ft);
+        same_r &= (row[3 * i + 2] == fr);
+    }
+    __shared__ int flags[3];
+    if (threadIdx.x == 0) flags[0] = flags[1] = flags[2] = 1;
+    __syncthreads();
+    if (!__all(same_h)) { if ((threadIdx.x & 63) == 0) atomicAnd(&flags[0], 0); }
+    if (!__all(same_t)) { if ((threadIdx.x & 63) == 0) atomicAnd(&flags[1], 0); }
+    if (!__all(same_r)) { if ((threadIdx.x & 63) == 0) atomicAnd(&flags[2], 0); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tail_row = flags[0];     // base_nbfnet.py:82 is_t_neg
+        side[b] = tail_row;
+        h0[b] = tail_row ? fh : ft;
+        r0[b] = tail_row ? fr : fr + num_direct_rel;
+        if (!((flags[0] | flags[1]) & flags[2])) atomicAnd(valid, 0);
+    }
+}
+
 }  // namespace ultra
+
+extern "C" int32_t ultra_batch_prologue(const int64_t *batch, int64_t batch_size, int64_t n_cand, int64_t num_direct_rel,
+                                        int64_t *h0, int64_t *r0, int32_t *side, int32_t *valid, void *stream) {
+    if (!batch || !h0 || !r0 || !side || !valid || batch_size < 0 || n_cand <= 0) {
+        ultra::set_error("ultra_batch_prologue: NULL operand or empty candidate set");
+        return ULTRA_ERR_INVALID;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(valid, 0xff, sizeof(int32_t), s) != hipSuccess) {
+        ultra::set_error("ultra_batch_prologue: hipMemsetAsync failed");
+        return ULTRA_ERR_HIP;
+    }
+    if (batch_size == 0) return ULTRA_OK;
+    hipLaunchKernelGGL(ultra::batch_prologue_kernel, dim3((unsigned)batch_size), dim3(256), 0, s, batch, (long long)n_cand,
+                       (long long)num_direct_rel, h0, r0, side, valid);
+    if (hipGetLastError() != hipSuccess) {
+        ultra::set_error("batch_prologue_kernel launch failed");
+        return ULTRA_ERR_HIP;
+    }
+    return ULTRA_OK;
+}
 
 extern "C" int32_t ultra_filtered_rank(const void *score, const int64_t *pos_index, const int64_t *known_ptr,
                                        const int64_t *known_index, int64_t batch, int64_t n_cand, int64_t *rank_out,

@@ -64,3 +64,31 @@ def readout(model, hidden, query, t_index):
                             mlp[2].weight.data_ptr(), mlp[2].bias.data_ptr(), score.data_ptr(), batch, num_node, n_cand,
                             64, 128, _stream()))
     return score
+
+
+def batch_prologue(batch, num_direct_rel):
+    """(h0, r0, side, valid) of a (bs, n_cand, 3) GPU batch in one kernel (models.py:190-197, base_nbfnet.py:79-86)."""
+    batch = batch.contiguous()
+    bs, n_cand = batch.shape[:2]
+    h0 = torch.empty(bs, dtype=torch.long, device=batch.device)
+    r0 = torch.empty_like(h0)
+    side = torch.empty(bs, dtype=torch.int32, device=batch.device)
+    valid = torch.empty(1, dtype=torch.int32, device=batch.device)
+    check(lib.ultra_batch_prologue(batch.data_ptr(), bs, n_cand, int(num_direct_rel), h0.data_ptr(), r0.data_ptr(),
+                                   side.data_ptr(), valid.data_ptr(), _stream()))
+    return batch, h0, r0, side, valid
+
+
+def readout_batch(model, hidden, query, batch, side):
+    """readout() with the candidate node read straight from the raw (bs, n_cand, 3) batch."""
+    mlp = model.mlp
+    w1 = mlp[0].weight
+    qbias = F.linear(query, w1[:, 64:], mlp[0].bias).contiguous()
+    hidden = hidden.contiguous()
+    bs, num_node = hidden.shape[:2]
+    n_cand = batch.shape[1]
+    score = torch.empty(bs, n_cand, dtype=hidden.dtype, device=hidden.device)
+    check(lib.ultra_readout_batch(hidden.data_ptr(), batch.data_ptr(), side.data_ptr(), w1.data_ptr(), qbias.data_ptr(),
+                                  mlp[2].weight.data_ptr(), mlp[2].bias.data_ptr(), score.data_ptr(), bs, num_node, n_cand,
+                                  64, 128, _stream()))
+    return score

@@ -38,5 +38,5 @@ class GraphedForward(object):
         self.static_batch.copy_(batch, non_blocking=True)
         self.graph.replay()
         if check and self.valid is not None:
-            assert self.valid, "every row of `batch` must share its head (or tail) and its relation (models.py:196-197)"
+            assert bool(self.valid.all()), "every row of `batch` must share its head (or tail) and its relation (models.py:196-197)"
         return self.static_out

@@ -251,6 +251,17 @@ class EntityNBFNet(BaseNBFNet):
                 data = self.remove_easy_edges(data, h_index, t_index, r_index)
 
         shape = h_index.shape
+        if (edge_weight is None and not self.training and not torch.is_grad_enabled() and batch.is_cuda
+                and batch.dtype == torch.long and batch.dim() == 3 and not self.concat_hidden):
+            # inference fast path: one prologue kernel (row uniformity, head->tail conversion, validity flag) and
+            # a readout that picks its candidate column straight from the raw batch
+            batch_c, h0, r0, side, valid = dense.batch_prologue(batch, data.num_relations // 2)
+            hiddens, _, query = self._bellmanford_hidden(data, h0, r0)
+            if dense.readout_supported(self, hiddens[-1]):
+                score = dense.readout_batch(self, hiddens[-1], query, batch_c, side).view(shape)
+                self._check_valid(valid)
+                return score
+            # (shape not covered by the fused readout: fall through to the generic path below)
         # One reduction tells, per row, whether heads / tails / relations are constant along the candidates:
         # it drives the head->tail conversion (base_nbfnet.py:82) AND replaces the two asserts of models.py:196-197
         # (two host syncs in the middle of the forward there; here the flag is checked after the whole forward has
@@ -283,7 +294,7 @@ class EntityNBFNet(BaseNBFNet):
         if valid.is_cuda and torch.cuda.is_current_stream_capturing():
             self._pending_valid = valid      # checked by the graph wrapper after replay (graph.py)
             return
-        assert valid, "every row of `batch` must share its head (or tail) and its relation (models.py:196-197)"
+        assert bool(valid.all()), "every row of `batch` must share its head (or tail) and its relation (models.py:196-197)"
 
 
 class QueryNBFNet(EntityNBFNet):
