@@ -49,7 +49,7 @@ int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1
  *   side[b] = 1 if row b keeps its head fixed (tail candidates), 0 if it keeps its tail fixed (head candidates, turned
  *             into a tail query with the inverse relation r + num_direct_rel);
  *   h0[b], r0[b] = source node / query relation of row b after that conversion;
- *   *valid = 1 iff every row shares its source node and its relation (the reference's two asserts), else 0.
+ *   valid[b] = 1 iff row b shares its source node and its relation (the reference's two asserts), else 0  (int32 [batch]).
  * ultra_readout_batch is ultra_readout reading the candidate node straight from `triples` (column 1 or 0 by side[b]).
  */
 int32_t ultra_batch_prologue(const int64_t *triples, int64_t batch, int64_t n_cand, int64_t num_direct_rel, int64_t *h0,

@@ -62,3 +62,31 @@ def test_evaluate_matches_reference_protocol(dev):
     assert res["hits@1"] == pytest.approx((ranking <= 1).float().mean().item())
     assert res["hits@10"] == pytest.approx((ranking <= 10).float().mean().item())
     assert res["mrr-tail"] == pytest.approx((1 / tail).mean().item())
+
+
+def test_graph_replay_stays_correct_when_interleaved_with_eager_work(dev):
+    """Regression: hipGraph replays of the forward interleaved with eager forwards / ranking kernels must keep
+    matching the eager scores (memset NODES captured from hipMemsetAsync were observed to go stale on ROCm 7.2
+    once eager memsets interleave; the captured path uses fill kernels instead)."""
+    from tests.test_oracle_model import load_golden
+    from ultra_amd import eval as ueval
+    from ultra_amd import models, synthetic, tasks
+    from ultra_amd.graph import GraphedForward
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    data = synthetic.make_kg(**synthetic.SHAPES["fb15k237"], seed=1234).to(dev)
+    model = models.Ultra(**cfg)
+    model.load_state_dict(state)
+    model = model.to(dev).eval()
+    triples = data.target_triples[:256]
+    graphed = None
+    with torch.no_grad():
+        for s in range(0, 256, 8):
+            for b in tasks.all_negative(data, triples[s:s + 8]):
+                if graphed is None:
+                    graphed = GraphedForward(model, data, b)
+                got = graphed(b).clone()
+                want = model(data, b)                         # eager forward between replays
+                assert torch.equal(got, want), "replay %d diverged" % s
+    a = ueval.evaluate(model, data, batch_size=8, max_triples=256, use_graph=True)
+    b = ueval.evaluate(model, data, batch_size=8, max_triples=256, use_graph=False)
+    assert a == b

@@ -48,7 +48,8 @@ __global__ void __launch_bounds__(256) filtered_rank_kernel(const float *__restr
 //   side[b]  = 1 if every candidate of row b shares the head (a tail-prediction row), else 0 (head-prediction row:
 //              the propagation then starts from the shared TAIL with the inverse relation r + num_direct_rel);
 //   h0[b], r0[b] = source node and query relation of the row after that conversion;
-//   *valid  &= the row really shares its source node and its relation (the reference's two asserts).
+//   valid[b] = the row really shares its source node and its relation (the reference's two asserts), per row:
+//              no initialisation pass / memset node is needed (hipGraph friendly).
 __global__ void __launch_bounds__(256) batch_prologue_kernel(const int64_t *__restrict__ batch, long long n_cand,
                                                              long long num_direct_rel, int64_t *h0, int64_t *r0,
                                                              int32_t *side, int32_t *valid) {
@@ -73,7 +74,7 @@ __global__ void __launch_bounds__(256) batch_prologue_kernel(const int64_t *__re
         side[b] = tail_row;
         h0[b] = tail_row ? fh : ft;
         r0[b] = tail_row ? fr : fr + num_direct_rel;
-        if (!((flags[0] | flags[1]) & flags[2])) atomicAnd(valid, 0);
+        valid[b] = ((flags[0] | flags[1]) & flags[2]) ? 1 : 0;
     }
 }
 
@@ -86,10 +87,6 @@ extern "C" int32_t ultra_batch_prologue(const int64_t *batch, int64_t batch_size
         return ULTRA_ERR_INVALID;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(valid, 0xff, sizeof(int32_t), s) != hipSuccess) {
-        ultra::set_error("ultra_batch_prologue: hipMemsetAsync failed");
-        return ULTRA_ERR_HIP;
-    }
     if (batch_size == 0) return ULTRA_OK;
     hipLaunchKernelGGL(ultra::batch_prologue_kernel, dim3((unsigned)batch_size), dim3(256), 0, s, batch, (long long)n_cand,
                        (long long)num_direct_rel, h0, r0, side, valid);

@@ -400,8 +400,13 @@ static int forward_onehot_impl(ultra_plan *p, int dtype, const void *w, const ul
     if ((rc = ensure_backward_plans(p))) return rc;
     if ((rc = upload_plan(p->tplan))) return rc;
     const size_t esz = dtype == ULTRA_F32 ? 4 : 8;
-    if (out->stride_row == row_len && (n_outer == 1 || out->stride_outer == out->n_row * row_len) && out->n_row == p->num_out) {
-        HIP_TRY(hipMemsetAsync(out->ptr, 0, (size_t)n_outer * p->num_out * row_len * esz, stream));   // contiguous: plain memset
+    if (out->stride_row == row_len && (n_outer == 1 || out->stride_outer == out->n_row * row_len) && out->n_row == p->num_out &&
+        aligned16(out->ptr) && ((size_t)n_outer * p->num_out * row_len * esz) % 16 == 0) {
+        // contiguous: streaming 16-byte zero fill.  (A kernel rather than hipMemsetAsync: memset nodes captured into a
+        // hipGraph were observed to replay wrongly once eager memsets interleave with the replays on ROCm 7.2.)
+        const long long n16 = (long long)((size_t)n_outer * p->num_out * row_len * esz / 16);
+        hipLaunchKernelGGL(zero16_kernel, dim3(1024), dim3(256), 0, stream, reinterpret_cast<float4 *>(out->ptr), n16);
+        HIP_TRY(hipGetLastError());
     } else if ((rc = launch_fill_zero(dtype, out, p->num_out, stream))) {
         return rc;
     }

@@ -172,6 +172,11 @@ __global__ void __launch_bounds__(256) rspmm_onehot_kernel(const OneHotParams p)
     }
 }
 
+__global__ void __launch_bounds__(256) zero16_kernel(float4 *ptr, long long n16) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) ptr[i] = z;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) fill_zero_kernel(T *ptr, int n_outer, long long so, long long n_row, long long sr,
                                                         int row_len) {

@@ -73,7 +73,7 @@ def batch_prologue(batch, num_direct_rel):
     h0 = torch.empty(bs, dtype=torch.long, device=batch.device)
     r0 = torch.empty_like(h0)
     side = torch.empty(bs, dtype=torch.int32, device=batch.device)
-    valid = torch.empty(1, dtype=torch.int32, device=batch.device)
+    valid = torch.empty(bs, dtype=torch.int32, device=batch.device)
     check(lib.ultra_batch_prologue(batch.data_ptr(), bs, n_cand, int(num_direct_rel), h0.data_ptr(), r0.data_ptr(),
                                    side.data_ptr(), valid.data_ptr(), _stream()))
     return batch, h0, r0, side, valid

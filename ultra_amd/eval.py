@@ -69,9 +69,16 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
             # full batches replay the captured hipGraph of the forward (ultra_amd/graph.py); the ragged last one runs eagerly
             if graphed is None:
                 from .graph import GraphedForward
-                graphed = GraphedForward(model, test_data, t_batch)
-            t_pred = graphed(t_batch).clone()
-            h_pred = graphed(h_batch).clone()
+                try:
+                    graphed = GraphedForward(model, test_data, t_batch)
+                except RuntimeError:       # model outside the fused inference path: stay eager
+                    use_graph = False
+            if graphed is not None:
+                t_pred = graphed(t_batch).clone()
+                h_pred = graphed(h_batch).clone()
+            else:
+                t_pred = model(test_data, t_batch)
+                h_pred = model(test_data, h_batch)
         else:
             t_pred = model(test_data, t_batch)
             h_pred = model(test_data, h_batch)

@@ -15,6 +15,10 @@ from torch import nn
 from . import dense, layers, tasks
 
 
+# inference fast path of EntityNBFNet.forward: fused batch prologue + readout from the raw batch (A/B switch for tests)
+PROLOGUE_FAST_PATH = True
+
+
 def index_to_mask(index, size):
     mask = torch.zeros(size, dtype=torch.bool, device=index.device)
     mask[index] = True
@@ -251,7 +255,7 @@ class EntityNBFNet(BaseNBFNet):
                 data = self.remove_easy_edges(data, h_index, t_index, r_index)
 
         shape = h_index.shape
-        if (edge_weight is None and not self.training and not torch.is_grad_enabled() and batch.is_cuda
+        if (PROLOGUE_FAST_PATH and edge_weight is None and not self.training and not torch.is_grad_enabled() and batch.is_cuda
                 and batch.dtype == torch.long and batch.dim() == 3 and not self.concat_hidden):
             # inference fast path: one prologue kernel (row uniformity, head->tail conversion, validity flag) and
             # a readout that picks its candidate column straight from the raw batch
@@ -262,6 +266,11 @@ class EntityNBFNet(BaseNBFNet):
                 self._check_valid(valid)
                 return score
             # (shape not covered by the fused readout: fall through to the generic path below)
+        if batch.is_cuda and torch.cuda.is_current_stream_capturing():
+            # the generic path goes through torch reductions / memsets whose captured nodes were seen to go stale
+            # when replays interleave with eager work (ROCm 7.2); only the fused inference path is graph-captured
+            raise RuntimeError("hipGraph capture is supported for the fused inference path only "
+                               "(64-d hidden, no concat_hidden, eval mode, no_grad)")
         # One reduction tells, per row, whether heads / tails / relations are constant along the candidates:
         # it drives the head->tail conversion (base_nbfnet.py:82) AND replaces the two asserts of models.py:196-197
         # (two host syncs in the middle of the forward there; here the flag is checked after the whole forward has
