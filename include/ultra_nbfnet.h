@@ -59,6 +59,14 @@ int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const in
                             int64_t n_cand, int32_t hidden_dim, int32_t feature_dim, void *stream);
 
 /*
+ * The NBFNet boundary condition (/root/reference/ultra/models.py:59-66, 135-141): out (batch, num_node, dim) fp32,
+ * out[b, n, :] = values[b, :] if n == rows[b] else 0; values (batch, dim) or NULL for all-ones (RelNBFNet's query).
+ * One pass, no memset (hipGraph friendly).  dim a multiple of 4.
+ */
+int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void *values, int64_t batch, int64_t num_node, int64_t dim,
+                          void *stream);
+
+/*
  * Filtered ranking without the (batch, N) mask (/root/reference/ultra/tasks.py:94-141):
  *     rank[q] = 1 + #{t : t not in known(q) and score[q, pos[q]] <= score[q, t]}
  *     num_negative[q] = n_cand - |known(q)|

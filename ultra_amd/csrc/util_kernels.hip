@@ -17,7 +17,40 @@ __global__ void __launch_bounds__(256) stream_copy_kernel(const float4 *__restri
         dst[i] = src[i];
 }
 
+// out[b, n, :] = (n == rows[b]) ? values[b, :] (or 1 when values == NULL) : 0 -- the NBFNet boundary condition
+// (models.py:59-66, 135-141: zeros + scatter_add of one row per sample) in a single pass, no memset node.
+__global__ void __launch_bounds__(256) onehot_rows_kernel(float4 *__restrict__ out, const int64_t *__restrict__ rows,
+                                                          const float4 *__restrict__ values, long long num_node, int dim4,
+                                                          long long total4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % dim4);
+        const long long r = i / dim4;
+        const long long n = r % num_node, b = r / num_node;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n == rows[b]) v = values ? values[b * dim4 + d] : make_float4(1.f, 1.f, 1.f, 1.f);
+        out[i] = v;
+    }
+}
+
 }  // namespace ultra
+
+extern "C" int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void *values, int64_t batch, int64_t num_node,
+                                     int64_t dim, void *stream) {
+    if (!out || !rows || batch < 0 || num_node < 0 || dim <= 0 || (dim & 3)) {
+        ultra::set_error("ultra_onehot_rows: NULL operand or dim not a multiple of 4");
+        return ULTRA_ERR_INVALID;
+    }
+    const long long total4 = (long long)batch * num_node * (dim / 4);
+    if (total4 == 0) return ULTRA_OK;
+    const int grid = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(ultra::onehot_rows_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (float4 *)out, rows, (const float4 *)values, (long long)num_node, (int)(dim / 4), total4);
+    if (hipGetLastError() != hipSuccess) {
+        ultra::set_error("onehot_rows_kernel launch failed");
+        return ULTRA_ERR_HIP;
+    }
+    return ULTRA_OK;
+}
 
 extern "C" int32_t ultra_stream_copy(void *dst, const void *src, int64_t bytes, void *stream) {
     if (!dst || !src || bytes < 0 || (bytes & 15)) {

@@ -92,3 +92,18 @@ def readout_batch(model, hidden, query, batch, side):
                                   mlp[2].weight.data_ptr(), mlp[2].bias.data_ptr(), score.data_ptr(), bs, num_node, n_cand,
                                   64, 128, _stream()))
     return score
+
+
+def boundary_supported(index, values):
+    return (index.is_cuda and not (torch.is_grad_enabled() and values is not None and values.requires_grad)
+            and (values is None or (values.dtype == torch.float32 and values.shape[-1] % 4 == 0)))
+
+
+def onehot_boundary(index, values, num_node, dim):
+    """(batch, num_node, dim) fp32 boundary: values[b] (or ones) at row index[b], zeros elsewhere -- one kernel."""
+    batch = index.shape[0]
+    out = torch.empty(batch, num_node, dim, dtype=torch.float32, device=index.device)
+    index = index.to(torch.int64).contiguous()
+    vptr = values.contiguous().data_ptr() if values is not None else None
+    check(lib.ultra_onehot_rows(out.data_ptr(), index.data_ptr(), vptr, batch, num_node, dim, _stream()))
+    return out

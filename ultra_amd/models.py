@@ -142,8 +142,11 @@ class RelNBFNet(BaseNBFNet):
         query = torch.ones(batch_size, self.dims[0], device=h_index.device, dtype=torch.float)
         index = h_index.unsqueeze(-1).expand_as(query)
         # boundary: ones at the query relation's node, zeros elsewhere (models.py:59-66)
-        boundary = torch.zeros(batch_size, data.num_nodes, self.dims[0], device=h_index.device)
-        boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
+        if dense.boundary_supported(h_index, None) and self.dims[0] % 4 == 0:
+            boundary = dense.onehot_boundary(h_index, None, data.num_nodes, self.dims[0])
+        else:
+            boundary = torch.zeros(batch_size, data.num_nodes, self.dims[0], device=h_index.device)
+            boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
 
         # layer 0 reads the one-hot boundary itself: tell the layer which row of each sample is non-zero
         hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad=False,
@@ -193,8 +196,11 @@ class EntityNBFNet(BaseNBFNet):
         # query = representation of each sample's query relation, scattered to its head node
         query = self.query[torch.arange(batch_size, device=r_index.device), r_index]
         index = h_index.unsqueeze(-1).expand_as(query)
-        boundary = torch.zeros(batch_size, data.num_nodes, self.dims[0], device=h_index.device, dtype=query.dtype)
-        boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
+        if dense.boundary_supported(h_index, query):
+            boundary = dense.onehot_boundary(h_index, query, data.num_nodes, self.dims[0])
+        else:
+            boundary = torch.zeros(batch_size, data.num_nodes, self.dims[0], device=h_index.device, dtype=query.dtype)
+            boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
         hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad,
                                                        relations=self._project_relations_batched(),
                                                        edge_weight=edge_weight, onehot_rows=h_index)
