@@ -7,6 +7,10 @@ module raises, and CPU tensors are rejected by the callers.
 import ctypes
 import os
 
+# PyTorch-ROCm ships its own HIP runtime; it must be the one already resident when libultra_amd.so resolves
+# libamdhip64 (a second runtime in the process sees "no ROCm-capable device").  Hence torch first.
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libultra_amd.so")
 

@@ -307,6 +307,7 @@ int32_t ultra_conv_update(const void *x, const void *agg, const void *weight, co
     p.eps = eps;
     p.flags = flags;
     const int grid = grid_for((rows + 31) / 32, 4);
+    (void)hipGetLastError();   // drop any stale error left by other users of the runtime
     hipLaunchKernelGGL(conv_update_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -342,6 +343,7 @@ int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1
     p.num_node = num_node;
     p.n_cand = n_cand;
     const int grid = grid_for((batch * n_cand + 31) / 32, 4);
+    (void)hipGetLastError();   // drop any stale error left by other users of the runtime
     hipLaunchKernelGGL(readout_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -377,6 +379,7 @@ int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const in
     p.num_node = num_node;
     p.n_cand = n_cand;
     const int grid = grid_for((batch * n_cand + 31) / 32, 4);
+    (void)hipGetLastError();   // drop any stale error left by other users of the runtime
     hipLaunchKernelGGL(readout_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -88,6 +88,7 @@ extern "C" int32_t ultra_batch_prologue(const int64_t *batch, int64_t batch_size
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (batch_size == 0) return ULTRA_OK;
+    (void)hipGetLastError();   // drop any stale error left by other users of the runtime
     hipLaunchKernelGGL(ultra::batch_prologue_kernel, dim3((unsigned)batch_size), dim3(256), 0, s, batch, (long long)n_cand,
                        (long long)num_direct_rel, h0, r0, side, valid);
     if (hipGetLastError() != hipSuccess) {
@@ -111,6 +112,7 @@ extern "C" int32_t ultra_filtered_rank(const void *score, const int64_t *pos_ind
         return ULTRA_ERR_HIP;
     }
     const dim3 grid((unsigned)((n_cand + ultra::RANK_CHUNK - 1) / ultra::RANK_CHUNK), (unsigned)batch);
+    (void)hipGetLastError();   // drop any stale error left by other users of the runtime
     hipLaunchKernelGGL(ultra::filtered_rank_kernel, grid, dim3(256), 0, s, (const float *)score, pos_index, known_ptr,
                        known_index, (long long)n_cand, reinterpret_cast<unsigned long long *>(rank_out),
                        reinterpret_cast<long long *>(num_negative_out));

@@ -144,6 +144,7 @@ static bool mat_vec_ok(const ultra_mat *m, int64_t step) {
 static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *w, const ultra_mat *rel,
                         const ultra_mat *x, const ultra_mat *bnd, const ultra_mat *out, hipStream_t stream) {
     if (!p) return invalid("plan is NULL");
+    (void)hipGetLastError();   // drop any stale error left by other users of the HIP runtime
     if (sum < 0 || sum > 2 || mul < 0 || mul > 3) return invalid("unknown sum/mul code");
     if (dtype != ULTRA_F32 && dtype != ULTRA_F64) return invalid("dtype must be ULTRA_F32 or ULTRA_F64");
     if (!out || !out->ptr) return invalid("output is NULL");
@@ -317,6 +318,7 @@ static int backward_impl(ultra_plan *p, int sum, int mul, int dtype, const void 
                          const ultra_mat *x, const ultra_mat *outm, const ultra_mat *og, void *wgrad,
                          const ultra_mat *rgrad, const ultra_mat *xgrad, hipStream_t stream) {
     if (!p) return invalid("plan is NULL");
+    (void)hipGetLastError();
     if (sum < 0 || sum > 2 || mul < 0 || mul > 1) return invalid("unknown sum/mul code");
     if (dtype != ULTRA_F32 && dtype != ULTRA_F64) return invalid("dtype must be ULTRA_F32 or ULTRA_F64");
     if (!og || !og->ptr) return invalid("output_grad is NULL");
@@ -387,6 +389,7 @@ static int backward_impl(ultra_plan *p, int sum, int mul, int dtype, const void 
 static int forward_onehot_impl(ultra_plan *p, int dtype, const void *w, const ultra_mat *rel, const ultra_mat *x,
                                const int64_t *src_rows, const ultra_mat *bnd, const ultra_mat *out, hipStream_t stream) {
     if (!p) return invalid("plan is NULL");
+    (void)hipGetLastError();
     if (dtype != ULTRA_F32 && dtype != ULTRA_F64) return invalid("dtype must be ULTRA_F32 or ULTRA_F64");
     if (!out || !out->ptr || !src_rows) return invalid("output / src_rows is NULL");
     if (p->flags & ULTRA_PLAN_TYPE_RUNS) return invalid("use the (row, col) plan for the one-hot path");

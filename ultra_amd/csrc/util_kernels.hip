@@ -43,10 +43,12 @@ extern "C" int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void 
     const long long total4 = (long long)batch * num_node * (dim / 4);
     if (total4 == 0) return ULTRA_OK;
     const int grid = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+    (void)hipGetLastError();   // drop any stale error left by other users of the runtime
     hipLaunchKernelGGL(ultra::onehot_rows_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        (float4 *)out, rows, (const float4 *)values, (long long)num_node, (int)(dim / 4), total4);
-    if (hipGetLastError() != hipSuccess) {
-        ultra::set_error("onehot_rows_kernel launch failed");
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ultra::set_error(std::string("onehot_rows_kernel launch: ") + hipGetErrorString(e));
         return ULTRA_ERR_HIP;
     }
     return ULTRA_OK;
@@ -58,6 +60,7 @@ extern "C" int32_t ultra_stream_copy(void *dst, const void *src, int64_t bytes, 
         return ULTRA_ERR_INVALID;
     }
     if (bytes == 0) return ULTRA_OK;
+    (void)hipGetLastError();   // drop any stale error left by other users of the runtime
     hipLaunchKernelGGL(ultra::stream_copy_kernel, dim3(2048), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        (const float4 *)src, (float4 *)dst, (long long)(bytes / 16));
     if (hipGetLastError() != hipSuccess) {
