@@ -35,7 +35,9 @@ def main(fetch_csv, write_csv, out):
                            "note": "FETCH_SIZE counts 1 KiB units at half rate for 16-B/lane streams on gfx950 (x2 correction); "
                                    "WRITE_SIZE is exact in KiB"},
            "points": []}
-    per = 4   # launches per (point, sum): 1 warm-up + 3 timed in --pmc mode
+    # launches per (point, sum) in --pmc mode: 1 warm-up + 3 back-to-back + 3 kernel-only timed calls
+    per = len(f["fwd_add"]) // len(POINTS)
+    assert per * len(POINTS) == len(f["fwd_add"]) == len(w["fwd_add"]), "unexpected dispatch count"
     for i, (shape, bs) in enumerate(POINTS):
         for sum_ in ("add", "max"):
             fk, xk = "fwd_" + sum_, "fix_" + sum_
