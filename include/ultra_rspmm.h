@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_ABI_VERSION 1
+#define ULTRA_ABI_VERSION 2
 
 typedef enum {
     ULTRA_OK = 0,
@@ -76,6 +76,13 @@ typedef struct {
 #define ULTRA_PLAN_TYPE_RUNS 2     /* edges sorted by (row, type, col) and cut at type changes: every item holds ONE relation, so
                                       add_mul sums the sources first and multiplies by rel[type] once per item.  Pays off when runs are
                                       long (dense graphs with few relation types, e.g. ULTRA's relation graph); add_mul only. */
+#define ULTRA_PLAN_DENSE 4         /* dense-format plan for graphs that are (nearly) complete: the edge multiplicities (<= 255) are stored as
+                                      num_relation dense (num_out_row x num_in_row) byte matrices in MFMA fragment order and
+                                      add_mul runs as out = sum_t rel[t] * (A_t . x) on the matrix cores.  Serves fp32 add_mul with
+                                      unit edge weights and row_len % 32 == 0 only (anything else: ULTRA_ERR_UNSUPPORTED);
+                                      num_in_row <= ULTRA_DENSE_MAX_IN_ROW.  ULTRA's relation graphs (a few hundred nodes, 4 types,
+                                      most (row, type, col) cells occupied) are the case it exists for. */
+#define ULTRA_DENSE_MAX_IN_ROW 1024
 
 typedef struct ultra_plan ultra_plan;
 
@@ -87,6 +94,7 @@ typedef struct {
     int32_t on_device;
     int32_t has_transpose;
     int64_t n_type_run;   /* number of distinct (row, type) pairs: num_edge / n_type_run = mean run length */
+    int64_t dense_bytes;  /* ULTRA_PLAN_DENSE: size of the fragment-ordered adjacency, else 0 */
 } ultra_plan_info;
 
 int32_t ultra_abi_version(void);
@@ -119,7 +127,10 @@ typedef enum {
     ULTRA_ARR_PERM = 3,      /* int32 [num_edge]  sorted position -> original edge id */
     ULTRA_ARR_ITEM = 4,      /* int32 [n_item][4] = {row, begin, len, slot}  (slot < 0: writes the output row directly) */
     ULTRA_ARR_SPLIT_ROW = 5, /* int32 [n_split_row] */
-    ULTRA_ARR_SPLIT_PTR = 6  /* int32 [n_split_row + 1] partial-slot ranges */
+    ULTRA_ARR_SPLIT_PTR = 6, /* int32 [n_split_row + 1] partial-slot ranges */
+    ULTRA_ARR_DENSE = 7      /* uint8 [row_tile][type_chunk][kgroup (padded to a multiple of 20)][lane 0..63][tl 0..tc-1][q 0..3], in 4-byte words
+                                (ULTRA_PLAN_DENSE only; tc = 1, 2, 4 for num_relation 1, 2, >= 3): multiplicity of edge
+                                (row = 32 row_tile + lane % 32, type = tc type_chunk + tl, col = 8 kgroup + 2 q + lane / 32) */
 } ultra_plan_array;
 int32_t ultra_plan_export(const ultra_plan *plan, int32_t which, void *dst_host, int64_t capacity_elems, int64_t *count);
 

@@ -162,3 +162,62 @@ def test_type_run_emulated_walk_matches_oracle(case):
     # other semirings keep using the (row, col) plan
     want = rspmm_oracle.generalized_rspmm(ei, et, w, rel, x, sum="max", mul="mul")
     assert torch.equal(helpers.emulate_plan_forward(plan, rel, x, edge_weight=w, sum="max", mul="mul"), want)
+
+
+def _dense_from_fragments(plan, N, R):
+    """Undo the MFMA A-operand order of ULTRA_ARR_DENSE: -> (R, N, N) multiplicities."""
+    frag = plan.export(_lib.ARR_DENSE)
+    n_rt, kg = (N + 31) // 32, ((N + 7) // 8 + 19) // 20 * 20          # k groups padded to whole pipeline blocks
+    tc = 1 if R <= 1 else (2 if R == 2 else 4)
+    ntc = (R + tc - 1) // tc
+    assert frag.dtype == torch.uint8 and frag.numel() == n_rt * ntc * kg * 64 * tc * 4 == plan.info()["dense_bytes"]
+    frag = frag.view(n_rt, ntc, kg, 64, tc, 4).float()         # [row tile][type chunk][k group][lane][type in chunk][q]
+    lane = torch.arange(64)
+    i, h = lane % 32, lane // 32
+    dense = torch.zeros(ntc * tc, n_rt * 32, kg * 8)
+    for rt in range(n_rt):
+        for c in range(ntc):
+            for g in range(kg):
+                for tl in range(tc):
+                    for q in range(4):
+                        # row = 32 row_tile + lane % 32, column = 8 kgroup + 2 q + lane // 32
+                        dense[c * tc + tl, rt * 32 + i, g * 8 + 2 * q + h] = frag[rt, c, g, :, tl, q]
+    assert dense[R:].abs().sum() == 0 and dense[:, N:].abs().sum() == 0 and dense[:, :, N:].abs().sum() == 0, \
+        "padding cells must stay zero"
+    return dense[:R, :N, :N]
+
+
+@pytest.mark.parametrize("case", [DENSE, dict(num_node=70, num_edge=6000, num_relation=2, seed=5, duplicates=300),
+                                  dict(num_node=33, num_edge=2000, num_relation=1, seed=6),
+                                  dict(num_node=20, num_edge=3000, num_relation=7, seed=7)])
+def test_dense_format_plan_holds_the_edge_multiplicities(case):
+    ei, et = helpers.random_graph(**case)
+    N, R = case["num_node"], case["num_relation"]
+    plan = Plan(ei, et, N, R, dense=True)
+    assert plan.dense is not None
+    got = _dense_from_fragments(plan.dense, N, R)
+    want = torch.zeros(R, N, N)
+    want.index_put_((et, ei[0], ei[1]), torch.ones(ei.shape[1]), accumulate=True)
+    assert torch.equal(got, want)
+
+
+def test_dense_format_needs_multiplicities_that_fit_a_byte():
+    ei = torch.zeros(2, 300, dtype=torch.long)                        # one edge repeated 300 times
+    et = torch.zeros(300, dtype=torch.long)
+    assert Plan(ei, et, 4, 1).dense is None                           # "auto": the edge walk serves it
+    with pytest.raises(RuntimeError):
+        Plan(ei, et, 4, 1, dense=True)
+    ok = Plan(ei[:, :255], et[:255], 4, 1, dense=True)
+    assert _dense_from_fragments(ok.dense, 4, 1)[0, 0, 0] == 255
+
+
+def test_dense_twin_is_automatic_only_for_filled_graphs():
+    ei, et = helpers.random_graph(**DENSE)                            # 3000 edges over 40 * 40 * 4 cells
+    assert Plan(ei, et, 40, 4).dense is not None
+    ei2, et2 = helpers.random_graph(**CASES[0])                       # 400 edges over 50 * 50 * 5 cells
+    assert Plan(ei2, et2, 50, 5).dense is None
+    assert Plan(ei, et, 40, 4, dense=False).dense is None
+    assert Plan(ei, et, 40, 4, exact_order=True).dense is None
+    with pytest.raises(RuntimeError):                                 # beyond ULTRA_DENSE_MAX_IN_ROW
+        big = torch.zeros(2, 1, dtype=torch.long)
+        Plan(big, torch.zeros(1, dtype=torch.long), 2000, 1, dense="only")

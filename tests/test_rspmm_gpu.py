@@ -281,3 +281,80 @@ def test_onehot_forward_equals_dense_forward(dev, case, layout, weights):
     ref = rspmm_oracle.generalized_rspmm(ei, et, w if weights else torch.ones(E), rel[0], x[0]) + x[0]
     helpers.assert_sum_close((got[0] if layout == "batch_major" else got).cpu(), ref, ei, et,
                              w if weights else torch.ones(E), rel[0], x[0], boundary=x[0])
+
+
+DENSE_CASES = [
+    dict(num_node=100, num_edge=20000, num_relation=4, seed=7),
+    dict(num_node=37, num_edge=3000, num_relation=3, seed=8, duplicates=500, empty_rows=3),   # ragged tile, one k group short
+    dict(num_node=260, num_edge=40000, num_relation=1, seed=9, hub=(5, 3000)),               # one type split over 4 waves
+    dict(num_node=33, num_edge=9000, num_relation=9, seed=10),                               # several types per wave
+]
+
+
+@pytest.mark.parametrize("case", DENSE_CASES)
+@pytest.mark.parametrize("layout,dim", [("node_major", 32), ("node_major", 192), ("batch_major", 64), ("shared_relation", 64)])
+@pytest.mark.parametrize("with_boundary", [False, True])
+def test_dense_format_forward_matches_oracle(dev, case, layout, dim, with_boundary):
+    """ULTRA_PLAN_DENSE: the matrix-core product over the multiplicity matrices == the edge walk of the oracle
+    (rspmm.cpp:50-75) up to the order of the fp32 additions; determinism; routing rules of Plan.forward."""
+    from ultra_amd.rspmm import Plan
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    bs = 1 if layout == "node_major" else 3
+    rel, x, _ = helpers.features(N, R, bs * dim, E, seed=case["seed"] + 100)
+    ones = torch.ones(E)
+    g = torch.Generator().manual_seed(case["seed"])
+    bnd = torch.randn(N, bs * dim, generator=g) if with_boundary else None
+    if layout == "shared_relation":
+        rel = rel[:, :dim].repeat(1, bs)
+    want = rspmm_oracle.generalized_rspmm(ei, et, ones, rel, x, sum="add", mul="mul")
+    if with_boundary:
+        want = want + bnd
+    plan = Plan(ei, et, N, R, dense=True)
+    assert plan.dense is not None
+    if layout == "node_major":
+        args = (rel.to(dev), x.to(dev))
+        kw = dict(boundary=bnd.to(dev) if with_boundary else None)
+        unpack = lambda t: t.cpu()
+    else:
+        to_b = lambda t: t.view(t.shape[0], bs, dim).transpose(0, 1).contiguous().to(dev)
+        relb = to_b(rel)
+        if layout == "shared_relation":
+            relb = relb[0].unsqueeze(0).expand(bs, -1, -1)
+        args = (relb, to_b(x))
+        kw = dict(boundary=to_b(bnd) if with_boundary else None)
+        unpack = lambda t: t.transpose(0, 1).reshape(N, bs * dim).cpu()
+    assert plan._twin_for("add", "mul", None, args[1], args[0], kw["boundary"]) is plan.dense
+    got = unpack(plan.forward(*args, **kw))
+    helpers.assert_sum_close(got, want, ei, et, ones, rel, x, mul="mul", boundary=bnd)
+    assert torch.equal(unpack(plan.forward(*args, **kw)), got), "deterministic"
+    # the sparse twin computes the same thing
+    sparse = Plan(ei, et, N, R, dense=False)
+    helpers.assert_sum_close(unpack(sparse.forward(*args, **kw)), want, ei, et, ones, rel, x, mul="mul", boundary=bnd)
+    # calls the dense format cannot serve fall through to the edge walk
+    w = torch.rand(E, generator=g) + 0.5
+    assert plan._twin_for("add", "mul", w.to(dev), args[1], args[0]) is not plan.dense
+    assert plan._twin_for("max", "mul", None, args[1], args[0]) is None
+    assert plan._twin_for("add", "mul", None, args[1].double(), args[0].double()) is not plan.dense
+    got_w = unpack(plan.forward(*args, edge_weight=w.to(dev), **kw))
+    want_w = rspmm_oracle.generalized_rspmm(ei, et, w, rel, x, sum="add", mul="mul")
+    helpers.assert_sum_close(got_w, want_w + bnd if with_boundary else want_w, ei, et, w, rel, x, mul="mul", boundary=bnd)
+
+
+def test_dense_format_plan_rejects_what_it_cannot_serve(dev):
+    from ultra_amd.rspmm import Plan
+    case = DENSE_CASES[0]
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    rel, x, w = helpers.features(N, R, 64, E, seed=1)
+    dense = Plan(ei, et, N, R, dense=True).dense
+    with pytest.raises(RuntimeError):
+        dense.forward(rel.to(dev), x.to(dev), sum="max")
+    with pytest.raises(RuntimeError):
+        dense.forward(rel.to(dev), x.to(dev), edge_weight=w.to(dev))
+    with pytest.raises(RuntimeError):
+        dense.forward(rel.to(dev)[:, :24].contiguous(), x.to(dev)[:, :24].contiguous())      # row_len % 32 != 0
+    with pytest.raises(RuntimeError):
+        dense.forward(rel.double().to(dev), x.double().to(dev))
+    with pytest.raises(RuntimeError):
+        dense.backward(rel.to(dev), x.to(dev), x.to(dev), x.to(dev))

@@ -27,6 +27,9 @@ F32, F64 = 0, 1
 ARR_ROW_PTR, ARR_COL, ARR_TYPE, ARR_PERM, ARR_ITEM, ARR_SPLIT_ROW, ARR_SPLIT_PTR = range(7)
 PLAN_EXACT_ORDER = 1
 PLAN_TYPE_RUNS = 2
+PLAN_DENSE = 4
+DENSE_MAX_IN_ROW = 1024
+ARR_DENSE = 7
 
 
 class UltraMat(ctypes.Structure):
@@ -45,7 +48,7 @@ class PlanInfo(ctypes.Structure):
                 ("n_unit", ctypes.c_int64), ("n_split_row", ctypes.c_int64), ("n_partial_slot", ctypes.c_int64),
                 ("seg_len", ctypes.c_int32), ("g_max", ctypes.c_int32), ("flags", ctypes.c_int32),
                 ("packed", ctypes.c_int32), ("on_device", ctypes.c_int32), ("has_transpose", ctypes.c_int32),
-                ("n_type_run", ctypes.c_int64)]
+                ("n_type_run", ctypes.c_int64), ("dense_bytes", ctypes.c_int64)]
 
 
 class Tuning(ctypes.Structure):
@@ -93,7 +96,7 @@ def _load():
 
 
 lib = _load()
-if lib.ultra_abi_version() != 1:
+if lib.ultra_abi_version() != 2:
     raise ImportError("ultra_amd: libultra_amd.so ABI version mismatch")
 
 

@@ -45,6 +45,26 @@ ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *ty
     const bool type_runs = !exact && (p->flags & ULTRA_PLAN_TYPE_RUNS) != 0;
     if (p->g_max > p->seg_len) p->g_max = p->seg_len;
 
+    if (p->flags & ULTRA_PLAN_DENSE) {
+        // dense format: only the multiplicity matrices, as bytes, laid out the way the MFMA A-operand is consumed
+        // (lane l of a 32x32x2 step holds A[i = l % 32][k = l / 32]; one load of 4 * tc bytes per lane covers the
+        // four steps of an 8-column group for tc relation types)
+        p->dense_rt = (int32_t)((num_out + 31) / 32);
+        p->dense_kg = (int32_t)(((num_in + 7) / 8 + ULTRA_DENSE_KG_ALIGN - 1) / ULTRA_DENSE_KG_ALIGN * ULTRA_DENSE_KG_ALIGN);
+        p->dense_tc = num_rel <= 1 ? 1 : (num_rel == 2 ? 2 : 4);
+        p->dense_ntc = (int32_t)std::max<int64_t>(1, (num_rel + p->dense_tc - 1) / p->dense_tc);
+        const int64_t tc = p->dense_tc;
+        p->a_frag.assign((size_t)p->dense_rt * p->dense_ntc * p->dense_kg * 64 * 4 * tc, 0);
+        for (int64_t e = 0; e < E; ++e) {
+            const int64_t rt = row[e] / 32, i = row[e] % 32, kg = col[e] / 8, within = col[e] % 8;
+            const int64_t lane = (within % 2) * 32 + i, q = within / 2, chunk = type[e] / tc, tl = type[e] % tc;
+            uint8_t &cell = p->a_frag[(size_t)(((((rt * p->dense_ntc + chunk) * p->dense_kg + kg) * 64 + lane) * tc + tl) * 4 + q)];
+            if (cell == 255) p->dense_overflow = true; else ++cell;
+        }
+        p->split_ptr.push_back(0);
+        return p;
+    }
+
     // ---- sort by (row, [type,] col), stable in the original edge id: LSD counting passes ----
     std::vector<int32_t> order((size_t)E);
     std::iota(order.begin(), order.end(), 0);
@@ -204,7 +224,21 @@ int32_t ultra_plan_create(ultra_plan **plan, const int64_t *edge_index, const in
         col[(size_t)e] = (int32_t)c;
         type[(size_t)e] = (int32_t)t;
     }
+    if (opts && (opts->flags & ULTRA_PLAN_DENSE)) {
+        const int64_t cells = ((num_out + 31) / 32) * 32 * ((num_in + 7) / 8 + ULTRA_DENSE_KG_ALIGN) * 8 * (num_rel + 3);
+        if (num_in > ULTRA_DENSE_MAX_IN_ROW || cells > (int64_t(1) << 28)) {
+            set_error("ultra_plan_create: ULTRA_PLAN_DENSE needs num_in_row <= " + std::to_string(ULTRA_DENSE_MAX_IN_ROW) +
+                      " and at most 2^28 adjacency cells");
+            return ULTRA_ERR_UNSUPPORTED;
+        }
+    }
     *plan = ultra::build_plan(row.data(), col.data(), type.data(), E, num_out, num_in, num_rel, opts, true);
+    if ((*plan)->dense_overflow) {
+        delete *plan;
+        *plan = nullptr;
+        set_error("ultra_plan_create: ULTRA_PLAN_DENSE stores multiplicities as bytes; an edge is repeated more than 255 times");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
     return ULTRA_OK;
 }
 
@@ -229,6 +263,7 @@ int32_t ultra_plan_get_info(const ultra_plan *p, ultra_plan_info *info) {
     info->on_device = p->on_device ? 1 : 0;
     info->has_transpose = (p->tplan && p->rplan) ? 1 : 0;
     info->n_type_run = p->n_type_run;
+    info->dense_bytes = (int64_t)p->a_frag.size();
     return ULTRA_OK;
 }
 
@@ -247,6 +282,7 @@ int32_t ultra_plan_export(const ultra_plan *p, int32_t which, void *dst, int64_t
         case ULTRA_ARR_ITEM: src = p->items.data(); n = (int64_t)p->items.size() * 4; break;
         case ULTRA_ARR_SPLIT_ROW: src = p->split_row.data(); n = (int64_t)p->split_row.size(); break;
         case ULTRA_ARR_SPLIT_PTR: src = p->split_ptr.data(); n = (int64_t)p->split_ptr.size(); break;
+        case ULTRA_ARR_DENSE: src = p->a_frag.data(); n = (int64_t)p->a_frag.size() / 4; break;
         default: set_error("ultra_plan_export: unknown array id"); return ULTRA_ERR_INVALID;
     }
     *count = n;

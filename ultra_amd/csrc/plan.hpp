@@ -31,6 +31,7 @@ struct DevicePlan {
     uint32_t *packed = nullptr;
     Item *items = nullptr;
     int32_t *split_row = nullptr, *split_ptr = nullptr;
+    uint8_t *a_frag = nullptr;   // ULTRA_PLAN_DENSE
     void *w_sorted = nullptr;
     size_t w_sorted_bytes = 0;
     void *partial = nullptr;
@@ -39,6 +40,10 @@ struct DevicePlan {
 };
 
 void set_error(const std::string &msg);
+
+// ULTRA_PLAN_DENSE: the number of 8-column groups is padded (with empty cells) to a multiple of this, so that each of
+// the four waves of a workgroup runs whole software-pipeline blocks (rspmm_dense.hip)
+#define ULTRA_DENSE_KG_ALIGN 20
 
 }  // namespace ultra
 
@@ -55,6 +60,12 @@ struct ultra_plan {
     std::vector<int32_t> split_row, split_ptr;
     int64_t n_slot = 0;
     int64_t n_type_run = 0;
+
+    // ULTRA_PLAN_DENSE: edge multiplicities as bytes, [row_tile][type_chunk][kgroup][lane][type_in_chunk][q]
+    // (see ULTRA_ARR_DENSE); dense_tc = types per chunk (1, 2 or 4), dense_ntc = number of chunks
+    std::vector<uint8_t> a_frag;
+    int32_t dense_rt = 0, dense_kg = 0, dense_tc = 0, dense_ntc = 0;
+    bool dense_overflow = false;   // some multiplicity exceeds 255
 
     // original (unsorted) edges, kept to derive the backward plans lazily
     std::vector<int32_t> h_row, h_col, h_type;

@@ -25,6 +25,9 @@ ULTRA_EXTERN_VARIANT(double, 1, 0)
 ULTRA_EXTERN_VARIANT(double, 4, 1)
 ULTRA_EXTERN_VARIANT(double, 4, 2)
 
+int launch_dense_forward(ultra_plan *p, int sum, int mul, int dtype, const void *w, const ultra_mat *rel, const ultra_mat *x,
+                         const ultra_mat *bnd, const ultra_mat *out, hipStream_t stream);   // rspmm_dense.hip
+
 static ultra_tuning g_tuning = {0, 0, -1, -1, 0, {0, 0, 0}};
 
 // measurement hook: when set, forward_impl records these events right before / after the main kernel launch
@@ -59,6 +62,12 @@ static int upload_plan(ultra_plan *p) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     int rc;
+    if (p->flags & ULTRA_PLAN_DENSE) {
+        if ((rc = upload_array(&p->d.a_frag, p->a_frag))) return rc;
+        p->d.device = dev;
+        p->on_device = true;
+        return ULTRA_OK;
+    }
     if ((rc = upload_array(&p->d.row_ptr, p->row_ptr))) return rc;
     if ((rc = upload_array(&p->d.col, p->col))) return rc;
     if ((rc = upload_array(&p->d.type, p->type))) return rc;
@@ -84,6 +93,7 @@ static void free_device(ultra_plan *p) {
     (void)hipFree(p->d.items);
     (void)hipFree(p->d.split_row);
     (void)hipFree(p->d.split_ptr);
+    if (p->d.a_frag) (void)hipFree(p->d.a_frag);
     if (p->d.w_sorted) (void)hipFree(p->d.w_sorted);
     if (p->d.partial) (void)hipFree(p->d.partial);
     p->d = DevicePlan();
@@ -157,6 +167,12 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
     if (bnd && (rc = check_mat(bnd, "boundary", p->num_out, n_outer, row_len))) return rc;
     if (p->num_out == 0) return ULTRA_OK;
     if ((rc = upload_plan(p))) return rc;
+    if (p->flags & ULTRA_PLAN_DENSE) {
+        if (g_ev_before) HIP_TRY(hipEventRecord(g_ev_before, stream));
+        if ((rc = launch_dense_forward(p, sum, mul, dtype, w, rel, x, bnd, out, stream))) return rc;
+        if (g_ev_after) HIP_TRY(hipEventRecord(g_ev_after, stream));
+        return ULTRA_OK;
+    }
     DevInfo di;
     if ((rc = device_info(&di))) return rc;
 
@@ -319,6 +335,7 @@ static int backward_impl(ultra_plan *p, int sum, int mul, int dtype, const void 
                          const ultra_mat *rgrad, const ultra_mat *xgrad, hipStream_t stream) {
     if (!p) return invalid("plan is NULL");
     (void)hipGetLastError();
+    if (p->flags & ULTRA_PLAN_DENSE) return invalid("a ULTRA_PLAN_DENSE plan has no backward; use the (row, col) plan");
     if (sum < 0 || sum > 2 || mul < 0 || mul > 1) return invalid("unknown sum/mul code");
     if (dtype != ULTRA_F32 && dtype != ULTRA_F64) return invalid("dtype must be ULTRA_F32 or ULTRA_F64");
     if (!og || !og->ptr) return invalid("output_grad is NULL");
@@ -392,7 +409,7 @@ static int forward_onehot_impl(ultra_plan *p, int dtype, const void *w, const ul
     (void)hipGetLastError();
     if (dtype != ULTRA_F32 && dtype != ULTRA_F64) return invalid("dtype must be ULTRA_F32 or ULTRA_F64");
     if (!out || !out->ptr || !src_rows) return invalid("output / src_rows is NULL");
-    if (p->flags & ULTRA_PLAN_TYPE_RUNS) return invalid("use the (row, col) plan for the one-hot path");
+    if (p->flags & (ULTRA_PLAN_TYPE_RUNS | ULTRA_PLAN_DENSE)) return invalid("use the (row, col) plan for the one-hot path");
     const int64_t n_outer = out->n_outer, row_len = out->row_len;
     int rc;
     if ((rc = check_mat(out, "output", p->num_out, n_outer, row_len))) return rc;

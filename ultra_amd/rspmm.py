@@ -66,9 +66,10 @@ class Plan(object):
     """Aggregation plan of one graph (sorted CSR + balanced work list), resident in HBM."""
 
     TYPE_RUN_MIN_MEAN_LENGTH = 16   # build the type-run twin when (row, type) runs average at least this many edges
+    DENSE_MIN_FILL = 0.25           # build the dense-format twin when this share of the (row, type, col) cells holds an edge
 
     def __init__(self, edge_index, edge_type, num_node, num_relation, seg_len=0, g_max=0, exact_order=False,
-                 num_in=None, type_runs="auto"):
+                 num_in=None, type_runs="auto", dense="auto"):
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise RuntimeError("Expected `edge_index` of shape (2, num_edge)")          # checkDim/checkSize
         if edge_type.dim() != 1 or edge_type.shape[0] != edge_index.shape[1]:
@@ -77,7 +78,8 @@ class Plan(object):
             raise RuntimeError("Expected `edge_index` and `edge_type` of the same type")  # checkSameType, rspmm.cpp:22
         ei = edge_index.detach().to("cpu", torch.int64).contiguous()
         et = edge_type.detach().to("cpu", torch.int64).contiguous()
-        flags = (_lib.PLAN_EXACT_ORDER if exact_order else 0) | (_lib.PLAN_TYPE_RUNS if type_runs == "only" else 0)
+        flags = ((_lib.PLAN_EXACT_ORDER if exact_order else 0) | (_lib.PLAN_TYPE_RUNS if type_runs == "only" else 0)
+                 | (_lib.PLAN_DENSE if dense == "only" else 0))
         opts = _lib.PlanOpts(int(seg_len), int(g_max), flags, 0)
         handle = ctypes.c_void_p()
         self.num_edge = ei.shape[1]
@@ -90,11 +92,35 @@ class Plan(object):
         # Dense graphs with few relation types (ULTRA's relation graph: 474 nodes, 4 types, ~470 edges per
         # (row, type) run) get a twin plan whose items hold one relation each; add_mul forwards use it.
         self.typed = None
+        self.dense = None
+        if dense == "only" or type_runs == "only":
+            return
+        # (Nearly) complete graphs -- again ULTRA's relation graph -- also get a dense-format twin: fp32 add_mul with unit
+        # edge weights then runs on the matrix cores (csrc/rspmm_dense.hip).
+        cells = self.num_node * self.num_in * max(self.num_relation, 1)
+        if dense in ("auto", True) and not exact_order and self.num_edge > 0 and self.num_in <= _lib.DENSE_MAX_IN_ROW \
+                and cells <= (1 << 26) and (dense is True or self.num_edge >= self.DENSE_MIN_FILL * cells):
+            try:
+                self.dense = Plan(ei, et, num_node, num_relation, num_in=num_in, type_runs=False, dense="only")
+            except _lib.UltraError:     # an edge repeated more than 255 times: the edge walk serves it
+                if dense is True:
+                    raise
         if type_runs in ("auto", True) and not exact_order and self.num_edge > 0:
             runs = max(1, self.info()["n_type_run"])
             if type_runs is True or self.num_edge / runs >= self.TYPE_RUN_MIN_MEAN_LENGTH:
                 self.typed = Plan(ei, et, num_node, num_relation, seg_len=seg_len, g_max=g_max, num_in=num_in,
-                                  type_runs="only")
+                                  type_runs="only", dense=False)
+
+    def _twin_for(self, sum, mul, edge_weight, input, *others):
+        """The specialised twin plan that serves this call, or None for the general (row, col) plan."""
+        if sum != "add" or mul != "mul":
+            return None
+        if self.dense is not None and edge_weight is None and input.dtype == torch.float32 \
+                and input.shape[-1] % 32 == 0 and input.dim() in (2, 3) \
+                and all(t is None or (t.stride(-1) == 1 and t.data_ptr() % 16 == 0
+                                      and all(st % 4 == 0 for st in t.stride()[:-1])) for t in (input,) + others):
+            return self.dense
+        return self.typed
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -117,12 +143,13 @@ class Plan(object):
         check(lib.ultra_plan_export(self._h, which, None, 0, ctypes.byref(n)))
         out = torch.empty(n.value, dtype=torch.int32)
         check(lib.ultra_plan_export(self._h, which, out.data_ptr(), n.value, ctypes.byref(n)))
-        return out
+        return out.view(torch.uint8) if which == _lib.ARR_DENSE else out
 
     # ---- kernels ----
     def forward(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", out=None):
-        if self.typed is not None and sum == "add" and mul == "mul":
-            return self.typed.forward(relation, input, edge_weight=edge_weight, boundary=boundary, sum=sum, mul=mul, out=out)
+        twin = self._twin_for(sum, mul, edge_weight, input, relation, boundary, out)
+        if twin is not None:
+            return twin.forward(relation, input, edge_weight=edge_weight, boundary=boundary, sum=sum, mul=mul, out=out)
         _require_gpu(relation, input, edge_weight, boundary)
         dt = _dtype_code(*([relation, input] + ([edge_weight] if edge_weight is not None else [])
                            + ([boundary] if boundary is not None else [])))
@@ -206,10 +233,11 @@ class Plan(object):
 
     def forward_timed(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", warmup=3, iters=20):
         """Mean HIP-event time (ms) of the forward launch sequence on the current stream."""
-        if self.typed is not None and sum == "add" and mul == "mul":
-            res = self.typed.forward_timed(relation, input, edge_weight=edge_weight, boundary=boundary, sum=sum,
-                                           mul=mul, warmup=warmup, iters=iters)
-            self.last_main_kernel_ms = self.typed.last_main_kernel_ms
+        twin = self._twin_for(sum, mul, edge_weight, input, relation, boundary)
+        if twin is not None:
+            res = twin.forward_timed(relation, input, edge_weight=edge_weight, boundary=boundary, sum=sum,
+                                     mul=mul, warmup=warmup, iters=iters)
+            self.last_main_kernel_ms = twin.last_main_kernel_ms
             return res
         dt = _dtype_code(relation, input)
         relation, mrel = as_mat(relation)
@@ -234,12 +262,12 @@ class Plan(object):
 # ---- plan cache: the graph is static across the 12 rspmm calls of a forward and across batches ----
 _PLAN_CACHE = OrderedDict()
 _PLAN_CACHE_SIZE = 16
-_plan_defaults = {"seg_len": 0, "g_max": 0, "exact_order": False, "type_runs": "auto"}
+_plan_defaults = {"seg_len": 0, "g_max": 0, "exact_order": False, "type_runs": "auto", "dense": "auto"}
 
 
-def set_plan_defaults(seg_len=0, g_max=0, exact_order=False, type_runs="auto"):
+def set_plan_defaults(seg_len=0, g_max=0, exact_order=False, type_runs="auto", dense="auto"):
     """Tuning hook: defaults for newly built plans (clears the cache)."""
-    _plan_defaults.update(seg_len=seg_len, g_max=g_max, exact_order=exact_order, type_runs=type_runs)
+    _plan_defaults.update(seg_len=seg_len, g_max=g_max, exact_order=exact_order, type_runs=type_runs, dense=dense)
     _PLAN_CACHE.clear()
 
 
