@@ -33,15 +33,17 @@ int32_t ultra_conv_update(const void *x, const void *agg, const void *weight, co
 /*
  * Readout of EntityNBFNet.forward (/root/reference/ultra/models.py:166-170, 202-209):
  *     feature = cat[hidden, query]; score = mlp.2( relu( mlp.0( feature.gather(t_index) ) ) )
- * The query half of mlp.0 is constant per sample and arrives pre-folded:
+ * The query half of mlp.0 is constant per sample:
  *     qbias[b] = mlp.0.weight[:, 64:] . query[b] + mlp.0.bias            (batch, 128)
+ * either passed pre-folded (qbias != NULL), or computed inside the kernel from query (batch, 64) and b1 = mlp.0.bias
+ * (qbias == NULL; batch <= 32, ULTRA_ERR_UNSUPPORTED beyond).
  * hidden (batch, num_node, 64) contiguous; t_index (batch, n_cand) int64 node ids or NULL for
  * all-tail (n_cand == num_node, identity); w1 = mlp.0.weight (128, 128) row-major; w2 = mlp.2.weight (128); b2 = mlp.2.bias (1);
  * score (batch, n_cand).
  */
-int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1, const void *qbias, const void *w2,
-                      const void *b2, void *score, int64_t batch, int64_t num_node, int64_t n_cand, int32_t hidden_dim,
-                      int32_t feature_dim, void *stream);
+int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1, const void *qbias, const void *query,
+                      const void *b1, const void *w2, const void *b2, void *score, int64_t batch, int64_t num_node,
+                      int64_t n_cand, int32_t hidden_dim, int32_t feature_dim, void *stream);
 
 /*
  * Batch prologue of EntityNBFNet.forward (/root/reference/ultra/models.py:190-197 with
@@ -55,8 +57,9 @@ int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1
 int32_t ultra_batch_prologue(const int64_t *triples, int64_t batch, int64_t n_cand, int64_t num_direct_rel, int64_t *h0,
                              int64_t *r0, int32_t *side, int32_t *valid, void *stream);
 int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const int32_t *side, const void *w1,
-                            const void *qbias, const void *w2, const void *b2, void *score, int64_t batch, int64_t num_node,
-                            int64_t n_cand, int32_t hidden_dim, int32_t feature_dim, void *stream);
+                            const void *qbias, const void *query, const void *b1, const void *w2, const void *b2, void *score,
+                            int64_t batch, int64_t num_node, int64_t n_cand, int32_t hidden_dim, int32_t feature_dim,
+                            void *stream);
 
 /*
  * The NBFNet boundary condition (/root/reference/ultra/models.py:59-66, 135-141): out (batch, num_node, dim) fp32,
@@ -65,6 +68,25 @@ int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const in
  */
 int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void *values, int64_t batch, int64_t num_node, int64_t dim,
                           void *stream);
+
+/*
+ * Boundary condition of EntityNBFNet (/root/reference/ultra/models.py:131-141) with the query gather fused:
+ *     query_out[b, :] = table[b, pick[b], :]            (query = relation_representations[arange(batch), r_index])
+ *     out[b, n, :]    = query_out[b, :] if n == rows[b] else 0
+ * table (batch, table_rows, dim) contiguous fp32; rows, pick int64 [batch]; dim a multiple of 4.
+ */
+int32_t ultra_query_boundary(void *out, void *query_out, const int64_t *rows, const void *table, const int64_t *pick,
+                             int64_t batch, int64_t num_node, int64_t table_rows, int64_t dim, void *stream);
+
+/*
+ * The relation_projection MLPs of all entity layers (/root/reference/ultra/layers.py:80, applied to the relation
+ * representations set by /root/reference/ultra/models.py:184-185) in one launch:
+ *     out[l, r, :] = w2[l] . relu(w0[l] . x[r, :] + b0[l]) + b2[l]
+ * x (rows, 64); w0, w2 (n_layer, 64, 64) = the stacked nn.Linear weights [out][in]; b0, b2 (n_layer, 64);
+ * out (n_layer, rows, 64).  dim must be 64.
+ */
+int32_t ultra_relation_projection(const void *x, const void *w0, const void *b0, const void *w2, const void *b2, void *out,
+                                  int64_t rows, int32_t n_layer, int32_t dim, void *stream);
 
 /*
  * Filtered ranking without the (batch, N) mask (/root/reference/ultra/tasks.py:94-141):

@@ -63,8 +63,12 @@ def test_dense_entry_points_validate_shapes():
     lib = _lib.lib
     rc = lib.ultra_conv_update(None, None, None, None, None, None, None, 10, 32, 64, 1e-5, 0, None)
     assert rc == _lib.ULTRA_ERR_UNSUPPORTED
-    rc = lib.ultra_readout(None, None, None, None, None, None, None, 1, 10, 10, 32, 64, None)
+    rc = lib.ultra_readout(None, None, None, None, None, None, None, None, None, 1, 10, 10, 32, 64, None)
     assert rc == _lib.ULTRA_ERR_UNSUPPORTED
+    rc = lib.ultra_relation_projection(None, None, None, None, None, None, 10, 6, 32, None)
+    assert rc == _lib.ULTRA_ERR_UNSUPPORTED
+    rc = lib.ultra_query_boundary(None, None, None, None, None, 2, 10, 4, 64, None)
+    assert rc == _lib.ULTRA_ERR_INVALID
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

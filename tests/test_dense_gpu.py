@@ -74,7 +74,8 @@ def test_conv_update_asymmetric_weight_layout(dev):
     assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("bs,n,cand", [(1, 40, None), (3, 100, None), (8, 14541, None), (4, 300, 9), (2, 50, 257)])
+@pytest.mark.parametrize("bs,n,cand", [(1, 40, None), (3, 100, None), (8, 14541, None), (4, 300, 9), (2, 50, 257),
+                                       (32, 70, None), (33, 70, None), (70, 20, 5)])     # > 32 samples: query bias by GEMM
 def test_readout_matches_torch(dev, bs, n, cand):
     from ultra_amd import dense, models, synthetic
     torch.manual_seed(bs)
@@ -95,3 +96,76 @@ def test_readout_matches_torch(dev, bs, n, cand):
     assert got.shape == want.shape
     err = (got - want).abs().max().item()
     assert err <= 2e-5, "max |fused - torch| = %g" % err
+
+
+@pytest.mark.parametrize("bs,rows", [(1, 1), (3, 31), (8, 474), (2, 129)])
+def test_relation_projection_matches_the_per_layer_modules(dev, bs, rows):
+    """ultra_relation_projection == relation_projection (layers.py:80) of every entity layer, in one launch."""
+    from ultra_amd import dense, models, synthetic
+    torch.manual_seed(rows)
+    net = models.EntityNBFNet(**{k: v for k, v in synthetic.default_model_cfg()["entity_model_cfg"].items() if k != "class"}).to(dev)
+    rel = torch.randn(bs, rows, 64, generator=torch.Generator().manual_seed(bs)).to(dev)
+    with torch.no_grad():
+        net.query = rel
+        got = net._project_relations_batched()
+        want = [layer.relation_projection(rel) for layer in net.layers]
+    assert len(got) == len(want) == 6
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        err = (g - w).abs().max().item()
+        assert err <= 2e-5 * max(1.0, w.abs().max().item()), "max |fused - torch| = %g" % err
+
+
+def test_relation_projection_weight_layout(dev):
+    """Fragment-order detector: permutation-like weights make every output a single, identifiable input."""
+    from ultra_amd import dense
+    n_layer = 2
+    w0 = torch.zeros(n_layer, 64, 64, device=dev)
+    w2 = torch.zeros(n_layer, 64, 64, device=dev)
+    for l in range(n_layer):
+        for f in range(64):
+            w0[l, f, (5 * f + 3 + l) % 64] = 1.0 + f          # hidden[f] = (1 + f) * x[(5 f + 3 + l) % 64]
+            w2[l, f, (11 * f + 7 * l + 1) % 64] = 2.0 + l      # out[f] = (2 + l) * hidden[(11 f + 7 l + 1) % 64]
+    b0 = torch.zeros(n_layer, 64, device=dev)
+    b2 = torch.arange(n_layer * 64, dtype=torch.float32, device=dev).view(n_layer, 64)
+    x = (torch.arange(40 * 64, dtype=torch.float32, device=dev).view(40, 64) % 97) / 8 + 0.125      # positive: relu is the identity
+    got = dense.relation_projection(x, w0, b0, w2, b2)
+    want = torch.stack([torch.relu(x @ w0[l].t() + b0[l]) @ w2[l].t() + b2[l] for l in range(n_layer)])
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("bs,n,rels", [(1, 5, 3), (8, 14541, 474), (5, 33, 12)])
+def test_query_boundary_matches_gather_and_scatter(dev, bs, n, rels):
+    """models.py:131-141: query = rel_repr[arange, r]; boundary = zeros.scatter_add(head row, query)."""
+    from ultra_amd import dense
+    g = torch.Generator().manual_seed(n)
+    table = torch.randn(bs, rels, 64, generator=g).to(dev)
+    h = torch.randint(0, n, (bs,), generator=g).to(dev)
+    r = torch.randint(0, rels, (bs,), generator=g).to(dev)
+    boundary, query = dense.query_boundary(h, table, r, n)
+    want_q = table[torch.arange(bs, device=dev), r]
+    want_b = torch.zeros(bs, n, 64, device=dev)
+    want_b.scatter_add_(1, h.view(bs, 1, 1).expand(-1, -1, 64), want_q.unsqueeze(1))
+    assert torch.equal(query, want_q) and torch.equal(boundary, want_b)
+
+
+@pytest.mark.parametrize("n_cand", [1, 2, 1023, 1024, 4095, 4096, 4097, 14541])
+def test_batch_prologue_matches_torch(dev, n_cand):
+    """base_nbfnet.py:79-86 + the asserts of models.py:196-197, for candidate counts around the kernel's unroll blocks."""
+    from ultra_amd import dense
+    g = torch.Generator().manual_seed(n_cand)
+    bs, num_direct = 6, 11
+    batch = torch.randint(0, 50, (bs, n_cand, 3), generator=g)
+    batch[:, :, 2] = batch[:, :1, 2] % num_direct            # one relation per row
+    batch[0::2, :, 0] = batch[0::2, :1, 0]                   # even rows: tail candidates (shared head)
+    batch[1::2, :, 1] = batch[1::2, :1, 1]                   # odd rows: head candidates (shared tail)
+    if n_cand > 1:
+        batch[1::2, -1, 0] = 49 - batch[1::2, 0, 0]          # make sure the heads of the odd rows really differ (last slot)
+        batch[4, n_cand // 2, 2] += 1                        # row 4 breaks the shared-relation rule -> invalid
+    _, h0, r0, side, valid = dense.batch_prologue(batch.to(dev), num_direct)
+    same = (batch == batch[:, :1]).all(dim=1)
+    is_t = same[:, 0]
+    assert torch.equal(side.cpu().bool(), is_t)
+    assert torch.equal(h0.cpu(), torch.where(is_t, batch[:, 0, 0], batch[:, 0, 1]))
+    assert torch.equal(r0.cpu(), torch.where(is_t, batch[:, 0, 2], batch[:, 0, 2] + num_direct))
+    assert torch.equal(valid.cpu().bool(), (same[:, 0] | same[:, 1]) & same[:, 2])

@@ -78,12 +78,14 @@ def _load():
     lib.ultra_rspmm_forward_timed.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp, i32, i32,
                                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     lib.ultra_conv_update.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, ctypes.c_float, i32, vp]
-    lib.ultra_readout.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
+    lib.ultra_readout.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
     lib.ultra_stream_copy.argtypes = [vp, vp, i64, vp]
     lib.ultra_filtered_rank.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
     lib.ultra_onehot_rows.argtypes = [vp, vp, vp, i64, i64, i64, vp]
     lib.ultra_batch_prologue.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp]
-    lib.ultra_readout_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
+    lib.ultra_readout_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
+    lib.ultra_query_boundary.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]
+    lib.ultra_relation_projection.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]
     lib.ultra_set_tuning.argtypes = [ctypes.POINTER(Tuning)]
     lib.ultra_get_tuning.argtypes = [ctypes.POINTER(Tuning)]
     for s in ("add", "min", "max"):

@@ -183,18 +183,42 @@ struct ReadoutParams {
     const int64_t *triples;  // alternative to t_index: the raw (batch, n_cand, 3) [h, t, r] batch ...
     const int32_t *side;     // ... with side[b] = 1 -> candidates are the tails (column 1), 0 -> the heads (column 0)
     const float *w1;         // (128, 128) row-major; only the first 64 input columns are used here
-    const float *qbias;      // (batch, 128) = W1[:, 64:] . query + b1
+    const float *qbias;      // (batch, 128) = W1[:, 64:] . query + b1, or NULL: computed here from ...
+    const float *query;      // ... query (batch, 64) and
+    const float *b1;         // ... mlp.0.bias (128); batch <= READOUT_MAX_INLINE_BATCH then
     const float *w2;         // (128)
     const float *b2;         // (1) = mlp.2.bias
     float *score;            // (batch, n_cand)
     long long batch, num_node, n_cand;
 };
 
+constexpr int READOUT_MAX_INLINE_BATCH = 32;
+
 __global__ void __launch_bounds__(256) readout_kernel(const ReadoutParams p) {
     // [tile m (4)][i (8)][lane][q] : W1[32 m + (lane & 31)][8 i + 4 (lane >> 5) + q]
     __shared__ __attribute__((aligned(16))) float lds_w[4 * 8 * 64 * 4];
     __shared__ float lds_w2[128];
+    __shared__ float lds_qb[READOUT_MAX_INLINE_BATCH * 128];
     const int tid = threadIdx.x;
+    if (!p.qbias) {
+        // the query half of mlp.0 (models.py:166-170 concatenates query to every node feature): one 64-term dot
+        // product per (sample, hidden unit), computed by every workgroup for itself instead of a GEMM launch
+        for (int idx = tid; idx < (int)p.batch * 128; idx += 256) {
+            const int b = idx >> 7, f = idx & 127;
+            const float4 *wr = reinterpret_cast<const float4 *>(p.w1 + f * 128 + 64);
+            const float4 *qr = reinterpret_cast<const float4 *>(p.query + b * 64);
+            float acc = p.b1[f];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float4 w = wr[k], q = qr[k];
+                acc += w.x * q.x;
+                acc += w.y * q.y;
+                acc += w.z * q.z;
+                acc += w.w * q.w;
+            }
+            lds_qb[idx] = acc;
+        }
+    }
     for (int idx4 = tid; idx4 < 4 * 8 * 64; idx4 += 256) {
         const int l = idx4 & 63, i = (idx4 >> 6) & 7, m = idx4 >> 9;
         reinterpret_cast<float4 *>(lds_w)[idx4] =
@@ -246,7 +270,7 @@ __global__ void __launch_bounds__(256) readout_kernel(const ReadoutParams p) {
             for (int m = 0; m < 4; ++m) a[m] = an[m];
             __builtin_amdgcn_sched_barrier(0);
         }
-        const float *qb = p.qbias + b * 128;
+        const float *qb = p.qbias ? p.qbias + b * 128 : lds_qb + b * 128;
         float s = 0.f;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -258,6 +282,106 @@ __global__ void __launch_bounds__(256) readout_kernel(const ReadoutParams p) {
             }
         s += __shfl_xor(s, 32);
         if (valid && h == 0) p.score[row] = s + p.b2[0];
+    }
+}
+
+// All layers' relation_projection MLPs (layers.py:80: Linear(64, 64) -> ReLU -> Linear(64, 64) applied to the
+// relation representations, models.py:184-185) in ONE launch: workgroup = (layer, 4 row tiles), both weight
+// matrices of the layer staged in LDS in MFMA fragment order.  Transposed products as in conv_update: a data row's
+// features live in one lane pair, so the hidden activation of the first product is consumed by the second one
+// straight from the accumulator registers -- the contraction index of the second product is simply enumerated in
+// the order the accumulators hold it (feat_of), and the second weight matrix is staged in that same order.
+struct RelProjParams {
+    const float *x;        // (rows, 64)
+    const float *w0, *b0;  // (n_layer, 64, 64) row-major [out][in], (n_layer, 64)
+    const float *w2, *b2;
+    float *out;            // (n_layer, rows, 64)
+    long long rows;
+    int n_layer;
+};
+
+__global__ void __launch_bounds__(256) relation_projection_kernel(const RelProjParams p) {
+    // lds_w0[m][i][lane][q] = W0[32 m + (lane & 31)][8 i + 4 (lane >> 5) + q]          (k = 8 i + 4 h + q: x chunk 2 i + h)
+    // lds_w2[m2][s][lane]   = W2[32 m2 + (lane & 31)][feat_of(s >> 4, s & 15, lane >> 5)]  (k enumerated as the accumulators)
+    __shared__ __attribute__((aligned(16))) float lds_w0[2 * 8 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float lds_w2[2 * 32 * 64];
+    __shared__ float lds_b[2 * 64];
+    const int tid = threadIdx.x;
+    const int layer = blockIdx.y;
+    const float *w0 = p.w0 + (size_t)layer * 64 * 64, *w2 = p.w2 + (size_t)layer * 64 * 64;
+    for (int idx4 = tid; idx4 < 2 * 8 * 64; idx4 += 256) {
+        const int l = idx4 & 63, i = (idx4 >> 6) & 7, m = idx4 >> 9;
+        reinterpret_cast<float4 *>(lds_w0)[idx4] =
+            *reinterpret_cast<const float4 *>(w0 + (32 * m + (l & 31)) * 64 + 8 * i + 4 * (l >> 5));
+    }
+    for (int idx = tid; idx < 2 * 32 * 64; idx += 256) {
+        const int l = idx & 63, st = (idx >> 6) & 31, m2 = idx >> 11;
+        lds_w2[idx] = w2[(32 * m2 + (l & 31)) * 64 + feat_of(st >> 4, st & 15, l >> 5)];
+    }
+    if (tid < 64) {
+        lds_b[tid] = p.b0[layer * 64 + tid];
+        lds_b[64 + tid] = p.b2[layer * 64 + tid];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const long long tile = (long long)blockIdx.x * 4 + wave;
+    if (tile * 32 >= p.rows) return;
+    const long long row = tile * 32 + j;
+    const bool valid = row < p.rows;
+    const float4 *xr = reinterpret_cast<const float4 *>(p.x + (valid ? row : p.rows - 1) * 64);
+    float4 bx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bx[i] = xr[2 * i + h];
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    const float4 *w04 = reinterpret_cast<const float4 *>(lds_w0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float4 a0 = w04[(0 * 8 + i) * 64 + lane], a1 = w04[(1 * 8 + i) * 64 + lane];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bx[i].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bx[i].x, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bx[i].y, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bx[i].y, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bx[i].z, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bx[i].z, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bx[i].w, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bx[i].w, acc[1], 0, 0, 0);
+    }
+    // hidden = relu(. + b0), kept in the accumulator layout: it is the B operand of the second product
+    float hid[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hid[m][r] = fmaxf(acc[m][r] + lds_b[feat_of(m, r, h)], 0.f);
+    f32x16 out[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[m][r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 32; ++st) {
+        const float b = hid[st >> 4][st & 15];
+        out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_w2[(0 * 32 + st) * 64 + lane], b, out[0], 0, 0, 0);
+        out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_w2[(1 * 32 + st) * 64 + lane], b, out[1], 0, 0, 0);
+    }
+    if (valid) {
+        float *orow = p.out + ((size_t)layer * p.rows + row) * 64;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = 32 * m + 8 * g + 4 * h;
+                float4 y;
+                y.x = out[m][4 * g + 0] + lds_b[64 + f + 0];
+                y.y = out[m][4 * g + 1] + lds_b[64 + f + 1];
+                y.z = out[m][4 * g + 2] + lds_b[64 + f + 2];
+                y.w = out[m][4 * g + 3] + lds_b[64 + f + 3];
+                *reinterpret_cast<float4 *>(orow + f) = y;
+            }
     }
 }
 
@@ -317,19 +441,35 @@ int32_t ultra_conv_update(const void *x, const void *agg, const void *weight, co
     return ULTRA_OK;
 }
 
-int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1, const void *qbias, const void *w2,
-                      const void *b2, void *score, int64_t batch, int64_t num_node, int64_t n_cand, int32_t hidden_dim,
-                      int32_t feature_dim, void *stream) {
+static int check_query_bias(const void *qbias, const void *query, const void *b1, int64_t batch) {
+    if (qbias) return ULTRA_OK;
+    if (!query || !b1) {
+        set_error("ultra_readout: pass qbias, or query and b1");
+        return ULTRA_ERR_INVALID;
+    }
+    if (batch > READOUT_MAX_INLINE_BATCH) {
+        set_error("ultra_readout: the in-kernel query bias serves batch <= 32; pass a precomputed qbias beyond");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    return ULTRA_OK;
+}
+
+int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1, const void *qbias, const void *query,
+                      const void *b1, const void *w2, const void *b2, void *score, int64_t batch, int64_t num_node,
+                      int64_t n_cand, int32_t hidden_dim, int32_t feature_dim, void *stream) {
     if (hidden_dim != 64 || feature_dim != 128) {
         set_error("ultra_readout: only hidden_dim = 64, feature_dim = 128 is built (the ULTRA checkpoints' shape)");
         return ULTRA_ERR_UNSUPPORTED;
     }
-    if (!hidden || !w1 || !qbias || !w2 || !b2 || !score || batch < 0 || n_cand < 0) {
+    if (!hidden || !w1 || !w2 || !b2 || !score || batch < 0 || n_cand < 0) {
         set_error("ultra_readout: NULL operand");
         return ULTRA_ERR_INVALID;
     }
+    if (int rc = check_query_bias(qbias, query, b1, batch)) return rc;
     if (batch * n_cand == 0) return ULTRA_OK;
     ReadoutParams p;
+    p.query = (const float *)query;
+    p.b1 = (const float *)b1;
     p.hidden = (const float *)hidden;
     p.t_index = t_index;
     p.triples = nullptr;
@@ -354,18 +494,22 @@ int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1
 }
 
 int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const int32_t *side, const void *w1,
-                            const void *qbias, const void *w2, const void *b2, void *score, int64_t batch, int64_t num_node,
-                            int64_t n_cand, int32_t hidden_dim, int32_t feature_dim, void *stream) {
+                            const void *qbias, const void *query, const void *b1, const void *w2, const void *b2, void *score,
+                            int64_t batch, int64_t num_node, int64_t n_cand, int32_t hidden_dim, int32_t feature_dim,
+                            void *stream) {
     if (hidden_dim != 64 || feature_dim != 128) {
         set_error("ultra_readout_batch: only hidden_dim = 64, feature_dim = 128 is built (the ULTRA checkpoints' shape)");
         return ULTRA_ERR_UNSUPPORTED;
     }
-    if (!hidden || !triples || !side || !w1 || !qbias || !w2 || !b2 || !score || batch < 0 || n_cand < 0) {
+    if (!hidden || !triples || !side || !w1 || !w2 || !b2 || !score || batch < 0 || n_cand < 0) {
         set_error("ultra_readout_batch: NULL operand");
         return ULTRA_ERR_INVALID;
     }
+    if (int rc = check_query_bias(qbias, query, b1, batch)) return rc;
     if (batch * n_cand == 0) return ULTRA_OK;
     ReadoutParams p;
+    p.query = (const float *)query;
+    p.b1 = (const float *)b1;
     p.hidden = (const float *)hidden;
     p.t_index = nullptr;
     p.triples = triples;
@@ -384,6 +528,37 @@ int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const in
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error(std::string("readout_kernel launch: ") + hipGetErrorString(e));
+        return ULTRA_ERR_HIP;
+    }
+    return ULTRA_OK;
+}
+
+int32_t ultra_relation_projection(const void *x, const void *w0, const void *b0, const void *w2, const void *b2, void *out,
+                                  int64_t rows, int32_t n_layer, int32_t dim, void *stream) {
+    if (dim != 64) {
+        set_error("ultra_relation_projection: only dim = 64 is built (the ULTRA checkpoints' shape)");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    if (!x || !w0 || !b0 || !w2 || !b2 || !out || rows < 0 || n_layer < 0) {
+        set_error("ultra_relation_projection: NULL operand");
+        return ULTRA_ERR_INVALID;
+    }
+    if (rows == 0 || n_layer == 0) return ULTRA_OK;
+    RelProjParams p;
+    p.x = (const float *)x;
+    p.w0 = (const float *)w0;
+    p.b0 = (const float *)b0;
+    p.w2 = (const float *)w2;
+    p.b2 = (const float *)b2;
+    p.out = (float *)out;
+    p.rows = rows;
+    p.n_layer = n_layer;
+    const dim3 grid((unsigned)((rows + 127) / 128), (unsigned)n_layer);
+    (void)hipGetLastError();   // drop any stale error left by other users of the runtime
+    hipLaunchKernelGGL(relation_projection_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error(std::string("relation_projection_kernel launch: ") + hipGetErrorString(e));
         return ULTRA_ERR_HIP;
     }
     return ULTRA_OK;

@@ -50,14 +50,29 @@ __global__ void __launch_bounds__(256) filtered_rank_kernel(const float *__restr
 //   h0[b], r0[b] = source node and query relation of the row after that conversion;
 //   valid[b] = the row really shares its source node and its relation (the reference's two asserts), per row:
 //              no initialisation pass / memset node is needed (hipGraph friendly).
-__global__ void __launch_bounds__(256) batch_prologue_kernel(const int64_t *__restrict__ batch, long long n_cand,
+__global__ void __launch_bounds__(1024) batch_prologue_kernel(const int64_t *__restrict__ batch, long long n_cand,
                                                              long long num_direct_rel, int64_t *h0, int64_t *r0,
                                                              int32_t *side, int32_t *valid) {
     const int b = blockIdx.x;
     const int64_t *row = batch + (long long)b * n_cand * 3;
     const int64_t fh = row[0], ft = row[1], fr = row[2];
     int same_h = 1, same_t = 1, same_r = 1;
-    for (long long i = threadIdx.x; i < n_cand; i += blockDim.x) {
+    // 4 candidates (12 independent loads) in flight per thread: one workgroup scans a whole row of the batch
+    long long i = threadIdx.x;
+    for (; i + 3 * (long long)blockDim.x < n_cand; i += 4 * (long long)blockDim.x) {
+        int64_t v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[u][c] = row[3 * (i + u * (long long)blockDim.x) + c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            same_h &= (v[u][0] == fh);
+            same_t &= (v[u][1] == ft);
+            same_r &= (v[u][2] == fr);
+        }
+    }
+    for (; i < n_cand; i += blockDim.x) {
         same_h &= (row[3 * i] == fh);
         same_t &= (row[3 * i + 1] == ft);
         same_r &= (row[3 * i + 2] == fr);
@@ -89,7 +104,7 @@ extern "C" int32_t ultra_batch_prologue(const int64_t *batch, int64_t batch_size
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (batch_size == 0) return ULTRA_OK;
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
-    hipLaunchKernelGGL(ultra::batch_prologue_kernel, dim3((unsigned)batch_size), dim3(256), 0, s, batch, (long long)n_cand,
+    hipLaunchKernelGGL(ultra::batch_prologue_kernel, dim3((unsigned)batch_size), dim3(1024), 0, s, batch, (long long)n_cand,
                        (long long)num_direct_rel, h0, r0, side, valid);
     if (hipGetLastError() != hipSuccess) {
         ultra::set_error("batch_prologue_kernel launch failed");

@@ -19,15 +19,28 @@ __global__ void __launch_bounds__(256) stream_copy_kernel(const float4 *__restri
 
 // out[b, n, :] = (n == rows[b]) ? values[b, :] (or 1 when values == NULL) : 0 -- the NBFNet boundary condition
 // (models.py:59-66, 135-141: zeros + scatter_add of one row per sample) in a single pass, no memset node.
+// With `table`: values[b] = table[b, pick[b], :] (the query relation's representation, models.py:131-133), also written
+// to values_out[b] for the readout.
 __global__ void __launch_bounds__(256) onehot_rows_kernel(float4 *__restrict__ out, const int64_t *__restrict__ rows,
-                                                          const float4 *__restrict__ values, long long num_node, int dim4,
+                                                          const float4 *__restrict__ values, const float4 *__restrict__ table,
+                                                          const int64_t *__restrict__ pick, long long table_rows,
+                                                          float4 *__restrict__ values_out, long long num_node, int dim4,
                                                           long long total4) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const int d = (int)(i % dim4);
         const long long r = i / dim4;
         const long long n = r % num_node, b = r / num_node;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n == rows[b]) v = values ? values[b * dim4 + d] : make_float4(1.f, 1.f, 1.f, 1.f);
+        if (n == rows[b]) {
+            if (table) {
+                long long t = pick[b];   // (an out-of-range relation id reads a valid row instead of faulting)
+                t = t < 0 ? 0 : (t >= table_rows ? table_rows - 1 : t);
+                v = table[(b * table_rows + t) * dim4 + d];
+                values_out[b * dim4 + d] = v;
+            } else {
+                v = values ? values[b * dim4 + d] : make_float4(1.f, 1.f, 1.f, 1.f);
+            }
+        }
         out[i] = v;
     }
 }
@@ -45,7 +58,30 @@ extern "C" int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void 
     const int grid = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
     hipLaunchKernelGGL(ultra::onehot_rows_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       (float4 *)out, rows, (const float4 *)values, (long long)num_node, (int)(dim / 4), total4);
+                       (float4 *)out, rows, (const float4 *)values, (const float4 *)nullptr, (const int64_t *)nullptr, 0ll,
+                       (float4 *)nullptr, (long long)num_node, (int)(dim / 4), total4);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ultra::set_error(std::string("onehot_rows_kernel launch: ") + hipGetErrorString(e));
+        return ULTRA_ERR_HIP;
+    }
+    return ULTRA_OK;
+}
+
+extern "C" int32_t ultra_query_boundary(void *out, void *query_out, const int64_t *rows, const void *table,
+                                        const int64_t *pick, int64_t batch, int64_t num_node, int64_t table_rows, int64_t dim,
+                                        void *stream) {
+    if (!out || !query_out || !rows || !table || !pick || batch < 0 || num_node <= 0 || table_rows <= 0 || dim <= 0 || (dim & 3)) {
+        ultra::set_error("ultra_query_boundary: NULL operand, empty graph or dim not a multiple of 4");
+        return ULTRA_ERR_INVALID;
+    }
+    const long long total4 = (long long)batch * num_node * (dim / 4);
+    if (total4 == 0) return ULTRA_OK;
+    const int grid = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+    (void)hipGetLastError();   // drop any stale error left by other users of the runtime
+    hipLaunchKernelGGL(ultra::onehot_rows_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (float4 *)out, rows, (const float4 *)nullptr, (const float4 *)table, pick, (long long)table_rows,
+                       (float4 *)query_out, (long long)num_node, (int)(dim / 4), total4);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         ultra::set_error(std::string("onehot_rows_kernel launch: ") + hipGetErrorString(e));

@@ -50,17 +50,29 @@ def readout_supported(model, hidden):
             and not (torch.is_grad_enabled() and (hidden.requires_grad or mlp[0].weight.requires_grad)))
 
 
+INLINE_QUERY_BIAS_MAX_BATCH = 32     # readout kernels fold the query half of mlp.0 themselves up to this batch size
+
+
+def _query_bias_args(mlp, query):
+    """(qbias, query, b1) pointers for the readout kernels: in-kernel bias for small batches, one GEMM beyond."""
+    if query.shape[0] <= INLINE_QUERY_BIAS_MAX_BATCH:
+        query = query.contiguous()
+        return None, query, (None, query.data_ptr(), mlp[0].bias.data_ptr())
+    qbias = F.linear(query, mlp[0].weight[:, 64:], mlp[0].bias).contiguous()      # (batch, 128)
+    return qbias, query, (qbias.data_ptr(), None, None)
+
+
 def readout(model, hidden, query, t_index):
     """score[b, i] = mlp(cat[hidden[b, t_index[b, i]], query[b]]) without materialising the concatenation."""
     mlp = model.mlp
     w1 = mlp[0].weight
-    qbias = F.linear(query, w1[:, 64:], mlp[0].bias).contiguous()      # (batch, 128): the query half of mlp.0
+    _keep_qb, _keep_q, qargs = _query_bias_args(mlp, query)
     hidden = hidden.contiguous()
     batch, num_node = hidden.shape[:2]
     t_index = t_index.contiguous()
     n_cand = t_index.shape[1]
     score = torch.empty(batch, n_cand, dtype=hidden.dtype, device=hidden.device)
-    check(lib.ultra_readout(hidden.data_ptr(), t_index.data_ptr(), w1.data_ptr(), qbias.data_ptr(),
+    check(lib.ultra_readout(hidden.data_ptr(), t_index.data_ptr(), w1.data_ptr(), *qargs,
                             mlp[2].weight.data_ptr(), mlp[2].bias.data_ptr(), score.data_ptr(), batch, num_node, n_cand,
                             64, 128, _stream()))
     return score
@@ -83,12 +95,12 @@ def readout_batch(model, hidden, query, batch, side):
     """readout() with the candidate node read straight from the raw (bs, n_cand, 3) batch."""
     mlp = model.mlp
     w1 = mlp[0].weight
-    qbias = F.linear(query, w1[:, 64:], mlp[0].bias).contiguous()
+    _keep_qb, _keep_q, qargs = _query_bias_args(mlp, query)
     hidden = hidden.contiguous()
     bs, num_node = hidden.shape[:2]
     n_cand = batch.shape[1]
     score = torch.empty(bs, n_cand, dtype=hidden.dtype, device=hidden.device)
-    check(lib.ultra_readout_batch(hidden.data_ptr(), batch.data_ptr(), side.data_ptr(), w1.data_ptr(), qbias.data_ptr(),
+    check(lib.ultra_readout_batch(hidden.data_ptr(), batch.data_ptr(), side.data_ptr(), w1.data_ptr(), *qargs,
                                   mlp[2].weight.data_ptr(), mlp[2].bias.data_ptr(), score.data_ptr(), bs, num_node, n_cand,
                                   64, 128, _stream()))
     return score
@@ -106,4 +118,28 @@ def onehot_boundary(index, values, num_node, dim):
     index = index.to(torch.int64).contiguous()
     vptr = values.contiguous().data_ptr() if values is not None else None
     check(lib.ultra_onehot_rows(out.data_ptr(), index.data_ptr(), vptr, batch, num_node, dim, _stream()))
+    return out
+
+
+def query_boundary(h_index, relation_representations, r_index, num_node):
+    """(boundary, query) of EntityNBFNet.bellmanford (models.py:131-141) in one kernel:
+    query = relation_representations[arange(bs), r_index]; boundary = zeros with query[b] at row h_index[b]."""
+    table = relation_representations.contiguous()
+    bs, num_rel, dim = table.shape
+    boundary = torch.empty(bs, num_node, dim, dtype=torch.float32, device=table.device)
+    query = torch.empty(bs, dim, dtype=torch.float32, device=table.device)
+    check(lib.ultra_query_boundary(boundary.data_ptr(), query.data_ptr(), h_index.to(torch.int64).contiguous().data_ptr(),
+                                   table.data_ptr(), r_index.to(torch.int64).contiguous().data_ptr(), bs, num_node, num_rel,
+                                   dim, _stream()))
+    return boundary, query
+
+
+def relation_projection(x, w0, b0, w2, b2):
+    """out[l] = relu(x @ w0[l].T + b0[l]) @ w2[l].T + b2[l] for the stacked (n_layer, 64, 64) weights: one MFMA kernel."""
+    x = x.contiguous()
+    rows = x.numel() // 64
+    n_layer = w0.shape[0]
+    out = torch.empty((n_layer,) + tuple(x.shape), dtype=torch.float32, device=x.device)
+    check(lib.ultra_relation_projection(x.data_ptr(), w0.data_ptr(), b0.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                        out.data_ptr(), rows, n_layer, 64, _stream()))
     return out

@@ -139,7 +139,12 @@ class RelNBFNet(BaseNBFNet):
 
     def bellmanford(self, data, h_index, separate_grad=False):
         batch_size = len(h_index)
-        query = torch.ones(batch_size, self.dims[0], device=h_index.device, dtype=torch.float)
+        ones = getattr(self, "_ones_query", None)
+        if ones is None or ones.shape[0] != batch_size or ones.device != h_index.device or torch.is_grad_enabled():
+            ones = torch.ones(batch_size, self.dims[0], device=h_index.device, dtype=torch.float)
+            if not torch.is_grad_enabled():
+                self._ones_query = ones        # constant: not refilled on every forward
+        query = ones
         index = h_index.unsqueeze(-1).expand_as(query)
         # boundary: ones at the query relation's node, zeros elsewhere (models.py:59-66)
         if dense.boundary_supported(h_index, None) and self.dims[0] % 4 == 0:
@@ -194,11 +199,12 @@ class EntityNBFNet(BaseNBFNet):
     def _bellmanford_hidden(self, data, h_index, r_index, separate_grad=False, edge_weight=None):
         batch_size = len(r_index)
         # query = representation of each sample's query relation, scattered to its head node
-        query = self.query[torch.arange(batch_size, device=r_index.device), r_index]
-        index = h_index.unsqueeze(-1).expand_as(query)
-        if dense.boundary_supported(h_index, query):
-            boundary = dense.onehot_boundary(h_index, query, data.num_nodes, self.dims[0])
+        if dense.boundary_supported(h_index, self.query) and self.query.dim() == 3 and self.query.shape[0] == batch_size \
+                and self.query.shape[-1] == self.dims[0]:
+            boundary, query = dense.query_boundary(h_index, self.query, r_index, data.num_nodes)   # gather + scatter, one kernel
         else:
+            query = self.query[torch.arange(batch_size, device=r_index.device), r_index]
+            index = h_index.unsqueeze(-1).expand_as(query)
             boundary = torch.zeros(batch_size, data.num_nodes, self.dims[0], device=h_index.device, dtype=query.dtype)
             boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
         hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad,
@@ -207,8 +213,9 @@ class EntityNBFNet(BaseNBFNet):
         return hiddens, edge_weights, query
 
     def _project_relations_batched(self):
-        """All layers' relation_projection MLPs (layers.py:80) read the same input: run them as two batched
-        GEMMs instead of 12 small ones.  Inference only; training keeps the per-layer modules."""
+        """All layers' relation_projection MLPs (layers.py:80) read the same input: one MFMA kernel for the ULTRA
+        shape (two batched GEMMs otherwise) instead of 12 small GEMMs.  Inference only; training keeps the per-layer
+        modules."""
         rel = self.query
         if torch.is_grad_enabled() or rel is None or not rel.is_cuda or not all(
                 getattr(l, "project_relations", False) and not l.dependent for l in self.layers):
@@ -220,8 +227,15 @@ class EntityNBFNet(BaseNBFNet):
             self._proj_b0 = torch.stack([l.relation_projection[0].bias for l in self.layers]).unsqueeze(1)
             self._proj_w2 = torch.stack([l.relation_projection[2].weight for l in self.layers]).transpose(1, 2).contiguous()
             self._proj_b2 = torch.stack([l.relation_projection[2].bias for l in self.layers]).unsqueeze(1)
+            # [out][in] stacks for the fused kernel
+            self._proj_k = [torch.stack([l.relation_projection[i].weight for l in self.layers]).contiguous() for i in (0, 2)] \
+                + [torch.stack([l.relation_projection[i].bias for l in self.layers]).contiguous() for i in (0, 2)]
             self._proj_key = key
         n = len(self.layers)
+        if rel.dtype == torch.float32 and rel.shape[-1] == 64 and all(
+                tuple(l.relation_projection[i].weight.shape) == (64, 64) for l in self.layers for i in (0, 2)):
+            w0, w2, b0, b2 = self._proj_k
+            return list(dense.relation_projection(rel, w0, b0, w2, b2).unbind(0))
         x = rel.reshape(1, -1, rel.shape[-1]).expand(n, -1, -1)
         h = torch.baddbmm(self._proj_b0, x, self._proj_w0).relu_()
         out = torch.baddbmm(self._proj_b2, h, self._proj_w2)
