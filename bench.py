@@ -115,8 +115,13 @@ def main():
         graphed = GraphedForward(model, data, tasks.all_negative(data, batch_for(0))[0])
         forward = lambda data_, batch_: graphed(batch_)
 
+    # synthetic input, resident in HBM before the timed region: one (bs, N, 3) all-tail candidate batch per step
+    # (distinct queries per step; cycled beyond 256 steps)
+    n_inputs = min(args.warmup + args.steps, 256)
+    inputs = [tasks.all_negative(data, batch_for(i))[0] for i in range(n_inputs)]
+
     def one_step(step):
-        t_batch, _ = tasks.all_negative(data, batch_for(step))
+        t_batch = inputs[step % n_inputs]
         score = forward(data, t_batch)                     # (bs, N)
         if world > 1 or launched:
             score = udist.all_gather_scores(score)         # (world * bs, N): one RCCL all-gather per step

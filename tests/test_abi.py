@@ -67,7 +67,7 @@ def test_dense_entry_points_validate_shapes():
     assert rc == _lib.ULTRA_ERR_UNSUPPORTED
     rc = lib.ultra_relation_projection(None, None, None, None, None, None, 10, 6, 32, None)
     assert rc == _lib.ULTRA_ERR_UNSUPPORTED
-    rc = lib.ultra_query_boundary(None, None, None, None, None, 2, 10, 4, 64, None)
+    rc = lib.ultra_query_boundary(None, None, None, None, None, 2, 10, 4, 64, None, None, None, None)
     assert rc == _lib.ULTRA_ERR_INVALID
 
 

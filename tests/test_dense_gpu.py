@@ -142,11 +142,18 @@ def test_query_boundary_matches_gather_and_scatter(dev, bs, n, rels):
     table = torch.randn(bs, rels, 64, generator=g).to(dev)
     h = torch.randint(0, n, (bs,), generator=g).to(dev)
     r = torch.randint(0, rels, (bs,), generator=g).to(dev)
-    boundary, query = dense.query_boundary(h, table, r, n)
+    boundary, query, qbias = dense.query_boundary(h, table, r, n)
     want_q = table[torch.arange(bs, device=dev), r]
     want_b = torch.zeros(bs, n, 64, device=dev)
     want_b.scatter_add_(1, h.view(bs, 1, 1).expand(-1, -1, 64), want_q.unsqueeze(1))
-    assert torch.equal(query, want_q) and torch.equal(boundary, want_b)
+    assert qbias is None and torch.equal(query, want_q) and torch.equal(boundary, want_b)
+    # with the readout MLP: the same launch also emits mlp.0's query half (models.py:166-170)
+    mlp = torch.nn.Sequential(torch.nn.Linear(128, 128), torch.nn.ReLU(), torch.nn.Linear(128, 1)).to(dev)
+    with torch.no_grad():
+        boundary2, query2, qbias = dense.query_boundary(h, table, r, n, readout_mlp=mlp)
+        want_qb = torch.nn.functional.linear(want_q, mlp[0].weight[:, 64:], mlp[0].bias)
+    assert torch.equal(query2, want_q) and torch.equal(boundary2, want_b)
+    assert qbias.shape == (bs, 128) and (qbias - want_qb).abs().max().item() <= 1e-5
 
 
 @pytest.mark.parametrize("n_cand", [1, 2, 1023, 1024, 4095, 4096, 4097, 14541])

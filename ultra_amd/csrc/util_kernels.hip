@@ -25,7 +25,30 @@ __global__ void __launch_bounds__(256) onehot_rows_kernel(float4 *__restrict__ o
                                                           const float4 *__restrict__ values, const float4 *__restrict__ table,
                                                           const int64_t *__restrict__ pick, long long table_rows,
                                                           float4 *__restrict__ values_out, long long num_node, int dim4,
-                                                          long long total4) {
+                                                          long long total4, const float *__restrict__ w1,
+                                                          const float *__restrict__ b1, float *__restrict__ qbias_out,
+                                                          int batch) {
+    if (qbias_out && blockIdx.x == gridDim.x - 1) {
+        // readout preamble riding on this launch (models.py:166-170 concatenates the query to every node feature; its half
+        // of mlp.0 is a per-sample constant): qbias[b, f] = b1[f] + sum_k w1[f, dim + k] * query[b, k], dim = 4 dim4 = 64
+        const int dim = 4 * dim4;
+        for (int idx = threadIdx.x; idx < batch * 2 * dim; idx += blockDim.x) {
+            const int b = idx / (2 * dim), f = idx % (2 * dim);
+            long long t = pick[b];
+            t = t < 0 ? 0 : (t >= table_rows ? table_rows - 1 : t);
+            const float4 *qr = table + ((long long)b * table_rows + t) * dim4;
+            const float4 *wr = reinterpret_cast<const float4 *>(w1 + (long long)f * 2 * dim + dim);
+            float acc = b1[f];
+            for (int k = 0; k < dim4; ++k) {
+                const float4 w = wr[k], q = qr[k];
+                acc += w.x * q.x;
+                acc += w.y * q.y;
+                acc += w.z * q.z;
+                acc += w.w * q.w;
+            }
+            qbias_out[idx] = acc;
+        }
+    }
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const int d = (int)(i % dim4);
         const long long r = i / dim4;
@@ -59,7 +82,8 @@ extern "C" int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void 
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
     hipLaunchKernelGGL(ultra::onehot_rows_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        (float4 *)out, rows, (const float4 *)values, (const float4 *)nullptr, (const int64_t *)nullptr, 0ll,
-                       (float4 *)nullptr, (long long)num_node, (int)(dim / 4), total4);
+                       (float4 *)nullptr, (long long)num_node, (int)(dim / 4), total4, (const float *)nullptr,
+                       (const float *)nullptr, (float *)nullptr, 0);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         ultra::set_error(std::string("onehot_rows_kernel launch: ") + hipGetErrorString(e));
@@ -70,7 +94,7 @@ extern "C" int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void 
 
 extern "C" int32_t ultra_query_boundary(void *out, void *query_out, const int64_t *rows, const void *table,
                                         const int64_t *pick, int64_t batch, int64_t num_node, int64_t table_rows, int64_t dim,
-                                        void *stream) {
+                                        const void *w1, const void *b1, void *qbias_out, void *stream) {
     if (!out || !query_out || !rows || !table || !pick || batch < 0 || num_node <= 0 || table_rows <= 0 || dim <= 0 || (dim & 3)) {
         ultra::set_error("ultra_query_boundary: NULL operand, empty graph or dim not a multiple of 4");
         return ULTRA_ERR_INVALID;
@@ -81,7 +105,8 @@ extern "C" int32_t ultra_query_boundary(void *out, void *query_out, const int64_
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
     hipLaunchKernelGGL(ultra::onehot_rows_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        (float4 *)out, rows, (const float4 *)nullptr, (const float4 *)table, pick, (long long)table_rows,
-                       (float4 *)query_out, (long long)num_node, (int)(dim / 4), total4);
+                       (float4 *)query_out, (long long)num_node, (int)(dim / 4), total4, (const float *)w1, (const float *)b1,
+                       (float *)((w1 && b1) ? qbias_out : nullptr), (int)batch);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         ultra::set_error(std::string("onehot_rows_kernel launch: ") + hipGetErrorString(e));

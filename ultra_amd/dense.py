@@ -53,8 +53,11 @@ def readout_supported(model, hidden):
 INLINE_QUERY_BIAS_MAX_BATCH = 32     # readout kernels fold the query half of mlp.0 themselves up to this batch size
 
 
-def _query_bias_args(mlp, query):
-    """(qbias, query, b1) pointers for the readout kernels: in-kernel bias for small batches, one GEMM beyond."""
+def _query_bias_args(mlp, query, qbias=None):
+    """(qbias, query, b1) pointers for the readout kernels: a bias computed upstream (query_boundary), else in-kernel
+    for small batches, one GEMM beyond."""
+    if qbias is not None:
+        return qbias, query, (qbias.data_ptr(), None, None)
     if query.shape[0] <= INLINE_QUERY_BIAS_MAX_BATCH:
         query = query.contiguous()
         return None, query, (None, query.data_ptr(), mlp[0].bias.data_ptr())
@@ -62,11 +65,11 @@ def _query_bias_args(mlp, query):
     return qbias, query, (qbias.data_ptr(), None, None)
 
 
-def readout(model, hidden, query, t_index):
+def readout(model, hidden, query, t_index, qbias=None):
     """score[b, i] = mlp(cat[hidden[b, t_index[b, i]], query[b]]) without materialising the concatenation."""
     mlp = model.mlp
     w1 = mlp[0].weight
-    _keep_qb, _keep_q, qargs = _query_bias_args(mlp, query)
+    _keep_qb, _keep_q, qargs = _query_bias_args(mlp, query, qbias)
     hidden = hidden.contiguous()
     batch, num_node = hidden.shape[:2]
     t_index = t_index.contiguous()
@@ -91,11 +94,11 @@ def batch_prologue(batch, num_direct_rel):
     return batch, h0, r0, side, valid
 
 
-def readout_batch(model, hidden, query, batch, side):
+def readout_batch(model, hidden, query, batch, side, qbias=None):
     """readout() with the candidate node read straight from the raw (bs, n_cand, 3) batch."""
     mlp = model.mlp
     w1 = mlp[0].weight
-    _keep_qb, _keep_q, qargs = _query_bias_args(mlp, query)
+    _keep_qb, _keep_q, qargs = _query_bias_args(mlp, query, qbias)
     hidden = hidden.contiguous()
     bs, num_node = hidden.shape[:2]
     n_cand = batch.shape[1]
@@ -121,17 +124,24 @@ def onehot_boundary(index, values, num_node, dim):
     return out
 
 
-def query_boundary(h_index, relation_representations, r_index, num_node):
-    """(boundary, query) of EntityNBFNet.bellmanford (models.py:131-141) in one kernel:
-    query = relation_representations[arange(bs), r_index]; boundary = zeros with query[b] at row h_index[b]."""
+def query_boundary(h_index, relation_representations, r_index, num_node, readout_mlp=None):
+    """(boundary, query, qbias) of EntityNBFNet.bellmanford (models.py:131-141) in one kernel:
+    query = relation_representations[arange(bs), r_index]; boundary = zeros with query[b] at row h_index[b];
+    with `readout_mlp` also qbias = mlp.0.weight[:, dim:] @ query + mlp.0.bias for the readout (else None)."""
     table = relation_representations.contiguous()
     bs, num_rel, dim = table.shape
     boundary = torch.empty(bs, num_node, dim, dtype=torch.float32, device=table.device)
     query = torch.empty(bs, dim, dtype=torch.float32, device=table.device)
+    qbias, w1, b1 = None, None, None
+    if readout_mlp is not None and bs <= 1024:
+        lin = readout_mlp[0]
+        if tuple(lin.weight.shape) == (2 * dim, 2 * dim) and lin.bias is not None and lin.weight.is_contiguous():
+            qbias = torch.empty(bs, 2 * dim, dtype=torch.float32, device=table.device)
+            w1, b1 = lin.weight.data_ptr(), lin.bias.data_ptr()
     check(lib.ultra_query_boundary(boundary.data_ptr(), query.data_ptr(), h_index.to(torch.int64).contiguous().data_ptr(),
                                    table.data_ptr(), r_index.to(torch.int64).contiguous().data_ptr(), bs, num_node, num_rel,
-                                   dim, _stream()))
-    return boundary, query
+                                   dim, w1, b1, qbias.data_ptr() if qbias is not None else None, _stream()))
+    return boundary, query, qbias
 
 
 def relation_projection(x, w0, b0, w2, b2):
