@@ -74,6 +74,8 @@ int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void *values, in
  *     query_out[b, :] = table[b, pick[b], :]            (query = relation_representations[arange(batch), r_index])
  *     out[b, n, :]    = query_out[b, :] if n == rows[b] else 0
  * table (batch, table_rows, dim) contiguous fp32; rows, pick int64 [batch]; dim a multiple of 4.
+ * out may be NULL: then only query_out (and qbias_out) are produced and the boundary stays in closed form for
+ * ultra_rspmm_forward_point / ultra_nbf_layer0.
  * Optionally (w1, b1, qbias_out all non-NULL) the same launch also emits the readout's per-sample bias
  *     qbias_out[b, f] = b1[f] + sum_k w1[f, dim + k] * query_out[b, k]      w1 (2 dim, 2 dim) = mlp.0.weight, f < 2 dim
  * i.e. the `qbias` operand of ultra_readout / ultra_readout_batch.

@@ -145,6 +145,29 @@ int32_t ultra_rspmm_forward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t 
                             const ultra_mat *boundary, const ultra_mat *output, void *stream);
 
 /*
+ * Forward with a POINT boundary: the NBFNet boundary condition (/root/reference/ultra/models.py:59-66, 135-141) is zero
+ * except for one row per outer slice, so `update + boundary` (/root/reference/ultra/layers.py:199-200) only touches that
+ * row.  point_values: (n_outer, 1, row_len) -- n_row == 1 -- is added to output row point_rows[outer]; nothing of size
+ * (n_outer, num_node, row_len) is read.  Sum aggregate only (zero is not the identity of min / max).
+ */
+int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t mul, int32_t dtype, const void *edge_weight_dev,
+                                  const ultra_mat *relation, const ultra_mat *input, const int64_t *point_rows_dev,
+                                  const ultra_mat *point_values, const ultra_mat *output, void *stream);
+
+/*
+ * Layer 0 of an NBFNet applied to its own boundary condition (/root/reference/ultra/models.py:72-80, 150-163 with
+ * /root/reference/ultra/layers.py:183-207, 233-240; sum aggregate, DistMult message, hidden dim 64, fp32):
+ *     x0[b, n] = src_values[b] (or ones if NULL) at n == src_rows[b], else 0
+ *     out = [x0 +] relu( LayerNorm_eps( weight . cat[x0, rspmm(x0) + x0] + bias ) )        flags: ULTRA_CONV_* of ultra_nbfnet.h
+ * Rows that are neither src_rows[b] nor a target of one of its out-edges all equal relu(LayerNorm(bias)); they are
+ * filled, the others are computed from the transposed plan.  relation: (n_outer, num_relation, 64); weight (64, 128)
+ * row-major = linear.weight; output (n_outer, num_node, 64).  Needs the (row, col) plan of a square graph.
+ */
+int32_t ultra_nbf_layer0(ultra_plan *plan, const void *edge_weight_dev, const ultra_mat *relation, const int64_t *src_rows_dev,
+                         const void *src_values_dev, const void *weight, const void *bias, const void *ln_weight,
+                         const void *ln_bias, float eps, int32_t flags, const ultra_mat *output, void *stream);
+
+/*
  * add_mul forward for a ROW-SPARSE input: input[o] is zero outside row src_rows_dev[o] (int64, one per outer
  * slice) -- the layer-0 input of every NBFNet, whose boundary condition puts the query vector at the head node
  * and zeros elsewhere (/root/reference/ultra/models.py:59-66, 135-141).  Zero rows contribute exact zeros to a

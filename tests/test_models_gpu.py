@@ -231,10 +231,36 @@ def test_onehot_layer0_path_matches_dense_path(dev, ckpt):
     t_batch, h_batch = tasks.all_negative(data, data.target_triples[:6])
     try:
         with torch.no_grad():
+            layers.POINT_BOUNDARY_FAST_PATH = False      # materialised boundary: the row-sparse rspmm serves layer 0
             layers.ONEHOT_FAST_PATH = True
             a_t, a_h = model(data, t_batch).clone(), model(data, h_batch).clone()
             layers.ONEHOT_FAST_PATH = False
             b_t, b_h = model(data, t_batch).clone(), model(data, h_batch).clone()
     finally:
         layers.ONEHOT_FAST_PATH = True
+        layers.POINT_BOUNDARY_FAST_PATH = True
     assert (a_t - b_t).abs().max().item() <= 2e-5 and (a_h - b_h).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("ckpt,aggr", [("ultra_3g", "sum"), ("ultra_50g", "max")])
+def test_closed_form_boundary_path_matches_materialised_boundary(dev, ckpt, aggr):
+    """PointBoundary (layer 0 on its special rows, boundary added to one row per sample) == the (batch, N, d) tensor path.
+    With the max aggregate the closed form does not apply (max(agg, 0) touches every row): both settings then take the
+    tensor path and must agree exactly."""
+    from ultra_amd import layers
+    _, state, _, cfg = load_golden(ckpt, aggr)
+    data = synthetic.make_kg(num_node=1500, num_triple=20000, num_relation_base=6, num_test=16, seed=15).to(dev)
+    model = build(state, cfg, dev)
+    t_batch, h_batch = tasks.all_negative(data, data.target_triples[:6])
+    try:
+        with torch.no_grad():
+            layers.POINT_BOUNDARY_FAST_PATH = True
+            a_t, a_h = model(data, t_batch).clone(), model(data, h_batch).clone()
+            layers.POINT_BOUNDARY_FAST_PATH = False
+            layers.ONEHOT_FAST_PATH = False
+            b_t, b_h = model(data, t_batch).clone(), model(data, h_batch).clone()
+    finally:
+        layers.ONEHOT_FAST_PATH = True
+        layers.POINT_BOUNDARY_FAST_PATH = True
+    tol = 2e-5 if aggr == "sum" else 2e-5
+    assert (a_t - b_t).abs().max().item() <= tol and (a_h - b_h).abs().max().item() <= tol

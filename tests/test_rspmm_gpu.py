@@ -358,3 +358,87 @@ def test_dense_format_plan_rejects_what_it_cannot_serve(dev):
         dense.forward(rel.double().to(dev), x.double().to(dev))
     with pytest.raises(RuntimeError):
         dense.backward(rel.to(dev), x.to(dev), x.to(dev), x.to(dev))
+
+
+@pytest.mark.parametrize("case,opts", [(CASES[1], dict()), (CASES[1], dict(seg_len=16, g_max=4)), (CASES[6], dict()),
+                                       (CASES[7], dict(dense=False)), (CASES[7], dict(dense=True)), (CASES[4], dict())])
+@pytest.mark.parametrize("layout", ["batch_major", "node_major"])
+@pytest.mark.parametrize("mul", MULS)
+def test_point_boundary_equals_the_materialised_boundary(dev, case, opts, layout, mul):
+    """ultra_rspmm_forward_point: adding values[o] to row rows[o] only == adding a boundary tensor that is zero elsewhere
+    (models.py:59-66, 135-141 build exactly that tensor).  Covers direct rows, split rows (fix-up kernel), the type-run
+    and dense-format twins, and a source that is a hub / an empty row."""
+    from ultra_amd.rspmm import Plan
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    bs, d = (3, 64) if layout == "batch_major" else (1, 128)
+    g = torch.Generator().manual_seed(case["seed"] + 7)
+    x = torch.randn(bs, N, d, generator=g).to(dev)
+    rel = torch.randn(bs, R, d, generator=g).to(dev)
+    vals = torch.randn(bs, d, generator=g).to(dev)
+    hub = case.get("hub", (0, 0))[0]
+    rows = torch.tensor([hub, N - 1, N // 2][:bs]).to(dev)      # the hub row (split), the last row (often empty), a plain row
+    bnd = torch.zeros(bs, N, d, device=dev)
+    bnd[torch.arange(bs), rows] = vals
+    plan = Plan(ei, et, N, R, **opts)
+    for w in (None, (torch.rand(E, generator=g) + 0.5).to(dev)):
+        if layout == "batch_major":
+            want = plan.forward(rel, x, edge_weight=w, boundary=bnd, mul=mul)
+            got = plan.forward(rel, x, edge_weight=w, mul=mul, point=(rows, vals))
+        else:
+            want = plan.forward(rel[0], x[0], edge_weight=w, boundary=bnd[0], mul=mul)
+            got = plan.forward(rel[0], x[0], edge_weight=w, mul=mul, point=(rows, vals))
+        assert torch.equal(got, want)
+    with pytest.raises(RuntimeError):
+        plan.forward(rel, x, sum="max", point=(rows, vals))
+    with pytest.raises(RuntimeError):
+        plan.forward(rel, x, boundary=bnd, point=(rows, vals))
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[6], CASES[7], CASES[5]])
+@pytest.mark.parametrize("layer_norm,residual,ones", [(True, True, False), (False, False, False), (True, False, True)])
+@pytest.mark.parametrize("weights", [False, True])
+def test_layer0_on_its_boundary_condition_matches_the_dense_layer(dev, case, layer_norm, residual, ones, weights):
+    """ultra_nbf_layer0 == GeneralizedRelationalConv applied to the materialised one-hot boundary (models.py:72-80,
+    150-163): constant rows everywhere but the source and the targets of its out-edges."""
+    from ultra_amd import layers as L
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    bs = 4
+    torch.manual_seed(case["seed"])
+    layer = L.GeneralizedRelationalConv(64, 64, R, 64, "distmult", "sum", layer_norm, "relu", dependent=False).to(dev)
+    with torch.no_grad():
+        layer.linear.bias.uniform_(-1, 1)
+        if layer_norm:
+            layer.layer_norm.weight.uniform_(0.5, 1.5)
+            layer.layer_norm.bias.uniform_(-0.5, 0.5)
+    g = torch.Generator().manual_seed(case["seed"] + 3)
+    hub = case.get("hub", (0, 0))[0]
+    rows = torch.tensor([hub, N - 1, N // 2, hub][:bs] if N > 1 else [0] * bs).to(dev)
+    vals = torch.ones(bs, 64, device=dev) if ones else torch.randn(bs, 64, generator=g).to(dev)
+    w = (torch.rand(E, generator=g) + 0.5).to(dev) if weights else None
+    point = L.PointBoundary(rows, vals, N)
+    eid, etd = ei.to(dev), et.to(dev)
+    with torch.no_grad():
+        assert layer.layer0_point_supported(point, None, w)
+        got = layer.forward_layer0_point(point, vals, eid, etd, N, edge_weight=w, residual=residual)
+        bnd = point.dense()
+        try:
+            L.ONEHOT_FAST_PATH = False
+            want = layer._forward_impl(bnd, vals, bnd, eid, etd, (N, N), w, residual=residual)
+        finally:
+            L.ONEHOT_FAST_PATH = True
+    assert got.shape == want.shape == (bs, N, 64)
+    scale = max(1.0, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    assert err <= 3e-5 * scale, "max |layer0 - dense layer| = %g (scale %g)" % (err, scale)
+    # the constant rows really are constant and equal relu(LayerNorm(bias))
+    c0 = layer.linear.bias
+    if layer_norm:
+        c0 = layer.layer_norm(c0)
+    c0 = torch.relu(c0)
+    touched = torch.zeros(bs, N, dtype=torch.bool, device=dev)
+    touched[torch.arange(bs), rows] = True
+    for b in range(bs):
+        touched[b, eid[0][eid[1] == rows[b]]] = True
+    assert (got[~touched] - c0).abs().max().item() <= 1e-6 if (~touched).any() else True

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "layer0_kernels.hpp"
 #include "rspmm_bwd_kernels.hpp"
 #include "rspmm_kernels.hpp"
 
@@ -26,7 +27,8 @@ ULTRA_EXTERN_VARIANT(double, 4, 1)
 ULTRA_EXTERN_VARIANT(double, 4, 2)
 
 int launch_dense_forward(ultra_plan *p, int sum, int mul, int dtype, const void *w, const ultra_mat *rel, const ultra_mat *x,
-                         const ultra_mat *bnd, const ultra_mat *out, hipStream_t stream);   // rspmm_dense.hip
+                         const ultra_mat *bnd, const int64_t *bnd_rows, const ultra_mat *out,
+                         hipStream_t stream);   // rspmm_dense.hip
 
 static ultra_tuning g_tuning = {0, 0, -1, -1, 0, {0, 0, 0}};
 
@@ -151,8 +153,11 @@ static bool mat_vec_ok(const ultra_mat *m, int64_t step) {
 }
 
 // Generic forward on a plan (internal: accepts the BIN_LHS / BIN_RHS variants used by backward).
+// bnd_rows != NULL: `bnd` is a POINT boundary -- one row per outer slice (n_row == 1), added to output row
+// bnd_rows[outer] only (the NBFNet boundary condition is zero everywhere else, models.py:135-141); sum aggregate only.
 static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *w, const ultra_mat *rel,
-                        const ultra_mat *x, const ultra_mat *bnd, const ultra_mat *out, hipStream_t stream) {
+                        const ultra_mat *x, const ultra_mat *bnd, const ultra_mat *out, hipStream_t stream,
+                        const int64_t *bnd_rows = nullptr) {
     if (!p) return invalid("plan is NULL");
     (void)hipGetLastError();   // drop any stale error left by other users of the HIP runtime
     if (sum < 0 || sum > 2 || mul < 0 || mul > 3) return invalid("unknown sum/mul code");
@@ -164,12 +169,14 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
     if ((rc = check_mat(out, "output", p->num_out, n_outer, row_len))) return rc;
     if (mul != BIN_RHS && (rc = check_mat(rel, "relation", p->num_rel, n_outer, row_len))) return rc;
     if (mul != BIN_LHS && (rc = check_mat(x, "input", p->num_in, n_outer, row_len))) return rc;
-    if (bnd && (rc = check_mat(bnd, "boundary", p->num_out, n_outer, row_len))) return rc;
+    if (bnd_rows && (!bnd || sum != ULTRA_SUM_ADD))
+        return invalid("a point boundary needs its value rows and serves the sum aggregate only (zero is not the identity of min/max)");
+    if (bnd && (rc = check_mat(bnd, "boundary", bnd_rows ? 1 : p->num_out, n_outer, row_len))) return rc;
     if (p->num_out == 0) return ULTRA_OK;
     if ((rc = upload_plan(p))) return rc;
     if (p->flags & ULTRA_PLAN_DENSE) {
         if (g_ev_before) HIP_TRY(hipEventRecord(g_ev_before, stream));
-        if ((rc = launch_dense_forward(p, sum, mul, dtype, w, rel, x, bnd, out, stream))) return rc;
+        if ((rc = launch_dense_forward(p, sum, mul, dtype, w, rel, x, bnd, bnd_rows, out, stream))) return rc;
         if (g_ev_after) HIP_TRY(hipEventRecord(g_ev_after, stream));
         return ULTRA_OK;
     }
@@ -196,7 +203,8 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
     fp.n_unit = (int32_t)p->n_unit;
     if (mul != BIN_RHS) fp.rel = MatArg{rel->ptr, rel->stride_outer, rel->stride_row};
     if (mul != BIN_LHS) fp.x = MatArg{x->ptr, x->stride_outer, x->stride_row};
-    if (bnd) fp.bnd = MatArg{bnd->ptr, bnd->stride_outer, bnd->stride_row};
+    if (bnd) fp.bnd = MatArg{bnd->ptr, bnd->stride_outer, bnd_rows ? 0 : bnd->stride_row};
+    fp.bnd_rows = bnd ? reinterpret_cast<const long long *>(bnd_rows) : nullptr;
     fp.out = out->ptr;
     fp.out_stride_outer = out->stride_outer;
     fp.out_stride_row = out->stride_row;
@@ -288,6 +296,7 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
         xp.n_split = (int32_t)p->split_row.size();
         xp.partial = p->d.partial;
         if (bnd) xp.bnd = fp.bnd;
+        xp.bnd_rows = fp.bnd_rows;
         xp.out = out->ptr;
         xp.out_stride_outer = out->stride_outer;
         xp.out_stride_row = out->stride_row;
@@ -461,6 +470,59 @@ static int forward_onehot_impl(ultra_plan *p, int dtype, const void *w, const ul
     return ULTRA_OK;
 }
 
+// Layer 0 of an NBFNet on its one-hot boundary condition (layer0_kernels.hpp).
+static int layer0_impl(ultra_plan *p, const void *w, const ultra_mat *rel, const int64_t *src_rows, const void *src_vals,
+                       const void *weight, const void *bias, const void *ln_w, const void *ln_b, float eps, int flags,
+                       const ultra_mat *out, hipStream_t stream) {
+    if (!p) return invalid("plan is NULL");
+    (void)hipGetLastError();
+    if (!out || !out->ptr || !src_rows || !weight) return invalid("ultra_nbf_layer0: NULL operand");
+    if ((flags & L0_LN) && (!ln_w || !ln_b)) return invalid("ultra_nbf_layer0: LayerNorm needs its weight and bias");
+    if (p->flags & (ULTRA_PLAN_TYPE_RUNS | ULTRA_PLAN_DENSE)) return invalid("use the (row, col) plan for the layer-0 path");
+    if (out->row_len != 64) {
+        set_error("ultra_nbf_layer0: only hidden dim 64 is built (the ULTRA checkpoints' shape)");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    const int64_t n_outer = out->n_outer;
+    int rc;
+    if ((rc = check_mat(out, "output", p->num_out, n_outer, 64))) return rc;
+    if ((rc = check_mat(rel, "relation", p->num_rel, n_outer, 64))) return rc;
+    if (p->num_out != p->num_in) return invalid("layer-0 path needs a square graph (source rows are output rows)");
+    if (!mat_vec_ok(out, 4) || !mat_vec_ok(rel, 4) || !aligned16(weight) || (src_vals && !aligned16(src_vals)))
+        return invalid("ultra_nbf_layer0: operands must be 16-byte aligned with strides that are multiples of 4");
+    if (n_outer == 0 || p->num_out == 0) return ULTRA_OK;
+    if ((rc = ensure_backward_plans(p))) return rc;
+    if ((rc = upload_plan(p->tplan))) return rc;
+    Layer0Params lp;
+    std::memset(&lp, 0, sizeof(lp));
+    lp.trow_ptr = p->tplan->d.row_ptr;
+    lp.tcol = p->tplan->d.col;
+    lp.ttype = p->tplan->d.type;
+    lp.tperm = p->tplan->d.perm;
+    lp.w = static_cast<const float *>(w);
+    lp.src = src_rows;
+    lp.q = static_cast<const float *>(src_vals);
+    lp.rel = MatArg{rel->ptr, rel->stride_outer, rel->stride_row};
+    lp.weight = static_cast<const float *>(weight);
+    lp.bias = static_cast<const float *>(bias);
+    lp.ln_w = static_cast<const float *>(ln_w);
+    lp.ln_b = static_cast<const float *>(ln_b);
+    lp.out = static_cast<float *>(out->ptr);
+    lp.out_so = out->stride_outer;
+    lp.out_sr = out->stride_row;
+    lp.num_node = p->num_out;
+    lp.n_outer = (int32_t)n_outer;
+    lp.eps = eps;
+    lp.flags = flags;
+    const long long rows = (long long)n_outer * p->num_out;
+    const int fill_blocks = (int)std::min<long long>((rows + 15) / 16, 2048);
+    hipLaunchKernelGGL(nbf_layer0_fill_kernel, dim3(fill_blocks), dim3(256), 0, stream, lp);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(nbf_layer0_rows_kernel, dim3(32, (unsigned)n_outer), dim3(256), 0, stream, lp);
+    HIP_TRY(hipGetLastError());
+    return ULTRA_OK;
+}
+
 static ultra_mat dense2d(const void *ptr, int64_t rows, int64_t dim) {
     ultra_mat m;
     m.ptr = const_cast<void *>(ptr);
@@ -531,11 +593,27 @@ int32_t ultra_rspmm_forward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t 
                         reinterpret_cast<hipStream_t>(stream));
 }
 
+int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t mul, int32_t dtype, const void *edge_weight_dev,
+                                  const ultra_mat *relation, const ultra_mat *input, const int64_t *point_rows_dev,
+                                  const ultra_mat *point_values, const ultra_mat *output, void *stream) {
+    if (mul < 0 || mul > 1) return invalid("unknown mul code");
+    if (!point_rows_dev || !point_values) return invalid("ultra_rspmm_forward_point: NULL point boundary");
+    return forward_impl(plan, ULTRA_SUM_ADD, mul, dtype, edge_weight_dev, relation, input, point_values, output,
+                        reinterpret_cast<hipStream_t>(stream), point_rows_dev);
+}
+
 int32_t ultra_rspmm_forward_onehot(ultra_plan *plan, int32_t dtype, const void *edge_weight_dev,
                                    const ultra_mat *relation, const ultra_mat *input, const int64_t *src_rows_dev,
                                    const ultra_mat *boundary, const ultra_mat *output, void *stream) {
     return forward_onehot_impl(plan, dtype, edge_weight_dev, relation, input, src_rows_dev, boundary, output,
                                reinterpret_cast<hipStream_t>(stream));
+}
+
+int32_t ultra_nbf_layer0(ultra_plan *plan, const void *edge_weight_dev, const ultra_mat *relation, const int64_t *src_rows_dev,
+                         const void *src_values_dev, const void *weight, const void *bias, const void *ln_weight,
+                         const void *ln_bias, float eps, int32_t flags, const ultra_mat *output, void *stream) {
+    return layer0_impl(plan, edge_weight_dev, relation, src_rows_dev, src_values_dev, weight, bias, ln_weight, ln_bias, eps,
+                       flags, output, reinterpret_cast<hipStream_t>(stream));
 }
 
 int32_t ultra_rspmm_backward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype, const void *edge_weight_dev,

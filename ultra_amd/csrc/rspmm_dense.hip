@@ -26,6 +26,7 @@ using f32x16 = float __attribute__((ext_vector_type(16)));
 struct DenseParams {
     const uint32_t *a_frag;   // [n_rt][n_tc][kg][64 lanes][tc] words of 4 multiplicity bytes
     const float *rel, *x, *bnd;
+    const long long *bnd_rows;   // point boundary (one row per outer slice, bnd_sr = 0) or NULL
     float *out;
     long long rel_so, rel_sr, x_so, x_sr, bnd_so, bnd_sr, out_so, out_sr;
     int n_out, n_in, n_rel, kg, n_rt, n_tc, n_ct, row_len, has_bnd;
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(256) rspmm_dense_kernel(const DenseParams p) {
     }
     const int row = rt * 32 + r;
     if (row < p.n_out) {
-        if (p.has_bnd) {
+        if (p.has_bnd && (!p.bnd_rows || p.bnd_rows[outer] == row)) {
             const float4 b = *reinterpret_cast<const float4 *>(p.bnd + (long long)outer * p.bnd_so + (long long)row * p.bnd_sr +
                                                                  d0 + c4 * 4);
             sum.x += b.x;
@@ -159,7 +160,7 @@ static bool ok16(const ultra_mat *m) {
 
 // Called by forward_impl for ULTRA_PLAN_DENSE plans (operands already shape-checked, plan uploaded).
 int launch_dense_forward(ultra_plan *p, int sum, int mul, int dtype, const void *w, const ultra_mat *rel, const ultra_mat *x,
-                         const ultra_mat *bnd, const ultra_mat *out, hipStream_t stream) {
+                         const ultra_mat *bnd, const int64_t *bnd_rows, const ultra_mat *out, hipStream_t stream) {
     if (sum != ULTRA_SUM_ADD || mul != ULTRA_MUL_MUL || dtype != ULTRA_F32 || w != nullptr) {
         set_error("a ULTRA_PLAN_DENSE plan serves fp32 add_mul with unit edge weights only");
         return ULTRA_ERR_UNSUPPORTED;
@@ -180,7 +181,8 @@ int launch_dense_forward(ultra_plan *p, int sum, int mul, int dtype, const void 
     dp.out = static_cast<float *>(out->ptr);
     dp.rel_so = rel->stride_outer, dp.rel_sr = rel->stride_row;
     dp.x_so = x->stride_outer, dp.x_sr = x->stride_row;
-    dp.bnd_so = bnd ? bnd->stride_outer : 0, dp.bnd_sr = bnd ? bnd->stride_row : 0;
+    dp.bnd_so = bnd ? bnd->stride_outer : 0, dp.bnd_sr = (bnd && !bnd_rows) ? bnd->stride_row : 0;
+    dp.bnd_rows = bnd ? reinterpret_cast<const long long *>(bnd_rows) : nullptr;
     dp.out_so = out->stride_outer, dp.out_sr = out->stride_row;
     dp.n_out = (int)p->num_out, dp.n_in = (int)p->num_in, dp.n_rel = (int)p->num_rel;
     dp.kg = p->dense_kg, dp.n_rt = p->dense_rt, dp.n_tc = p->dense_ntc;

@@ -65,6 +65,7 @@ struct FwdParams {
     const Item *items;
     int32_t n_w, n_item, n_unit;
     MatArg rel, x, bnd;
+    const long long *bnd_rows;   // point boundary: bnd holds ONE row per outer slice, added at row bnd_rows[outer] only
     void *out;
     long long out_stride_outer, out_stride_row;
     void *partial;
@@ -82,6 +83,7 @@ struct FixupParams {
     int32_t n_split;
     const void *partial;
     MatArg bnd;
+    const long long *bnd_rows;
     void *out;
     long long out_stride_outer, out_stride_row;
     int32_t n_outer, row_len, has_bnd;
@@ -382,6 +384,7 @@ __global__ void __launch_bounds__(1024) rspmm_fwd_kernel(const FwdParams p) {
         const char *relbase =
             reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.rel.ptr) + outer * p.rel.stride_outer);
         const uint32_t lane_bytes = (uint32_t)d0c * (uint32_t)sizeof(T);
+        const long long bnd_row = p.bnd_rows ? p.bnd_rows[outer] : -1;   // (stride_row of a point boundary is 0)
 
         if (MODE >= MODE_REL_LDS) {
             __syncthreads();  // readers of the previous span are done with the LDS image
@@ -470,7 +473,7 @@ __global__ void __launch_bounds__(1024) rspmm_fwd_kernel(const FwdParams p) {
                     T *dst = reinterpret_cast<T *>(p.partial) + ((long long)slot * p.n_outer + outer) * p.row_len + d0;
                     *reinterpret_cast<P *>(dst) = acc;
                 } else {
-                    if (p.has_bnd) {
+                    if (p.has_bnd && (bnd_row < 0 || bnd_row == row)) {
                         const P b = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.bnd.ptr) +
                                                                  outer * p.bnd.stride_outer +
                                                                  (long long)row * p.bnd.stride_row + d0);
@@ -522,7 +525,7 @@ __global__ void __launch_bounds__(256) rspmm_fixup_kernel(const FixupParams p) {
                 }
             }
         }
-        if (p.has_bnd) {
+        if (p.has_bnd && (!p.bnd_rows || p.bnd_rows[outer] == row)) {
             const P b = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.bnd.ptr) +
                                                      outer * p.bnd.stride_outer + (long long)row * p.bnd.stride_row + d0);
 #pragma unroll

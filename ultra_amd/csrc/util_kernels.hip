@@ -28,6 +28,15 @@ __global__ void __launch_bounds__(256) onehot_rows_kernel(float4 *__restrict__ o
                                                           long long total4, const float *__restrict__ w1,
                                                           const float *__restrict__ b1, float *__restrict__ qbias_out,
                                                           int batch) {
+    if (table && blockIdx.x == gridDim.x - 1) {
+        // the gathered query rows themselves (read back by the layers and the readout)
+        for (int idx = threadIdx.x; idx < batch * dim4; idx += blockDim.x) {
+            const int b = idx / dim4, d = idx % dim4;
+            long long t = pick[b];   // (an out-of-range relation id reads a valid row instead of faulting)
+            t = t < 0 ? 0 : (t >= table_rows ? table_rows - 1 : t);
+            values_out[idx] = table[((long long)b * table_rows + t) * dim4 + d];
+        }
+    }
     if (qbias_out && blockIdx.x == gridDim.x - 1) {
         // readout preamble riding on this launch (models.py:166-170 concatenates the query to every node feature; its half
         // of mlp.0 is a per-sample constant): qbias[b, f] = b1[f] + sum_k w1[f, dim + k] * query[b, k], dim = 4 dim4 = 64
@@ -56,10 +65,9 @@ __global__ void __launch_bounds__(256) onehot_rows_kernel(float4 *__restrict__ o
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n == rows[b]) {
             if (table) {
-                long long t = pick[b];   // (an out-of-range relation id reads a valid row instead of faulting)
+                long long t = pick[b];
                 t = t < 0 ? 0 : (t >= table_rows ? table_rows - 1 : t);
                 v = table[(b * table_rows + t) * dim4 + d];
-                values_out[b * dim4 + d] = v;
             } else {
                 v = values ? values[b * dim4 + d] : make_float4(1.f, 1.f, 1.f, 1.f);
             }
@@ -95,13 +103,14 @@ extern "C" int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void 
 extern "C" int32_t ultra_query_boundary(void *out, void *query_out, const int64_t *rows, const void *table,
                                         const int64_t *pick, int64_t batch, int64_t num_node, int64_t table_rows, int64_t dim,
                                         const void *w1, const void *b1, void *qbias_out, void *stream) {
-    if (!out || !query_out || !rows || !table || !pick || batch < 0 || num_node <= 0 || table_rows <= 0 || dim <= 0 || (dim & 3)) {
+    if (!query_out || !rows || !table || !pick || batch < 0 || num_node <= 0 || table_rows <= 0 || dim <= 0 || (dim & 3)) {
         ultra::set_error("ultra_query_boundary: NULL operand, empty graph or dim not a multiple of 4");
         return ULTRA_ERR_INVALID;
     }
-    const long long total4 = (long long)batch * num_node * (dim / 4);
-    if (total4 == 0) return ULTRA_OK;
-    const int grid = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+    if (batch == 0) return ULTRA_OK;
+    // out == NULL: only the gathers (query_out, qbias_out) -- the boundary stays in closed form (ultra_rspmm_forward_point)
+    const long long total4 = out ? (long long)batch * num_node * (dim / 4) : 0;
+    const int grid = out ? (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048) : 1;
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
     hipLaunchKernelGGL(ultra::onehot_rows_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        (float4 *)out, rows, (const float4 *)nullptr, (const float4 *)table, pick, (long long)table_rows,

@@ -124,13 +124,14 @@ def onehot_boundary(index, values, num_node, dim):
     return out
 
 
-def query_boundary(h_index, relation_representations, r_index, num_node, readout_mlp=None):
+def query_boundary(h_index, relation_representations, r_index, num_node, readout_mlp=None, materialize=True):
     """(boundary, query, qbias) of EntityNBFNet.bellmanford (models.py:131-141) in one kernel:
     query = relation_representations[arange(bs), r_index]; boundary = zeros with query[b] at row h_index[b];
-    with `readout_mlp` also qbias = mlp.0.weight[:, dim:] @ query + mlp.0.bias for the readout (else None)."""
+    with `readout_mlp` also qbias = mlp.0.weight[:, dim:] @ query + mlp.0.bias for the readout (else None).
+    materialize=False skips the (bs, num_node, dim) boundary tensor (returned as None): only the gathers run."""
     table = relation_representations.contiguous()
     bs, num_rel, dim = table.shape
-    boundary = torch.empty(bs, num_node, dim, dtype=torch.float32, device=table.device)
+    boundary = torch.empty(bs, num_node, dim, dtype=torch.float32, device=table.device) if materialize else None
     query = torch.empty(bs, dim, dtype=torch.float32, device=table.device)
     qbias, w1, b1 = None, None, None
     if readout_mlp is not None and bs <= 1024:
@@ -138,7 +139,7 @@ def query_boundary(h_index, relation_representations, r_index, num_node, readout
         if tuple(lin.weight.shape) == (2 * dim, 2 * dim) and lin.bias is not None and lin.weight.is_contiguous():
             qbias = torch.empty(bs, 2 * dim, dtype=torch.float32, device=table.device)
             w1, b1 = lin.weight.data_ptr(), lin.bias.data_ptr()
-    check(lib.ultra_query_boundary(boundary.data_ptr(), query.data_ptr(), h_index.to(torch.int64).contiguous().data_ptr(),
+    check(lib.ultra_query_boundary(boundary.data_ptr() if materialize else None, query.data_ptr(), h_index.to(torch.int64).contiguous().data_ptr(),
                                    table.data_ptr(), r_index.to(torch.int64).contiguous().data_ptr(), bs, num_node, num_rel,
                                    dim, w1, b1, qbias.data_ptr() if qbias is not None else None, _stream()))
     return boundary, query, qbias

@@ -18,6 +18,30 @@ from . import dense, rspmm
 # With sum aggregation and DistMult messages only that row's out-edges contribute (exactly), so the layer can ask
 # the engine for the row-sparse forward instead of the dense one.  Module-level switch for A/B tests.
 ONEHOT_FAST_PATH = True
+# the boundary condition kept as (row, value) per sample instead of a (batch, N, d) tensor; layer 0 computed on its
+# special rows only (A/B switch for tests)
+POINT_BOUNDARY_FAST_PATH = True
+
+
+class PointBoundary(object):
+    """The NBFNet boundary condition (models.py:59-66, 135-141) in closed form: zero everywhere except row rows[b]
+    of sample b, which holds values[b]."""
+
+    def __init__(self, rows, values, num_node):
+        self.rows, self.values, self.num_node = rows, values, num_node
+
+    @property
+    def requires_grad(self):
+        return self.values.requires_grad
+
+    def dense(self):
+        """The (batch, num_node, dim) tensor the reference builds with zeros + scatter_add_."""
+        if dense.boundary_supported(self.rows, self.values):
+            return dense.onehot_boundary(self.rows, self.values, self.num_node, self.values.shape[-1])
+        out = torch.zeros(len(self.rows), self.num_node, self.values.shape[-1], device=self.values.device,
+                          dtype=self.values.dtype)
+        index = self.rows.view(-1, 1, 1).expand(-1, 1, self.values.shape[-1])
+        return out.scatter_add_(1, index, self.values.unsqueeze(1))
 
 
 def _scatter(src, index, dim_size, reduce):
@@ -96,23 +120,49 @@ class GeneralizedRelationalConv(nn.Module):
         outside row onehot_rows[b] of every sample (the layer-0 boundary condition, models.py:139-141)."""
         batch_size = len(query)
 
-        if relation is not None:
-            pass
-        elif self.dependent:
-            relation = self.relation_linear(query).view(batch_size, self.num_relation, self.input_dim)
-        else:
-            if not self.project_relations:
-                relation = self.relation.weight.expand(batch_size, -1, -1)   # stride-0 view, never materialised
-            else:
-                relation = self.relation_projection(self.relation)
+        if relation is None:
+            relation = self._relation_for(query, batch_size)
         # edge_weight=None means "all ones" (what every caller on the fused path passes, models.py:143):
         # the kernel then skips the weight stream instead of multiplying by 1.
         return self.propagate(input=input, relation=relation, boundary=boundary, edge_index=edge_index,
                               edge_type=edge_type, size=size, edge_weight=edge_weight, residual=residual,
                               onehot_rows=onehot_rows)
 
+    def _relation_for(self, query, batch_size):
+        if self.dependent:
+            return self.relation_linear(query).view(batch_size, self.num_relation, self.input_dim)
+        if not self.project_relations:
+            return self.relation.weight.expand(batch_size, -1, -1)   # stride-0 view, never materialised
+        return self.relation_projection(self.relation)
+
+    def layer0_point_supported(self, point, relation, edge_weight):
+        """Can ultra_nbf_layer0 run this layer on a one-hot input?  (sum / DistMult, 64-d, fp32, inference)"""
+        return (POINT_BOUNDARY_FAST_PATH and point.values.is_cuda and point.values.dtype == torch.float32
+                and not torch.is_grad_enabled() and self.aggregate_func == "sum" and self.message_func == "distmult"
+                and self.input_dim == 64 and self.output_dim == 64 and self.linear.in_features == 128
+                and (self.activation is None or self.activation is F.relu)
+                and (relation is None or (relation.dtype == torch.float32 and relation.shape[-1] == 64))
+                and (edge_weight is None or not edge_weight.requires_grad))
+
+    def forward_layer0_point(self, point, query, edge_index, edge_type, num_node, edge_weight=None, residual=False,
+                             relation=None):
+        """This layer applied to the boundary condition itself (what layer 0 of every NBFNet does, models.py:72-80,
+        150-163), evaluated only where the result differs from relu(LayerNorm(bias))."""
+        batch_size = len(point.rows)
+        if relation is None:
+            relation = self._relation_for(query, batch_size)
+        plan = rspmm.get_plan(edge_index, edge_type, num_node, relation.shape[1])
+        return plan.layer0(relation, point.rows, point.values, self.linear, self.layer_norm,
+                           relu=self.activation is not None, residual=residual, edge_weight=edge_weight)
+
     def propagate(self, edge_index, size=None, residual=False, onehot_rows=None, **kwargs):
         edge_weight = kwargs["edge_weight"]
+        if isinstance(kwargs["boundary"], PointBoundary) and (
+                (edge_weight is not None and edge_weight.requires_grad) or self.message_func == "rotate"
+                or self.aggregate_func != "sum" or not kwargs["input"].is_cuda
+                or (torch.is_grad_enabled() and (kwargs["input"].requires_grad or kwargs["relation"].requires_grad
+                                                 or kwargs["boundary"].requires_grad))):
+            kwargs["boundary"] = kwargs["boundary"].dense()     # paths that need the boundary as a tensor
         if (edge_weight is not None and edge_weight.requires_grad) or self.message_func == "rotate":
             # layers.py:91-94: the fused kernel covers TransE / DistMult with constant edge weights only
             out = self._propagate_unfused(edge_index, size, **kwargs)
@@ -190,7 +240,13 @@ class GeneralizedRelationalConv(nn.Module):
         needs_grad = torch.is_grad_enabled() and (input.requires_grad or relation.requires_grad or
                                                    boundary.requires_grad)
 
+        point = None
+        if isinstance(boundary, PointBoundary):     # (propagate() only lets it through for the fused sum path)
+            point, boundary = (boundary.rows, boundary.values), None
+
         def agg(sum, rel=relation, x=input, fuse_boundary=None):
+            if point is not None:
+                return plan.forward(rel, x, edge_weight=edge_weight, sum=sum, mul=mul, point=point)
             if needs_grad:
                 out = rspmm.plan_rspmm(plan, rel, x, edge_weight, sum=sum, mul=mul)
                 if fuse_boundary is None:
@@ -205,7 +261,7 @@ class GeneralizedRelationalConv(nn.Module):
             degree_out = (torch.bincount(index, minlength=dim_size).to(input.dtype) + 1).view(1, -1, 1)
 
         if (ONEHOT_FAST_PATH and onehot_rows is not None and not needs_grad and self.aggregate_func == "sum"
-                and mul == "mul" and input.is_cuda):
+                and mul == "mul" and input.is_cuda and point is None):
             # row-sparse input (layer 0): only the edges leaving the source rows contribute to a sum of products
             update = plan.forward_onehot(relation, input, onehot_rows, edge_weight=edge_weight, boundary=boundary)
         elif self.aggregate_func == "sum":

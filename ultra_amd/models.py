@@ -95,11 +95,31 @@ class BaseNBFNet(nn.Module):
                           edge_weight=None, onehot_rows=None):
         """The Bellman-Ford loop shared by every model (models.py:72-80, 150-163, 233-246).
         `relations`: optional per-layer relation features computed up front (EntityNBFNet batches the six
-        relation_projection MLPs, which all read the same relation representations)."""
+        relation_projection MLPs, which all read the same relation representations).
+        `boundary` may be a layers.PointBoundary (then `layer_input` is ignored: layer 0 reads the boundary condition)."""
         size = (data.num_nodes, data.num_nodes)
         # edge_weight None = all ones (only materialised when its gradient is asked for); a 0/1 vector = edge dropout
         hiddens, edge_weights = [], []
+        first = 0
+        if isinstance(boundary, layers.PointBoundary):
+            layer = self.layers[0]
+            rel0 = None if relations is None else relations[0]
+            if not separate_grad and layer.layer0_point_supported(boundary, rel0, edge_weight):
+                # layer 0 on its one-hot input: constant fill + the rows reached from the source (ultra_nbf_layer0);
+                # the boundary condition never becomes a (batch, N, d) tensor on this path
+                residual = self.short_cut and layer.output_dim == layer.input_dim
+                hidden = layer.forward_layer0_point(boundary, query, data.edge_index, data.edge_type, data.num_nodes,
+                                                    edge_weight=edge_weight, residual=residual, relation=rel0)
+                hiddens.append(hidden)
+                edge_weights.append(edge_weight)
+                layer_input = hidden
+                first = 1
+            else:
+                boundary = boundary.dense()
+                layer_input = boundary
         for i, layer in enumerate(self.layers):
+            if i < first:
+                continue
             if separate_grad:
                 edge_weight = torch.ones(data.num_edges, device=layer_input.device).requires_grad_()
             # residual connection (models.py:158-160) is fused into the layer's update kernel
@@ -146,13 +166,10 @@ class RelNBFNet(BaseNBFNet):
                 self._ones_query = ones        # constant: not refilled on every forward
         query = ones
         index = h_index.unsqueeze(-1).expand_as(query)
-        # boundary: ones at the query relation's node, zeros elsewhere (models.py:59-66)
-        if dense.boundary_supported(h_index, None) and self.dims[0] % 4 == 0:
-            boundary = dense.onehot_boundary(h_index, None, data.num_nodes, self.dims[0])
-        else:
-            boundary = torch.zeros(batch_size, data.num_nodes, self.dims[0], device=h_index.device)
-            boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
-
+        # boundary: ones at the query relation's node, zeros elsewhere (models.py:59-66) -- in closed form
+        boundary = layers.PointBoundary(h_index, query, data.num_nodes)
+        if not (layers.POINT_BOUNDARY_FAST_PATH and h_index.is_cuda and not torch.is_grad_enabled()):
+            boundary = boundary.dense()
         # layer 0 reads the one-hot boundary itself: tell the layer which row of each sample is non-zero
         hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad=False,
                                                        onehot_rows=h_index)
@@ -199,14 +216,21 @@ class EntityNBFNet(BaseNBFNet):
     def _bellmanford_hidden(self, data, h_index, r_index, separate_grad=False, edge_weight=None):
         batch_size = len(r_index)
         # query = representation of each sample's query relation, scattered to its head node
-        if dense.boundary_supported(h_index, self.query) and self.query.dim() == 3 and self.query.shape[0] == batch_size \
-                and self.query.shape[-1] == self.dims[0]:
+        fused = (dense.boundary_supported(h_index, self.query) and self.query.dim() == 3
+                 and self.query.shape[0] == batch_size and self.query.shape[-1] == self.dims[0])
+        self._qbias = None
+        if fused and layers.POINT_BOUNDARY_FAST_PATH and not torch.is_grad_enabled():
+            # gather the query rows (+ the readout's per-sample bias); the boundary stays in closed form
+            _, query, self._qbias = dense.query_boundary(
+                h_index, self.query, r_index, data.num_nodes, materialize=False,
+                readout_mlp=self.mlp if not self.concat_hidden else None)
+            boundary = layers.PointBoundary(h_index, query, data.num_nodes)
+        elif fused:
             # gather + scatter (+ the readout's per-sample bias), one kernel
             boundary, query, self._qbias = dense.query_boundary(
                 h_index, self.query, r_index, data.num_nodes,
                 readout_mlp=self.mlp if not torch.is_grad_enabled() and not self.concat_hidden else None)
         else:
-            self._qbias = None
             query = self.query[torch.arange(batch_size, device=r_index.device), r_index]
             index = h_index.unsqueeze(-1).expand_as(query)
             boundary = torch.zeros(batch_size, data.num_nodes, self.dims[0], device=h_index.device, dtype=query.dtype)

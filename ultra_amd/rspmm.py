@@ -146,10 +146,18 @@ class Plan(object):
         return out.view(torch.uint8) if which == _lib.ARR_DENSE else out
 
     # ---- kernels ----
-    def forward(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", out=None):
-        twin = self._twin_for(sum, mul, edge_weight, input, relation, boundary, out)
+    def forward(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", out=None, point=None):
+        """point=(rows, values): a boundary that is zero except row rows[o] of outer slice o, where it is values[o]
+        (the NBFNet boundary condition) -- added to that row only, sum aggregate only; excludes `boundary`."""
+        if point is not None:
+            if boundary is not None or sum != "add":
+                raise RuntimeError("a point boundary excludes `boundary` and serves the sum aggregate only")
+            twin = self._twin_for(sum, mul, edge_weight, input, relation, point[1], out)
+        else:
+            twin = self._twin_for(sum, mul, edge_weight, input, relation, boundary, out)
         if twin is not None:
-            return twin.forward(relation, input, edge_weight=edge_weight, boundary=boundary, sum=sum, mul=mul, out=out)
+            return twin.forward(relation, input, edge_weight=edge_weight, boundary=boundary, sum=sum, mul=mul, out=out,
+                                point=point)
         _require_gpu(relation, input, edge_weight, boundary)
         dt = _dtype_code(*([relation, input] + ([edge_weight] if edge_weight is not None else [])
                            + ([boundary] if boundary is not None else [])))
@@ -172,6 +180,18 @@ class Plan(object):
                 raise RuntimeError("Expected `edge_weight` of shape (num_edge,)")
             edge_weight = edge_weight.contiguous()
             w = edge_weight.data_ptr()
+        if point is not None:
+            rows, vals = point
+            n_outer = 1 if input.dim() == 2 else input.shape[0]
+            rows = rows.to(torch.int64).contiguous()
+            vals = vals.reshape(n_outer, 1, vals.shape[-1]) if input.dim() == 3 else vals.reshape(1, vals.shape[-1])
+            if rows.numel() != n_outer:
+                raise RuntimeError("Expected one boundary row per outer slice (%d), got %d" % (n_outer, rows.numel()))
+            _require_gpu(rows, vals)
+            vals, mv = as_mat(vals)
+            check(lib.ultra_rspmm_forward_point(self._h, _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel), ctypes.byref(mx),
+                                                rows.data_ptr(), ctypes.byref(mv), ctypes.byref(mout), _stream()))
+            return out
         check(lib.ultra_rspmm_forward(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
                                       ctypes.byref(mx), mb, ctypes.byref(mout), _stream()))
         return out
@@ -203,6 +223,30 @@ class Plan(object):
             w = edge_weight.data_ptr()
         check(lib.ultra_rspmm_forward_onehot(self._h, dt, w, ctypes.byref(mrel), ctypes.byref(mx), src_rows.data_ptr(), mb,
                                              ctypes.byref(mout), _stream()))
+        return out
+
+    def layer0(self, relation, src_rows, src_values, linear, layer_norm=None, relu=True, residual=False, edge_weight=None):
+        """Layer 0 of an NBFNet on its one-hot boundary condition (ultra_nbf_layer0): returns the (batch, N, 64) hidden
+        state of `relu(LayerNorm(linear(cat[x0, rspmm(x0) + x0]))) [+ x0]`, x0 = src_values[b] (ones if None) at row
+        src_rows[b] and zero elsewhere, without materialising x0 or the aggregate."""
+        _require_gpu(relation, src_rows, src_values, edge_weight)
+        relation, mrel = as_mat(relation)
+        bs = relation.shape[0]
+        out = torch.empty(bs, self.num_node, 64, dtype=torch.float32, device=relation.device)
+        _, mout = as_mat(out)
+        src_rows = src_rows.to(torch.int64).contiguous()
+        if src_values is not None:
+            src_values = src_values.contiguous()
+        if edge_weight is not None:
+            edge_weight = edge_weight.to(torch.float32).contiguous()
+        flags = (1 if layer_norm is not None else 0) | (2 if relu else 0) | (4 if residual else 0)
+        check(lib.ultra_nbf_layer0(self._h, edge_weight.data_ptr() if edge_weight is not None else None, ctypes.byref(mrel),
+                                   src_rows.data_ptr(), src_values.data_ptr() if src_values is not None else None,
+                                   linear.weight.data_ptr(), linear.bias.data_ptr() if linear.bias is not None else None,
+                                   layer_norm.weight.data_ptr() if layer_norm is not None else None,
+                                   layer_norm.bias.data_ptr() if layer_norm is not None else None,
+                                   float(layer_norm.eps) if layer_norm is not None else 1e-5, flags, ctypes.byref(mout),
+                                   _stream()))
         return out
 
     def backward(self, relation, input, output, output_grad, edge_weight=None, need_weight_grad=False, sum="add",
