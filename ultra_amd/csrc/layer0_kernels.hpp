@@ -27,6 +27,7 @@ struct Layer0Params {
     const int32_t *tcol;       // = aggregation target
     const int32_t *ttype;
     const int32_t *tperm;
+    const uint8_t *self_loop;  // [num_node] 1 if the node has an edge onto itself
     const float *w;            // edge weights in original edge order, or NULL
     const int64_t *src;        // [n_outer] source row s[b]
     const float *q;            // [n_outer][64] boundary value of the source row, or NULL = ones (RelNBFNet)
@@ -42,7 +43,22 @@ struct Layer0Params {
 };
 
 // LayerNorm / ReLU of one 64-feature row held by a 16-lane group (4 features per lane), layers.py:235-238
-__device__ __forceinline__ void l0_finish(float (&y)[4], const Layer0Params &p, int l16) {
+struct L0Vec {
+    float bias[4], ln_w[4], ln_b[4];
+};
+
+__device__ __forceinline__ L0Vec l0_load_vectors(const Layer0Params &p, int l16) {
+    L0Vec v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v.bias[e] = p.bias ? p.bias[4 * l16 + e] : 0.f;
+        v.ln_w[e] = (p.flags & L0_LN) ? p.ln_w[4 * l16 + e] : 1.f;
+        v.ln_b[e] = (p.flags & L0_LN) ? p.ln_b[4 * l16 + e] : 0.f;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void l0_finish(float (&y)[4], const Layer0Params &p, const L0Vec &vec) {
     if (p.flags & L0_LN) {
         float s = (y[0] + y[1]) + (y[2] + y[3]);
 #pragma unroll
@@ -58,7 +74,7 @@ __device__ __forceinline__ void l0_finish(float (&y)[4], const Layer0Params &p, 
         for (int off = 8; off > 0; off >>= 1) qv += __shfl_xor(qv, off, 16);
         const float rstd = 1.f / sqrtf(qv * (1.f / 64.f) + p.eps);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = (y[e] - mean) * rstd * p.ln_w[4 * l16 + e] + p.ln_b[4 * l16 + e];
+        for (int e = 0; e < 4; ++e) y[e] = (y[e] - mean) * rstd * vec.ln_w[e] + vec.ln_b[e];
     }
     if (p.flags & L0_RELU) {
 #pragma unroll
@@ -69,11 +85,20 @@ __device__ __forceinline__ void l0_finish(float (&y)[4], const Layer0Params &p, 
 // out[b, n, :] = c0 = relu(LayerNorm(bias)) for every row: what the layer makes of x0 = agg = 0.
 __global__ void __launch_bounds__(256) nbf_layer0_fill_kernel(const Layer0Params p) {
     const int l16 = threadIdx.x & 15;
+    const L0Vec vec = l0_load_vectors(p, l16);
     float c0[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) c0[e] = p.bias ? p.bias[4 * l16 + e] : 0.f;
-    l0_finish(c0, p, l16);
+    for (int e = 0; e < 4; ++e) c0[e] = vec.bias[e];
+    l0_finish(c0, p, vec);
     const float4 v = make_float4(c0[0], c0[1], c0[2], c0[3]);
+    if (p.out_sr == 64 && p.out_so == p.num_node * 64) {
+        // contiguous output: a plain 16-byte stream; the stride is a multiple of 16 chunks, so a thread always writes
+        // the same four features
+        float4 *o4 = reinterpret_cast<float4 *>(p.out);
+        const long long n16 = (long long)p.n_outer * p.num_node * 16;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) o4[i] = v;
+        return;
+    }
     const long long total = (long long)p.n_outer * p.num_node;
     const long long g0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((long long)gridDim.x * blockDim.x) >> 4;
     for (long long r = g0; r < total; r += ng) {
@@ -84,9 +109,12 @@ __global__ void __launch_bounds__(256) nbf_layer0_fill_kernel(const Layer0Params
 
 // The special rows.  grid = (blocks per sample, n_outer); one 16-lane group per run of equal targets in s[b]'s
 // out-edge list (sorted by target in the transposed plan), group 0 of block 0 also covers s[b] itself when no edge
-// leads back to it.  lds_wt[k][f] = W[f][k]: a lane reads the 4 weights of its features with one 16-byte LDS load.
-__global__ void __launch_bounds__(256) nbf_layer0_rows_kernel(const Layer0Params p) {
+// leads back to it.  W is staged transposed in LDS (lds_wt[k][f] = W[f][k]: a lane reads
+// the 4 weights of its features with one 16-byte load); the group's 64-vector goes through a 256-byte LDS slot and
+// is read back as 16-byte broadcasts, so the 64-term dot products are plain unrolled FMAs on pipelined LDS reads.
+__global__ void __launch_bounds__(1024) nbf_layer0_rows_kernel(const Layer0Params p) {
     __shared__ __attribute__((aligned(16))) float lds_wt[128 * 64];
+    __shared__ __attribute__((aligned(16))) float lds_vec[64 * 64];   // one 64-vector per group
     const int outer = blockIdx.y;
     const int l16 = threadIdx.x & 15;
     const int grp = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
@@ -95,8 +123,14 @@ __global__ void __launch_bounds__(256) nbf_layer0_rows_kernel(const Layer0Params
     s = s < 0 ? 0 : (s >= p.num_node ? p.num_node - 1 : s);   // (an out-of-range id reads a valid row instead of faulting)
     const int k0 = p.trow_ptr[s], k1 = p.trow_ptr[s + 1];
     if (blockIdx.x > 0 && k0 + (int)blockIdx.x * (int)(blockDim.x >> 4) >= k1) return;   // no run can start in this block
+    // small vectors first: their latency hides under the weight staging instead of ending the dependency chain
+    const L0Vec vec = l0_load_vectors(p, l16);
+    float qv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) qv[e] = p.q ? p.q[(long long)outer * 64 + 4 * l16 + e] : 1.f;
     {   // transpose W[f][k] -> [k][f]: lane = f (64 distinct LDS banks per store), 16 bytes of one weight row per load
         const int f = threadIdx.x & 63;
+#pragma unroll
         for (int kc = 4 * (threadIdx.x >> 6); kc < 128; kc += 4 * (blockDim.x >> 6)) {
             const float4 wv = *reinterpret_cast<const float4 *>(p.weight + f * 128 + kc);
             lds_wt[(kc + 0) * 64 + f] = wv.x;
@@ -106,36 +140,46 @@ __global__ void __launch_bounds__(256) nbf_layer0_rows_kernel(const Layer0Params
         }
     }
     __syncthreads();
-    float qv[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) qv[e] = p.q ? p.q[(long long)outer * 64 + 4 * l16 + e] : 1.f;
     const float *relb = reinterpret_cast<const float *>(p.rel.ptr) + outer * p.rel.stride_outer;
     float *outb = p.out + outer * p.out_so;
+    float *slot = lds_vec + (threadIdx.x >> 4) * 64;
 
     // y = bias + W[:, :64] . x + W[:, 64:] . agg for this group's row; x = q on the source row, 0 elsewhere
     const auto update_row = [&](const float (&agg)[4], bool is_src, long long row) {
         float y[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = p.bias ? p.bias[4 * l16 + e] : 0.f;
-        if (is_src) {
-            for (int k = 0; k < 64; ++k) {
-                const float xk = __shfl(qv[k & 3], k >> 2, 16);
-                const float4 wv = *reinterpret_cast<const float4 *>(lds_wt + k * 64 + 4 * l16);
-                y[0] += wv.x * xk;
-                y[1] += wv.y * xk;
-                y[2] += wv.z * xk;
-                y[3] += wv.w * xk;
+        for (int e = 0; e < 4; ++e) y[e] = vec.bias[e];
+        if (is_src) {   // once per sample: the input half of W
+            *reinterpret_cast<float4 *>(slot + 4 * l16) = make_float4(qv[0], qv[1], qv[2], qv[3]);
+#pragma unroll
+            for (int k4 = 0; k4 < 16; ++k4) {
+                const float4 x4 = *reinterpret_cast<const float4 *>(slot + 4 * k4);
+                const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float4 wv = *reinterpret_cast<const float4 *>(lds_wt + (4 * k4 + e) * 64 + 4 * l16);
+                    y[0] += wv.x * xs[e];
+                    y[1] += wv.y * xs[e];
+                    y[2] += wv.z * xs[e];
+                    y[3] += wv.w * xs[e];
+                }
             }
         }
-        for (int k = 0; k < 64; ++k) {
-            const float ak = __shfl(agg[k & 3], k >> 2, 16);
-            const float4 wv = *reinterpret_cast<const float4 *>(lds_wt + (64 + k) * 64 + 4 * l16);
-            y[0] += wv.x * ak;
-            y[1] += wv.y * ak;
-            y[2] += wv.z * ak;
-            y[3] += wv.w * ak;
+        *reinterpret_cast<float4 *>(slot + 4 * l16) = make_float4(agg[0], agg[1], agg[2], agg[3]);
+#pragma unroll
+        for (int k4 = 0; k4 < 16; ++k4) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(slot + 4 * k4);   // same address in the group: broadcast
+            const float as[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 wv = *reinterpret_cast<const float4 *>(lds_wt + (64 + 4 * k4 + e) * 64 + 4 * l16);
+                y[0] += wv.x * as[e];
+                y[1] += wv.y * as[e];
+                y[2] += wv.z * as[e];
+                y[3] += wv.w * as[e];
+            }
         }
-        l0_finish(y, p, l16);
+        l0_finish(y, p, vec);
         if (is_src && (p.flags & L0_RESIDUAL)) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] += qv[e];
@@ -144,19 +188,43 @@ __global__ void __launch_bounds__(256) nbf_layer0_rows_kernel(const Layer0Params
     };
 
     for (int k = k0 + grp; k < k1; k += ngrp) {
-        const int target = p.tcol[k];
-        if (k > k0 && p.tcol[k - 1] == target) continue;
-        int kend = k + 1;
-        while (kend < k1 && p.tcol[kend] == target) ++kend;
-        float agg[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int kk = k; kk < kend; ++kk) {   // edge order of the run (deterministic)
-            const float4 rv = *reinterpret_cast<const float4 *>(relb + (long long)p.ttype[kk] * p.rel.stride_row + 4 * l16);
-            const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
+        // run head test and the first four entries of the run in one round of loads (runs are short: one edge per
+        // relation type at most in a simple graph)
+        const int last = k1 - 1;
+        const int prev = p.tcol[k > k0 ? k - 1 : k0];
+        int tc[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float m = r4[e] * qv[e];
-                if (p.w) m = p.w[p.tperm[kk]] * m;
-                agg[e] += m;
+        for (int u = 0; u < 4; ++u) tc[u] = p.tcol[min(k + u, last)];
+        const int target = tc[0];
+        if (k > k0 && prev == target) continue;
+        int kend = k + 1;
+        if (kend < k1 && tc[1] == target) ++kend;
+        if (kend == k + 2 && kend < k1 && tc[2] == target) ++kend;
+        if (kend == k + 3 && kend < k1 && tc[3] == target) ++kend;
+        if (kend == k + 4)
+            while (kend < k1 && p.tcol[kend] == target) ++kend;
+        float agg[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int kb = k; kb < kend; kb += 4) {   // edge order of the run (deterministic)
+            float4 rv[4];
+            float wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = min(kb + u, kend - 1);
+                const int ty = p.ttype[kk];
+                rv[u] = *reinterpret_cast<const float4 *>(relb + (long long)ty * p.rel.stride_row + 4 * l16);
+                wv[u] = p.w ? p.w[p.tperm[kk]] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (kb + u < kend) {
+                    const float r4[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float m = r4[e] * qv[e];
+                        if (p.w) m = wv[u] * m;
+                        agg[e] += m;
+                    }
+                }
             }
         }
         const bool is_src = target == (int)s;
@@ -166,15 +234,8 @@ __global__ void __launch_bounds__(256) nbf_layer0_rows_kernel(const Layer0Params
         }
         update_row(agg, is_src, target);
     }
-    if (grp == 0) {
-        // no edge leads back to the source row: its aggregate is the boundary value alone
-        int lo = k0, hi = k1;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (p.tcol[mid] < (int)s) lo = mid + 1; else hi = mid;
-        }
-        if (!(lo < k1 && p.tcol[lo] == (int)s)) update_row(qv, true, s);
-    }
+    // no edge leads back to the source row: its aggregate is the boundary value alone
+    if (grp == 0 && !p.self_loop[s]) update_row(qv, true, s);
 }
 
 }  // namespace ultra

@@ -32,6 +32,7 @@ struct DevicePlan {
     Item *items = nullptr;
     int32_t *split_row = nullptr, *split_ptr = nullptr;
     uint8_t *a_frag = nullptr;   // ULTRA_PLAN_DENSE
+    uint8_t *self_loop = nullptr;   // per node: has an edge onto itself (layer-0 path)
     void *w_sorted = nullptr;
     size_t w_sorted_bytes = 0;
     void *partial = nullptr;
@@ -66,6 +67,8 @@ struct ultra_plan {
     std::vector<uint8_t> a_frag;
     int32_t dense_rt = 0, dense_kg = 0, dense_tc = 0, dense_ntc = 0;
     bool dense_overflow = false;   // some multiplicity exceeds 255
+
+    std::vector<uint8_t> self_loop;   // [num_out] built with the edge list (square graphs)
 
     // original (unsorted) edges, kept to derive the backward plans lazily
     std::vector<int32_t> h_row, h_col, h_type;

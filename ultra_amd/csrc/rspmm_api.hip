@@ -79,6 +79,7 @@ static int upload_plan(ultra_plan *p) {
     if ((rc = upload_array(&p->d.items, p->items))) return rc;
     if ((rc = upload_array(&p->d.split_row, p->split_row))) return rc;
     if ((rc = upload_array(&p->d.split_ptr, p->split_ptr))) return rc;
+    if (!p->self_loop.empty() && (rc = upload_array(&p->d.self_loop, p->self_loop))) return rc;
     p->d.device = dev;
     p->on_device = true;
     return ULTRA_OK;
@@ -96,6 +97,7 @@ static void free_device(ultra_plan *p) {
     (void)hipFree(p->d.split_row);
     (void)hipFree(p->d.split_ptr);
     if (p->d.a_frag) (void)hipFree(p->d.a_frag);
+    if (p->d.self_loop) (void)hipFree(p->d.self_loop);
     if (p->d.w_sorted) (void)hipFree(p->d.w_sorted);
     if (p->d.partial) (void)hipFree(p->d.partial);
     p->d = DevicePlan();
@@ -493,12 +495,15 @@ static int layer0_impl(ultra_plan *p, const void *w, const ultra_mat *rel, const
     if (n_outer == 0 || p->num_out == 0) return ULTRA_OK;
     if ((rc = ensure_backward_plans(p))) return rc;
     if ((rc = upload_plan(p->tplan))) return rc;
+    if ((rc = upload_plan(p))) return rc;
+    if (!p->d.self_loop) return invalid("plan was built without its edge list; layer-0 path unavailable");
     Layer0Params lp;
     std::memset(&lp, 0, sizeof(lp));
     lp.trow_ptr = p->tplan->d.row_ptr;
     lp.tcol = p->tplan->d.col;
     lp.ttype = p->tplan->d.type;
     lp.tperm = p->tplan->d.perm;
+    lp.self_loop = p->d.self_loop;
     lp.w = static_cast<const float *>(w);
     lp.src = src_rows;
     lp.q = static_cast<const float *>(src_vals);
@@ -515,10 +520,10 @@ static int layer0_impl(ultra_plan *p, const void *w, const ultra_mat *rel, const
     lp.eps = eps;
     lp.flags = flags;
     const long long rows = (long long)n_outer * p->num_out;
-    const int fill_blocks = (int)std::min<long long>((rows + 15) / 16, 2048);
+    const int fill_blocks = (int)std::min<long long>((rows + 15) / 16, 1024);
     hipLaunchKernelGGL(nbf_layer0_fill_kernel, dim3(fill_blocks), dim3(256), 0, stream, lp);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(nbf_layer0_rows_kernel, dim3(32, (unsigned)n_outer), dim3(256), 0, stream, lp);
+    hipLaunchKernelGGL(nbf_layer0_rows_kernel, dim3(32, (unsigned)n_outer), dim3(1024), 0, stream, lp);
     HIP_TRY(hipGetLastError());
     return ULTRA_OK;
 }

@@ -28,6 +28,29 @@ __global__ void __launch_bounds__(256) onehot_rows_kernel(float4 *__restrict__ o
                                                           long long total4, const float *__restrict__ w1,
                                                           const float *__restrict__ b1, float *__restrict__ qbias_out,
                                                           int batch) {
+    if (!out && table) {
+        // gather-only launch (one block per sample): query row and the readout's per-sample bias
+        const int b = blockIdx.x, dim = 4 * dim4;
+        long long t = pick[b];
+        t = t < 0 ? 0 : (t >= table_rows ? table_rows - 1 : t);
+        const float4 *qr = table + ((long long)b * table_rows + t) * dim4;
+        for (int d = threadIdx.x; d < dim4; d += blockDim.x) values_out[b * dim4 + d] = qr[d];
+        if (qbias_out) {
+            for (int f = threadIdx.x; f < 2 * dim; f += blockDim.x) {
+                const float4 *wr = reinterpret_cast<const float4 *>(w1 + (long long)f * 2 * dim + dim);
+                float acc = b1[f];
+                for (int k = 0; k < dim4; ++k) {
+                    const float4 w = wr[k], q = qr[k];
+                    acc += w.x * q.x;
+                    acc += w.y * q.y;
+                    acc += w.z * q.z;
+                    acc += w.w * q.w;
+                }
+                qbias_out[b * 2 * dim + f] = acc;
+            }
+        }
+        return;
+    }
     if (table && blockIdx.x == gridDim.x - 1) {
         // the gathered query rows themselves (read back by the layers and the readout)
         for (int idx = threadIdx.x; idx < batch * dim4; idx += blockDim.x) {
@@ -110,7 +133,7 @@ extern "C" int32_t ultra_query_boundary(void *out, void *query_out, const int64_
     if (batch == 0) return ULTRA_OK;
     // out == NULL: only the gathers (query_out, qbias_out) -- the boundary stays in closed form (ultra_rspmm_forward_point)
     const long long total4 = out ? (long long)batch * num_node * (dim / 4) : 0;
-    const int grid = out ? (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048) : 1;
+    const int grid = out ? (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048) : (int)batch;
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
     hipLaunchKernelGGL(ultra::onehot_rows_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        (float4 *)out, rows, (const float4 *)nullptr, (const float4 *)table, pick, (long long)table_rows,

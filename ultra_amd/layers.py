@@ -28,7 +28,8 @@ class PointBoundary(object):
     of sample b, which holds values[b]."""
 
     def __init__(self, rows, values, num_node):
-        self.rows, self.values, self.num_node = rows, values, num_node
+        # (made contiguous once here: every layer hands these pointers to a kernel)
+        self.rows, self.values, self.num_node = rows.to(torch.int64).contiguous(), values.contiguous(), num_node
 
     @property
     def requires_grad(self):
