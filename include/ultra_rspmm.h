@@ -168,6 +168,18 @@ int32_t ultra_nbf_layer0(ultra_plan *plan, const void *edge_weight_dev, const ul
                          const void *ln_bias, float eps, int32_t flags, const ultra_mat *output, void *stream);
 
 /*
+ * One whole layer on a ULTRA_PLAN_DENSE plan (at most 4 relation types, square graph, hidden dim 64, fp32) in one launch:
+ *     agg = rspmm add_mul (unit weights) + boundary;   out = [input +] relu( LayerNorm_eps( weight . cat[input, agg] + bias ) )
+ * i.e. /root/reference/ultra/layers.py:183-207 + 233-240 with the residual of /root/reference/ultra/models.py:158-160 --
+ * the steady-state layer of RelNBFNet.  boundary: NULL, a (n_outer, num_node, 64) tensor (point_rows_dev == NULL) or a
+ * point boundary (n_outer, 1, 64) with point_rows_dev.  flags: ULTRA_CONV_* of ultra_nbfnet.h.  The aggregate never
+ * leaves the chip.  ULTRA_ERR_UNSUPPORTED when the plan / shapes do not fit (callers then run rspmm + conv_update).
+ */
+int32_t ultra_nbf_dense_layer(ultra_plan *plan, const ultra_mat *relation, const ultra_mat *input, const ultra_mat *boundary,
+                              const int64_t *point_rows_dev, const void *weight, const void *bias, const void *ln_weight,
+                              const void *ln_bias, float eps, int32_t flags, const ultra_mat *output, void *stream);
+
+/*
  * add_mul forward for a ROW-SPARSE input: input[o] is zero outside row src_rows_dev[o] (int64, one per outer
  * slice) -- the layer-0 input of every NBFNet, whose boundary condition puts the query vector at the head node
  * and zeros elsewhere (/root/reference/ultra/models.py:59-66, 135-141).  Zero rows contribute exact zeros to a

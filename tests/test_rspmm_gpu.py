@@ -442,3 +442,53 @@ def test_layer0_on_its_boundary_condition_matches_the_dense_layer(dev, case, lay
     for b in range(bs):
         touched[b, eid[0][eid[1] == rows[b]]] = True
     assert (got[~touched] - c0).abs().max().item() <= 1e-6 if (~touched).any() else True
+
+
+@pytest.mark.parametrize("case", DENSE_CASES[:3] + [dict(num_node=474, num_edge=800000, num_relation=4, seed=11)])
+@pytest.mark.parametrize("bnd", ["none", "tensor", "point"])
+@pytest.mark.parametrize("layer_norm,residual", [(True, True), (False, False)])
+def test_fused_dense_layer_matches_rspmm_plus_update(dev, case, bnd, layer_norm, residual):
+    """ultra_nbf_dense_layer == ultra_rspmm_forward (add_mul + boundary) followed by ultra_conv_update
+    (layers.py:183-207 + 233-240, models.py:158-160) on graphs with a dense-format plan and <= 4 relation types."""
+    from ultra_amd import dense as D
+    from ultra_amd import layers as L
+    from ultra_amd.rspmm import Plan
+    ei, et = helpers.random_graph(**case)
+    N, R = case["num_node"], case["num_relation"]
+    bs = 3
+    torch.manual_seed(case["seed"])
+    layer = L.GeneralizedRelationalConv(64, 64, R, 64, "distmult", "sum", layer_norm, "relu", dependent=False).to(dev)
+    with torch.no_grad():
+        layer.linear.bias.uniform_(-1, 1)
+        if layer_norm:
+            layer.layer_norm.weight.uniform_(0.5, 1.5)
+            layer.layer_norm.bias.uniform_(-0.5, 0.5)
+    g = torch.Generator().manual_seed(case["seed"] + 5)
+    x = (torch.randn(bs, N, 64, generator=g) / 8).to(dev)
+    rel = torch.randn(bs, R, 64, generator=g).to(dev)
+    rows = torch.tensor([0, N - 1, N // 2]).to(dev)
+    vals = torch.randn(bs, 64, generator=g).to(dev)
+    boundary, point = None, None
+    if bnd == "tensor":
+        boundary = torch.randn(bs, N, 64, generator=g).to(dev)
+    elif bnd == "point":
+        point = (rows, vals)
+    plan = Plan(ei, et, N, R, dense=True)
+    with torch.no_grad():
+        got = plan.fused_layer(rel, x, layer.linear, layer.layer_norm, relu=True, residual=residual, boundary=boundary,
+                               point=point)
+        assert got is not None
+        agg = plan.forward(rel, x, boundary=boundary, point=point)
+        want = D.conv_update(layer, x, agg, residual)
+    scale = max(1.0, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    assert err <= 3e-5 * scale, "max |fused layer - (rspmm + update)| = %g (scale %g)" % (err, scale)
+    with torch.no_grad():
+        again = plan.fused_layer(rel, x, layer.linear, layer.layer_norm, relu=True, residual=residual, boundary=boundary,
+                                 point=point)
+    assert torch.equal(got, again), "deterministic"
+    # not served: more than 4 relation types, no dense twin
+    ei5, et5 = helpers.random_graph(**DENSE_CASES[3])
+    assert Plan(ei5, et5, 33, 9, dense=True).fused_layer(torch.zeros(1, 9, 64, device=dev), torch.zeros(1, 33, 64, device=dev),
+                                                         layer.linear) is None
+    assert Plan(ei, et, N, R, dense=False).fused_layer(rel, x, layer.linear) is None

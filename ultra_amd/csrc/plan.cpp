@@ -61,6 +61,17 @@ ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *ty
             uint8_t &cell = p->a_frag[(size_t)(((((rt * p->dense_ntc + chunk) * p->dense_kg + kg) * 64 + lane) * tc + tl) * 4 + q)];
             if (cell == 255) p->dense_overflow = true; else ++cell;
         }
+        if (num_rel <= 4 && num_out == num_in) {
+            const int64_t rt16 = (num_out + 15) / 16;
+            p->a16_chunks = (int32_t)(((num_in + 15) / 16 + 3) / 4 * 4);
+            p->a16.assign((size_t)rt16 * p->a16_chunks * 64 * 16, 0);
+            for (int64_t e = 0; e < E; ++e) {
+                const int64_t rt = row[e] / 16, i = row[e] % 16, chunk = col[e] / 16, within = col[e] % 16;
+                const int64_t lane = i + 16 * (within % 4), step = within / 4;
+                uint8_t &cell = p->a16[(size_t)((((rt * p->a16_chunks + chunk) * 64 + lane) * 4 + step) * 4 + type[e])];
+                if (cell < 255) ++cell;   // (overflow already flagged above)
+            }
+        }
         p->split_ptr.push_back(0);
         return p;
     }

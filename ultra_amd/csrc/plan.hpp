@@ -32,6 +32,7 @@ struct DevicePlan {
     Item *items = nullptr;
     int32_t *split_row = nullptr, *split_ptr = nullptr;
     uint8_t *a_frag = nullptr;   // ULTRA_PLAN_DENSE
+    uint8_t *a16 = nullptr;         // ULTRA_PLAN_DENSE, 16-row tiles (fused layer kernel)
     uint8_t *self_loop = nullptr;   // per node: has an edge onto itself (layer-0 path)
     void *w_sorted = nullptr;
     size_t w_sorted_bytes = 0;
@@ -67,6 +68,10 @@ struct ultra_plan {
     std::vector<uint8_t> a_frag;
     int32_t dense_rt = 0, dense_kg = 0, dense_tc = 0, dense_ntc = 0;
     bool dense_overflow = false;   // some multiplicity exceeds 255
+    // the same multiplicities for 16-row tiles and v_mfma_f32_16x16x4_f32 (dense_layer.hip), at most 4 relation types:
+    // [row_tile16][chunk of 16 columns][lane = (row % 16) + 16 (col % 4)][step = (col % 16) / 4][type]; a16_chunks % 4 == 0
+    std::vector<uint8_t> a16;
+    int32_t a16_chunks = 0;
 
     std::vector<uint8_t> self_loop;   // [num_out] built with the edge list (square graphs)
 

@@ -30,6 +30,10 @@ int launch_dense_forward(ultra_plan *p, int sum, int mul, int dtype, const void 
                          const ultra_mat *bnd, const int64_t *bnd_rows, const ultra_mat *out,
                          hipStream_t stream);   // rspmm_dense.hip
 
+int launch_dense_layer(ultra_plan *p, const ultra_mat *rel, const ultra_mat *x, const ultra_mat *bnd, const int64_t *bnd_rows,
+                       const void *weight, const void *bias, const void *ln_w, const void *ln_b, float eps, int flags,
+                       const ultra_mat *out, hipStream_t stream);   // dense_layer.hip
+
 static ultra_tuning g_tuning = {0, 0, -1, -1, 0, {0, 0, 0}};
 
 // measurement hook: when set, forward_impl records these events right before / after the main kernel launch
@@ -66,6 +70,7 @@ static int upload_plan(ultra_plan *p) {
     int rc;
     if (p->flags & ULTRA_PLAN_DENSE) {
         if ((rc = upload_array(&p->d.a_frag, p->a_frag))) return rc;
+        if (!p->a16.empty() && (rc = upload_array(&p->d.a16, p->a16))) return rc;
         p->d.device = dev;
         p->on_device = true;
         return ULTRA_OK;
@@ -97,6 +102,7 @@ static void free_device(ultra_plan *p) {
     (void)hipFree(p->d.split_row);
     (void)hipFree(p->d.split_ptr);
     if (p->d.a_frag) (void)hipFree(p->d.a_frag);
+    if (p->d.a16) (void)hipFree(p->d.a16);
     if (p->d.self_loop) (void)hipFree(p->d.self_loop);
     if (p->d.w_sorted) (void)hipFree(p->d.w_sorted);
     if (p->d.partial) (void)hipFree(p->d.partial);
@@ -619,6 +625,26 @@ int32_t ultra_nbf_layer0(ultra_plan *plan, const void *edge_weight_dev, const ul
                          const void *ln_bias, float eps, int32_t flags, const ultra_mat *output, void *stream) {
     return layer0_impl(plan, edge_weight_dev, relation, src_rows_dev, src_values_dev, weight, bias, ln_weight, ln_bias, eps,
                        flags, output, reinterpret_cast<hipStream_t>(stream));
+}
+
+int32_t ultra_nbf_dense_layer(ultra_plan *plan, const ultra_mat *relation, const ultra_mat *input, const ultra_mat *boundary,
+                              const int64_t *point_rows_dev, const void *weight, const void *bias, const void *ln_weight,
+                              const void *ln_bias, float eps, int32_t flags, const ultra_mat *output, void *stream) {
+    if (!plan) return invalid("plan is NULL");
+    (void)hipGetLastError();
+    if (!output || !output->ptr || !weight) return invalid("ultra_nbf_dense_layer: NULL operand");
+    if ((flags & 1) && (!ln_weight || !ln_bias)) return invalid("ultra_nbf_dense_layer: LayerNorm needs its weight and bias");
+    if (point_rows_dev && !boundary) return invalid("ultra_nbf_dense_layer: point rows without their values");
+    const int64_t n_outer = output->n_outer;
+    int rc;
+    if ((rc = check_mat(output, "output", plan->num_out, n_outer, output->row_len))) return rc;
+    if ((rc = check_mat(relation, "relation", plan->num_rel, n_outer, output->row_len))) return rc;
+    if ((rc = check_mat(input, "input", plan->num_in, n_outer, output->row_len))) return rc;
+    if (boundary && (rc = check_mat(boundary, "boundary", point_rows_dev ? 1 : plan->num_out, n_outer, output->row_len))) return rc;
+    if (n_outer == 0 || plan->num_out == 0) return ULTRA_OK;
+    if ((rc = upload_plan(plan))) return rc;
+    return launch_dense_layer(plan, relation, input, boundary, point_rows_dev, weight, bias, ln_weight, ln_bias, eps, flags,
+                              output, reinterpret_cast<hipStream_t>(stream));
 }
 
 int32_t ultra_rspmm_backward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype, const void *edge_weight_dev,

@@ -21,6 +21,8 @@ ONEHOT_FAST_PATH = True
 # the boundary condition kept as (row, value) per sample instead of a (batch, N, d) tensor; layer 0 computed on its
 # special rows only (A/B switch for tests)
 POINT_BOUNDARY_FAST_PATH = True
+# aggregate + update of a layer in one launch on dense-format plans (A/B switch for tests)
+FUSED_DENSE_LAYER = True
 
 
 class PointBoundary(object):
@@ -169,10 +171,27 @@ class GeneralizedRelationalConv(nn.Module):
             out = self._propagate_unfused(edge_index, size, **kwargs)
             return out + kwargs["input"] if residual else out
         num_node = size[0] if size is not None else kwargs["input"].shape[1]
+        fused = self._fused_dense_layer(edge_index, kwargs, num_node, residual, onehot_rows)
+        if fused is not None:
+            return fused
         out = self.message_and_aggregate(edge_index, kwargs["input"], kwargs["relation"], kwargs["boundary"],
                                          kwargs["edge_type"], edge_weight, edge_index[1], num_node,
                                          onehot_rows=onehot_rows)
         return self.update(out, kwargs["input"], residual=residual)
+
+    def _fused_dense_layer(self, edge_index, kwargs, num_node, residual, onehot_rows):
+        """Aggregate + update in one launch where the graph has a dense-format plan (ULTRA's relation graph)."""
+        input, relation, boundary = kwargs["input"], kwargs["relation"], kwargs["boundary"]
+        if not (FUSED_DENSE_LAYER and kwargs["edge_weight"] is None and self.aggregate_func == "sum"
+                and self.message_func == "distmult" and input.is_cuda and not torch.is_grad_enabled()
+                and onehot_rows is None and dense.conv_update_supported(self, input, input)):
+            return None
+        plan = rspmm.get_plan(edge_index, kwargs["edge_type"], num_node, relation.shape[1])
+        if plan.dense is None:
+            return None
+        point = (boundary.rows, boundary.values) if isinstance(boundary, PointBoundary) else None
+        return plan.fused_layer(relation, input, self.linear, self.layer_norm, relu=self.activation is not None,
+                                residual=residual, boundary=None if point is not None else boundary, point=point)
 
     # ---- unfused path: PyG semantics (gather edge_index[0], scatter to edge_index[1]; layers.py:135-181) ----
     def _propagate_unfused(self, edge_index, size, input, relation, boundary, edge_type, edge_weight):

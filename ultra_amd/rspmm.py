@@ -225,6 +225,39 @@ class Plan(object):
                                              ctypes.byref(mout), _stream()))
         return out
 
+    def fused_layer(self, relation, input, linear, layer_norm=None, relu=True, residual=False, boundary=None, point=None):
+        """A whole layer -- add_mul aggregate (+ boundary), Linear(cat[input, agg]), LayerNorm, ReLU, residual -- in one
+        launch on the dense-format twin (ultra_nbf_dense_layer).  Returns None when this plan / these operands are not
+        served (the caller then runs forward() + the update kernel)."""
+        d = self.dense
+        if d is None or self.num_relation > 4 or self.num_node != self.num_in or input.dim() != 3 or input.shape[-1] != 64 \
+                or input.dtype != torch.float32 or relation.dtype != torch.float32 or tuple(linear.weight.shape) != (64, 128):
+            return None
+        others = (relation, boundary, point[1] if point is not None else None)
+        if self._twin_for("add", "mul", None, input, *others) is not d:
+            return None
+        relation, mrel = as_mat(relation)
+        input, mx = as_mat(input)
+        out = torch.empty_like(input)
+        _, mout = as_mat(out)
+        mb, rows_ptr = None, None
+        if point is not None:
+            rows, vals = point
+            rows = rows.to(torch.int64).contiguous()
+            vals, mbv = as_mat(vals.reshape(input.shape[0], 1, 64))
+            mb, rows_ptr = ctypes.byref(mbv), rows.data_ptr()
+        elif boundary is not None:
+            boundary, mbv = as_mat(boundary)
+            mb = ctypes.byref(mbv)
+        flags = (1 if layer_norm is not None else 0) | (2 if relu else 0) | (4 if residual else 0)
+        check(lib.ultra_nbf_dense_layer(d._h, ctypes.byref(mrel), ctypes.byref(mx), mb, rows_ptr, linear.weight.data_ptr(),
+                                        linear.bias.data_ptr() if linear.bias is not None else None,
+                                        layer_norm.weight.data_ptr() if layer_norm is not None else None,
+                                        layer_norm.bias.data_ptr() if layer_norm is not None else None,
+                                        float(layer_norm.eps) if layer_norm is not None else 1e-5, flags, ctypes.byref(mout),
+                                        _stream()))
+        return out
+
     def layer0(self, relation, src_rows, src_values, linear, layer_norm=None, relu=True, residual=False, edge_weight=None):
         """Layer 0 of an NBFNet on its one-hot boundary condition (ultra_nbf_layer0): returns the (batch, N, 64) hidden
         state of `relu(LayerNorm(linear(cat[x0, rspmm(x0) + x0]))) [+ x0]`, x0 = src_values[b] (ones if None) at row
