@@ -67,6 +67,36 @@ __global__ void __launch_bounds__(512) dense_layer_kernel(const DenseLayerParams
         for (int s = 0; s < 32; ++s) wfrag[s] = p.weight[(16 * kq + i16) * 128 + 4 * s + kk];
     }
 
+    // every small operand of phases 2 and 3 is requested here as well: its latency then hides under phase 1 instead of
+    // forming a chain of dependent loads behind it
+    float relv[2][4];
+    {
+        const float *relb = p.rel + (long long)outer * p.rel_so + 32 * ch + i16;   // lane owns column i16 of its two tiles
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) relv[c][t] = t < p.n_rel ? relb[(long long)t * p.rel_sr + 16 * c] : 0.f;
+    }
+    const int f0 = 16 * kq + 4 * kk;   // first of this lane's 4 features in phase 3 (feature tile = kq)
+    float biasv[4], lnw[4], lnb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        biasv[r] = p.bias ? p.bias[f0 + r] : 0.f;
+        lnw[r] = (p.flags & DL_LN) ? p.ln_w[f0 + r] : 1.f;
+        lnb[r] = (p.flags & DL_LN) ? p.ln_b[f0 + r] : 0.f;
+    }
+    float bndv[2] = {0.f, 0.f};   // boundary addends of the two tile elements this thread finalises in phase 2
+    if (p.has_bnd) {
+        const long long bnd_row = p.bnd_rows ? p.bnd_rows[outer] : -1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 512 * u;
+            const int row = row0 + (e >> 6), col = e & 63;
+            if (row < p.n_out && (bnd_row < 0 || bnd_row == row))
+                bndv[u] = p.bnd[(long long)outer * p.bnd_so + (long long)row * p.bnd_sr + col];   // (bnd_sr == 0 for a point)
+        }
+    }
+
     // ---- phase 1: adjacency product ----
     f32x4 acc[2][4];
 #pragma unroll
@@ -80,35 +110,43 @@ __global__ void __launch_bounds__(512) dense_layer_kernel(const DenseLayerParams
     const char *ap = reinterpret_cast<const char *>(p.a16 + ((size_t)rt * p.n_chunk * 64 + lane) * 4);
     const char *xb = reinterpret_cast<const char *>(xo + 32 * ch + i16);   // B operand: lane (kk, j) holds x[4 s + kk][col + j]
     const uint32_t x_row_bytes = (uint32_t)p.x_sr * 4u;
+    // one stage = 2 chunks = 32 source rows = 64 matrix instructions; the next stage's loads are all issued before
+    // the current stage's matrix work and only waited for after it (two waves share a SIMD: >= 2 us of cover)
     struct Stage {
-        uint4 a;
-        float x[4][2];
+        uint4 a[2];
+        float x[8][2];
     };
     const auto fetch = [&](int chunk, Stage &st) {
-        st.a = *reinterpret_cast<const uint4 *>(ap + (uint32_t)chunk * (uint32_t)(64 * 16));
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k = 16 * chunk + 4 * s + kk;   // rows past n_in: read a valid row, zeroed where it is consumed
-            const char *xr = xb + (uint32_t)min(k, p.n_in - 1) * x_row_bytes;
-            st.x[s][0] = *reinterpret_cast<const float *>(xr);
-            st.x[s][1] = *reinterpret_cast<const float *>(xr + 64);
+        for (int h = 0; h < 2; ++h) {
+            st.a[h] = *reinterpret_cast<const uint4 *>(ap + (uint32_t)(chunk + h) * (uint32_t)(64 * 16));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = 16 * (chunk + h) + 4 * s + kk;   // rows past n_in: read a valid row, zeroed where it is consumed
+                const char *xr = xb + (uint32_t)min(k, p.n_in - 1) * x_row_bytes;
+                st.x[4 * h + s][0] = *reinterpret_cast<const float *>(xr);
+                st.x[4 * h + s][1] = *reinterpret_cast<const float *>(xr + 64);
+            }
         }
     };
     Stage cur, nxt;
     fetch(c_begin, cur);
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
-        fetch(min(chunk + 1, c_end - 1), nxt);   // (the last chunk re-reads itself: harmless)
+    for (int chunk = c_begin; chunk < c_end; chunk += 2) {
+        fetch(min(chunk + 2, c_end - 2), nxt);   // (the last stage re-reads itself: harmless)
         __builtin_amdgcn_sched_barrier(0);
-        const uint32_t aw[4] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const bool in = 16 * chunk + 4 * s + kk < p.n_in;   // padding rows: multiplicity 0 times an exact 0
-            const float x0 = in ? cur.x[s][0] : 0.f, x1 = in ? cur.x[s][1] : 0.f;
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t aw[4] = {cur.a[h].x, cur.a[h].y, cur.a[h].z, cur.a[h].w};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float a = (float)((aw[s] >> (8 * t)) & 0xffu);
-                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x0, acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x1, acc[1][t], 0, 0, 0);
+            for (int s = 0; s < 4; ++s) {
+                const bool in = 16 * (chunk + h) + 4 * s + kk < p.n_in;   // padding rows: multiplicity 0 times an exact 0
+                const float x0 = in ? cur.x[4 * h + s][0] : 0.f, x1 = in ? cur.x[4 * h + s][1] : 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float a = (float)((aw[s] >> (8 * t)) & 0xffu);
+                    acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x0, acc[0][t], 0, 0, 0);
+                    acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x1, acc[1][t], 0, 0, 0);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -117,7 +155,6 @@ __global__ void __launch_bounds__(512) dense_layer_kernel(const DenseLayerParams
 
     // ---- phase 2: rel scaling (lane owns column i16 of each tile), k-quarters through LDS, boundary ----
     {
-        const float *relb = p.rel + (long long)outer * p.rel_so + 32 * ch + i16;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             f32x4 tot;
@@ -126,9 +163,8 @@ __global__ void __launch_bounds__(512) dense_layer_kernel(const DenseLayerParams
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (t < p.n_rel) {
-                    const float rv = relb[(long long)t * p.rel_sr + 16 * c];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) tot[r] += rv * acc[c][t][r];
+                    for (int r = 0; r < 4; ++r) tot[r] += relv[c][t] * acc[c][t][r];
                 }
             }
 #pragma unroll
@@ -138,8 +174,6 @@ __global__ void __launch_bounds__(512) dense_layer_kernel(const DenseLayerParams
     __syncthreads();
     {
         // 1024 tile elements, two per thread.  D layout: lane l, reg r -> tile row 4 (l >> 4) + r, column l & 15
-        long long bnd_row = -2;
-        if (p.has_bnd && p.bnd_rows) bnd_row = p.bnd_rows[outer];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + 512 * u;
@@ -149,13 +183,7 @@ __global__ void __launch_bounds__(512) dense_layer_kernel(const DenseLayerParams
             float v = red[((0 * 4 + ct) * 4 + reg) * 64 + l];
 #pragma unroll
             for (int q = 1; q < 4; ++q) v += red[((q * 4 + ct) * 4 + reg) * 64 + l];
-            const int row = row0 + r;
-            if (p.has_bnd && row < p.n_out) {
-                if (!p.bnd_rows)
-                    v += p.bnd[(long long)outer * p.bnd_so + (long long)row * p.bnd_sr + col];
-                else if (bnd_row == row)
-                    v += p.bnd[(long long)outer * p.bnd_so + col];
-            }
+            if (p.has_bnd) v += bndv[u];   // (exactly 0 where there is no boundary value: same bits as not adding)
             agg_lds[r * DL_ROW_STRIDE + col] = v;
         }
     }
@@ -176,10 +204,9 @@ __global__ void __launch_bounds__(512) dense_layer_kernel(const DenseLayerParams
             d = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[16 + s], agg_lds[i16 * DL_ROW_STRIDE + 4 * s + kk], d, 0, 0, 0);
     }
     // D: lane l, reg r -> feature 16 ft + 4 (l >> 4) + r of tile row l & 15
-    const int f0 = 16 * ft + 4 * kk;
     float y[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) y[r] = d[r] + (p.bias ? p.bias[f0 + r] : 0.f);
+    for (int r = 0; r < 4; ++r) y[r] = d[r] + biasv[r];
     if (p.flags & DL_LN) {
         // two-pass LayerNorm over the 64 features of a row: 4 regs x 4 lane groups x 4 waves
         float s = (y[0] + y[1]) + (y[2] + y[3]);
@@ -201,7 +228,7 @@ __global__ void __launch_bounds__(512) dense_layer_kernel(const DenseLayerParams
         const float var = (((ln_part[1][0][i16] + ln_part[1][1][i16]) + ln_part[1][2][i16]) + ln_part[1][3][i16]) * (1.f / 64.f);
         const float rstd = 1.f / sqrtf(var + p.eps);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[r] = (y[r] - mean) * rstd * p.ln_w[f0 + r] + p.ln_b[f0 + r];
+        for (int r = 0; r < 4; ++r) y[r] = (y[r] - mean) * rstd * lnw[r] + lnb[r];
     }
     if (ch == 0) {
         if (p.flags & DL_RELU) {

@@ -63,7 +63,7 @@ ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *ty
         }
         if (num_rel <= 4 && num_out == num_in) {
             const int64_t rt16 = (num_out + 15) / 16;
-            p->a16_chunks = (int32_t)(((num_in + 15) / 16 + 3) / 4 * 4);
+            p->a16_chunks = (int32_t)(((num_in + 15) / 16 + 7) / 8 * 8);   // whole 2-chunk stages per k-quarter
             p->a16.assign((size_t)rt16 * p->a16_chunks * 64 * 16, 0);
             for (int64_t e = 0; e < E; ++e) {
                 const int64_t rt = row[e] / 16, i = row[e] % 16, chunk = col[e] / 16, within = col[e] % 16;

@@ -69,7 +69,7 @@ struct ultra_plan {
     int32_t dense_rt = 0, dense_kg = 0, dense_tc = 0, dense_ntc = 0;
     bool dense_overflow = false;   // some multiplicity exceeds 255
     // the same multiplicities for 16-row tiles and v_mfma_f32_16x16x4_f32 (dense_layer.hip), at most 4 relation types:
-    // [row_tile16][chunk of 16 columns][lane = (row % 16) + 16 (col % 4)][step = (col % 16) / 4][type]; a16_chunks % 4 == 0
+    // [row_tile16][chunk of 16 columns][lane = (row % 16) + 16 (col % 4)][step = (col % 16) / 4][type]; a16_chunks % 8 == 0
     std::vector<uint8_t> a16;
     int32_t a16_chunks = 0;
 
