@@ -248,11 +248,12 @@ int32_t ultra_get_tuning(ultra_tuning *t);
  *   *ms_main_kernel : (optional) mean duration of the main rspmm_fwd_kernel alone, events recorded right
  *                     around its launch, one call at a time -- the figure bench.py's roofline block uses
  *                     and the one comparable with rocprofv3's per-kernel average.
+ * point_rows_dev != NULL: `boundary` is a point boundary (see ultra_rspmm_forward_point), sum aggregate only.
  */
 int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype,
                                   const void *edge_weight_dev, const ultra_mat *relation, const ultra_mat *input,
-                                  const ultra_mat *boundary, const ultra_mat *output, void *stream,
-                                  int32_t warmup, int32_t iters, float *ms_per_call, float *ms_main_kernel);
+                                  const ultra_mat *boundary, const int64_t *point_rows_dev, const ultra_mat *output,
+                                  void *stream, int32_t warmup, int32_t iters, float *ms_per_call, float *ms_main_kernel);
 
 /* Measurement helper: streaming 16-B/lane copy of `bytes` (multiple of 16) device bytes.  Used for the
  * achievable-HBM-copy ceiling and to calibrate the FETCH_SIZE / WRITE_SIZE counters on a known byte count. */

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Collect the round's measurement artefacts on a GPU box into gpurun_out/ (copied to profiles/ afterwards).
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh A'      bench lines, kernel stats, smoke, 1-process torchrun
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh B'      roofline points, HBM-traffic PMC passes, parity, eval, secondary
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+OUT=gpurun_out/r1
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+part="${1:-A}"
+if [ "$part" = "A" ]; then
+    python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$OUT/smoke.txt" 2>&1
+    python bench.py --steps 50 --warmup 5 > "$OUT/r1_bench.json" 2> "$OUT/bench.err"
+    python bench.py --steps 50 --warmup 5 --no-graph --no-cpu-baseline > "$OUT/r1_bench_eager.json" 2>> "$OUT/bench.err"
+    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o run -- \
+        python "$OLDPWD/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2>&1)
+    find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} "$OUT/r1_bench_kernel_stats.csv" \;
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
+        bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/r1_bench_torchrun1.json" 2>> "$OUT/bench.err"
+else
+    python tools/roofline_points.py --out "$OUT/r1_roofline_points.json" > "$OUT/roofline_points.txt" 2>&1
+    for c in FETCH_SIZE WRITE_SIZE; do
+        (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o run -- \
+            python "$OLDPWD/tools/roofline_points.py" --pmc --out /tmp/rp_$c.json > /dev/null 2>&1)
+        mkdir -p "$OUT/r1_pmc"
+        find /tmp/pmc_$c -name "*counter_collection.csv" -exec cp {} "$OUT/r1_pmc/${c}_counter_collection.csv" \;
+    done
+    python tools/parse_pmc.py "$OUT/r1_pmc/FETCH_SIZE_counter_collection.csv" "$OUT/r1_pmc/WRITE_SIZE_counter_collection.csv" \
+        "$OUT/r1_rspmm_hbm_traffic.json" > "$OUT/parse_pmc.txt" 2>&1
+    python tools/parity_report.py > "$OUT/parity.txt" 2>&1; cp gpurun_out/parity_report.json "$OUT/r1_parity_report.json"
+    python tools/eval_speed.py 512 > "$OUT/r1_eval_speed.txt" 2>&1
+    python tools/secondary_bench.py > "$OUT/r1_secondary.jsonl" 2> "$OUT/secondary.err"
+fi
+ls -la "$OUT"

@@ -18,6 +18,7 @@ for graph, R in ((data, data.num_relations), (data.relation_graph, 4)):
     rel = torch.randn(bs, R, 64, generator=g).to(dev)
     bnd = torch.randn(bs, N, 64, generator=g).to(dev)
     plan = rspmm.Plan(graph.edge_index, graph.edge_type, N, R)
-    ms, _ = plan.forward_timed(rel, x, boundary=bnd, warmup=1, iters=3)
+    point = (torch.arange(bs, device=dev), bnd[:, 0].contiguous())
+    ms, _ = plan.forward_timed(rel, x, point=point, warmup=1, iters=3)
     print("N=%d ms=%.4f" % (N, ms))
     del plan

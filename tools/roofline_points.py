@@ -57,11 +57,15 @@ def main():
         x = torch.randn(bs, N, 64, generator=g).to(dev)
         rel = torch.randn(bs, R, 64, generator=g).to(dev)
         bnd = torch.randn(bs, N, 64, generator=g).to(dev)
+        point = (torch.arange(bs, device=dev) * 7 % N, torch.randn(bs, 64, generator=g).to(dev))
         plan = rspmm.Plan(data.edge_index, data.edge_type, N, R)
         for sum in ("add", "max"):
             iters = 3 if args.pmc else 20
-            ms, _ = plan.forward_timed(rel, x, boundary=bnd, sum=sum, mul="mul", warmup=1 if args.pmc else 3, iters=iters)
-            alg, low = b_gather(E, N, R, D, True), b_min(E, N, R, D, True)
+            # sum: the boundary condition is one row per sample (ultra_rspmm_forward_point, what the forward passes);
+            # max: a full boundary tensor (zero is not the identity of max)
+            kw = dict(point=point) if sum == "add" else dict(boundary=bnd)
+            ms, _ = plan.forward_timed(rel, x, sum=sum, mul="mul", warmup=1 if args.pmc else 3, iters=iters, **kw)
+            alg, low = b_gather(E, N, R, D, sum != "add"), b_min(E, N, R, D, sum != "add")
             rec = dict(shape=shape, bs=bs, sum=sum, N=N, E=E, R=R, D=D, ms=ms, launches=iters + (1 if args.pmc else 3),
                        b_gather=alg, b_min=low, gbs_gather=alg / (ms * 1e-3) / 1e9, gbs_min=low / (ms * 1e-3) / 1e9,
                        x_plus_out_MB=2 * 4 * D * N / 1e6, info={k: v for k, v in plan.info().items() if k.startswith("n_")})

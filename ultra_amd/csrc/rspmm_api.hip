@@ -657,13 +657,18 @@ int32_t ultra_rspmm_backward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t
 
 int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype,
                                   const void *edge_weight_dev, const ultra_mat *relation, const ultra_mat *input,
-                                  const ultra_mat *boundary, const ultra_mat *output, void *stream, int32_t warmup,
-                                  int32_t iters, float *ms_per_call, float *ms_main_kernel) {
+                                  const ultra_mat *boundary, const int64_t *point_rows_dev, const ultra_mat *output,
+                                  void *stream, int32_t warmup, int32_t iters, float *ms_per_call, float *ms_main_kernel) {
+    if (mul < 0 || mul > 1) return invalid("unknown mul code");
+    const auto once = [&]() {
+        return forward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, boundary, output,
+                            reinterpret_cast<hipStream_t>(stream), point_rows_dev);
+    };
     if (!ms_per_call || iters <= 0) return invalid("ultra_rspmm_forward_timed: bad iters / ms_per_call");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
     for (int i = 0; i < warmup; ++i)
-        if ((rc = ultra_rspmm_forward(plan, sum, mul, dtype, edge_weight_dev, relation, input, boundary, output, stream)))
+        if ((rc = once()))
             return rc;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
@@ -671,7 +676,7 @@ int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, in
     // (1) the whole launch sequence (weight permute + main kernel + fix-up), back to back
     HIP_TRY(hipEventRecord(e0, s));
     for (int i = 0; i < iters; ++i)
-        if ((rc = ultra_rspmm_forward(plan, sum, mul, dtype, edge_weight_dev, relation, input, boundary, output, stream)))
+        if ((rc = once()))
             return rc;
     HIP_TRY(hipEventRecord(e1, s));
     HIP_TRY(hipEventSynchronize(e1));
@@ -684,7 +689,7 @@ int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, in
         for (int i = 0; i < iters; ++i) {
             g_ev_before = e0;
             g_ev_after = e1;
-            rc = ultra_rspmm_forward(plan, sum, mul, dtype, edge_weight_dev, relation, input, boundary, output, stream);
+            rc = once();
             g_ev_before = g_ev_after = nullptr;
             if (rc) return rc;
             HIP_TRY(hipEventSynchronize(e1));

@@ -308,12 +308,13 @@ class Plan(object):
                                        ctypes.byref(mxg), _stream()))
         return wgrad, rgrad, xgrad
 
-    def forward_timed(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", warmup=3, iters=20):
-        """Mean HIP-event time (ms) of the forward launch sequence on the current stream."""
-        twin = self._twin_for(sum, mul, edge_weight, input, relation, boundary)
+    def forward_timed(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", warmup=3, iters=20,
+                      point=None):
+        """Mean HIP-event time (ms) of the forward launch sequence on the current stream; `point` as in forward()."""
+        twin = self._twin_for(sum, mul, edge_weight, input, relation, boundary if point is None else point[1])
         if twin is not None:
             res = twin.forward_timed(relation, input, edge_weight=edge_weight, boundary=boundary, sum=sum,
-                                     mul=mul, warmup=warmup, iters=iters)
+                                     mul=mul, warmup=warmup, iters=iters, point=point)
             self.last_main_kernel_ms = twin.last_main_kernel_ms
             return res
         dt = _dtype_code(relation, input)
@@ -323,14 +324,20 @@ class Plan(object):
         shape[-2] = self.num_node
         out = torch.empty(shape, dtype=input.dtype, device=input.device)
         out, mout = as_mat(out)
-        mb = None
-        if boundary is not None:
+        mb, rows_ptr = None, None
+        if point is not None:
+            rows, vals = point
+            rows = rows.to(torch.int64).contiguous()
+            n_outer = 1 if input.dim() == 2 else input.shape[0]
+            vals, mbv = as_mat(vals.reshape(n_outer, 1, vals.shape[-1]) if input.dim() == 3 else vals.reshape(1, vals.shape[-1]))
+            mb, rows_ptr = ctypes.byref(mbv), rows.data_ptr()
+        elif boundary is not None:
             boundary, mbv = as_mat(boundary)
             mb = ctypes.byref(mbv)
         w = edge_weight.contiguous().data_ptr() if edge_weight is not None else None
         ms, ms_kernel = ctypes.c_float(), ctypes.c_float()
         check(lib.ultra_rspmm_forward_timed(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
-                                            ctypes.byref(mx), mb, ctypes.byref(mout), _stream(), warmup, iters,
+                                            ctypes.byref(mx), mb, rows_ptr, ctypes.byref(mout), _stream(), warmup, iters,
                                             ctypes.byref(ms), ctypes.byref(ms_kernel)))
         self.last_main_kernel_ms = ms_kernel.value
         return ms.value, out
