@@ -18,6 +18,8 @@ Extra blocks of the JSON line:
   parity       -- max |gpu - cpu| on the scores of the baseline batch and ranking mismatches.
 """
 import argparse
+import contextlib
+import ctypes
 import json
 import os
 import sys
@@ -53,6 +55,23 @@ def b_gather(E, N, R, D, boundary):
     return 4 * D * (E + N + R + (N if boundary else 0)) + 12 * E + 4 * (N + 1)
 
 
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)      # C stdio buffers of the libraries that printed
+        except Exception:
+            pass
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,7 +94,12 @@ def main():
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # started by torch.distributed.run
     if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)                   # "nccl" is RCCL on ROCm
+        # RCCL prints a version banner on stdout when its communicator comes up; stdout carries exactly one JSON
+        # line here, so the banner goes to stderr (file-descriptor level: it is written by C code)
+        with _stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=dev)               # "nccl" is RCCL on ROCm
+            dist.barrier()                                                # (communicator creation happens here)
+            torch.cuda.synchronize()
     assert world == args.gpus or world == 1, "--gpus must match the launcher's world size"
 
     import __graft_entry__ as entry
