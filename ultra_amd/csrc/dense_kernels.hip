@@ -194,7 +194,7 @@ struct ReadoutParams {
 
 constexpr int READOUT_MAX_INLINE_BATCH = 32;
 
-__global__ void __launch_bounds__(256) readout_kernel(const ReadoutParams p) {
+__global__ void __launch_bounds__(256, 2) readout_kernel(const ReadoutParams p) {
     // [tile m (4)][i (8)][lane][q] : W1[32 m + (lane & 31)][8 i + 4 (lane >> 5) + q]
     __shared__ __attribute__((aligned(16))) float lds_w[4 * 8 * 64 * 4];
     __shared__ float lds_w2[128];

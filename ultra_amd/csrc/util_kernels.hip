@@ -154,8 +154,10 @@ extern "C" int32_t ultra_stream_copy(void *dst, const void *src, int64_t bytes, 
     }
     if (bytes == 0) return ULTRA_OK;
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
-    hipLaunchKernelGGL(ultra::stream_copy_kernel, dim3(2048), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       (const float4 *)src, (float4 *)dst, (long long)(bytes / 16));
+    const long long n16 = bytes / 16;
+    const unsigned blocks = (unsigned)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(ultra::stream_copy_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const float4 *)src, (float4 *)dst, n16);
     if (hipGetLastError() != hipSuccess) {
         ultra::set_error("stream_copy_kernel launch failed");
         return ULTRA_ERR_HIP;

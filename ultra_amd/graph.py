@@ -1,9 +1,9 @@
 """hipGraph capture of the inference forward.
 
-The forward of one batch is ~60 short launches (12 rspmm + fix-ups, 12 fused updates, two batched
-relation-projection GEMMs, index glue); on a static graph with a fixed batch shape the launch sequence never
-changes, so it is captured once into a HIP graph (torch.cuda.CUDAGraph drives hipStreamBeginCapture /
-hipGraphLaunch) and replayed: one host call per forward instead of ~60.  Our kernels are enqueued on
+The forward of one batch is ~30 short launches (layer-0 kernels, 5 rspmm + fix-ups + updates on the entity
+graph, 5 fused relation-graph layers, prologue, projections, readout); on a static graph with a fixed batch shape
+the launch sequence never changes, so it is captured once into a HIP graph (torch.cuda.CUDAGraph drives
+hipStreamBeginCapture / hipGraphLaunch) and replayed: one host call per forward instead of ~30.  Our kernels are enqueued on
 torch's current stream, which is the capturing stream during capture; plans, scratch buffers and the
 LDS opt-in are created by the eager warm-up runs, so nothing allocates inside the captured region.
 """
@@ -31,11 +31,24 @@ class GraphedForward(object):
             self.static_out = model(data, self.static_batch)
         self.valid = getattr(model.entity_model, "_pending_valid", None) if hasattr(model, "entity_model") else None
 
+    def _load_input(self, batch):
+        """batch -> the graph's input buffer.  A plain 16-byte streaming kernel: the runtime's device-to-device memcpy
+        costs ~9 us for these 2.8 MB, a third of it launch overhead of its generic copy kernel."""
+        nbytes = batch.numel() * batch.element_size()
+        if batch.is_cuda and batch.is_contiguous() and batch.dtype == self.static_batch.dtype and nbytes % 16 == 0 \
+                and batch.data_ptr() % 16 == 0 and self.static_batch.data_ptr() % 16 == 0:
+            import ctypes
+            from ._lib import check, lib
+            check(lib.ultra_stream_copy(self.static_batch.data_ptr(), batch.data_ptr(), nbytes,
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        else:
+            self.static_batch.copy_(batch, non_blocking=True)
+
     def __call__(self, batch, check=False):
         if batch.shape != self.static_batch.shape:
             raise ValueError("GraphedForward was captured for batch shape %s, got %s"
                              % (tuple(self.static_batch.shape), tuple(batch.shape)))
-        self.static_batch.copy_(batch, non_blocking=True)
+        self._load_input(batch)
         self.graph.replay()
         if check and self.valid is not None:
             assert bool(self.valid.all()), "every row of `batch` must share its head (or tail) and its relation (models.py:196-197)"
