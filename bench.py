@@ -268,7 +268,19 @@ def main():
             r_gpu = tasks.compute_ranking(got, pos_t, t_mask)
             r_cpu = tasks.compute_ranking(ref_score, pos_t, t_mask)
             r_true = tasks.compute_ranking(truth.float(), pos_t, t_mask)
+            # the same forward with the reference's summation order (ULTRA_PLAN_EXACT_ORDER: every row walked sequentially
+            # in (row, col) order like rspmm.cpp:50-75) -- slow, not the timed path; isolates summation order as the only
+            # difference between the timed path and the reference's fp32 result
+            rspmm.set_plan_defaults(exact_order=True)
+            with torch.no_grad():
+                got_ro = model(data, t_batch_cpu.to(dev)).cpu()
+            rspmm.set_plan_defaults()
+            r_ro = tasks.compute_ranking(got_ro, pos_t, t_mask)
             out["parity"] = {"max_abs_score_diff": (got - ref_score).abs().max().item(), "tolerance": 1e-4,
+                             "reference_order": {"max_abs_score_diff": (got_ro - ref_score).abs().max().item(),
+                                                 "rank_mismatches": int((r_ro != r_cpu).sum()),
+                                                 "note": "GPU forward with ULTRA_PLAN_EXACT_ORDER plans (the reference's "
+                                                         "sequential per-row summation order); not the timed path"},
                              "rank_mismatches": int((r_gpu != r_cpu).sum()), "queries": bs,
                              "max_abs_err_gpu_vs_fp64": (got.double() - truth).abs().max().item(),
                              "max_abs_err_reference_fp32_vs_fp64": (ref_score.double() - truth).abs().max().item(),

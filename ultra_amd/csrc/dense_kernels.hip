@@ -40,13 +40,13 @@ enum { CONV_LN = 1, CONV_RELU = 2, CONV_RESIDUAL = 4 };
 // feature owned by accumulator register r of feature tile m in lane half h (32x32 C/D layout)
 __device__ __forceinline__ int feat_of(int m, int r, int h) { return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-__global__ void __launch_bounds__(256) conv_update_kernel(const ConvParams p) {
+__global__ void __launch_bounds__(512, 2) conv_update_kernel(const ConvParams p) {
     // [tile m][i][lane][q] : W[32 m + (lane & 31)][8 i + 4 (lane >> 5) + q]
     __shared__ __attribute__((aligned(16))) float lds_w[2 * 16 * 64 * 4];
     __shared__ float lds_vec[3 * 64];
     const int tid = threadIdx.x;
     // 16-byte staging loads: fragment (m, i, lane) = 4 consecutive k of one weight row
-    for (int idx4 = tid; idx4 < 2 * 16 * 64; idx4 += 256) {
+    for (int idx4 = tid; idx4 < 2 * 16 * 64; idx4 += blockDim.x) {
         const int l = idx4 & 63, i = (idx4 >> 6) & 15, m = idx4 >> 10;
         reinterpret_cast<float4 *>(lds_w)[idx4] =
             *reinterpret_cast<const float4 *>(p.weight + (32 * m + (l & 31)) * 128 + 8 * i + 4 * (l >> 5));
@@ -63,8 +63,9 @@ __global__ void __launch_bounds__(256) conv_update_kernel(const ConvParams p) {
     const long long ntile = (p.rows + 31) / 32;
     // persistent waves: the rows of the NEXT tile are requested before the 128 MFMAs of the current one, so
     // their HBM/L2 latency hides under ~8k cycles of matrix work
-    const long long tstride = (long long)gridDim.x * 4;
-    long long tile = (long long)blockIdx.x * 4 + wave;
+    const int wpb = blockDim.x >> 6;   // waves per block
+    const long long tstride = (long long)gridDim.x * wpb;
+    long long tile = (long long)blockIdx.x * wpb + wave;
     float4 bx[8], ba[8];
     if (tile < ntile) {
         const long long r0 = tile * 32 + j;
@@ -385,7 +386,7 @@ __global__ void __launch_bounds__(256) relation_projection_kernel(const RelProjP
     }
 }
 
-static int grid_for(long long ntile, int waves_per_block) {
+static int grid_for(long long ntile, int waves_per_block, int blocks_per_cu = 2) {
     static int cu = 0;   // queried once (kept out of hipGraph capture)
     if (cu == 0) {
         int dev = 0, v = 0;
@@ -395,7 +396,7 @@ static int grid_for(long long ntile, int waves_per_block) {
             cu = v;
     }
     long long blocks = (ntile + waves_per_block - 1) / waves_per_block;
-    const long long cap = (long long)cu * 2;   // 8 waves per CU = 2 per SIMD (the kernels' VGPR budget), persistent over tiles
+    const long long cap = (long long)cu * blocks_per_cu;   // 8 waves per CU = 2 per SIMD (the kernels' VGPR budget), persistent over tiles
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
@@ -430,9 +431,13 @@ int32_t ultra_conv_update(const void *x, const void *agg, const void *weight, co
     p.rows = rows;
     p.eps = eps;
     p.flags = flags;
-    const int grid = grid_for((rows + 31) / 32, 4);
+    // big inputs: one 8-wave workgroup per CU (half the weight staging and workgroup launches of two 4-wave ones:
+    // 33.6 -> 31.9 us at 116 k rows); small inputs keep 4-wave workgroups so that the tiles spread over more CUs
+    const long long ntile = (rows + 31) / 32;
+    const int threads = ntile >= 2048 ? 512 : 256;
+    const int grid = grid_for(ntile, threads / 64, threads == 512 ? 1 : 2);
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
-    hipLaunchKernelGGL(conv_update_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(conv_update_kernel, dim3(grid), dim3(threads), 0, reinterpret_cast<hipStream_t>(stream), p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error(std::string("conv_update_kernel launch: ") + hipGetErrorString(e));
