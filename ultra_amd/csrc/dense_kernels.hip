@@ -195,7 +195,7 @@ struct ReadoutParams {
 
 constexpr int READOUT_MAX_INLINE_BATCH = 32;
 
-__global__ void __launch_bounds__(256, 2) readout_kernel(const ReadoutParams p) {
+__global__ void __launch_bounds__(512, 2) readout_kernel(const ReadoutParams p) {
     // [tile m (4)][i (8)][lane][q] : W1[32 m + (lane & 31)][8 i + 4 (lane >> 5) + q]
     __shared__ __attribute__((aligned(16))) float lds_w[4 * 8 * 64 * 4];
     __shared__ float lds_w2[128];
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256, 2) readout_kernel(const ReadoutParams p) 
     if (!p.qbias) {
         // the query half of mlp.0 (models.py:166-170 concatenates query to every node feature): one 64-term dot
         // product per (sample, hidden unit), computed by every workgroup for itself instead of a GEMM launch
-        for (int idx = tid; idx < (int)p.batch * 128; idx += 256) {
+        for (int idx = tid; idx < (int)p.batch * 128; idx += blockDim.x) {
             const int b = idx >> 7, f = idx & 127;
             const float4 *wr = reinterpret_cast<const float4 *>(p.w1 + f * 128 + 64);
             const float4 *qr = reinterpret_cast<const float4 *>(p.query + b * 64);
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256, 2) readout_kernel(const ReadoutParams p) 
             lds_qb[idx] = acc;
         }
     }
-    for (int idx4 = tid; idx4 < 4 * 8 * 64; idx4 += 256) {
+    for (int idx4 = tid; idx4 < 4 * 8 * 64; idx4 += blockDim.x) {
         const int l = idx4 & 63, i = (idx4 >> 6) & 7, m = idx4 >> 9;
         reinterpret_cast<float4 *>(lds_w)[idx4] =
             *reinterpret_cast<const float4 *>(p.w1 + (32 * m + (l & 31)) * 128 + 8 * i + 4 * (l >> 5));
@@ -232,7 +232,8 @@ __global__ void __launch_bounds__(256, 2) readout_kernel(const ReadoutParams p) 
     const float4 *w4 = reinterpret_cast<const float4 *>(lds_w);
     const long long total = p.batch * p.n_cand;
     const long long ntile = (total + 31) / 32;
-    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
+    const int wpb = blockDim.x >> 6;
+    for (long long tile = (long long)blockIdx.x * wpb + wave; tile < ntile; tile += (long long)gridDim.x * wpb) {
         const long long row = tile * 32 + j;
         const bool valid = row < total;
         const long long rowc = valid ? row : total - 1;
@@ -487,9 +488,11 @@ int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1
     p.batch = batch;
     p.num_node = num_node;
     p.n_cand = n_cand;
-    const int grid = grid_for((batch * n_cand + 31) / 32, 4);
+    const long long ntile = (batch * n_cand + 31) / 32;
+    const int threads = ntile >= 2048 ? 512 : 256;   // as in ultra_conv_update
+    const int grid = grid_for(ntile, threads / 64, threads == 512 ? 1 : 2);
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
-    hipLaunchKernelGGL(readout_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(readout_kernel, dim3(grid), dim3(threads), 0, reinterpret_cast<hipStream_t>(stream), p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error(std::string("readout_kernel launch: ") + hipGetErrorString(e));
@@ -527,9 +530,11 @@ int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const in
     p.batch = batch;
     p.num_node = num_node;
     p.n_cand = n_cand;
-    const int grid = grid_for((batch * n_cand + 31) / 32, 4);
+    const long long ntile = (batch * n_cand + 31) / 32;
+    const int threads = ntile >= 2048 ? 512 : 256;   // as in ultra_conv_update
+    const int grid = grid_for(ntile, threads / 64, threads == 512 ? 1 : 2);
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
-    hipLaunchKernelGGL(readout_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(readout_kernel, dim3(grid), dim3(threads), 0, reinterpret_cast<hipStream_t>(stream), p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error(std::string("readout_kernel launch: ") + hipGetErrorString(e));
