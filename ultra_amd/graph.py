@@ -27,7 +27,9 @@ class GraphedForward(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        # thread-local capture mode: helper threads of the process (RCCL's watchdog polls events) must not be able to
+        # invalidate the capture; everything captured here is enqueued by this thread
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.static_out = model(data, self.static_batch)
         self.valid = getattr(model.entity_model, "_pending_valid", None) if hasattr(model, "entity_model") else None
 
