@@ -42,3 +42,27 @@ def test_negative_sample_to_tail():
     nh, nt, nr = net.negative_sample_to_tail(h, t, r, num_direct_rel=10)
     assert nh.tolist() == [[9, 9, 9], [1, 1, 1]] and nt.tolist() == [[5, 6, 7], [2, 3, 4]]
     assert nr.tolist() == [[12, 12, 12], [0, 0, 0]]
+
+
+def test_point_boundary_is_the_reference_boundary_tensor():
+    """layers.PointBoundary.dense() == zeros + scatter_add_ of one row per sample (models.py:59-66, 135-141)."""
+    from ultra_amd import layers
+    g = torch.Generator().manual_seed(3)
+    bs, n, d = 5, 17, 64
+    rows = torch.randint(0, n, (bs,), generator=g)
+    vals = torch.randn(bs, d, generator=g)
+    want = torch.zeros(bs, n, d)
+    want.scatter_add_(1, rows.view(bs, 1, 1).expand(-1, 1, d), vals.unsqueeze(1))
+    point = layers.PointBoundary(rows[::1], vals, n)
+    assert torch.equal(point.dense(), want)
+    assert point.rows.is_contiguous() and point.rows.dtype == torch.long and not point.requires_grad
+    # strided row ids (batch[:, 0, 2] in Ultra.forward) are made contiguous once
+    strided = torch.stack([rows, rows + 1], dim=1)[:, 0]
+    assert layers.PointBoundary(strided, vals, n).rows.is_contiguous()
+
+
+def test_fast_path_switches_default_on():
+    """The inference fast paths are module-level switches (A/B tests flip them); they must ship enabled."""
+    from ultra_amd import layers, models
+    assert layers.ONEHOT_FAST_PATH and layers.POINT_BOUNDARY_FAST_PATH and layers.FUSED_DENSE_LAYER
+    assert models.PROLOGUE_FAST_PATH
