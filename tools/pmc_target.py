@@ -1,24 +1,37 @@
-"""Minimal PMC target: the two rspmm kernels of the benchmark forward (FB15k237-shaped, batch 8,
-add_mul + fused boundary), 1 warm-up + 3 launches each.  Run under rocprofv3 --pmc <counters>."""
+"""Minimal PMC target: the three kernels that make up 80 % of the benchmark forward (FB15k237 shape, batch 8) --
+entity-graph rspmm (add_mul, point boundary), the entity-graph layer update, the fused relation-graph layer.
+1 warm-up + a few launches each.  Run under rocprofv3 --pmc <counters> (tools/collect_profiles.sh C)."""
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ultra_amd import rspmm, synthetic  # noqa: E402
+from ultra_amd import dense, layers, rspmm, synthetic  # noqa: E402
 
 dev = torch.device("cuda:0")
 data = synthetic.make_kg(**synthetic.SHAPES["fb15k237"], seed=1234)
 bs = 8
 g = torch.Generator().manual_seed(0)
-for graph, R in ((data, data.num_relations), (data.relation_graph, 4)):
-    N = graph.num_nodes
+layer = layers.GeneralizedRelationalConv(64, 64, 4, 64, "distmult", "sum", True, "relu").to(dev)
+with torch.no_grad():
+    # entity graph: rspmm main kernel (+ fix-up), then the update kernel
+    N, R = data.num_nodes, data.num_relations
     x = torch.randn(bs, N, 64, generator=g).to(dev)
     rel = torch.randn(bs, R, 64, generator=g).to(dev)
-    bnd = torch.randn(bs, N, 64, generator=g).to(dev)
-    plan = rspmm.Plan(graph.edge_index, graph.edge_type, N, R)
-    point = (torch.arange(bs, device=dev), bnd[:, 0].contiguous())
-    ms, _ = plan.forward_timed(rel, x, point=point, warmup=1, iters=3)
-    print("N=%d ms=%.4f" % (N, ms))
-    del plan
+    point = (torch.arange(bs, device=dev) * 7 % N, torch.randn(bs, 64, generator=g).to(dev))
+    plan = rspmm.Plan(data.edge_index, data.edge_type, N, R)
+    for _ in range(4):
+        agg = plan.forward(rel, x, point=point)
+    for _ in range(4):
+        dense.conv_update(layer, x, agg, True)
+    # relation graph: the whole layer in one launch
+    rg = data.relation_graph
+    xr = torch.randn(bs, rg.num_nodes, 64, generator=g).to(dev)
+    relr = torch.randn(1, 4, 64, generator=g).to(dev).expand(bs, -1, -1)
+    plan_r = rspmm.Plan(rg.edge_index, rg.edge_type, rg.num_nodes, 4)
+    pr = (torch.arange(bs, device=dev), torch.ones(bs, 64, device=dev))
+    for _ in range(4):
+        out = plan_r.fused_layer(relr, xr, layer.linear, layer.layer_norm, residual=True, point=pr)
+    torch.cuda.synchronize()
+    print("ok", float(agg.abs().mean()), float(out.abs().mean()))

@@ -3,16 +3,18 @@ import collections
 import csv
 import sys
 
+NAMES = (("rspmm_fwd_kernel", "entity rspmm"), ("conv_update_kernel", "entity update"), ("dense_layer_kernel", "relation layer"),
+         ("rspmm_fixup_kernel", "fix-up"))
 out = []
 for path in sys.argv[1:]:
     agg = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"]
-        if "rspmm_fwd" not in k:
+        label = next((lab for key, lab in NAMES if key in r["Kernel_Name"]), None)
+        if label is None:
             continue
-        key = ("entity(REL_LDS)" if ", 0, 0, 1>" in k else "relation(ALL_LDS)", r["Counter_Name"])
-        agg.setdefault(key, []).append(float(r["Counter_Value"]))
+        agg.setdefault((label, r["Counter_Name"]), []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     for (g, c), v in agg.items():
+        v = [x for _, x in sorted(v)]
         v = v[1:] or v            # drop the warm-up launch
-        out.append("%-18s %-24s %16.0f   (mean of %d launches)" % (g, c, sum(v) / len(v), len(v)))
+        out.append("%-15s %-26s %16.0f   (mean of %d launches)" % (g, c, sum(v) / len(v), len(v)))
 print("\n".join(out))
