@@ -264,3 +264,29 @@ def test_closed_form_boundary_path_matches_materialised_boundary(dev, ckpt, aggr
         layers.POINT_BOUNDARY_FAST_PATH = True
     tol = 2e-5 if aggr == "sum" else 2e-5
     assert (a_t - b_t).abs().max().item() <= tol and (a_h - b_h).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("bs", [1, 2, 5])
+def test_every_combination_of_fast_path_switches_scores_the_same(dev, bs):
+    """The four inference fast paths are independent: all 16 on/off combinations give the same scores as the generic
+    path.  (Regression: with the prologue and the closed-form boundary both off, the strided head / relation index
+    views reached a kernel through contiguous temporaries that were freed inside the argument list.)"""
+    import itertools
+    from ultra_amd import layers, models
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    data = synthetic.make_kg(num_node=1500, num_triple=20000, num_relation_base=6, num_test=16, seed=16).to(dev)
+    model = build(state, cfg, dev)
+    t_batch, h_batch = tasks.all_negative(data, data.target_triples[3:3 + bs])
+    outs = {}
+    try:
+        for combo in itertools.product([True, False], repeat=4):
+            layers.ONEHOT_FAST_PATH, layers.POINT_BOUNDARY_FAST_PATH, layers.FUSED_DENSE_LAYER, models.PROLOGUE_FAST_PATH = combo
+            with torch.no_grad():
+                outs[combo] = torch.cat([model(data, t_batch), model(data, h_batch)]).clone()
+    finally:
+        layers.ONEHOT_FAST_PATH = layers.POINT_BOUNDARY_FAST_PATH = layers.FUSED_DENSE_LAYER = True
+        models.PROLOGUE_FAST_PATH = True
+    base = outs[(False, False, False, False)]
+    for combo, out in outs.items():
+        err = (out - base).abs().max().item()
+        assert err <= 3e-5, "switches %s: max |d| = %g" % (combo, err)

@@ -119,8 +119,9 @@ def onehot_boundary(index, values, num_node, dim):
     batch = index.shape[0]
     out = torch.empty(batch, num_node, dim, dtype=torch.float32, device=index.device)
     index = index.to(torch.int64).contiguous()
-    vptr = values.contiguous().data_ptr() if values is not None else None
-    check(lib.ultra_onehot_rows(out.data_ptr(), index.data_ptr(), vptr, batch, num_node, dim, _stream()))
+    values = values.contiguous() if values is not None else None     # (kept referenced until the launch is enqueued)
+    check(lib.ultra_onehot_rows(out.data_ptr(), index.data_ptr(), values.data_ptr() if values is not None else None, batch,
+                                num_node, dim, _stream()))
     return out
 
 
@@ -139,8 +140,12 @@ def query_boundary(h_index, relation_representations, r_index, num_node, readout
         if tuple(lin.weight.shape) == (2 * dim, 2 * dim) and lin.bias is not None and lin.weight.is_contiguous():
             qbias = torch.empty(bs, 2 * dim, dtype=torch.float32, device=table.device)
             w1, b1 = lin.weight.data_ptr(), lin.bias.data_ptr()
-    check(lib.ultra_query_boundary(boundary.data_ptr() if materialize else None, query.data_ptr(), h_index.to(torch.int64).contiguous().data_ptr(),
-                                   table.data_ptr(), r_index.to(torch.int64).contiguous().data_ptr(), bs, num_node, num_rel,
+    # contiguous copies of strided index views (h_index[:, 0] on the generic path) must stay referenced until the launch
+    # is enqueued: a temporary freed inside the argument list hands its memory to the next temporary
+    rows = h_index.to(torch.int64).contiguous()
+    pick = r_index.to(torch.int64).contiguous()
+    check(lib.ultra_query_boundary(boundary.data_ptr() if materialize else None, query.data_ptr(), rows.data_ptr(),
+                                   table.data_ptr(), pick.data_ptr(), bs, num_node, num_rel,
                                    dim, w1, b1, qbias.data_ptr() if qbias is not None else None, _stream()))
     return boundary, query, qbias
 

@@ -334,7 +334,8 @@ class Plan(object):
         elif boundary is not None:
             boundary, mbv = as_mat(boundary)
             mb = ctypes.byref(mbv)
-        w = edge_weight.contiguous().data_ptr() if edge_weight is not None else None
+        edge_weight = edge_weight.contiguous() if edge_weight is not None else None
+        w = edge_weight.data_ptr() if edge_weight is not None else None
         ms, ms_kernel = ctypes.c_float(), ctypes.c_float()
         check(lib.ultra_rspmm_forward_timed(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
                                             ctypes.byref(mx), mb, rows_ptr, ctypes.byref(mout), _stream(), warmup, iters,

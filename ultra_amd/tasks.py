@@ -160,10 +160,11 @@ def filtered_ranking(data, batch, pred, mode="tail"):
         raise RuntimeError("ultra_amd.tasks.filtered_ranking: expected a GPU tensor; the MI355X engine has no CPU path")
     pos = (batch[:, 1] if mode == "tail" else batch[:, 0]).contiguous()
     ptr, index = known_answers(data, batch, mode)
+    ptr, index = ptr.contiguous(), index.contiguous()      # (referenced until the launch is enqueued)
     pred = pred.float().contiguous()
     rank = torch.empty(len(batch), dtype=torch.long, device=pred.device)
     num_neg = torch.empty_like(rank)
-    check(lib.ultra_filtered_rank(pred.data_ptr(), pos.data_ptr(), ptr.contiguous().data_ptr(), index.contiguous().data_ptr(),
+    check(lib.ultra_filtered_rank(pred.data_ptr(), pos.data_ptr(), ptr.data_ptr(), index.data_ptr(),
                                   pred.shape[0], pred.shape[1], rank.data_ptr(), num_neg.data_ptr(),
                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return rank, num_neg
