@@ -290,3 +290,28 @@ def test_every_combination_of_fast_path_switches_scores_the_same(dev, bs):
     for combo, out in outs.items():
         err = (out - base).abs().max().item()
         assert err <= 3e-5, "switches %s: max |d| = %g" % (combo, err)
+
+
+@pytest.mark.parametrize("dim,layers_n,layer_norm,short_cut,message", [(32, 3, True, True, "distmult"), (64, 2, False, False, "distmult"),
+                                                                     (48, 2, True, False, "transe"), (128, 2, True, True, "distmult")])
+def test_shapes_outside_the_fused_kernels_match_the_oracle(dev, dim, layers_n, layer_norm, short_cut, message):
+    """Hidden sizes other than the checkpoints' 64 (and LayerNorm / short-cut variants) take the generic rspmm kernels with
+    the torch update / readout chain; randomly initialised weights, scores against the CPU oracle model."""
+    torch.manual_seed(dim + layers_n)
+    def one(cls):
+        return {"class": cls, "input_dim": dim, "hidden_dims": [dim] * layers_n, "message_func": message,
+                "aggregate_func": "sum", "short_cut": short_cut, "layer_norm": layer_norm}
+    cfg = {"rel_model_cfg": one("RelNBFNet"), "entity_model_cfg": one("EntityNBFNet")}
+    model = models.Ultra(rel_model_cfg=dict(cfg["rel_model_cfg"]), entity_model_cfg=dict(cfg["entity_model_cfg"])).eval()
+    data_cpu = synthetic.make_kg(num_node=400, num_triple=5000, num_relation_base=5, num_test=8, seed=dim)
+    t_batch, h_batch = tasks.all_negative(data_cpu, data_cpu.target_triples[:3])
+    want_t = ultra_oracle_model.ultra_forward(model.state_dict(), cfg, data_cpu, t_batch)
+    want_h = ultra_oracle_model.ultra_forward(model.state_dict(), cfg, data_cpu, h_batch)
+    data = data_cpu.to(dev)
+    model = model.to(dev)
+    with torch.no_grad():
+        got_t = model(data, t_batch.to(dev)).cpu()
+        got_h = model(data, h_batch.to(dev)).cpu()
+    scale = max(1.0, want_t.abs().max().item(), want_h.abs().max().item())
+    assert (got_t - want_t).abs().max().item() <= 1e-4 * scale
+    assert (got_h - want_h).abs().max().item() <= 1e-4 * scale
