@@ -315,3 +315,26 @@ def test_shapes_outside_the_fused_kernels_match_the_oracle(dev, dim, layers_n, l
     scale = max(1.0, want_t.abs().max().item(), want_h.abs().max().item())
     assert (got_t - want_t).abs().max().item() <= 1e-4 * scale
     assert (got_h - want_h).abs().max().item() <= 1e-4 * scale
+
+
+def test_mixed_tail_and_head_rows_in_one_batch(dev):
+    """base_nbfnet.py:79-86 converts head-prediction rows per ROW: one batch may hold both kinds (training batches do).
+    Scores of a mixed batch == scores of the same rows scored in pure batches, on the fast and on the generic path."""
+    from ultra_amd import layers
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    data = synthetic.make_kg(num_node=900, num_triple=9000, num_relation_base=5, num_test=16, seed=21).to(dev)
+    model = build(state, cfg, dev)
+    t_batch, h_batch = tasks.all_negative(data, data.target_triples[:6])
+    mixed = torch.cat([t_batch[:2], h_batch[2:4], t_batch[4:5], h_batch[5:6]])
+    with torch.no_grad():
+        want = torch.cat([model(data, t_batch)[:2], model(data, h_batch)[2:4], model(data, t_batch)[4:5], model(data, h_batch)[5:6]])
+        got = model(data, mixed)
+        try:
+            models.PROLOGUE_FAST_PATH = False
+            layers.POINT_BOUNDARY_FAST_PATH = False
+            generic = model(data, mixed)
+        finally:
+            models.PROLOGUE_FAST_PATH = True
+            layers.POINT_BOUNDARY_FAST_PATH = True
+    assert (got - want).abs().max().item() <= 2e-5
+    assert (generic - want).abs().max().item() <= 2e-5
