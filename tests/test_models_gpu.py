@@ -338,3 +338,23 @@ def test_mixed_tail_and_head_rows_in_one_batch(dev):
             layers.POINT_BOUNDARY_FAST_PATH = True
     assert (got - want).abs().max().item() <= 2e-5
     assert (generic - want).abs().max().item() <= 2e-5
+
+
+def test_sparse_relation_graph_takes_the_edge_walk(dev):
+    """Many relations, few triples: the relation graph is far from complete, gets no dense-format plan and runs through the
+    edge-walk kernels (point boundary, layer-0 kernels); scores against the CPU oracle model."""
+    from ultra_amd import rspmm
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    data_cpu = synthetic.make_kg(num_node=500, num_triple=1500, num_relation_base=150, num_test=8, seed=23)
+    rg = data_cpu.relation_graph
+    fill = rg.num_edges / float(rg.num_nodes ** 2 * 4)
+    assert fill < 0.25, fill
+    t_batch, h_batch = tasks.all_negative(data_cpu, data_cpu.target_triples[:4])
+    want_t = ultra_oracle_model.ultra_forward(state, cfg, data_cpu, t_batch)
+    want_h = ultra_oracle_model.ultra_forward(state, cfg, data_cpu, h_batch)
+    data = data_cpu.to(dev)
+    model = build(state, cfg, dev)
+    with torch.no_grad():
+        got_t, got_h = model(data, t_batch.to(dev)).cpu(), model(data, h_batch.to(dev)).cpu()
+    assert rspmm.get_plan(data.relation_graph.edge_index, data.relation_graph.edge_type, rg.num_nodes, 4).dense is None
+    assert (got_t - want_t).abs().max().item() <= 1e-4 and (got_h - want_h).abs().max().item() <= 1e-4
