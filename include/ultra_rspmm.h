@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_ABI_VERSION 2
+#define ULTRA_ABI_VERSION 3
 
 typedef enum {
     ULTRA_OK = 0,
@@ -66,13 +66,18 @@ typedef struct {
 
 /* Plan build options; zero-initialise for defaults. */
 typedef struct {
-    int32_t seg_len;   /* rows with more edges are split into segments of this many edges (0 -> 256) */
+    int32_t seg_len;   /* rows with more edges are split into segments of this many edges (0 -> 256);
+                          ULTRA_PLAN_EXACT_ORDER: rows with more edges become chain rows (never split) */
     int32_t g_max;     /* rows with <= g_max edges are walked by one 16-lane group, longer ones by a whole wave (0 -> 64) */
     int32_t flags;     /* ULTRA_PLAN_* */
     int32_t reserved;
 } ultra_plan_opts;
 
-#define ULTRA_PLAN_EXACT_ORDER 1   /* no splitting, every row walked sequentially in (row, col) order: bit-reproduces the oracle's summation order */
+#define ULTRA_PLAN_EXACT_ORDER 1   /* the reference's summation order (rspmm.cpp:61-72): every row is summed sequentially in sorted
+                                      (row, col, edge id) order -- by one 16-lane group, or for rows longer than seg_len by a
+                                      workgroup-wide producer / consumer chain -- so sums equal the reference's bit for bit.
+                                      No partial slots, no fix-up launch, no scratch: such a plan is immutable after upload and
+                                      may be shared by concurrent streams. */
 #define ULTRA_PLAN_TYPE_RUNS 2     /* edges sorted by (row, type, col) and cut at type changes: every item holds ONE relation, so
                                       add_mul sums the sources first and multiplies by rel[type] once per item.  Pays off when runs are
                                       long (dense graphs with few relation types, e.g. ULTRA's relation graph); add_mul only. */
@@ -95,6 +100,7 @@ typedef struct {
     int32_t has_transpose;
     int64_t n_type_run;   /* number of distinct (row, type) pairs: num_edge / n_type_run = mean run length */
     int64_t dense_bytes;  /* ULTRA_PLAN_DENSE: size of the fragment-ordered adjacency, else 0 */
+    int64_t n_chain_row;  /* ULTRA_PLAN_EXACT_ORDER: rows longer than seg_len, walked by a whole workgroup (items[0, n_chain_row)) */
 } ultra_plan_info;
 
 int32_t ultra_abi_version(void);

@@ -1,0 +1,181 @@
+"""Reference-order plans (ULTRA_PLAN_EXACT_ORDER) on the order kernels (csrc/rspmm_order_kernels.hpp): every
+aggregate -- sums included -- must equal the oracle's sequential loop (rspmm.cpp:50-75) BIT FOR BIT, for group
+items and for chain rows (whole-workgroup walk through the LDS ring) alike."""
+import itertools
+
+import pytest
+import torch
+
+from oracle import rspmm_oracle
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+SUMS = ["add", "min", "max"]
+MULS = ["mul", "add"]
+CASES = [
+    dict(num_node=50, num_edge=400, num_relation=5, seed=0),
+    dict(num_node=64, num_edge=300, num_relation=3, seed=1, hub=(7, 700)),          # one chain row at the default threshold
+    dict(num_node=40, num_edge=100, num_relation=4, seed=2, empty_rows=10),
+    dict(num_node=30, num_edge=200, num_relation=1, seed=3, duplicates=50),
+    dict(num_node=5, num_edge=0, num_relation=2, seed=4),
+    dict(num_node=1, num_edge=17, num_relation=2, seed=5),
+    dict(num_node=700, num_edge=9000, num_relation=800, seed=6, hub=(3, 1500)),     # relation slice does not fit LDS
+    dict(num_node=100, num_edge=20000, num_relation=4, seed=7),                    # dense: rows of ~200 edges
+    dict(num_node=300, num_edge=2000, num_relation=9, seed=8, hub=(11, 4321)),      # 73 chunks, partial last chunk
+]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _reset():
+    from ultra_amd import rspmm
+    rspmm.set_tuning()
+    rspmm.set_plan_defaults()
+    yield
+    rspmm.set_tuning()
+    rspmm.set_plan_defaults()
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("sum,mul", list(itertools.product(SUMS, MULS)))
+@pytest.mark.parametrize("dtype,dim", [(torch.float32, 64), (torch.float32, 192), (torch.float64, 128)])
+def test_bit_exact_against_oracle(dev, case, sum, mul, dtype, dim):
+    from ultra_amd.rspmm import Plan
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    rel, x, w = helpers.features(N, R, dim, E, dtype=dtype, seed=case["seed"])
+    plan = Plan(ei, et, N, R, exact_order=True)
+    want = rspmm_oracle.generalized_rspmm(ei, et, w, rel, x, sum=sum, mul=mul)
+    got = plan.forward(rel.to(dev), x.to(dev), edge_weight=w.to(dev), sum=sum, mul=mul).cpu()
+    assert torch.equal(got, want), "max |d| = %g" % (got - want).abs().max().item()
+    ones = torch.ones(E, dtype=dtype)
+    want1 = rspmm_oracle.generalized_rspmm(ei, et, ones, rel, x, sum=sum, mul=mul)
+    got1 = plan.forward(rel.to(dev), x.to(dev), edge_weight=None, sum=sum, mul=mul).cpu()
+    assert torch.equal(got1, want1)
+
+
+@pytest.mark.parametrize("case", [CASES[1], CASES[7], CASES[8]])
+@pytest.mark.parametrize("chain_min", [4, 59, 60, 61, 1000000])
+def test_chain_threshold_does_not_change_a_bit(dev, case, chain_min):
+    """Whether a row is walked by one lane group or by the workgroup's chain pipeline is a scheduling decision."""
+    from ultra_amd.rspmm import Plan
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    rel, x, w = helpers.features(N, R, 128, E, seed=case["seed"])
+    want = rspmm_oracle.generalized_rspmm(ei, et, w, rel, x, sum="add", mul="mul")
+    plan = Plan(ei, et, N, R, exact_order=True, seg_len=chain_min)
+    info = plan.info()
+    got = plan.forward(rel.to(dev), x.to(dev), edge_weight=w.to(dev)).cpu()
+    assert torch.equal(got, want), info
+    deg = torch.bincount(ei[0], minlength=N)
+    assert info["n_chain_row"] == int((deg > chain_min).sum())
+
+
+@pytest.mark.parametrize("sum", SUMS)
+@pytest.mark.parametrize("layout", ["node_major", "batch_major", "shared_relation"])
+@pytest.mark.parametrize("boundary", ["none", "tensor", "point"])
+def test_layouts_and_boundaries(dev, sum, layout, boundary):
+    from ultra_amd.rspmm import Plan
+    if boundary == "point" and sum != "add":
+        pytest.skip("a point boundary serves the sum aggregate only")
+    case = CASES[8]
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    bs, d = 3, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(bs, N, d, generator=g)
+    rel = torch.randn(1 if layout == "shared_relation" else bs, R, d, generator=g).expand(bs, -1, -1)
+    bnd = torch.randn(bs, N, d, generator=g)
+    rows = torch.tensor([11, 0, N - 1])
+    vals = torch.randn(bs, d, generator=g)
+    if boundary == "point":
+        bnd = torch.zeros(bs, N, d)
+        bnd[torch.arange(bs), rows] = vals
+    ones = torch.ones(E)
+    # the reference's data flow: node-major (N, batch * d), boundary combined after the aggregate (layers.py:190-207)
+    xn, reln, bndn = (t.transpose(0, 1).flatten(1).contiguous() for t in (x, rel, bnd))
+    want = rspmm_oracle.generalized_rspmm(ei, et, ones, reln, xn, sum=sum, mul="mul")
+    if boundary != "none":
+        want = want + bndn if sum == "add" else (torch.max(want, bndn) if sum == "max" else torch.min(want, bndn))
+    plan = Plan(ei, et, N, R, exact_order=True)
+    kw = {}
+    if boundary == "tensor":
+        kw["boundary"] = bndn.to(dev) if layout == "node_major" else bnd.to(dev)
+    if layout == "node_major":
+        if boundary == "point":
+            pytest.skip("point boundaries ride on the batch-major layout")
+        got = plan.forward(reln.to(dev), xn.to(dev), sum=sum, **kw).cpu()
+    else:
+        if boundary == "point":
+            kw["point"] = (rows.to(dev), vals.to(dev))
+        rel_dev = rel[:1].to(dev).expand(bs, -1, -1) if layout == "shared_relation" else rel.contiguous().to(dev)
+        got = plan.forward(rel_dev, x.to(dev), sum=sum, **kw).cpu().transpose(0, 1).flatten(1)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("grid", [1, 3, 8, 77, 256, 1000])
+def test_any_grid_same_bits(dev, grid):
+    """Schedules are built per workgroups-per-span; more spans than workgroups loop inside the workgroup."""
+    from ultra_amd import rspmm
+    case = CASES[8]
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    rel, x, w = helpers.features(N, R, 64 * 5, E, seed=1)      # 5 spans
+    want = rspmm_oracle.generalized_rspmm(ei, et, w, rel, x)
+    plan = rspmm.Plan(ei, et, N, R, exact_order=True)
+    rspmm.set_tuning(grid=grid)
+    got = plan.forward(rel.to(dev), x.to(dev), edge_weight=w.to(dev)).cpu()
+    assert torch.equal(got, want)
+    rspmm.set_tuning(grid=grid, rel_lds=0)
+    got = plan.forward(rel.to(dev), x.to(dev), edge_weight=w.to(dev)).cpu()
+    assert torch.equal(got, want)
+
+
+def test_two_streams_share_one_plan(dev):
+    """The plan is immutable after upload (no partial slots, no weight scratch): concurrent launches on two streams
+    with different operands do not disturb one another."""
+    from ultra_amd.rspmm import Plan
+    case = CASES[8]
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    plan = Plan(ei, et, N, R, exact_order=True)
+    ops = []
+    for seed in (1, 2):
+        rel, x, w = helpers.features(N, R, 256, E, seed=seed)
+        ops.append((rel, x, w, rspmm_oracle.generalized_rspmm(ei, et, w, rel, x)))
+    dev_ops = [(r.to(dev), x.to(dev), w.to(dev)) for r, x, w, _ in ops]
+    plan.forward(dev_ops[0][0], dev_ops[0][1], edge_weight=dev_ops[0][2])      # upload + schedule
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for it in range(20):
+        for k, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                outs[k].append(plan.forward(dev_ops[k][0], dev_ops[k][1], edge_weight=dev_ops[k][2]))
+    torch.cuda.synchronize()
+    for k in range(2):
+        for o in outs[k]:
+            assert torch.equal(o.cpu(), ops[k][3])
+
+
+def test_headline_shape_bit_exact(dev):
+    """FB15k237-shaped entity graph, batch 8 (the benchmark's rspmm call): 97 chain rows up to 9,067 edges."""
+    from ultra_amd import synthetic
+    from ultra_amd.rspmm import Plan
+    data = synthetic.make_kg(**synthetic.SHAPES["fb15k237"], seed=1234, relation_graph=False)
+    N, R, E = data.num_nodes, data.num_relations, data.num_edges
+    g = torch.Generator().manual_seed(0)
+    bs = 8
+    x = torch.randn(bs, N, 64, generator=g)
+    rel = torch.randn(bs, R, 64, generator=g)
+    want = rspmm_oracle.generalized_rspmm(data.edge_index, data.edge_type, torch.ones(E), rel.transpose(0, 1).flatten(1),
+                                          x.transpose(0, 1).flatten(1))
+    plan = Plan(data.edge_index, data.edge_type, N, R, exact_order=True)
+    got = plan.forward(rel.to(dev), x.to(dev)).cpu().transpose(0, 1).flatten(1)
+    assert torch.equal(got, want)

@@ -48,7 +48,7 @@ class PlanInfo(ctypes.Structure):
                 ("n_unit", ctypes.c_int64), ("n_split_row", ctypes.c_int64), ("n_partial_slot", ctypes.c_int64),
                 ("seg_len", ctypes.c_int32), ("g_max", ctypes.c_int32), ("flags", ctypes.c_int32),
                 ("packed", ctypes.c_int32), ("on_device", ctypes.c_int32), ("has_transpose", ctypes.c_int32),
-                ("n_type_run", ctypes.c_int64), ("dense_bytes", ctypes.c_int64)]
+                ("n_type_run", ctypes.c_int64), ("dense_bytes", ctypes.c_int64), ("n_chain_row", ctypes.c_int64)]
 
 
 class Tuning(ctypes.Structure):
@@ -101,7 +101,7 @@ def _load():
 
 
 lib = _load()
-if lib.ultra_abi_version() != 2:
+if lib.ultra_abi_version() != 3:
     raise ImportError("ultra_amd: libultra_amd.so ABI version mismatch")
 
 

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstring>
 #include <numeric>
+#include <queue>
 
 namespace ultra {
 
@@ -44,6 +45,7 @@ ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *ty
     const bool exact = (p->flags & ULTRA_PLAN_EXACT_ORDER) != 0;
     const bool type_runs = !exact && (p->flags & ULTRA_PLAN_TYPE_RUNS) != 0;
     if (p->g_max > p->seg_len) p->g_max = p->seg_len;
+    if (exact) p->chain_min = p->seg_len;   // rows longer than this are walked by a whole workgroup (plan.hpp)
 
     if (p->flags & ULTRA_PLAN_DENSE) {
         // dense format: only the multiplicity matrices, as bytes, laid out the way the MFMA A-operand is consumed
@@ -122,8 +124,16 @@ ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *ty
         p->n_type_run = runs;
     }
 
+    if (exact) {
+        p->rec.resize((size_t)E * 2);
+        for (int64_t k = 0; k < E; ++k) {
+            p->rec[(size_t)2 * k] = p->col[(size_t)k];
+            p->rec[(size_t)2 * k + 1] = p->type[(size_t)k];
+        }
+    }
+
     // ---- items ----
-    std::vector<Item> witems, gitems;
+    std::vector<Item> witems, gitems, chain;
     int32_t next_slot = 0;
     p->split_ptr.push_back(0);
     for (int64_t r = 0; r < num_out; ++r) {
@@ -154,9 +164,13 @@ ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *ty
             for (auto &it : mine) (it.len <= p->g_max ? gitems : witems).push_back(it);
             continue;
         }
-        if (exact || deg <= p->seg_len) {
+        if (exact) {
+            // one item per row, never split: the walk order is the sorted edge order.  Long rows are chain rows.
             Item it{(int32_t)r, b, deg, -1};
-            if (exact || deg <= p->g_max)
+            (deg > p->chain_min ? chain : gitems).push_back(it);
+        } else if (deg <= p->seg_len) {
+            Item it{(int32_t)r, b, deg, -1};
+            if (deg <= p->g_max)
                 gitems.push_back(it);
             else
                 witems.push_back(it);
@@ -182,10 +196,14 @@ ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *ty
     auto by_len_desc = [](const Item &a, const Item &b) { return a.len > b.len; };
     std::stable_sort(witems.begin(), witems.end(), by_len_desc);
     std::stable_sort(gitems.begin(), gitems.end(), by_len_desc);
+    std::stable_sort(chain.begin(), chain.end(), by_len_desc);
+    // (kernels without the chain walk see the chain rows as ordinary -- very long -- group items at the head of the list)
+    p->n_chain = (int64_t)chain.size();
     p->n_w = (int64_t)witems.size();
-    p->n_g = (int64_t)gitems.size();
+    p->n_g = (int64_t)(chain.size() + gitems.size());
     p->n_unit = p->n_w + (p->n_g + 3) / 4;
-    p->items.reserve(witems.size() + gitems.size());
+    p->items.reserve(chain.size() + witems.size() + gitems.size());
+    p->items.insert(p->items.end(), chain.begin(), chain.end());
     p->items.insert(p->items.end(), witems.begin(), witems.end());
     p->items.insert(p->items.end(), gitems.begin(), gitems.end());
 
@@ -198,6 +216,68 @@ ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *ty
         p->h_type.assign(type, type + E);
     }
     return p;
+}
+
+// ---- schedule of a reference-order plan ----
+// Cost model in workgroup-cycles (calibrated on MI355X): a chain row costs its consumer wave one
+// dependent add per edge plus a ring hand-over per chunk; a group unit costs one wave (a sixteenth of the workgroup's
+// issue slots) one walk step per edge of its longest row.
+static const double COST_CHAIN_EDGE = 6.5, COST_CHAIN_CHUNK = 60.0, COST_CHAIN_ROW = 250.0;
+static const double COST_UNIT_STEP = 30.0, COST_UNIT = 60.0;
+
+Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
+    Schedule *s = new Schedule();
+    s->nparts = nparts;
+    const int64_t n_chain = p->n_chain, n_item = (int64_t)p->items.size();
+    const int64_t n_unit = (n_item - n_chain + 3) / 4;
+    struct Work {
+        double cost;
+        int32_t id;   // chain item index, or n_chain + unit id
+    };
+    std::vector<Work> work;
+    work.reserve((size_t)(n_chain + n_unit));
+    for (int64_t c = 0; c < n_chain; ++c) {
+        const int32_t len = p->items[(size_t)c].len;
+        const int32_t nchunk = (len + CHAIN_SLOTS - 1) / CHAIN_SLOTS;
+        work.push_back(Work{COST_CHAIN_ROW + COST_CHAIN_EDGE * len + COST_CHAIN_CHUNK * nchunk, (int32_t)c});
+    }
+    for (int64_t u = 0; u < n_unit; ++u) {
+        const int32_t steps = p->items[(size_t)(n_chain + 4 * u)].len;   // group items are sorted by descending length
+        work.push_back(Work{COST_UNIT + COST_UNIT_STEP * steps, (int32_t)(n_chain + u)});
+    }
+    std::stable_sort(work.begin(), work.end(), [](const Work &a, const Work &b) { return a.cost > b.cost; });
+    // longest processing time first onto the least loaded workgroup
+    typedef std::pair<double, int32_t> Load;
+    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+    for (int32_t q = 0; q < nparts; ++q) heap.push(Load(0.0, q));
+    std::vector<std::vector<int32_t>> part_chain((size_t)nparts), part_unit((size_t)nparts);
+    std::vector<double> load((size_t)nparts, 0.0);
+    for (const Work &w : work) {
+        Load l = heap.top();
+        heap.pop();
+        (w.id < n_chain ? part_chain : part_unit)[(size_t)l.second].push_back(w.id < n_chain ? w.id : w.id - (int32_t)n_chain);
+        l.first += w.cost;
+        load[(size_t)l.second] = l.first;
+        heap.push(l);
+    }
+    s->chunk_ptr.assign((size_t)nparts + 1, 0);
+    s->unit_ptr.assign((size_t)nparts + 1, 0);
+    for (int32_t q = 0; q < nparts; ++q) {
+        for (int32_t c : part_chain[(size_t)q]) {
+            const Item &it = p->items[(size_t)c];
+            for (int32_t pos = 0; pos < it.len; pos += CHAIN_SLOTS) {
+                const int32_t cnt = std::min<int32_t>(CHAIN_SLOTS, it.len - pos);
+                s->chunks.push_back(Chunk{it.row, it.begin + pos, cnt,
+                                          (pos == 0 ? CHUNK_FIRST : 0) | (pos + cnt == it.len ? CHUNK_LAST : 0)});
+            }
+        }
+        s->chunk_ptr[(size_t)q + 1] = (int32_t)s->chunks.size();
+        s->units.insert(s->units.end(), part_unit[(size_t)q].begin(), part_unit[(size_t)q].end());
+        s->unit_ptr[(size_t)q + 1] = (int32_t)s->units.size();
+        s->max_cost = std::max(s->max_cost, load[(size_t)q]);
+        s->mean_cost += load[(size_t)q] / nparts;
+    }
+    return s;
 }
 
 }  // namespace ultra
@@ -278,6 +358,7 @@ int32_t ultra_plan_get_info(const ultra_plan *p, ultra_plan_info *info) {
     info->has_transpose = (p->tplan && p->rplan) ? 1 : 0;
     info->n_type_run = p->n_type_run;
     info->dense_bytes = (int64_t)p->a_frag.size();
+    info->n_chain_row = p->n_chain;
     return ULTRA_OK;
 }
 

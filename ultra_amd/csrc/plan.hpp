@@ -15,6 +15,8 @@
 #pragma once
 
 #include <cstdint>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -26,8 +28,30 @@ struct Item {
     int32_t row, begin, len, slot;
 };
 
+// Reference-order plans (ULTRA_PLAN_EXACT_ORDER): rows with more than chain_min edges are "chain" rows.  A workgroup
+// walks one in chunks of CHAIN_SLOTS edges: fifteen producer waves (sixty 16-lane groups) compute one message each and
+// park it in an LDS ring, one consumer wave adds the parked messages in sorted edge order -- the reference's
+// sequential summation order (rspmm.cpp:61-72) without a 9,000-step walk by a single lane group.
+struct Chunk {
+    int32_t row, begin, count, flags;   // flags: CHUNK_FIRST / CHUNK_LAST chunk of its row
+};
+enum { CHUNK_FIRST = 1, CHUNK_LAST = 2 };
+constexpr int CHAIN_SLOTS = 60;          // producer groups of a 1024-thread workgroup (15 waves x 4)
+
+// Static work assignment of one launch geometry: `nparts` workgroups share the items of a span.  Built on first use
+// (longest-processing-time-first over a cost model of chain rows and group units), then kept on the device.
+struct Schedule {
+    int32_t nparts = 0;
+    std::vector<int32_t> chunk_ptr, unit_ptr, units;   // [nparts + 1], [nparts + 1], unit ids in launch order
+    std::vector<Chunk> chunks;
+    int32_t *d_chunk_ptr = nullptr, *d_unit_ptr = nullptr, *d_units = nullptr;
+    Chunk *d_chunks = nullptr;
+    double max_cost = 0.0, mean_cost = 0.0;             // cost model's load of the fullest / average workgroup
+};
+
 struct DevicePlan {
     int32_t *row_ptr = nullptr, *col = nullptr, *type = nullptr, *perm = nullptr, *erow = nullptr;
+    int32_t *rec = nullptr;      // (col, type) pairs per sorted edge: the record stream of the reference-order kernel
     uint32_t *packed = nullptr;
     Item *items = nullptr;
     int32_t *split_row = nullptr, *split_ptr = nullptr;
@@ -59,6 +83,13 @@ struct ultra_plan {
     std::vector<uint32_t> packed;
     std::vector<ultra::Item> items;
     int64_t n_w = 0, n_g = 0, n_unit = 0;
+    // ULTRA_PLAN_EXACT_ORDER: items[0, n_chain) are the chain rows (longest first), group items follow; `rec` interleaves
+    // (col, type); schedules are keyed by nparts
+    int64_t n_chain = 0;
+    int32_t chain_min = 256;
+    std::vector<int32_t> rec;
+    std::map<int32_t, ultra::Schedule *> schedules;
+    std::mutex sched_mu;
     std::vector<int32_t> split_row, split_ptr;
     int64_t n_slot = 0;
     int64_t n_type_run = 0;
@@ -94,5 +125,9 @@ namespace ultra {
 ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *type, int64_t num_edge,
                        int64_t num_out, int64_t num_in, int64_t num_rel, const ultra_plan_opts *opts,
                        bool keep_edges);
+
+// The schedule of a reference-order plan for `nparts` workgroups per span (host arrays only; cached in the plan by
+// the caller under sched_mu).
+Schedule *build_schedule(const ultra_plan *p, int32_t nparts);
 
 }  // namespace ultra

@@ -10,6 +10,7 @@
 #include "layer0_kernels.hpp"
 #include "rspmm_bwd_kernels.hpp"
 #include "rspmm_kernels.hpp"
+#include "rspmm_order_kernels.hpp"
 
 namespace ultra {
 
@@ -25,6 +26,15 @@ ULTRA_EXTERN_VARIANT(double, 4, 0)
 ULTRA_EXTERN_VARIANT(double, 1, 0)
 ULTRA_EXTERN_VARIANT(double, 4, 1)
 ULTRA_EXTERN_VARIANT(double, 4, 2)
+
+// explicit instantiations live in rspmm_order_*.hip
+#define ULTRA_EXTERN_ORDER_VARIANT(T_, L_) \
+    template <>                            \
+    hipError_t launch_order_variant<T_, L_>(int, int, const OrderParams &, int, size_t, hipStream_t);
+ULTRA_EXTERN_ORDER_VARIANT(float, true)
+ULTRA_EXTERN_ORDER_VARIANT(float, false)
+ULTRA_EXTERN_ORDER_VARIANT(double, true)
+ULTRA_EXTERN_ORDER_VARIANT(double, false)
 
 int launch_dense_forward(ultra_plan *p, int sum, int mul, int dtype, const void *w, const ultra_mat *rel, const ultra_mat *x,
                          const ultra_mat *bnd, const int64_t *bnd_rows, const ultra_mat *out,
@@ -82,6 +92,7 @@ static int upload_plan(ultra_plan *p) {
     if ((rc = upload_array(&p->d.erow, p->erow))) return rc;
     if ((rc = upload_array(&p->d.packed, p->packed))) return rc;
     if ((rc = upload_array(&p->d.items, p->items))) return rc;
+    if (!p->rec.empty() && (rc = upload_array(&p->d.rec, p->rec))) return rc;
     if ((rc = upload_array(&p->d.split_row, p->split_row))) return rc;
     if ((rc = upload_array(&p->d.split_ptr, p->split_ptr))) return rc;
     if (!p->self_loop.empty() && (rc = upload_array(&p->d.self_loop, p->self_loop))) return rc;
@@ -90,7 +101,42 @@ static int upload_plan(ultra_plan *p) {
     return ULTRA_OK;
 }
 
+static void free_schedules(ultra_plan *p) {
+    std::lock_guard<std::mutex> lock(p->sched_mu);
+    for (auto &kv : p->schedules) {
+        Schedule *s = kv.second;
+        if (s->d_chunk_ptr) (void)hipFree(s->d_chunk_ptr);
+        if (s->d_unit_ptr) (void)hipFree(s->d_unit_ptr);
+        if (s->d_units) (void)hipFree(s->d_units);
+        if (s->d_chunks) (void)hipFree(s->d_chunks);
+        delete s;
+    }
+    p->schedules.clear();
+}
+
+// The static work assignment of a reference-order plan for `nparts` workgroups per span: built and uploaded on first
+// use (warm-up calls do that before any hipGraph capture), then read-only.
+static int get_schedule(ultra_plan *p, int32_t nparts, Schedule **out) {
+    std::lock_guard<std::mutex> lock(p->sched_mu);
+    auto it = p->schedules.find(nparts);
+    if (it != p->schedules.end()) {
+        *out = it->second;
+        return ULTRA_OK;
+    }
+    Schedule *s = build_schedule(p, nparts);
+    int rc;
+    if ((rc = upload_array(&s->d_chunk_ptr, s->chunk_ptr)) || (rc = upload_array(&s->d_unit_ptr, s->unit_ptr)) ||
+        (rc = upload_array(&s->d_units, s->units)) || (rc = upload_array(&s->d_chunks, s->chunks))) {
+        delete s;
+        return rc;
+    }
+    p->schedules[nparts] = s;
+    *out = s;
+    return ULTRA_OK;
+}
+
 static void free_device(ultra_plan *p) {
+    free_schedules(p);
     if (!p->on_device) return;
     (void)hipFree(p->d.row_ptr);
     (void)hipFree(p->d.col);
@@ -99,6 +145,7 @@ static void free_device(ultra_plan *p) {
     (void)hipFree(p->d.erow);
     (void)hipFree(p->d.packed);
     (void)hipFree(p->d.items);
+    if (p->d.rec) (void)hipFree(p->d.rec);
     (void)hipFree(p->d.split_row);
     (void)hipFree(p->d.split_ptr);
     if (p->d.a_frag) (void)hipFree(p->d.a_frag);
@@ -242,6 +289,56 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
     }
     if (mul != BIN_LHS) fp.x_row_bytes = (uint32_t)(x->stride_row * (int64_t)esz);
     if (mul != BIN_RHS) fp.rel_row_bytes = (uint32_t)(rel->stride_row * (int64_t)esz);
+
+    // ---- reference-order plans: the order kernels (no scratch, no fix-up launch) ----
+    if ((p->flags & ULTRA_PLAN_EXACT_ORDER) && VEC == 4 && g_tuning.reserved[0] == 0 && p->num_in < (1 << 24) &&
+        p->num_rel < (1 << 24) && (mul == BIN_LHS || x->stride_row * (int64_t)esz < (1 << 24)) &&
+        (mul == BIN_RHS || rel->stride_row * (int64_t)esz < (1 << 24))) {
+        const size_t rel_bytes = (mul != BIN_RHS) ? (size_t)p->num_rel * 64 * esz : 0;
+        const size_t ring_bytes = p->n_chain > 0 ? (size_t)2 * CHAIN_SLOTS * 64 * esz : 0;
+        if (ring_bytes <= di.lds_optin) {
+            const bool rel_lds = g_tuning.rel_lds != 0 && rel_bytes > 0 && rel_bytes + ring_bytes <= di.lds_optin;
+            int grid = g_tuning.grid > 0 ? g_tuning.grid : di.cu;
+            if (grid < 1) grid = 1;
+            OrderParams op;
+            std::memset(&op, 0, sizeof(op));
+            op.smod = std::min<int32_t>(fp.n_span, grid);
+            op.nparts = grid / op.smod;
+            Schedule *sched = nullptr;
+            if ((rc = get_schedule(p, op.nparts, &sched))) return rc;
+            op.rec = p->d.rec;
+            op.perm = p->d.perm;
+            op.w = w;
+            op.items = reinterpret_cast<const int4 *>(p->d.items);
+            op.unit_ptr = sched->d_unit_ptr;
+            op.units = sched->d_units;
+            op.chunk_ptr = sched->d_chunk_ptr;
+            op.chunks = reinterpret_cast<const int4 *>(sched->d_chunks);
+            op.n_chain = (int32_t)p->n_chain;
+            op.n_item = (int32_t)p->items.size();
+            op.rel = fp.rel, op.x = fp.x, op.bnd = fp.bnd;
+            op.bnd_rows = fp.bnd_rows;
+            op.out = fp.out;
+            op.out_stride_outer = fp.out_stride_outer, op.out_stride_row = fp.out_stride_row;
+            op.n_outer = fp.n_outer, op.row_len = fp.row_len, op.spans_per_outer = fp.spans_per_outer, op.n_span = fp.n_span;
+            op.num_rel = fp.num_rel;
+            op.has_bnd = fp.has_bnd;
+            op.has_chain = p->n_chain > 0 ? 1 : 0;
+            op.x_row_bytes = fp.x_row_bytes, op.rel_row_bytes = fp.rel_row_bytes;
+            const size_t lds = (rel_lds ? rel_bytes : 0) + ring_bytes;
+            hipError_t e = hipErrorInvalidValue;
+            if (g_ev_before) HIP_TRY(hipEventRecord(g_ev_before, stream));
+            if (dtype == ULTRA_F32)
+                e = rel_lds ? launch_order_variant<float, true>(sum, mul, op, grid, lds, stream)
+                            : launch_order_variant<float, false>(sum, mul, op, grid, lds, stream);
+            else
+                e = rel_lds ? launch_order_variant<double, true>(sum, mul, op, grid, lds, stream)
+                            : launch_order_variant<double, false>(sum, mul, op, grid, lds, stream);
+            if (e != hipSuccess) return hip_fail(e, "rspmm_order_kernel launch");
+            if (g_ev_after) HIP_TRY(hipEventRecord(g_ev_after, stream));
+            return ULTRA_OK;
+        }
+    }
 
     // per-call edge weights -> sorted order
     if (w && p->num_edge > 0) {
