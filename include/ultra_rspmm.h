@@ -235,6 +235,28 @@ ULTRA_DECLARE_REFERENCE_ENTRY(add, add) /* rspmm.h:84-89  */
 ULTRA_DECLARE_REFERENCE_ENTRY(min, add) /* rspmm.h:91-96  */
 ULTRA_DECLARE_REFERENCE_ENTRY(max, add) /* rspmm.h:98-103 */
 
+/*
+ * Static schedule of a ULTRA_PLAN_EXACT_ORDER plan when `nparts` workgroups share a span (what a launch with
+ * n_span spans on a `grid`-workgroup device uses: nparts = grid / min(n_span, grid)): chain rows and group units are
+ * dealt longest-processing-time-first over a cycle cost model; max_cost / mean_cost is the modelled imbalance.
+ */
+typedef struct {
+    int32_t nparts, reserved;
+    int64_t n_chunk, n_unit;                 /* chain chunks (60 edges each) and group units (4 rows each) in total */
+    int64_t max_chunk_per_part, max_unit_per_part;
+    double max_cost, mean_cost;              /* modelled workgroup-cycles of the fullest / the average workgroup */
+} ultra_schedule_info;
+int32_t ultra_plan_schedule_info(ultra_plan *plan, int32_t nparts, ultra_schedule_info *info);
+/* The schedule's arrays (tests, tooling): which = 0 chunk_ptr [nparts + 1], 1 unit_ptr [nparts + 1], 2 unit ids (a unit =
+ * group items n_chain_row + 4 u .. + 3 of ULTRA_ARR_ITEM), 3 chunks as {row, begin, count, flags} quadruples (flags: 1 first,
+ * 2 last chunk of its row).  Workgroup q of a span walks chunks [chunk_ptr[q], chunk_ptr[q + 1]) then its units. */
+int32_t ultra_plan_schedule_export(ultra_plan *plan, int32_t nparts, int32_t which, int32_t *dst_host, int64_t capacity_elems,
+                                   int64_t *count);
+
+/* Measurement hook: while non-NULL (calling thread), the reference-order kernel stores three shader-clock samples per
+ * workgroup -- start, chain rows done, end -- at trace_dev[3 * workgroup + {0, 1, 2}] (int64, device memory). */
+int32_t ultra_order_trace(void *trace_dev);
+
 /* Tuning / measurement hooks. */
 typedef struct {
     int32_t threads;      /* workgroup size of the main kernel (0 -> default 1024) */
@@ -242,7 +264,7 @@ typedef struct {
     int32_t rel_lds;      /* -1 auto, 0 never stage the relation slice in LDS, 1 force when it fits */
     int32_t x_lds;        /* -1 auto, 0 never stage the input slice in LDS, 1 force when it fits */
     int32_t unroll;       /* edges in flight per lane group (0 -> default) */
-    int32_t reserved[3];
+    int32_t reserved[3];  /* [0] != 0: ULTRA_PLAN_EXACT_ORDER plans run on the general walk kernel instead of the order kernels */
 } ultra_tuning;
 int32_t ultra_set_tuning(const ultra_tuning *t);   /* NULL restores defaults */
 int32_t ultra_get_tuning(ultra_tuning *t);

@@ -51,6 +51,12 @@ class PlanInfo(ctypes.Structure):
                 ("n_type_run", ctypes.c_int64), ("dense_bytes", ctypes.c_int64), ("n_chain_row", ctypes.c_int64)]
 
 
+class ScheduleInfo(ctypes.Structure):
+    _fields_ = [("nparts", ctypes.c_int32), ("reserved", ctypes.c_int32), ("n_chunk", ctypes.c_int64),
+                ("n_unit", ctypes.c_int64), ("max_chunk_per_part", ctypes.c_int64), ("max_unit_per_part", ctypes.c_int64),
+                ("max_cost", ctypes.c_double), ("mean_cost", ctypes.c_double)]
+
+
 class Tuning(ctypes.Structure):
     _fields_ = [("threads", ctypes.c_int32), ("grid", ctypes.c_int32), ("rel_lds", ctypes.c_int32),
                 ("x_lds", ctypes.c_int32), ("unroll", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
@@ -89,6 +95,9 @@ def _load():
     lib.ultra_readout_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
     lib.ultra_query_boundary.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp]
     lib.ultra_relation_projection.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]
+    lib.ultra_plan_schedule_info.argtypes = [vp, i32, ctypes.POINTER(ScheduleInfo)]
+    lib.ultra_order_trace.argtypes = [vp]
+    lib.ultra_plan_schedule_export.argtypes = [vp, i32, i32, vp, i64, ctypes.POINTER(i64)]
     lib.ultra_set_tuning.argtypes = [ctypes.POINTER(Tuning)]
     lib.ultra_get_tuning.argtypes = [ctypes.POINTER(Tuning)]
     for s in ("add", "min", "max"):

@@ -3,6 +3,8 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <queue>
@@ -222,10 +224,20 @@ ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *ty
 // Cost model in workgroup-cycles (calibrated on MI355X): a chain row costs its consumer wave one
 // dependent add per edge plus a ring hand-over per chunk; a group unit costs one wave (a sixteenth of the workgroup's
 // issue slots) one walk step per edge of its longest row.
-static const double COST_CHAIN_EDGE = 6.5, COST_CHAIN_CHUNK = 60.0, COST_CHAIN_ROW = 250.0;
-static const double COST_UNIT_STEP = 30.0, COST_UNIT = 60.0;
+static double COST_CHAIN_EDGE = 9.0, COST_CHAIN_CHUNK = 250.0, COST_CHAIN_ROW = 2000.0;
+static double COST_UNIT_STEP = 28.0, COST_UNIT = 100.0;
+
+static void read_cost_override() {   // calibration runs only: ULTRA_SCHED_COSTS="edge,chunk,row,step,unit"
+    const char *env = std::getenv("ULTRA_SCHED_COSTS");
+    if (!env) return;
+    double v[5];
+    if (std::sscanf(env, "%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5) {
+        COST_CHAIN_EDGE = v[0], COST_CHAIN_CHUNK = v[1], COST_CHAIN_ROW = v[2], COST_UNIT_STEP = v[3], COST_UNIT = v[4];
+    }
+}
 
 Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
+    read_cost_override();
     Schedule *s = new Schedule();
     s->nparts = nparts;
     const int64_t n_chain = p->n_chain, n_item = (int64_t)p->items.size();

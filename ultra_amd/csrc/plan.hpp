@@ -37,6 +37,7 @@ struct Chunk {
 };
 enum { CHUNK_FIRST = 1, CHUNK_LAST = 2 };
 constexpr int CHAIN_SLOTS = 60;          // producer groups of a 1024-thread workgroup (15 waves x 4)
+constexpr int ORDER_PAD = 128;           // the device record / perm streams are readable this many entries past the last edge
 
 // Static work assignment of one launch geometry: `nparts` workgroups share the items of a span.  Built on first use
 // (longest-processing-time-first over a cost model of chain rows and group units), then kept on the device.

@@ -28,13 +28,17 @@ ULTRA_EXTERN_VARIANT(double, 4, 1)
 ULTRA_EXTERN_VARIANT(double, 4, 2)
 
 // explicit instantiations live in rspmm_order_*.hip
-#define ULTRA_EXTERN_ORDER_VARIANT(T_, L_) \
-    template <>                            \
-    hipError_t launch_order_variant<T_, L_>(int, int, const OrderParams &, int, size_t, hipStream_t);
-ULTRA_EXTERN_ORDER_VARIANT(float, true)
-ULTRA_EXTERN_ORDER_VARIANT(float, false)
-ULTRA_EXTERN_ORDER_VARIANT(double, true)
-ULTRA_EXTERN_ORDER_VARIANT(double, false)
+#define ULTRA_EXTERN_ORDER_VARIANT(T_, L_, W_) \
+    template <>                                \
+    hipError_t launch_order_variant<T_, L_, W_>(int, int, const OrderParams &, int, size_t, hipStream_t);
+ULTRA_EXTERN_ORDER_VARIANT(float, true, true)
+ULTRA_EXTERN_ORDER_VARIANT(float, true, false)
+ULTRA_EXTERN_ORDER_VARIANT(float, false, true)
+ULTRA_EXTERN_ORDER_VARIANT(float, false, false)
+ULTRA_EXTERN_ORDER_VARIANT(double, true, true)
+ULTRA_EXTERN_ORDER_VARIANT(double, true, false)
+ULTRA_EXTERN_ORDER_VARIANT(double, false, true)
+ULTRA_EXTERN_ORDER_VARIANT(double, false, false)
 
 int launch_dense_forward(ultra_plan *p, int sum, int mul, int dtype, const void *w, const ultra_mat *rel, const ultra_mat *x,
                          const ultra_mat *bnd, const int64_t *bnd_rows, const ultra_mat *out,
@@ -48,6 +52,8 @@ static ultra_tuning g_tuning = {0, 0, -1, -1, 0, {0, 0, 0}};
 
 // measurement hook: when set, forward_impl records these events right before / after the main kernel launch
 static thread_local hipEvent_t g_ev_before = nullptr, g_ev_after = nullptr;
+// measurement hook: per-workgroup clock trace of the order kernel (ultra_order_trace)
+static thread_local long long *g_order_trace = nullptr;
 
 static int hip_fail(hipError_t e, const char *what) {
     set_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -88,11 +94,19 @@ static int upload_plan(ultra_plan *p) {
     if ((rc = upload_array(&p->d.row_ptr, p->row_ptr))) return rc;
     if ((rc = upload_array(&p->d.col, p->col))) return rc;
     if ((rc = upload_array(&p->d.type, p->type))) return rc;
-    if ((rc = upload_array(&p->d.perm, p->perm))) return rc;
+    if (p->flags & ULTRA_PLAN_EXACT_ORDER) {
+        // the order kernels prefetch records unconditionally: both streams are padded with readable zeros
+        std::vector<int32_t> perm_pad(p->perm), rec_pad(p->rec);
+        perm_pad.resize(p->perm.size() + ORDER_PAD, 0);
+        rec_pad.resize(p->rec.size() + 2 * ORDER_PAD, 0);
+        if ((rc = upload_array(&p->d.perm, perm_pad))) return rc;
+        if ((rc = upload_array(&p->d.rec, rec_pad))) return rc;
+    } else if ((rc = upload_array(&p->d.perm, p->perm))) {
+        return rc;
+    }
     if ((rc = upload_array(&p->d.erow, p->erow))) return rc;
     if ((rc = upload_array(&p->d.packed, p->packed))) return rc;
     if ((rc = upload_array(&p->d.items, p->items))) return rc;
-    if (!p->rec.empty() && (rc = upload_array(&p->d.rec, p->rec))) return rc;
     if ((rc = upload_array(&p->d.split_row, p->split_row))) return rc;
     if ((rc = upload_array(&p->d.split_ptr, p->split_ptr))) return rc;
     if (!p->self_loop.empty() && (rc = upload_array(&p->d.self_loop, p->self_loop))) return rc;
@@ -325,15 +339,17 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
             op.has_bnd = fp.has_bnd;
             op.has_chain = p->n_chain > 0 ? 1 : 0;
             op.x_row_bytes = fp.x_row_bytes, op.rel_row_bytes = fp.rel_row_bytes;
+            op.trace = g_order_trace;
             const size_t lds = (rel_lds ? rel_bytes : 0) + ring_bytes;
             hipError_t e = hipErrorInvalidValue;
             if (g_ev_before) HIP_TRY(hipEventRecord(g_ev_before, stream));
-            if (dtype == ULTRA_F32)
-                e = rel_lds ? launch_order_variant<float, true>(sum, mul, op, grid, lds, stream)
-                            : launch_order_variant<float, false>(sum, mul, op, grid, lds, stream);
-            else
-                e = rel_lds ? launch_order_variant<double, true>(sum, mul, op, grid, lds, stream)
-                            : launch_order_variant<double, false>(sum, mul, op, grid, lds, stream);
+#define ULTRA_ORDER_LAUNCH(T_)                                                                          \
+    (rel_lds ? (w ? launch_order_variant<T_, true, true>(sum, mul, op, grid, lds, stream)                \
+                  : launch_order_variant<T_, true, false>(sum, mul, op, grid, lds, stream))              \
+             : (w ? launch_order_variant<T_, false, true>(sum, mul, op, grid, lds, stream)               \
+                  : launch_order_variant<T_, false, false>(sum, mul, op, grid, lds, stream)))
+            e = dtype == ULTRA_F32 ? ULTRA_ORDER_LAUNCH(float) : ULTRA_ORDER_LAUNCH(double);
+#undef ULTRA_ORDER_LAUNCH
             if (e != hipSuccess) return hip_fail(e, "rspmm_order_kernel launch");
             if (g_ev_after) HIP_TRY(hipEventRecord(g_ev_after, stream));
             return ULTRA_OK;
@@ -799,6 +815,54 @@ int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, in
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return ULTRA_OK;
+}
+
+int32_t ultra_order_trace(void *trace_dev) {
+    g_order_trace = static_cast<long long *>(trace_dev);
+    return ULTRA_OK;
+}
+
+int32_t ultra_plan_schedule_info(ultra_plan *plan, int32_t nparts, ultra_schedule_info *info) {
+    if (!plan || !info || nparts <= 0) return invalid("ultra_plan_schedule_info: bad argument");
+    if (!(plan->flags & ULTRA_PLAN_EXACT_ORDER)) return invalid("schedules belong to ULTRA_PLAN_EXACT_ORDER plans");
+    Schedule *s = build_schedule(plan, nparts);
+    info->nparts = nparts;
+    info->n_chunk = (int64_t)s->chunks.size();
+    info->n_unit = (int64_t)s->units.size();
+    info->max_cost = s->max_cost;
+    info->mean_cost = s->mean_cost;
+    int64_t mc = 0, mu = 0;
+    for (int32_t q = 0; q < nparts; ++q) {
+        mc = std::max<int64_t>(mc, s->chunk_ptr[(size_t)q + 1] - s->chunk_ptr[(size_t)q]);
+        mu = std::max<int64_t>(mu, s->unit_ptr[(size_t)q + 1] - s->unit_ptr[(size_t)q]);
+    }
+    info->max_chunk_per_part = mc;
+    info->max_unit_per_part = mu;
+    delete s;
+    return ULTRA_OK;
+}
+
+int32_t ultra_plan_schedule_export(ultra_plan *plan, int32_t nparts, int32_t which, int32_t *dst, int64_t capacity, int64_t *count) {
+    if (!plan || !count || nparts <= 0) return invalid("ultra_plan_schedule_export: bad argument");
+    if (!(plan->flags & ULTRA_PLAN_EXACT_ORDER)) return invalid("schedules belong to ULTRA_PLAN_EXACT_ORDER plans");
+    Schedule *s = build_schedule(plan, nparts);
+    const int32_t *src = nullptr;
+    int64_t n = 0;
+    switch (which) {
+        case 0: src = s->chunk_ptr.data(), n = (int64_t)s->chunk_ptr.size(); break;
+        case 1: src = s->unit_ptr.data(), n = (int64_t)s->unit_ptr.size(); break;
+        case 2: src = s->units.data(), n = (int64_t)s->units.size(); break;
+        case 3: src = reinterpret_cast<const int32_t *>(s->chunks.data()), n = (int64_t)s->chunks.size() * 4; break;
+        default: delete s; return invalid("ultra_plan_schedule_export: unknown array id");
+    }
+    *count = n;
+    int rc = ULTRA_OK;
+    if (dst) {
+        if (capacity < n) rc = invalid("ultra_plan_schedule_export: destination too small");
+        else if (n) std::memcpy(dst, src, (size_t)n * sizeof(int32_t));
+    }
+    delete s;
+    return rc;
 }
 
 int32_t ultra_set_tuning(const ultra_tuning *t) {

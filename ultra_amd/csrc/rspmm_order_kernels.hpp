@@ -48,6 +48,7 @@ struct OrderParams {
     int32_t num_rel, has_bnd, has_chain;
     int32_t smod, nparts;
     uint32_t x_row_bytes, rel_row_bytes;
+    long long *trace;         // measurement hook (NULL in production): per workgroup {start, chains done, end} shader clocks
 };
 
 // value of lane K of each 16-lane row, in every lane of that row (ds_swizzle bit mode: lane' = (lane & 0x10) | K within
@@ -70,6 +71,20 @@ __device__ __forceinline__ double bcast16(double v) {
 template <int J>
 using StepTag = std::integral_constant<int, J>;
 
+// Read-only schedule data addressed by a wave-uniform index: loaded through the constant address space so that it
+// comes in over the scalar cache (s_load) -- off the vector-memory counter, whose in-order bookkeeping would otherwise
+// make a descriptor prefetch drain the gathers queued behind it.
+template <typename U>
+__device__ __forceinline__ U load_uniform(const U *ptr) {
+    return *(const __attribute__((address_space(4))) U *)(ptr);
+}
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// Loads that sit behind a branch defeat the compiler's vmcnt bookkeeping at the join (it must assume the shorter
+// queue and drains everything), so the walks below issue every load unconditionally: the record streams are padded
+// (ORDER_PAD entries past the last edge are readable), lanes past the end of their row read the NEXT rows' records
+// -- valid node / relation ids -- and their products are discarded by the step predicate.
+
 // ---- group items: four rows per wave, each walked sequentially by one 16-lane group ----
 template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED>
 __device__ __forceinline__ Pack<T, 4> walk_row_in_order(const OrderParams &p, const int begin, const int cnt, const int nsteps,
@@ -80,22 +95,12 @@ __device__ __forceinline__ Pack<T, 4> walk_row_in_order(const OrderParams &p, co
     using V = typename VecOf<T, 4>::type;
     V acc = V(nary_zero<T, SUM>());
     const T *wt = reinterpret_cast<const T *>(p.w);
+    const int2 *recs = reinterpret_cast<const int2 *>(p.rec) + begin + l16;
+    const int32_t *perm = p.perm + begin + l16;
 
     struct Records {   // this lane holds the record of step (batch base + l16) of its group's row
         int c, t;
         T w;
-    };
-    const auto load_records = [&](Records &r, const int k0) {
-        r.c = 0;
-        r.t = 0;
-        r.w = T(1);
-        const int k = k0 + l16;
-        if (k0 < nsteps && k < cnt) {
-            const int2 ct = *reinterpret_cast<const int2 *>(p.rec + 2 * (size_t)(begin + k));
-            r.c = ct.x;
-            r.t = ct.y;
-            if (WEIGHTED) r.w = wt[p.perm[begin + k]];
-        }
     };
     struct Fetched {   // one chunk = 4 consecutive steps
         int t[4];
@@ -152,68 +157,92 @@ __device__ __forceinline__ Pack<T, 4> walk_row_in_order(const OrderParams &p, co
 
     if (nsteps > 0) {
         Records cur, nxt;
-        load_records(cur, 0);
-        load_records(nxt, 16);
+        int pm = 0;   // WEIGHTED: original edge id of the record two batches ahead (w[perm[.]] is a dependent load)
+        {
+            const int2 a = recs[0], b = recs[16];
+            cur.c = a.x, cur.t = a.y, nxt.c = b.x, nxt.t = b.y;
+            cur.w = nxt.w = T(1);
+            if (WEIGHTED) {
+                const int pa = perm[0], pb = perm[16];
+                pm = perm[32];
+                cur.w = wt[pa];
+                nxt.w = wt[pb];
+            }
+        }
         Fetched fa, fb;
         fetch(StepTag<0>{}, fa, cur);
-        for (int b0 = 0; b0 < nsteps; b0 += 16) {
-            // the loads of chunk i + 1 are issued before chunk i is reduced; the next batch's records were requested a
-            // whole batch (16 steps) ago
-            if (b0 + 4 < nsteps) fetch(StepTag<4>{}, fb, cur);
-            reduce(fa, b0);
-            if (b0 + 8 < nsteps) fetch(StepTag<8>{}, fa, cur);
-            if (b0 + 4 < nsteps) reduce(fb, b0 + 4);
-            if (b0 + 12 < nsteps) fetch(StepTag<12>{}, fb, cur);
-            if (b0 + 8 < nsteps) reduce(fa, b0 + 8);
+        // Steady state: the gathers of chunk i + 1 are issued before chunk i is reduced (8 source rows in flight per
+        // lane).  Two exits per 16-step batch, straight-line code between them; a walk that ends inside a half reduces
+        // the rest of it under the step predicate and leaves one chunk of speculative gathers behind.
+        for (int kb = 0;; kb += 16) {
+            fetch(StepTag<4>{}, fb, cur);
+            reduce(fa, kb);
+            fetch(StepTag<8>{}, fa, cur);
+            reduce(fb, kb + 4);
+            if (kb + 8 >= nsteps) break;
+            fetch(StepTag<12>{}, fb, cur);
+            reduce(fa, kb + 8);
             cur = nxt;
-            load_records(nxt, b0 + 32);
-            if (b0 + 16 < nsteps) fetch(StepTag<0>{}, fa, cur);
-            if (b0 + 12 < nsteps) reduce(fb, b0 + 12);
+            {
+                const int2 b = recs[kb + 32];       // requested a whole batch before its first use
+                nxt.c = b.x, nxt.t = b.y;
+                if (WEIGHTED) {
+                    nxt.w = wt[pm];
+                    pm = perm[kb + 48];
+                }
+            }
+            fetch(StepTag<0>{}, fa, cur);
+            reduce(fb, kb + 12);
+            if (kb + 16 >= nsteps) break;
         }
     }
     return to_pack<T, 4>(acc);
 }
 
-// ---- consumer side of a chain chunk: acc (+)= ring[0], ring[1], ... in slot order ----
-// The adds form one dependent chain per lane; the LDS reads are independent of it and are kept a block ahead.
-template <typename T, int SUM>
-__device__ __forceinline__ T consume_chunk(T acc, const T *ring_lane, const int count) {
-    constexpr int SPAN = 64;
-    constexpr int BLK = 15;
-    if (count == CHAIN_SLOTS) {
-        T a[BLK], b[BLK];
+// ---- consumer side of a chain chunk ----
+// The adds form one dependent chain per lane -- the serial part of the whole kernel; the LDS reads do not depend on it.
+// A full chunk is taken in two halves of CHAIN_HALF messages: the reads of a half are in flight while the previous
+// half is added, and the second half of chunk i is added behind barrier i + 1 (its values are in registers by then),
+// so the chain only ever waits for the barrier.
+constexpr int CHAIN_HALF = CHAIN_SLOTS / 2;
+
+template <typename T, int N>
+__device__ __forceinline__ void ring_read(T (&v)[N], const T *ring_lane) {
 #pragma unroll
-        for (int k = 0; k < BLK; ++k) a[k] = ring_lane[(0 * BLK + k) * SPAN];
+    for (int k = 0; k < N; ++k) v[k] = ring_lane[k * 64];
+}
+template <typename T, int SUM, int N>
+__device__ __forceinline__ T chain_add(T acc, const T (&v)[N]) {
 #pragma unroll
-        for (int k = 0; k < BLK; ++k) b[k] = ring_lane[(1 * BLK + k) * SPAN];
+    for (int k = 0; k < N; ++k) acc = nary<T, SUM>(acc, v[k]);
+    return acc;
+}
+// acc (+)= v[0..N) while the next half is requested: the reads issue in the shadow of the dependent adds
+template <typename T, int SUM, int N>
+__device__ __forceinline__ T chain_add_and_read(T acc, const T (&v)[N], T (&next)[N], const T *ring_lane) {
 #pragma unroll
-        for (int k = 0; k < BLK; ++k) acc = nary<T, SUM>(acc, a[k]);
-#pragma unroll
-        for (int k = 0; k < BLK; ++k) a[k] = ring_lane[(2 * BLK + k) * SPAN];
-#pragma unroll
-        for (int k = 0; k < BLK; ++k) acc = nary<T, SUM>(acc, b[k]);
-#pragma unroll
-        for (int k = 0; k < BLK; ++k) b[k] = ring_lane[(3 * BLK + k) * SPAN];
-#pragma unroll
-        for (int k = 0; k < BLK; ++k) acc = nary<T, SUM>(acc, a[k]);
-#pragma unroll
-        for (int k = 0; k < BLK; ++k) acc = nary<T, SUM>(acc, b[k]);
-        return acc;
+    for (int k = 0; k < N; ++k) {
+        next[k] = ring_lane[k * 64];
+        acc = nary<T, SUM>(acc, v[k]);
     }
+    return acc;
+}
+template <typename T, int SUM>
+__device__ __forceinline__ T consume_partial(T acc, const T *ring_lane, const int count) {
     int k = 0;
     for (; k + 4 <= count; k += 4) {
-        const T v0 = ring_lane[(k + 0) * SPAN], v1 = ring_lane[(k + 1) * SPAN], v2 = ring_lane[(k + 2) * SPAN],
-                v3 = ring_lane[(k + 3) * SPAN];
+        const T v0 = ring_lane[(k + 0) * 64], v1 = ring_lane[(k + 1) * 64], v2 = ring_lane[(k + 2) * 64],
+                v3 = ring_lane[(k + 3) * 64];
         acc = nary<T, SUM>(acc, v0);
         acc = nary<T, SUM>(acc, v1);
         acc = nary<T, SUM>(acc, v2);
         acc = nary<T, SUM>(acc, v3);
     }
-    for (; k < count; ++k) acc = nary<T, SUM>(acc, ring_lane[k * SPAN]);
+    for (; k < count; ++k) acc = nary<T, SUM>(acc, ring_lane[k * 64]);
     return acc;
 }
 
-template <typename T, int SUM, int MUL, bool REL_LDS>
+template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED>
 __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderParams p) {
     constexpr int SPAN = 64;
     using P = Pack<T, 4>;
@@ -232,6 +261,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
     if (part >= p.nparts) return;
     const T *wt = reinterpret_cast<const T *>(p.w);
 
+    if (p.trace && tid == 0) p.trace[3 * blockIdx.x + 0] = clock64();
     for (int span = blockIdx.x % p.smod; span < p.n_span; span += p.smod) {
         const int outer = span / p.spans_per_outer;
         const int inner = span - outer * p.spans_per_outer;
@@ -253,101 +283,178 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
         }
 
         // ================= chain rows of this workgroup =================
+        // Chunk i of the workgroup's chunk list is produced into ring half (i & 1) before barrier i and consumed after
+        // it; the consumer reaches barrier i + 1 only after it has drained chunk i, so a ring half is never overwritten
+        // early.  Producers and the consumer run separate loops with the same number of barriers.
         const int c0 = p.has_chain ? p.chunk_ptr[part] : 0, c1 = p.has_chain ? p.chunk_ptr[part + 1] : 0;
         if (c1 > c0) {
-            const bool consumer = wave == 0;   // wave-uniform
-            const int slot = (wave - 1) * 4 + grp;
-            // producer pipeline registers: x0 = source row of chunk `it` (in flight since iteration it - 1),
-            // r1 = record of chunk it + 1 (requested in iteration it - 1)
-            struct Rec {
-                int c, t;
-                T w;
-                bool valid;
-            };
-            const auto load_rec = [&](const int ci) {
-                Rec r;
-                r.c = 0, r.t = 0, r.w = T(1), r.valid = false;
-                if (ci < c1) {
-                    const int4 ch = p.chunks[ci];
-                    if (slot < ch.z) {
-                        const int e = ch.y + slot;
-                        const int2 ct = *reinterpret_cast<const int2 *>(p.rec + 2 * (size_t)e);
-                        r.c = ct.x, r.t = ct.y, r.valid = true;
-                        if (wt) r.w = wt[p.perm[e]];
+            if (wave == 0) {
+                T cacc = nary_zero<T, SUM>();
+                const auto finish_row = [&](const int row) {
+                    const int d = inner * SPAN + lane;
+                    if (d < p.row_len) {
+                        T v = cacc;
+                        if (p.has_bnd && (bnd_row < 0 || bnd_row == row))
+                            v = nary<T, SUM>(v, reinterpret_cast<const T *>(p.bnd.ptr)[outer * p.bnd.stride_outer +
+                                                                                      (long long)row * p.bnd.stride_row + d]);
+                        reinterpret_cast<T *>(p.out)[outer * p.out_stride_outer + (long long)row * p.out_stride_row + d] = v;
                     }
-                }
-                return r;
-            };
-            const auto gather = [&](const Rec &r) {
-                P v;
+                };
+                // chunk descriptors are requested four chunks before their barrier (a load issued right before the
+                // barrier and used right behind it would put an L2 round trip into every link of the chain)
+                v4i dq[4];
+                const v4i *chunks = reinterpret_cast<const v4i *>(p.chunks);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v.v[e] = T(0);
-                if (MUL != BIN_LHS && r.valid)
-                    v = *reinterpret_cast<const P *>(xbase + (__umul24((uint32_t)r.c, p.x_row_bytes) + lane_bytes));
-                return v;
-            };
-            Rec r0, r1;
-            P x0;
-            T cacc = nary_zero<T, SUM>();
-            if (!consumer) {
-                r0 = load_rec(c0);
-                r1 = load_rec(c0 + 1);
-                x0 = gather(r0);
-            }
-            for (int it = c0; it <= c1; ++it) {
-                if (!consumer) {
-                    // issue next chunk's gather and the record after that, then finish this chunk
-                    const P x1 = gather(r1);
-                    const Rec r2 = load_rec(it + 2);
-                    if (it < c1 && r0.valid) {
-                        P rv;
-                        if (MUL != BIN_RHS) {
-                            if (REL_LDS)
-                                rv = *reinterpret_cast<const P *>(lds_rel_lane + r0.t * SPAN);
-                            else
-                                rv = *reinterpret_cast<const P *>(relbase + (__umul24((uint32_t)r0.t, p.rel_row_bytes) + lane_bytes));
+                for (int j = 0; j < 4; ++j) dq[j] = load_uniform(chunks + min(c0 + j, c1 - 1));
+                T va[CHAIN_HALF], vb[CHAIN_HALF];
+                bool pend = false;            // vb holds the second half of the previous chunk, not yet added
+                int pend_row = -1;            // ... and that chunk closes this row (-1: it does not)
+                const auto consume = [&](auto jtag, const int it) {
+                    constexpr int J = decltype(jtag)::value;
+                    const v4i ch = dq[J];
+                    const int row = ch[0], count = ch[2], flags = ch[3];
+                    const T *ring_lane = ring + (size_t)((it - c0) & 1) * CHAIN_SLOTS * SPAN + lane;
+                    __syncthreads();
+                    // (scalar loads count on lgkmcnt, which the barrier drains: requested right behind it, consumed
+                    // four barriers later)
+                    dq[J] = load_uniform(chunks + min(it + 4, c1 - 1));
+                    if (count == CHAIN_SLOTS) {
+                        if (pend) {
+                            cacc = chain_add_and_read<T, SUM>(cacc, vb, va, ring_lane);
+                            if (pend_row >= 0) finish_row(pend_row);
+                        } else {
+                            ring_read(va, ring_lane);
                         }
-                        const V rr = (MUL != BIN_RHS) ? to_vec<T, 4>(rv) : V(T(0));
-                        const V xx = (MUL != BIN_LHS) ? to_vec<T, 4>(x0) : V(T(0));
-                        V y = binary_vec<V, MUL>(rr, xx);
-                        if (wt) y = V(r0.w) * y;
-                        *reinterpret_cast<P *>(ring + ((size_t)(it & 1) * CHAIN_SLOTS + slot) * SPAN + l16 * 4) = to_pack<T, 4>(y);
-                    }
-                    r0 = r1;
-                    r1 = r2;
-                    x0 = x1;
-                } else if (it > c0) {
-                    const int4 ch = p.chunks[it - 1];
-                    const int row = rfl(ch.x), count = rfl(ch.z), flags = rfl(ch.w);
-                    if (flags & CHUNK_FIRST) cacc = nary_zero<T, SUM>();
-                    cacc = consume_chunk<T, SUM>(cacc, ring + (size_t)((it - 1) & 1) * CHAIN_SLOTS * SPAN + lane, count);
-                    if (flags & CHUNK_LAST) {
-                        const int d = inner * SPAN + lane;
-                        if (d < p.row_len) {
-                            T v = cacc;
-                            if (p.has_bnd && (bnd_row < 0 || bnd_row == row))
-                                v = nary<T, SUM>(v, reinterpret_cast<const T *>(p.bnd.ptr)[outer * p.bnd.stride_outer +
-                                                                                          (long long)row * p.bnd.stride_row + d]);
-                            reinterpret_cast<T *>(p.out)[outer * p.out_stride_outer + (long long)row * p.out_stride_row + d] = v;
+                        if (flags & CHUNK_FIRST) cacc = nary_zero<T, SUM>();
+                        cacc = chain_add_and_read<T, SUM>(cacc, va, vb, ring_lane + CHAIN_HALF * SPAN);
+                        pend = true;
+                        pend_row = (flags & CHUNK_LAST) ? row : -1;
+                    } else {
+                        if (pend) {
+                            cacc = chain_add<T, SUM>(cacc, vb);
+                            if (pend_row >= 0) finish_row(pend_row);
+                            pend = false;
                         }
+                        if (flags & CHUNK_FIRST) cacc = nary_zero<T, SUM>();
+                        cacc = consume_partial<T, SUM>(cacc, ring_lane, count);
+                        if (flags & CHUNK_LAST) finish_row(row);
                     }
+                };
+                for (int it = c0;; it += 4) {
+                    consume(StepTag<0>{}, it);
+                    if (it + 1 >= c1) break;
+                    consume(StepTag<1>{}, it + 1);
+                    if (it + 2 >= c1) break;
+                    consume(StepTag<2>{}, it + 2);
+                    if (it + 3 >= c1) break;
+                    consume(StepTag<3>{}, it + 3);
+                    if (it + 4 >= c1) break;
                 }
-                __syncthreads();
+                if (pend) {
+                    cacc = chain_add<T, SUM>(cacc, vb);
+                    if (pend_row >= 0) finish_row(pend_row);
+                }
+            } else {
+                // Producer group `slot` computes message `slot` of every chunk.  Software pipeline per lane: source rows
+                // of the next 4 chunks in flight (xq), records of the 4 chunks after those requested (rq) -- all loads
+                // unconditional (a slot past its chunk's count reads a neighbouring record; nobody consumes its message).
+                const int slot = (wave - 1) * 4 + grp;
+                const int2 *recs = reinterpret_cast<const int2 *>(p.rec) + slot;
+                const int32_t *perm = p.perm + slot;
+                const auto chunk_begin = [&](const int ci) {
+                    return load_uniform(reinterpret_cast<const int32_t *>(p.chunks + min(ci, c1 - 1)) + 1);
+                };
+                struct Rec {
+                    int c, t;
+                    T w;
+                };
+                const auto load_rec = [&](const int b) {   // b: first edge of the chunk
+                    const int2 ct = recs[b];
+                    Rec r;
+                    r.c = ct.x, r.t = ct.y, r.w = T(1);
+                    if (WEIGHTED) r.w = wt[perm[b]];
+                    return r;
+                };
+                const auto gather = [&](const Rec &r) {
+                    P v;
+                    if (MUL != BIN_LHS)
+                        v = *reinterpret_cast<const P *>(xbase + (__umul24((uint32_t)r.c, p.x_row_bytes) + lane_bytes));
+                    return v;
+                };
+                // depth of the pipeline in chunks (8 measured slower than 4: the compiler's in-order vmcnt bookkeeping
+                // collapses at the loop back-edge and drains the deeper queue once per round)
+                constexpr int D = 4;
+                Rec rx[D], rq[D];   // rx[j]: record whose source row is in xq[j]; rq[j]: record of the chunk D further on
+                P xq[D];
+                int sb[D];          // first edge of the chunk 2 D further on (scalar loads, requested D chunks before use)
+#pragma unroll
+                for (int j = 0; j < D; ++j) rx[j] = load_rec(chunk_begin(c0 + j));
+#pragma unroll
+                for (int j = 0; j < D; ++j) rq[j] = load_rec(chunk_begin(c0 + D + j));
+#pragma unroll
+                for (int j = 0; j < D; ++j) sb[j] = chunk_begin(c0 + 2 * D + j);
+#pragma unroll
+                for (int j = 0; j < D; ++j) xq[j] = gather(rx[j]);
+                const auto produce = [&](auto jtag, const int it) {
+                    constexpr int J = decltype(jtag)::value;
+                    const int b_next = sb[J];
+                    sb[J] = chunk_begin(it + 3 * D);   // scalar load: issued right behind the previous barrier (see the consumer)
+                    P rv;
+                    if (MUL != BIN_RHS) {
+                        if (REL_LDS)
+                            rv = *reinterpret_cast<const P *>(lds_rel_lane + rx[J].t * SPAN);
+                        else
+                            rv = *reinterpret_cast<const P *>(relbase + (__umul24((uint32_t)rx[J].t, p.rel_row_bytes) + lane_bytes));
+                    }
+                    const V rr = (MUL != BIN_RHS) ? to_vec<T, 4>(rv) : V(T(0));
+                    const V xx = (MUL != BIN_LHS) ? to_vec<T, 4>(xq[J]) : V(T(0));
+                    V y = binary_vec<V, MUL>(rr, xx);
+                    if (WEIGHTED) y = V(rx[J].w) * y;
+                    *reinterpret_cast<P *>(ring + ((size_t)((it - c0) & 1) * CHAIN_SLOTS + slot) * SPAN + l16 * 4) = to_pack<T, 4>(y);
+                    // refill this pipeline stage: source row of chunk it + D, record of chunk it + 2 D
+                    rx[J] = rq[J];
+                    xq[J] = gather(rx[J]);
+                    rq[J] = load_rec(b_next);
+                    __syncthreads();
+                };
+                for (int it = c0;; it += D) {
+                    produce(StepTag<0>{}, it);
+                    if (it + 1 >= c1) break;
+                    produce(StepTag<1>{}, it + 1);
+                    if (it + 2 >= c1) break;
+                    produce(StepTag<2>{}, it + 2);
+                    if (it + 3 >= c1) break;
+                    produce(StepTag<3>{}, it + 3);
+                    if (it + 4 >= c1) break;
+                }
             }
         }
 
+        if (p.trace && tid == 0) p.trace[3 * blockIdx.x + 1] = clock64();
         // ================= group units of this workgroup =================
+        // (the next unit's item is requested before the current one is walked: two dependent loads off the critical path;
+        // the unit list is read with a clamped index so that the request is unconditional)
         const int u1 = p.unit_ptr[part + 1];
-        for (int ui = p.unit_ptr[part] + wave; ui < u1; ui += nwave) {
-            const int u = p.units[ui];
-            const int q = p.n_chain + 4 * u + grp;
-            int row = -1, begin = 0, cnt = 0;
-            if (q < p.n_item) {
-                const int4 it = p.items[q];
-                row = it.x;
-                begin = it.y;
-                cnt = it.z;
-            }
+        const auto load_item = [&](const int ui) {
+            const int u = load_uniform(p.units + min(ui, u1 - 1));
+            return p.items[min(p.n_chain + 4 * u + grp, p.n_item - 1)];
+        };
+        const auto item_valid = [&](const int ui) {   // (re-reads the unit id: L1 / L2 resident by then)
+            return p.n_chain + 4 * load_uniform(p.units + min(ui, u1 - 1)) + grp < p.n_item;
+        };
+        int ui = p.unit_ptr[part] + wave;
+        int4 item_next = make_int4(-1, 0, 0, 0);
+        bool valid_next = false;
+        if (ui < u1) {
+            item_next = load_item(ui);
+            valid_next = item_valid(ui);
+        }
+        for (; ui < u1; ui += nwave) {
+            const int4 item = item_next;
+            const bool valid = valid_next;
+            item_next = load_item(ui + nwave);
+            valid_next = item_valid(ui + nwave);
+            const int row = valid ? item.x : -1, begin = valid ? item.y : 0, cnt = valid ? item.z : 0;
             const int m01 = max(__shfl(cnt, 0), __shfl(cnt, 16));
             const int m23 = max(__shfl(cnt, 32), __shfl(cnt, 48));
             const int nsteps = rfl(max(m01, m23));
@@ -355,13 +462,8 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
             const int n23 = min(__shfl(cnt, 32), __shfl(cnt, 48));
             const int nfull = rfl(min(n01, n23));
 
-            P acc;
-            if (p.w)
-                acc = walk_row_in_order<T, SUM, MUL, REL_LDS, true>(p, begin, cnt, nsteps, nfull, l16, xbase, relbase, lane_bytes,
-                                                                    lds_rel_lane);
-            else
-                acc = walk_row_in_order<T, SUM, MUL, REL_LDS, false>(p, begin, cnt, nsteps, nfull, l16, xbase, relbase, lane_bytes,
-                                                                     lds_rel_lane);
+            P acc = walk_row_in_order<T, SUM, MUL, REL_LDS, WEIGHTED>(p, begin, cnt, nsteps, nfull, l16, xbase, relbase, lane_bytes,
+                                                                      lds_rel_lane);
             if (row >= 0 && dvalid) {
                 if (p.has_bnd && (bnd_row < 0 || bnd_row == row)) {
                     const P b = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.bnd.ptr) + outer * p.bnd.stride_outer +
@@ -374,12 +476,16 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
             }
         }
     }
+    if (p.trace) {
+        __syncthreads();
+        if (tid == 0) p.trace[3 * blockIdx.x + 2] = clock64();
+    }
 }
 
 // ---- per-variant launchers (explicitly instantiated in rspmm_order_*.hip) ----
-template <typename T, int SUM, int MUL, bool REL_LDS>
+template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED>
 inline hipError_t launch_order_one(const OrderParams &p, int grid, size_t lds, hipStream_t s) {
-    auto kern = rspmm_order_kernel<T, SUM, MUL, REL_LDS>;
+    auto kern = rspmm_order_kernel<T, SUM, MUL, REL_LDS, WEIGHTED>;
     static size_t lds_opted_in = 0;   // (see launch_one in rspmm_kernels.hpp)
     if (lds > 48 * 1024 && lds > lds_opted_in) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -390,18 +496,19 @@ inline hipError_t launch_order_one(const OrderParams &p, int grid, size_t lds, h
     return hipGetLastError();
 }
 
-template <typename T, bool REL_LDS>
+template <typename T, bool REL_LDS, bool WEIGHTED>
 hipError_t launch_order_variant(int sum, int mul, const OrderParams &p, int grid, size_t lds, hipStream_t s);
 
 #define ULTRA_ORDER_CASE(S, M) \
     case (S) * 4 + (M):        \
-        return launch_order_one<T, S, M, REL_LDS>(p, grid, lds, s);
+        return launch_order_one<T, S, M, REL_LDS, WEIGHTED>(p, grid, lds, s);
 
-#define ULTRA_DEFINE_ORDER_VARIANT(T_, REL_LDS_)                                                                            \
+#define ULTRA_DEFINE_ORDER_VARIANT(T_, REL_LDS_, WEIGHTED_)                                                                 \
     template <>                                                                                                             \
-    hipError_t launch_order_variant<T_, REL_LDS_>(int sum, int mul, const OrderParams &p, int grid, size_t lds, hipStream_t s) { \
+    hipError_t launch_order_variant<T_, REL_LDS_, WEIGHTED_>(int sum, int mul, const OrderParams &p, int grid, size_t lds,   \
+                                                             hipStream_t s) {                                               \
         using T = T_;                                                                                                       \
-        constexpr bool REL_LDS = REL_LDS_;                                                                                  \
+        constexpr bool REL_LDS = REL_LDS_, WEIGHTED = WEIGHTED_;                                                            \
         switch (sum * 4 + mul) {                                                                                            \
             ULTRA_ORDER_CASE(0, 0) ULTRA_ORDER_CASE(0, 1) ULTRA_ORDER_CASE(0, 2) ULTRA_ORDER_CASE(0, 3)                     \
             ULTRA_ORDER_CASE(1, 0) ULTRA_ORDER_CASE(1, 1) ULTRA_ORDER_CASE(1, 2) ULTRA_ORDER_CASE(1, 3)                     \

@@ -138,6 +138,22 @@ class Plan(object):
         check(lib.ultra_plan_get_info(self._h, ctypes.byref(info)))
         return {name: getattr(info, name) for name, _ in _lib.PlanInfo._fields_}
 
+    def schedule_info(self, nparts):
+        info = _lib.ScheduleInfo()
+        check(lib.ultra_plan_schedule_info(self._h, int(nparts), ctypes.byref(info)))
+        return {name: getattr(info, name) for name, _ in _lib.ScheduleInfo._fields_ if name != "reserved"}
+
+    def schedule(self, nparts):
+        """(chunk_ptr, unit_ptr, units, chunks[n, 4]) of the static schedule for `nparts` workgroups per span."""
+        out = []
+        for which in range(4):
+            n = ctypes.c_int64()
+            check(lib.ultra_plan_schedule_export(self._h, int(nparts), which, None, 0, ctypes.byref(n)))
+            t = torch.empty(n.value, dtype=torch.int32)
+            check(lib.ultra_plan_schedule_export(self._h, int(nparts), which, t.data_ptr(), n.value, ctypes.byref(n)))
+            out.append(t.view(-1, 4) if which == 3 else t)
+        return tuple(out)
+
     def export(self, which):
         n = ctypes.c_int64()
         check(lib.ultra_plan_export(self._h, which, None, 0, ctypes.byref(n)))
