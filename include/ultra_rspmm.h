@@ -101,6 +101,8 @@ typedef struct {
     int64_t n_type_run;   /* number of distinct (row, type) pairs: num_edge / n_type_run = mean run length */
     int64_t dense_bytes;  /* ULTRA_PLAN_DENSE: size of the fragment-ordered adjacency, else 0 */
     int64_t n_chain_row;  /* ULTRA_PLAN_EXACT_ORDER: rows longer than seg_len, walked by a whole workgroup (items[0, n_chain_row)) */
+    int64_t dense_order_bytes;  /* ULTRA_PLAN_DENSE: size of the adjacency of the reference-order layer kernel; 0 when the graph does
+                                   not qualify (more than 4 relation types, repeated edges, parallel edges not sorted by type) */
 } ultra_plan_info;
 
 int32_t ultra_abi_version(void);
@@ -178,9 +180,13 @@ int32_t ultra_nbf_layer0(ultra_plan *plan, const void *edge_weight_dev, const ul
  *     agg = rspmm add_mul (unit weights) + boundary;   out = [input +] relu( LayerNorm_eps( weight . cat[input, agg] + bias ) )
  * i.e. /root/reference/ultra/layers.py:183-207 + 233-240 with the residual of /root/reference/ultra/models.py:158-160 --
  * the steady-state layer of RelNBFNet.  boundary: NULL, a (n_outer, num_node, 64) tensor (point_rows_dev == NULL) or a
- * point boundary (n_outer, 1, 64) with point_rows_dev.  flags: ULTRA_CONV_* of ultra_nbfnet.h.  The aggregate never
- * leaves the chip.  ULTRA_ERR_UNSUPPORTED when the plan / shapes do not fit (callers then run rspmm + conv_update).
+ * point boundary (n_outer, 1, 64) with point_rows_dev.  flags: ULTRA_CONV_* of ultra_nbfnet.h, plus
+ * ULTRA_LAYER_REFERENCE_ORDER: the aggregate is summed in the reference's order (sorted edge order of every row,
+ * /root/reference/ultra/rspmm/source/rspmm.cpp:61-72) -- bit-identical to the reference's rspmm + boundary; needs
+ * dense_order_bytes > 0.  The aggregate never leaves the chip.  ULTRA_ERR_UNSUPPORTED when the plan / shapes do not fit
+ * (callers then run rspmm + conv_update).
  */
+#define ULTRA_LAYER_REFERENCE_ORDER 8
 int32_t ultra_nbf_dense_layer(ultra_plan *plan, const ultra_mat *relation, const ultra_mat *input, const ultra_mat *boundary,
                               const int64_t *point_rows_dev, const void *weight, const void *bias, const void *ln_weight,
                               const void *ln_bias, float eps, int32_t flags, const ultra_mat *output, void *stream);

@@ -179,3 +179,99 @@ def test_headline_shape_bit_exact(dev):
     plan = Plan(data.edge_index, data.edge_type, N, R, exact_order=True)
     got = plan.forward(rel.to(dev), x.to(dev)).cpu().transpose(0, 1).flatten(1)
     assert torch.equal(got, want)
+
+
+def _relation_like_graph(num_node, fill, seed, num_type=4):
+    """Edges listed type block after type block (hh, tt, ht, th in tasks.py:186-189), each (row, col, type) at most once."""
+    g = torch.Generator().manual_seed(seed)
+    blocks = []
+    for t in range(num_type):
+        mask = torch.rand(num_node, num_node, generator=g) < fill
+        rc = mask.nonzero().t()
+        blocks.append(torch.cat([rc, torch.full((1, rc.shape[1]), t)]))
+    e = torch.cat(blocks, dim=1)
+    return e[:2].contiguous(), e[2].contiguous()
+
+
+@pytest.mark.parametrize("num_node,fill", [(100, 0.9), (474, 0.995), (37, 0.5), (130, 1.0)])
+@pytest.mark.parametrize("boundary", ["none", "tensor", "point"])
+def test_dense_layer_aggregate_in_reference_order_is_bit_exact(dev, num_node, fill, boundary):
+    """ultra_nbf_dense_layer with ULTRA_LAYER_REFERENCE_ORDER: with W = [0 | I], no bias / LayerNorm / ReLU the layer's
+    output IS its aggregate, which must equal the oracle's rspmm (+ boundary) bit for bit."""
+    from torch import nn
+    from ultra_amd.rspmm import Plan
+    ei, et = _relation_like_graph(num_node, fill, seed=num_node)
+    N, E, bs = num_node, ei.shape[1], 3
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(bs, N, 64, generator=g)
+    rel = torch.randn(bs, 4, 64, generator=g)
+    bnd = torch.randn(bs, N, 64, generator=g)
+    rows = torch.tensor([5, 0, N - 1])
+    vals = torch.randn(bs, 64, generator=g)
+    if boundary == "point":
+        bnd = torch.zeros(bs, N, 64)
+        bnd[torch.arange(bs), rows] = vals
+    want = rspmm_oracle.generalized_rspmm(ei, et, torch.ones(E), rel.transpose(0, 1).flatten(1), x.transpose(0, 1).flatten(1))
+    if boundary != "none":
+        want = want + bnd.transpose(0, 1).flatten(1)
+    want = want.view(N, bs, 64).transpose(0, 1)
+    plan = Plan(ei, et, N, 4, exact_order=True)
+    assert plan.dense is not None and plan.dense.info()["dense_order_bytes"] > 0
+    lin = nn.Linear(128, 64, bias=False)
+    with torch.no_grad():
+        lin.weight.zero_()
+        lin.weight[:, 64:] = torch.eye(64)
+    lin = lin.to(dev)
+    kw = {}
+    if boundary == "tensor":
+        kw["boundary"] = bnd.to(dev)
+    elif boundary == "point":
+        kw["point"] = (rows.to(dev), vals.to(dev))
+    got = plan.fused_layer(rel.to(dev), x.to(dev), lin, layer_norm=None, relu=False, residual=False, **kw)
+    assert got is not None
+    assert torch.equal(got.cpu(), want), "max |d| = %g" % (got.cpu() - want).abs().max().item()
+    # the order kernels agree (they serve graphs that do not qualify for the dense format)
+    sparse = Plan(ei, et, N, 4, exact_order=True, dense=False)
+    got2 = sparse.forward(rel.to(dev), x.to(dev), **kw).cpu()
+    assert torch.equal(got2, want)
+
+
+def test_dense_layer_declines_graphs_it_cannot_order(dev):
+    """Parallel edges not sorted by type (or repeated): no reference-order dense twin, the order kernels serve the plan."""
+    from ultra_amd.rspmm import Plan
+    ei, et = _relation_like_graph(60, 0.9, seed=3)
+    perm = torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(0))
+    shuffled = Plan(ei[:, perm], et[perm], 60, 4, exact_order=True)
+    assert shuffled.dense is None
+    dup = Plan(torch.cat([ei, ei[:, :5]], dim=1), torch.cat([et, et[:5]]), 60, 4, exact_order=True)
+    assert dup.dense is None
+    assert Plan(ei, et, 60, 4, exact_order=True).dense is not None
+
+
+@pytest.mark.parametrize("residual,layer_norm,relu", [(True, True, True), (False, True, False), (True, False, True)])
+def test_dense_order_layer_matches_rspmm_plus_update(dev, residual, layer_norm, relu):
+    """The whole layer against order-kernel aggregate + the stand-alone update kernel (different product blocking: 1e-5)."""
+    from torch import nn
+    from ultra_amd import dense
+    from ultra_amd.rspmm import Plan
+    ei, et = _relation_like_graph(474, 0.995, seed=9)
+    N, bs = 474, 8
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(bs, N, 64, generator=g).to(dev)
+    rel = torch.randn(bs, 4, 64, generator=g).to(dev) * 0.1
+    point = (torch.arange(bs).to(dev) * 3, torch.randn(bs, 64, generator=g).to(dev))
+    torch.manual_seed(0)
+    lin = nn.Linear(128, 64).to(dev)
+    ln = nn.LayerNorm(64).to(dev) if layer_norm else None
+    plan = Plan(ei, et, N, 4, exact_order=True)
+    got = plan.fused_layer(rel, x, lin, layer_norm=ln, relu=relu, residual=residual, point=point)
+    agg = Plan(ei, et, N, 4, exact_order=True, dense=False).forward(rel, x, point=point)
+    want = lin(torch.cat([x, agg], dim=-1))
+    if ln is not None:
+        want = ln(want)
+    if relu:
+        want = torch.relu(want)
+    if residual:
+        want = want + x
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 2e-5 * max(scale, 1.0)

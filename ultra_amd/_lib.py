@@ -28,6 +28,7 @@ ARR_ROW_PTR, ARR_COL, ARR_TYPE, ARR_PERM, ARR_ITEM, ARR_SPLIT_ROW, ARR_SPLIT_PTR
 PLAN_EXACT_ORDER = 1
 PLAN_TYPE_RUNS = 2
 PLAN_DENSE = 4
+LAYER_REFERENCE_ORDER = 8
 DENSE_MAX_IN_ROW = 1024
 ARR_DENSE = 7
 
@@ -48,7 +49,8 @@ class PlanInfo(ctypes.Structure):
                 ("n_unit", ctypes.c_int64), ("n_split_row", ctypes.c_int64), ("n_partial_slot", ctypes.c_int64),
                 ("seg_len", ctypes.c_int32), ("g_max", ctypes.c_int32), ("flags", ctypes.c_int32),
                 ("packed", ctypes.c_int32), ("on_device", ctypes.c_int32), ("has_transpose", ctypes.c_int32),
-                ("n_type_run", ctypes.c_int64), ("dense_bytes", ctypes.c_int64), ("n_chain_row", ctypes.c_int64)]
+                ("n_type_run", ctypes.c_int64), ("dense_bytes", ctypes.c_int64), ("n_chain_row", ctypes.c_int64),
+                ("dense_order_bytes", ctypes.c_int64)]
 
 
 class ScheduleInfo(ctypes.Structure):

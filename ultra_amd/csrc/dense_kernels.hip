@@ -19,6 +19,7 @@
 
 #include "../../include/ultra_rspmm.h"
 #include "plan.hpp"
+#include "torch_math.hpp"
 
 namespace ultra {
 
@@ -40,16 +41,56 @@ enum { CONV_LN = 1, CONV_RELU = 2, CONV_RESIDUAL = 4 };
 // feature owned by accumulator register r of feature tile m in lane half h (32x32 C/D layout)
 __device__ __forceinline__ int feat_of(int m, int r, int h) { return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// v_permlane32_swap: lanes 32..63 of `lo_pair` trade places with lanes 0..31 of `hi_pair`.  A lane half h holds the
+// 16-byte chunk k = 8 i + 4 h .. + 3 of its row; after swapping (.x, .y) and (.z, .w) the four registers hold, in lane
+// half h, element 2 s + h of the k pairs s = 4 i, 4 i + 2 and 4 i + 1, 4 i + 3: each v_mfma_f32_32x32x2_f32 then consumes
+// two CONSECUTIVE k, and the accumulator chain runs over k = 0, 1, 2, ... exactly like the reference's nn.Linear
+// (torch_math.hpp).
+__device__ __forceinline__ void swap32(float &lo_pair, float &hi_pair) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_pair), __float_as_uint(hi_pair), false, false);
+    lo_pair = __uint_as_float(r[0]);
+    hi_pair = __uint_as_float(r[1]);
+}
+
+// LayerNorm statistics of a row held by the lane pair (lane, lane ^ 32) in the accumulator layout of the transposed
+// product: lane half h owns features 32 m + (r & 3) + 8 (r >> 2) + 4 h, i.e. ALL eight members 8 j + i of the Welford
+// accumulators i = (r & 3) + 4 h (torch_math.hpp) -- four accumulators per lane, the other four come over one swap.
+__device__ __forceinline__ void row_moments_pair(const float (&v)[2][16], const int h, const float eps, float &mean, float &rstd) {
+    Moments own[4], other[4];
+#pragma unroll
+    for (int il = 0; il < 4; ++il) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = v[j >> 2][4 * (j & 3) + il];
+        own[il] = welford8(x);
+        other[il].m1 = __shfl_xor(own[il].m1, 32);
+        other[il].m2 = __shfl_xor(own[il].m2, 32);
+    }
+    Moments all[8];
+#pragma unroll
+    for (int il = 0; il < 4; ++il) {
+        all[il].m1 = h ? other[il].m1 : own[il].m1;
+        all[il].m2 = h ? other[il].m2 : own[il].m2;
+        all[4 + il].m1 = h ? own[il].m1 : other[il].m1;
+        all[4 + il].m2 = h ? own[il].m2 : other[il].m2;
+    }
+    merge8(all, eps, mean, rstd);
+}
+
 __global__ void __launch_bounds__(512, 2) conv_update_kernel(const ConvParams p) {
-    // [tile m][i][lane][q] : W[32 m + (lane & 31)][8 i + 4 (lane >> 5) + q]
+    // [tile m][i][lane][q] : W[32 m + (lane & 31)][2 s + (lane >> 5)], s = 4 i + {0, 2, 1, 3}[q] -- the k pair that
+    // register q of the swapped data chunk i holds (see swap32)
     __shared__ __attribute__((aligned(16))) float lds_w[2 * 16 * 64 * 4];
     __shared__ float lds_vec[3 * 64];
     const int tid = threadIdx.x;
-    // 16-byte staging loads: fragment (m, i, lane) = 4 consecutive k of one weight row
     for (int idx4 = tid; idx4 < 2 * 16 * 64; idx4 += blockDim.x) {
         const int l = idx4 & 63, i = (idx4 >> 6) & 15, m = idx4 >> 10;
+        const float *wr = p.weight + (32 * m + (l & 31)) * 128 + 8 * i;
+        const float4 w0 = *reinterpret_cast<const float4 *>(wr), w1 = *reinterpret_cast<const float4 *>(wr + 4);
+        const bool odd = (l >> 5) != 0;
+        // q = 0: s = 4 i (k 8 i, 8 i + 1); q = 1: s = 4 i + 2 (k 8 i + 4, + 5); q = 2: s = 4 i + 1 (k 8 i + 2, + 3); q = 3: s = 4 i + 3
         reinterpret_cast<float4 *>(lds_w)[idx4] =
-            *reinterpret_cast<const float4 *>(p.weight + (32 * m + (l & 31)) * 128 + 8 * i + 4 * (l >> 5));
+            make_float4(odd ? w0.y : w0.x, odd ? w1.y : w1.x, odd ? w0.w : w0.z, odd ? w1.w : w1.z);
     }
     if (tid < 64) {
         lds_vec[tid] = p.bias ? p.bias[tid] : 0.f;
@@ -104,50 +145,44 @@ __global__ void __launch_bounds__(512, 2) conv_update_kernel(const ConvParams p)
         float4 a1 = w4[(1 * 16 + 0) * 64 + lane];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float4 b = i < 8 ? bx[i] : ba[i - 8];
+            float4 b = i < 8 ? bx[i] : ba[i - 8];
+            swap32(b.x, b.y);   // b.x: k pair s = 4 i,     b.y: s = 4 i + 2
+            swap32(b.z, b.w);   // b.z: k pair s = 4 i + 1, b.w: s = 4 i + 3
             float4 a0n = a0, a1n = a1;
             if (i + 1 < 16) {
                 a0n = w4[(0 * 16 + i + 1) * 64 + lane];
                 a1n = w4[(1 * 16 + i + 1) * 64 + lane];
             }
+            // k ascending: s = 4 i, 4 i + 1, 4 i + 2, 4 i + 3 (weights staged as .x, .z, .y, .w to match)
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
             a0 = a0n;
             a1 = a1n;
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- epilogue: bias, LayerNorm over the row's 64 features (32 here + 32 in lane ^ 32), ReLU, residual ----
+        // ---- epilogue: bias (added after the chain, like addmm), LayerNorm in the reference's operation order
+        // (torch_math.hpp), ReLU, residual ----
         float v[2][16];
-        float s = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             v[0][r] = acc0[r] + lds_vec[feat_of(0, r, h)];
             v[1][r] = acc1[r] + lds_vec[feat_of(1, r, h)];
-            s += v[0][r] + v[1][r];
         }
         if (p.flags & CONV_LN) {
-            s += __shfl_xor(s, 32);
-            const float mean = s * (1.f / 64.f);
-            float q = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float d0 = v[0][r] - mean, d1 = v[1][r] - mean;
-                q += d0 * d0 + d1 * d1;
-            }
-            q += __shfl_xor(q, 32);
-            const float rstd = 1.f / sqrtf(q * (1.f / 64.f) + p.eps);
+            float mean, rstd;
+            row_moments_pair(v, h, p.eps, mean, rstd);
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int f = feat_of(m, r, h);
-                    v[m][r] = (v[m][r] - mean) * rstd * lds_vec[64 + f] + lds_vec[128 + f];
+                    v[m][r] = ln_apply(v[m][r], mean, rstd, lds_vec[64 + f], lds_vec[128 + f]);
                 }
         }
 #pragma unroll
@@ -288,11 +323,9 @@ __global__ void __launch_bounds__(512, 2) readout_kernel(const ReadoutParams p) 
 }
 
 // All layers' relation_projection MLPs (layers.py:80: Linear(64, 64) -> ReLU -> Linear(64, 64) applied to the
-// relation representations, models.py:184-185) in ONE launch: workgroup = (layer, 4 row tiles), both weight
-// matrices of the layer staged in LDS in MFMA fragment order.  Transposed products as in conv_update: a data row's
-// features live in one lane pair, so the hidden activation of the first product is consumed by the second one
-// straight from the accumulator registers -- the contraction index of the second product is simply enumerated in
-// the order the accumulators hold it (feat_of), and the second weight matrix is staged in that same order.
+// relation representations, models.py:184-185) in ONE launch: workgroup = (16 rows, layer), wave = 16 output features.
+// Both products run on v_mfma_f32_16x16x4_f32 with k ascending -- the reference's nn.Linear chain (torch_math.hpp),
+// bias added after the chain -- the hidden activation passes through LDS between them.
 struct RelProjParams {
     const float *x;        // (rows, 64)
     const float *w0, *b0;  // (n_layer, 64, 64) row-major [out][in], (n_layer, 64)
@@ -303,88 +336,51 @@ struct RelProjParams {
 };
 
 __global__ void __launch_bounds__(256) relation_projection_kernel(const RelProjParams p) {
-    // lds_w0[m][i][lane][q] = W0[32 m + (lane & 31)][8 i + 4 (lane >> 5) + q]          (k = 8 i + 4 h + q: x chunk 2 i + h)
-    // lds_w2[m2][s][lane]   = W2[32 m2 + (lane & 31)][feat_of(s >> 4, s & 15, lane >> 5)]  (k enumerated as the accumulators)
-    __shared__ __attribute__((aligned(16))) float lds_w0[2 * 8 * 64 * 4];
-    __shared__ __attribute__((aligned(16))) float lds_w2[2 * 32 * 64];
-    __shared__ float lds_b[2 * 64];
-    const int tid = threadIdx.x;
+    constexpr int STRIDE = 68;
+    __shared__ __attribute__((aligned(16))) float x_lds[16 * STRIDE];
+    __shared__ __attribute__((aligned(16))) float h_lds[16 * STRIDE];
+    using f32x4 = float __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kk = lane >> 4;
     const int layer = blockIdx.y;
+    const long long row0 = (long long)blockIdx.x * 16;
     const float *w0 = p.w0 + (size_t)layer * 64 * 64, *w2 = p.w2 + (size_t)layer * 64 * 64;
-    for (int idx4 = tid; idx4 < 2 * 8 * 64; idx4 += 256) {
-        const int l = idx4 & 63, i = (idx4 >> 6) & 7, m = idx4 >> 9;
-        reinterpret_cast<float4 *>(lds_w0)[idx4] =
-            *reinterpret_cast<const float4 *>(w0 + (32 * m + (l & 31)) * 64 + 8 * i + 4 * (l >> 5));
+    {
+        const long long row = min(row0 + (tid >> 4), p.rows - 1);
+        *reinterpret_cast<float4 *>(x_lds + (tid >> 4) * STRIDE + 4 * (tid & 15)) =
+            *reinterpret_cast<const float4 *>(p.x + row * 64 + 4 * (tid & 15));
     }
-    for (int idx = tid; idx < 2 * 32 * 64; idx += 256) {
-        const int l = idx & 63, st = (idx >> 6) & 31, m2 = idx >> 11;
-        lds_w2[idx] = w2[(32 * m2 + (l & 31)) * 64 + feat_of(st >> 4, st & 15, l >> 5)];
+    // A operands: lane (i, kk) holds W[16 wave + i][4 s + kk]
+    float a0[16], a2[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        a0[s] = w0[(16 * wave + i16) * 64 + 4 * s + kk];
+        a2[s] = w2[(16 * wave + i16) * 64 + 4 * s + kk];
     }
-    if (tid < 64) {
-        lds_b[tid] = p.b0[layer * 64 + tid];
-        lds_b[64 + tid] = p.b2[layer * 64 + tid];
+    const int f0 = 16 * wave + 4 * kk;   // D: lane l, reg r -> feature 16 wave + 4 (l >> 4) + r of tile row l & 15
+    float b0v[4], b2v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        b0v[r] = p.b0[layer * 64 + f0 + r];
+        b2v[r] = p.b2[layer * 64 + f0 + r];
     }
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const long long tile = (long long)blockIdx.x * 4 + wave;
-    if (tile * 32 >= p.rows) return;
-    const long long row = tile * 32 + j;
-    const bool valid = row < p.rows;
-    const float4 *xr = reinterpret_cast<const float4 *>(p.x + (valid ? row : p.rows - 1) * 64);
-    float4 bx[8];
+    f32x4 d;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bx[i] = xr[2 * i + h];
-    f32x16 acc[2];
+    for (int r = 0; r < 4; ++r) d[r] = 0.f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int s = 0; s < 16; ++s) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], x_lds[i16 * STRIDE + 4 * s + kk], d, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-    const float4 *w04 = reinterpret_cast<const float4 *>(lds_w0);
+    for (int r = 0; r < 4; ++r) h_lds[i16 * STRIDE + f0 + r] = fmaxf(d[r] + b0v[r], 0.f);
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float4 a0 = w04[(0 * 8 + i) * 64 + lane], a1 = w04[(1 * 8 + i) * 64 + lane];
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bx[i].x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bx[i].x, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bx[i].y, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bx[i].y, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bx[i].z, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bx[i].z, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bx[i].w, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bx[i].w, acc[1], 0, 0, 0);
-    }
-    // hidden = relu(. + b0), kept in the accumulator layout: it is the B operand of the second product
-    float hid[2][16];
+    for (int r = 0; r < 4; ++r) d[r] = 0.f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hid[m][r] = fmaxf(acc[m][r] + lds_b[feat_of(m, r, h)], 0.f);
-    f32x16 out[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) out[m][r] = 0.f;
-#pragma unroll
-    for (int st = 0; st < 32; ++st) {
-        const float b = hid[st >> 4][st & 15];
-        out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_w2[(0 * 32 + st) * 64 + lane], b, out[0], 0, 0, 0);
-        out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_w2[(1 * 32 + st) * 64 + lane], b, out[1], 0, 0, 0);
-    }
-    if (valid) {
-        float *orow = p.out + ((size_t)layer * p.rows + row) * 64;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = 32 * m + 8 * g + 4 * h;
-                float4 y;
-                y.x = out[m][4 * g + 0] + lds_b[64 + f + 0];
-                y.y = out[m][4 * g + 1] + lds_b[64 + f + 1];
-                y.z = out[m][4 * g + 2] + lds_b[64 + f + 2];
-                y.w = out[m][4 * g + 3] + lds_b[64 + f + 3];
-                *reinterpret_cast<float4 *>(orow + f) = y;
-            }
-    }
+    for (int s = 0; s < 16; ++s) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s], h_lds[i16 * STRIDE + 4 * s + kk], d, 0, 0, 0);
+    const long long row = row0 + i16;
+    if (row < p.rows)
+        *reinterpret_cast<float4 *>(p.out + ((size_t)layer * p.rows + row) * 64 + f0) =
+            make_float4(d[0] + b2v[0], d[1] + b2v[1], d[2] + b2v[2], d[3] + b2v[3]);
 }
 
 static int grid_for(long long ntile, int waves_per_block, int blocks_per_cu = 2) {
@@ -563,7 +559,7 @@ int32_t ultra_relation_projection(const void *x, const void *w0, const void *b0,
     p.out = (float *)out;
     p.rows = rows;
     p.n_layer = n_layer;
-    const dim3 grid((unsigned)((rows + 127) / 128), (unsigned)n_layer);
+    const dim3 grid((unsigned)((rows + 15) / 16), (unsigned)n_layer);
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
     hipLaunchKernelGGL(relation_projection_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
     hipError_t e = hipGetLastError();

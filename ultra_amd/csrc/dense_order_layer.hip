@@ -1,0 +1,257 @@
+// One whole GeneralizedRelationalConv layer on a dense-format plan, IN THE REFERENCE'S SUMMATION ORDER:
+//
+//     agg[i] = (((0 + m(i, j0, t0)) + m(i, j0, t1)) + ... )   over the edges of row i in sorted (col, edge id) order,
+//              m(i, j, t) = rel[b, t] * x[b, j]                                              rspmm.cpp:61-72
+//     out    = [x +] relu( LayerNorm( W . cat[x, agg + boundary] + bias ) )                   layers.py:199-200, 233-240
+//
+// ULTRA's relation graph (a few hundred nodes, 4 edge types, nearly every (row, type, col) cell occupied) gives every row
+// ~1,900 edges: one long sequential sum per output element.  On the matrix pipe that sum costs nothing extra:
+// v_mfma_f32_16x16x4_f32 is, bit for bit, a k-ordered chain of fp32 fmaf (cdna_hip_programming.md, section 3), so with
+//     A[i][k] = 1 if the edge (row i <- col j, type k) exists else 0,     B[k][n] = fl(rel[k][n] * x[j][n])
+// one instruction per source column j performs  acc = fma(A[i][3], B[3], fma(A[i][2], B[2], fma(A[i][1], B[1],
+// fma(A[i][0], B[0], acc))))  -- fma(1, b, c) = fl(c + b) and fma(0, b, c) = c exactly (finite b) -- i.e. it adds the
+// separately rounded messages of column j's up to four parallel edges in type order, and the columns follow in
+// ascending order: exactly the reference's loop, provided parallel edges are sorted by type (checked when the plan is
+// built: ULTRA's relation graphs list hh, tt, ht, th in that order, tasks.py:186-189) and no edge is repeated.
+//
+// A workgroup (4 waves) owns 16 output rows of one sample; wave w owns the 16 features [16 w, 16 w + 16).  Its chain of
+// num_node dependent matrix instructions (40 cycles each) is the critical path: ~8 us at 474 nodes; the operands (one
+// byte of adjacency, one float of x per instruction and lane) are prefetched 16 columns ahead.  Phases 2 / 3: boundary,
+// update product on the matrix pipe with k ascending (= the reference's nn.Linear chain), LayerNorm in the reference's
+// operation order (torch_math.hpp), ReLU, residual.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "plan.hpp"
+#include "torch_math.hpp"
+
+#pragma clang fp contract(off)
+
+namespace ultra {
+
+using f32x4 = float __attribute__((ext_vector_type(4)));
+
+enum { DOL_LN = 1, DOL_RELU = 2, DOL_RESIDUAL = 4 };
+
+struct DenseOrderParams {
+    const uint4 *a_ex;        // [n_rt16][n_jc][64 lanes] : 16 bytes = A[row0 + lane % 16][type lane / 16][16 jc + 0..15]
+    const float *rel, *x, *bnd;
+    const long long *bnd_rows;
+    const float *weight, *bias, *ln_w, *ln_b;
+    float *out;
+    long long rel_so, rel_sr, x_so, x_sr, bnd_so, bnd_sr, out_so, out_sr;
+    int n_out, n_in, n_rel, n_jc, n_rt16, has_bnd, flags;
+    float eps;
+};
+
+constexpr int DOL_ROW_STRIDE = 68;   // floats per LDS tile row (see dense_layer.hip)
+
+__device__ __forceinline__ float byte_of(uint32_t w, int q) { return (float)((w >> (8 * q)) & 0xffu); }
+
+__global__ void __launch_bounds__(256) dense_order_layer_kernel(const DenseOrderParams p) {
+    __shared__ __attribute__((aligned(16))) float x_lds[16 * DOL_ROW_STRIDE];     // this tile's own rows of x
+    __shared__ __attribute__((aligned(16))) float agg_lds[16 * DOL_ROW_STRIDE];
+    __shared__ float ln_mom[16][8][2];
+    __shared__ float ln_stat[16][2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kk = lane >> 4;
+    const int rt = blockIdx.x % p.n_rt16, outer = blockIdx.x / p.n_rt16;
+    const float *xo = p.x + (long long)outer * p.x_so;
+    const int row0 = rt * 16;
+    const int c0 = 16 * wave;
+
+    // ---- phase 1 operands: all requested before anything waits ----
+    const uint4 *ap = p.a_ex + (size_t)rt * p.n_jc * 64 + lane;
+    const char *xcol = reinterpret_cast<const char *>(xo + c0 + i16);   // B operand: lane (kk, n) reads x[j][c0 + n]
+    const uint32_t x_row_bytes = (uint32_t)p.x_sr * 4u;
+    struct Stage {
+        uint4 a;
+        float x[16];
+    };
+    const auto fetch = [&](const int jc, Stage &st) {
+        const int jcc = min(jc, p.n_jc - 1);
+        st.a = ap[(size_t)jcc * 64];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int j = min(16 * jcc + q, p.n_in - 1);   // columns past n_in: adjacency bytes are 0 there
+            st.x[q] = *reinterpret_cast<const float *>(xcol + (uint32_t)j * x_row_bytes);
+        }
+    };
+    Stage cur, nxt;
+    fetch(0, cur);
+    const float relv = kk < p.n_rel ? p.rel[(long long)outer * p.rel_so + (long long)kk * p.rel_sr + c0 + i16] : 0.f;
+
+    // the tile's own x rows (update input and residual), the update weights of this wave's feature tile and the small
+    // vectors of phases 2 / 3: requested now, consumed after the chain
+    float4 xtile;
+    {
+        const int row = min(row0 + (tid >> 4), p.n_out - 1);
+        xtile = *reinterpret_cast<const float4 *>(xo + (long long)row * p.x_sr + 4 * (tid & 15));
+    }
+    float wfrag[32];   // A operand of phase 3: lane (i, kk) holds W[16 ft + i][4 s + kk], ft = wave
+#pragma unroll
+    for (int s = 0; s < 32; ++s) wfrag[s] = p.weight[(16 * wave + i16) * 128 + 4 * s + kk];
+    const int f0 = 16 * wave + 4 * kk;   // first of this lane's 4 features in phase 3
+    float biasv[4], lnw[4], lnb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        biasv[r] = p.bias ? p.bias[f0 + r] : 0.f;
+        lnw[r] = (p.flags & DOL_LN) ? p.ln_w[f0 + r] : 1.f;
+        lnb[r] = (p.flags & DOL_LN) ? p.ln_b[f0 + r] : 0.f;
+    }
+    float bndv[4] = {0.f, 0.f, 0.f, 0.f};   // boundary addends of the accumulator elements (row 4 kk + r, column c0 + i16)
+    if (p.has_bnd) {
+        const long long bnd_row = p.bnd_rows ? p.bnd_rows[outer] : -1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + 4 * kk + r;
+            if (row < p.n_out && (bnd_row < 0 || bnd_row == row))
+                bndv[r] = p.bnd[(long long)outer * p.bnd_so + (long long)row * p.bnd_sr + c0 + i16];   // (bnd_sr == 0 for a point)
+        }
+    }
+
+    // ---- phase 1: the chain ----
+    f32x4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = 0.f;
+    for (int jc = 0; jc < p.n_jc; ++jc) {
+        fetch(jc + 1, nxt);   // (the last round re-reads itself: harmless)
+        const uint32_t aw[4] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float a = byte_of(aw[q >> 2], q & 3);
+            const float b = relv * cur.x[q];          // the message, rounded on its own like rspmm.cpp:67
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+        cur = nxt;
+    }
+
+    // ---- phase 2: + boundary (layers.py:199-200), aggregate tile and x tile to LDS ----
+    // D layout: lane l, reg r -> tile row 4 (l >> 4) + r, column l & 15
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = acc[r];
+        if (p.has_bnd) v += bndv[r];   // (exactly 0 where there is no boundary value: same bits as not adding)
+        agg_lds[(4 * kk + r) * DOL_ROW_STRIDE + c0 + i16] = v;
+    }
+    *reinterpret_cast<float4 *>(x_lds + (tid >> 4) * DOL_ROW_STRIDE + 4 * (tid & 15)) = xtile;
+    __syncthreads();
+
+    // ---- phase 3: update (feature tile ft = wave): B operand lane (kk, j) holds data[row j][4 s + kk], data = cat[x, agg] ----
+    f32x4 d;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[s], x_lds[i16 * DOL_ROW_STRIDE + 4 * s + kk], d, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[16 + s], agg_lds[i16 * DOL_ROW_STRIDE + 4 * s + kk], d, 0, 0, 0);
+    // D: lane l, reg r -> feature 16 ft + 4 (l >> 4) + r of tile row l & 15
+    float y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = d[r] + biasv[r];
+    if (p.flags & DOL_LN) {
+        // LayerNorm in the reference's operation order (torch_math.hpp): the pre-norm tile goes through LDS (agg_lds is
+        // free again), 8 threads per row run the Welford accumulators i = 0..7 over features 8 j + i, one merges them.
+        __syncthreads();   // every wave is done reading agg_lds as its B operand
+#pragma unroll
+        for (int r = 0; r < 4; ++r) agg_lds[i16 * DOL_ROW_STRIDE + f0 + r] = y[r];
+        __syncthreads();
+        if (tid < 128) {
+            const int row = tid >> 3, i = tid & 7;
+            float xv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] = agg_lds[row * DOL_ROW_STRIDE + 8 * j + i];
+            const Moments w = welford8(xv);
+            ln_mom[row][i][0] = w.m1;
+            ln_mom[row][i][1] = w.m2;
+        }
+        __syncthreads();
+        if (tid < 16) {
+            Moments all[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) all[i] = Moments{ln_mom[tid][i][0], ln_mom[tid][i][1]};
+            float mean, rstd;
+            merge8(all, p.eps, mean, rstd);
+            ln_stat[tid][0] = mean;
+            ln_stat[tid][1] = rstd;
+        }
+        __syncthreads();
+        const float mean = ln_stat[i16][0], rstd = ln_stat[i16][1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = ln_apply(y[r], mean, rstd, lnw[r], lnb[r]);
+    }
+    if (p.flags & DOL_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.f);
+    }
+    if (p.flags & DOL_RESIDUAL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] += x_lds[i16 * DOL_ROW_STRIDE + f0 + r];
+    }
+    const int row = row0 + i16;
+    if (row < p.n_out)
+        *reinterpret_cast<float4 *>(p.out + (long long)outer * p.out_so + (long long)row * p.out_sr + f0) =
+            make_float4(y[0], y[1], y[2], y[3]);
+}
+
+static bool dol_ok16(const ultra_mat *m) {
+    return (reinterpret_cast<uintptr_t>(m->ptr) & 15u) == 0 && m->stride_row % 4 == 0 && m->stride_outer % 4 == 0;
+}
+
+// Called by ultra_nbf_dense_layer (rspmm_api.hip) with the plan uploaded, when the caller asks for the reference order.
+int launch_dense_order_layer(ultra_plan *p, const ultra_mat *rel, const ultra_mat *x, const ultra_mat *bnd, const int64_t *bnd_rows,
+                             const void *weight, const void *bias, const void *ln_w, const void *ln_b, float eps, int flags,
+                             const ultra_mat *out, hipStream_t stream) {
+    if (!(p->flags & ULTRA_PLAN_DENSE) || p->a_ex.empty() || !p->d.a_ex) {
+        set_error("ultra_nbf_dense_layer (reference order) needs a ULTRA_PLAN_DENSE plan of a graph with at most 4 relation types "
+                  "whose parallel edges are sorted by type and never repeated");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    if (out->row_len != 64 || p->num_out != p->num_in) {
+        set_error("ultra_nbf_dense_layer: hidden dim 64 on a square graph only");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    if (!dol_ok16(rel) || !dol_ok16(x) || !dol_ok16(out) || (bnd && !dol_ok16(bnd)) || (reinterpret_cast<uintptr_t>(weight) & 15u)) {
+        set_error("ultra_nbf_dense_layer: operands must be 16-byte aligned with strides that are multiples of 4");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    if ((uint64_t)p->num_in * (uint64_t)x->stride_row * 4u >= (1ull << 32)) {
+        set_error("ultra_nbf_dense_layer: an input slice (rows * stride_row) exceeds 4 GiB");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    DenseOrderParams dp;
+    dp.a_ex = reinterpret_cast<const uint4 *>(p->d.a_ex);
+    dp.rel = static_cast<const float *>(rel->ptr);
+    dp.x = static_cast<const float *>(x->ptr);
+    dp.bnd = bnd ? static_cast<const float *>(bnd->ptr) : nullptr;
+    dp.bnd_rows = bnd ? reinterpret_cast<const long long *>(bnd_rows) : nullptr;
+    dp.weight = static_cast<const float *>(weight);
+    dp.bias = static_cast<const float *>(bias);
+    dp.ln_w = static_cast<const float *>(ln_w);
+    dp.ln_b = static_cast<const float *>(ln_b);
+    dp.out = static_cast<float *>(out->ptr);
+    dp.rel_so = rel->stride_outer, dp.rel_sr = rel->stride_row;
+    dp.x_so = x->stride_outer, dp.x_sr = x->stride_row;
+    dp.bnd_so = bnd ? bnd->stride_outer : 0, dp.bnd_sr = (bnd && !bnd_rows) ? bnd->stride_row : 0;
+    dp.out_so = out->stride_outer, dp.out_sr = out->stride_row;
+    dp.n_out = (int)p->num_out, dp.n_in = (int)p->num_in, dp.n_rel = (int)p->num_rel;
+    dp.n_jc = (int)((p->num_in + 15) / 16), dp.n_rt16 = (int)((p->num_out + 15) / 16);
+    dp.has_bnd = bnd ? 1 : 0;
+    dp.flags = flags;
+    dp.eps = eps;
+    const long long blocks = (long long)dp.n_rt16 * out->n_outer;
+    hipLaunchKernelGGL(dense_order_layer_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error(std::string("dense_order_layer_kernel launch: ") + hipGetErrorString(e));
+        return ULTRA_ERR_HIP;
+    }
+    return ULTRA_OK;
+}
+
+}  // namespace ultra

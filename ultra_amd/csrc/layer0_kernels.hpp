@@ -17,6 +17,7 @@
 #include <cstdint>
 
 #include "rspmm_kernels.hpp"
+#include "torch_math.hpp"
 
 namespace ultra {
 
@@ -58,23 +59,28 @@ __device__ __forceinline__ L0Vec l0_load_vectors(const Layer0Params &p, int l16)
     return v;
 }
 
-__device__ __forceinline__ void l0_finish(float (&y)[4], const Layer0Params &p, const L0Vec &vec) {
+// LayerNorm (the reference's operation order, torch_math.hpp) and ReLU of a row held by a 16-lane group, feature
+// 4 l16 + e in register e.  `slot` = 64 + 16 floats of LDS private to the group: the row is parked there, lanes 0..7 run
+// the Welford accumulator i = l16 over features 8 j + i, every lane merges the eight (LDS operations of one wave
+// execute in order: no barrier between the group's writes and reads).
+__device__ __forceinline__ void l0_finish(float (&y)[4], const Layer0Params &p, const L0Vec &vec, float *slot, const int l16) {
     if (p.flags & L0_LN) {
-        float s = (y[0] + y[1]) + (y[2] + y[3]);
+        *reinterpret_cast<float4 *>(slot + 4 * l16) = make_float4(y[0], y[1], y[2], y[3]);
+        float xv[8];
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
-        const float mean = s * (1.f / 64.f);
-        float qv = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float d = y[e] - mean;
-            qv += d * d;
+        for (int j = 0; j < 8; ++j) xv[j] = slot[8 * j + (l16 & 7)];
+        const Moments w = welford8(xv);
+        if (l16 < 8) {
+            slot[64 + 2 * l16] = w.m1;
+            slot[64 + 2 * l16 + 1] = w.m2;
         }
+        Moments all[8];
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) qv += __shfl_xor(qv, off, 16);
-        const float rstd = 1.f / sqrtf(qv * (1.f / 64.f) + p.eps);
+        for (int i = 0; i < 8; ++i) all[i] = Moments{slot[64 + 2 * i], slot[64 + 2 * i + 1]};
+        float mean, rstd;
+        merge8(all, p.eps, mean, rstd);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = (y[e] - mean) * rstd * vec.ln_w[e] + vec.ln_b[e];
+        for (int e = 0; e < 4; ++e) y[e] = ln_apply(y[e], mean, rstd, vec.ln_w[e], vec.ln_b[e]);
     }
     if (p.flags & L0_RELU) {
 #pragma unroll
@@ -84,12 +90,13 @@ __device__ __forceinline__ void l0_finish(float (&y)[4], const Layer0Params &p, 
 
 // out[b, n, :] = c0 = relu(LayerNorm(bias)) for every row: what the layer makes of x0 = agg = 0.
 __global__ void __launch_bounds__(256) nbf_layer0_fill_kernel(const Layer0Params p) {
+    __shared__ __attribute__((aligned(16))) float lds_slot[16 * 80];   // one (64 + 16)-float slot per 16-lane group
     const int l16 = threadIdx.x & 15;
     const L0Vec vec = l0_load_vectors(p, l16);
     float c0[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) c0[e] = vec.bias[e];
-    l0_finish(c0, p, vec);
+    for (int e = 0; e < 4; ++e) c0[e] = vec.bias[e];   // W . 0 + bias
+    l0_finish(c0, p, vec, lds_slot + (threadIdx.x >> 4) * 80, l16);
     const float4 v = make_float4(c0[0], c0[1], c0[2], c0[3]);
     if (p.out_sr == 64 && p.out_so == p.num_node * 64) {
         // contiguous output: a plain 16-byte stream; the stride is a multiple of 16 chunks, so a thread always writes
@@ -114,7 +121,7 @@ __global__ void __launch_bounds__(256) nbf_layer0_fill_kernel(const Layer0Params
 // is read back as 16-byte broadcasts, so the 64-term dot products are plain unrolled FMAs on pipelined LDS reads.
 __global__ void __launch_bounds__(1024) nbf_layer0_rows_kernel(const Layer0Params p) {
     __shared__ __attribute__((aligned(16))) float lds_wt[128 * 64];
-    __shared__ __attribute__((aligned(16))) float lds_vec[64 * 64];   // one 64-vector per group
+    __shared__ __attribute__((aligned(16))) float lds_vec[64 * 80];   // one 64-vector (+ 16 LayerNorm moments) per group
     const int outer = blockIdx.y;
     const int l16 = threadIdx.x & 15;
     const int grp = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
@@ -142,13 +149,13 @@ __global__ void __launch_bounds__(1024) nbf_layer0_rows_kernel(const Layer0Param
     __syncthreads();
     const float *relb = reinterpret_cast<const float *>(p.rel.ptr) + outer * p.rel.stride_outer;
     float *outb = p.out + outer * p.out_so;
-    float *slot = lds_vec + (threadIdx.x >> 4) * 64;
+    float *slot = lds_vec + (threadIdx.x >> 4) * 80;
 
-    // y = bias + W[:, :64] . x + W[:, 64:] . agg for this group's row; x = q on the source row, 0 elsewhere
+    // y = (W[:, :64] . x + W[:, 64:] . agg) + bias for this group's row; x = q on the source row, 0 elsewhere.  One fmaf
+    // chain per output over k = 0..127, bias added last: the reference's nn.Linear order (torch_math.hpp); the terms of
+    // an all-zero x are exact zeros and are skipped.
     const auto update_row = [&](const float (&agg)[4], bool is_src, long long row) {
-        float y[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = vec.bias[e];
+        float y[4] = {0.f, 0.f, 0.f, 0.f};
         if (is_src) {   // once per sample: the input half of W
             *reinterpret_cast<float4 *>(slot + 4 * l16) = make_float4(qv[0], qv[1], qv[2], qv[3]);
 #pragma unroll
@@ -158,10 +165,10 @@ __global__ void __launch_bounds__(1024) nbf_layer0_rows_kernel(const Layer0Param
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float4 wv = *reinterpret_cast<const float4 *>(lds_wt + (4 * k4 + e) * 64 + 4 * l16);
-                    y[0] += wv.x * xs[e];
-                    y[1] += wv.y * xs[e];
-                    y[2] += wv.z * xs[e];
-                    y[3] += wv.w * xs[e];
+                    y[0] = __builtin_fmaf(xs[e], wv.x, y[0]);
+                    y[1] = __builtin_fmaf(xs[e], wv.y, y[1]);
+                    y[2] = __builtin_fmaf(xs[e], wv.z, y[2]);
+                    y[3] = __builtin_fmaf(xs[e], wv.w, y[3]);
                 }
             }
         }
@@ -173,13 +180,15 @@ __global__ void __launch_bounds__(1024) nbf_layer0_rows_kernel(const Layer0Param
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float4 wv = *reinterpret_cast<const float4 *>(lds_wt + (64 + 4 * k4 + e) * 64 + 4 * l16);
-                y[0] += wv.x * as[e];
-                y[1] += wv.y * as[e];
-                y[2] += wv.z * as[e];
-                y[3] += wv.w * as[e];
+                y[0] = __builtin_fmaf(as[e], wv.x, y[0]);
+                y[1] = __builtin_fmaf(as[e], wv.y, y[1]);
+                y[2] = __builtin_fmaf(as[e], wv.z, y[2]);
+                y[3] = __builtin_fmaf(as[e], wv.w, y[3]);
             }
         }
-        l0_finish(y, p, vec);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] += vec.bias[e];
+        l0_finish(y, p, vec, slot, l16);
         if (is_src && (p.flags & L0_RESIDUAL)) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] += qv[e];

@@ -76,6 +76,25 @@ ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *ty
                 if (cell < 255) ++cell;   // (overflow already flagged above)
             }
         }
+        if (num_rel <= 4 && num_out == num_in && num_out * num_in <= (int64_t(1) << 26)) {
+            // reference-order layer kernel: parallel edges of a (row, col) pair must come in ascending type order
+            // (original edge order = the stable sort's order), each type at most once
+            std::vector<int8_t> last((size_t)(num_out * num_in), (int8_t)-1);
+            bool ok = true;
+            for (int64_t e = 0; e < E && ok; ++e) {
+                int8_t &l = last[(size_t)(row[e] * num_in + col[e])];
+                if (type[e] <= l) ok = false;
+                l = (int8_t)type[e];
+            }
+            if (ok) {
+                const int64_t rt16 = (num_out + 15) / 16, njc = (num_in + 15) / 16;
+                p->a_ex.assign((size_t)(rt16 * njc * 64 * 16), 0);
+                for (int64_t e = 0; e < E; ++e) {
+                    const int64_t rt = row[e] / 16, i = row[e] % 16, jc = col[e] / 16, q = col[e] % 16;
+                    p->a_ex[(size_t)((((rt * njc + jc) * 64) + i + 16 * type[e]) * 16 + q)] = 1;
+                }
+            }
+        }
         p->split_ptr.push_back(0);
         return p;
     }
@@ -371,6 +390,7 @@ int32_t ultra_plan_get_info(const ultra_plan *p, ultra_plan_info *info) {
     info->n_type_run = p->n_type_run;
     info->dense_bytes = (int64_t)p->a_frag.size();
     info->n_chain_row = p->n_chain;
+    info->dense_order_bytes = (int64_t)p->a_ex.size();
     return ULTRA_OK;
 }
 

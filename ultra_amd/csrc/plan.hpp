@@ -58,6 +58,7 @@ struct DevicePlan {
     int32_t *split_row = nullptr, *split_ptr = nullptr;
     uint8_t *a_frag = nullptr;   // ULTRA_PLAN_DENSE
     uint8_t *a16 = nullptr;         // ULTRA_PLAN_DENSE, 16-row tiles (fused layer kernel)
+    uint8_t *a_ex = nullptr;        // ULTRA_PLAN_DENSE, reference-order layer kernel (dense_order_layer.hip)
     uint8_t *self_loop = nullptr;   // per node: has an edge onto itself (layer-0 path)
     void *w_sorted = nullptr;
     size_t w_sorted_bytes = 0;
@@ -104,6 +105,11 @@ struct ultra_plan {
     // [row_tile16][chunk of 16 columns][lane = (row % 16) + 16 (col % 4)][step = (col % 16) / 4][type]; a16_chunks % 8 == 0
     std::vector<uint8_t> a16;
     int32_t a16_chunks = 0;
+    // the adjacency for the reference-order layer kernel (dense_order_layer.hip): [row_tile16][chunk of 16 columns]
+    // [lane = (row % 16) + 16 type][col % 16], one byte (0 / 1) per cell.  Only built when every (row, col) pair lists its
+    // parallel edges in ascending type order without repeats (then the kernel's k-ordered fma chain IS the reference's
+    // summation order); empty otherwise.
+    std::vector<uint8_t> a_ex;
 
     std::vector<uint8_t> self_loop;   // [num_out] built with the edge list (square graphs)
 

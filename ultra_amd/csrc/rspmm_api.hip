@@ -44,6 +44,10 @@ int launch_dense_forward(ultra_plan *p, int sum, int mul, int dtype, const void 
                          const ultra_mat *bnd, const int64_t *bnd_rows, const ultra_mat *out,
                          hipStream_t stream);   // rspmm_dense.hip
 
+int launch_dense_order_layer(ultra_plan *p, const ultra_mat *rel, const ultra_mat *x, const ultra_mat *bnd, const int64_t *bnd_rows,
+                             const void *weight, const void *bias, const void *ln_w, const void *ln_b, float eps, int flags,
+                             const ultra_mat *out, hipStream_t stream);   // dense_order_layer.hip
+
 int launch_dense_layer(ultra_plan *p, const ultra_mat *rel, const ultra_mat *x, const ultra_mat *bnd, const int64_t *bnd_rows,
                        const void *weight, const void *bias, const void *ln_w, const void *ln_b, float eps, int flags,
                        const ultra_mat *out, hipStream_t stream);   // dense_layer.hip
@@ -87,6 +91,7 @@ static int upload_plan(ultra_plan *p) {
     if (p->flags & ULTRA_PLAN_DENSE) {
         if ((rc = upload_array(&p->d.a_frag, p->a_frag))) return rc;
         if (!p->a16.empty() && (rc = upload_array(&p->d.a16, p->a16))) return rc;
+        if (!p->a_ex.empty() && (rc = upload_array(&p->d.a_ex, p->a_ex))) return rc;
         p->d.device = dev;
         p->on_device = true;
         return ULTRA_OK;
@@ -164,6 +169,7 @@ static void free_device(ultra_plan *p) {
     (void)hipFree(p->d.split_ptr);
     if (p->d.a_frag) (void)hipFree(p->d.a_frag);
     if (p->d.a16) (void)hipFree(p->d.a16);
+    if (p->d.a_ex) (void)hipFree(p->d.a_ex);
     if (p->d.self_loop) (void)hipFree(p->d.self_loop);
     if (p->d.w_sorted) (void)hipFree(p->d.w_sorted);
     if (p->d.partial) (void)hipFree(p->d.partial);
@@ -756,6 +762,9 @@ int32_t ultra_nbf_dense_layer(ultra_plan *plan, const ultra_mat *relation, const
     if (boundary && (rc = check_mat(boundary, "boundary", point_rows_dev ? 1 : plan->num_out, n_outer, output->row_len))) return rc;
     if (n_outer == 0 || plan->num_out == 0) return ULTRA_OK;
     if ((rc = upload_plan(plan))) return rc;
+    if (flags & ULTRA_LAYER_REFERENCE_ORDER)
+        return launch_dense_order_layer(plan, relation, input, boundary, point_rows_dev, weight, bias, ln_weight, ln_bias, eps,
+                                        flags & 7, output, reinterpret_cast<hipStream_t>(stream));
     return launch_dense_layer(plan, relation, input, boundary, point_rows_dev, weight, bias, ln_weight, ln_bias, eps, flags,
                               output, reinterpret_cast<hipStream_t>(stream));
 }

@@ -89,6 +89,7 @@ class Plan(object):
         check(lib.ultra_plan_create(ctypes.byref(handle), ei.data_ptr(), et.data_ptr(), self.num_edge, self.num_node,
                                     self.num_in, self.num_relation, ctypes.byref(opts)))
         self._h = handle
+        self.exact = bool(exact_order)
         # Dense graphs with few relation types (ULTRA's relation graph: 474 nodes, 4 types, ~470 edges per
         # (row, type) run) get a twin plan whose items hold one relation each; add_mul forwards use it.
         self.typed = None
@@ -98,13 +99,17 @@ class Plan(object):
         # (Nearly) complete graphs -- again ULTRA's relation graph -- also get a dense-format twin: fp32 add_mul with unit
         # edge weights then runs on the matrix cores (csrc/rspmm_dense.hip).
         cells = self.num_node * self.num_in * max(self.num_relation, 1)
-        if dense in ("auto", True) and not exact_order and self.num_edge > 0 and self.num_in <= _lib.DENSE_MAX_IN_ROW \
+        if dense in ("auto", True) and self.num_edge > 0 and self.num_in <= _lib.DENSE_MAX_IN_ROW \
                 and cells <= (1 << 26) and (dense is True or self.num_edge >= self.DENSE_MIN_FILL * cells):
             try:
                 self.dense = Plan(ei, et, num_node, num_relation, num_in=num_in, type_runs=False, dense="only")
             except _lib.UltraError:     # an edge repeated more than 255 times: the edge walk serves it
                 if dense is True:
                     raise
+            # a reference-order plan only keeps the twin for the reference-order layer kernel (fused_layer), and only
+            # when the graph qualifies for it (parallel edges sorted by type, no repeats, at most 4 types)
+            if exact_order and self.dense is not None and self.dense.info()["dense_order_bytes"] == 0:
+                self.dense = None
         if type_runs in ("auto", True) and not exact_order and self.num_edge > 0:
             runs = max(1, self.info()["n_type_run"])
             if type_runs is True or self.num_edge / runs >= self.TYPE_RUN_MIN_MEAN_LENGTH:
@@ -113,7 +118,7 @@ class Plan(object):
 
     def _twin_for(self, sum, mul, edge_weight, input, *others):
         """The specialised twin plan that serves this call, or None for the general (row, col) plan."""
-        if sum != "add" or mul != "mul":
+        if sum != "add" or mul != "mul" or self.exact:     # (the twins' kernels re-associate the sum)
             return None
         if self.dense is not None and edge_weight is None and input.dtype == torch.float32 \
                 and input.shape[-1] % 32 == 0 and input.dim() in (2, 3) \
@@ -250,7 +255,8 @@ class Plan(object):
                 or input.dtype != torch.float32 or relation.dtype != torch.float32 or tuple(linear.weight.shape) != (64, 128):
             return None
         others = (relation, boundary, point[1] if point is not None else None)
-        if self._twin_for("add", "mul", None, input, *others) is not d:
+        if not all(t is None or (t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and all(st % 4 == 0 for st in t.stride()[:-1]))
+                   for t in (input,) + others):
             return None
         relation, mrel = as_mat(relation)
         input, mx = as_mat(input)
@@ -265,7 +271,8 @@ class Plan(object):
         elif boundary is not None:
             boundary, mbv = as_mat(boundary)
             mb = ctypes.byref(mbv)
-        flags = (1 if layer_norm is not None else 0) | (2 if relu else 0) | (4 if residual else 0)
+        flags = (1 if layer_norm is not None else 0) | (2 if relu else 0) | (4 if residual else 0) \
+            | (_lib.LAYER_REFERENCE_ORDER if self.exact else 0)
         check(lib.ultra_nbf_dense_layer(d._h, ctypes.byref(mrel), ctypes.byref(mx), mb, rows_ptr, linear.weight.data_ptr(),
                                         linear.bias.data_ptr() if linear.bias is not None else None,
                                         layer_norm.weight.data_ptr() if layer_norm is not None else None,
@@ -363,10 +370,13 @@ class Plan(object):
 # ---- plan cache: the graph is static across the 12 rspmm calls of a forward and across batches ----
 _PLAN_CACHE = OrderedDict()
 _PLAN_CACHE_SIZE = 16
-_plan_defaults = {"seg_len": 0, "g_max": 0, "exact_order": False, "type_runs": "auto", "dense": "auto"}
+# Plans built for the operator / module API sum in the reference's order (rspmm.cpp:61-72) by default: scores and
+# rankings then reproduce the reference's.  exact_order=False selects the re-associating plans (split hub rows,
+# type-run / dense-format twins): same sums up to fp32 rounding, a different rounding pattern.
+_plan_defaults = {"seg_len": 0, "g_max": 0, "exact_order": True, "type_runs": "auto", "dense": "auto"}
 
 
-def set_plan_defaults(seg_len=0, g_max=0, exact_order=False, type_runs="auto", dense="auto"):
+def set_plan_defaults(seg_len=0, g_max=0, exact_order=True, type_runs="auto", dense="auto"):
     """Tuning hook: defaults for newly built plans (clears the cache)."""
     _plan_defaults.update(seg_len=seg_len, g_max=g_max, exact_order=exact_order, type_runs=type_runs, dense=dense)
     _PLAN_CACHE.clear()
