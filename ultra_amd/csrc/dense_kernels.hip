@@ -335,27 +335,36 @@ struct RelProjParams {
     int n_layer;
 };
 
+constexpr int RELPROJ_TILES = 4;   // row tiles (16 rows each) per workgroup: the weight fragments are fetched once for all of them
+
 __global__ void __launch_bounds__(256) relation_projection_kernel(const RelProjParams p) {
     constexpr int STRIDE = 68;
-    __shared__ __attribute__((aligned(16))) float x_lds[16 * STRIDE];
-    __shared__ __attribute__((aligned(16))) float h_lds[16 * STRIDE];
+    __shared__ __attribute__((aligned(16))) float x_lds[RELPROJ_TILES][16 * STRIDE];
+    __shared__ __attribute__((aligned(16))) float h_lds[RELPROJ_TILES][16 * STRIDE];
     using f32x4 = float __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kk = lane >> 4;
     const int layer = blockIdx.y;
-    const long long row0 = (long long)blockIdx.x * 16;
+    const long long row_base = (long long)blockIdx.x * (16 * RELPROJ_TILES);
     const float *w0 = p.w0 + (size_t)layer * 64 * 64, *w2 = p.w2 + (size_t)layer * 64 * 64;
-    {
-        const long long row = min(row0 + (tid >> 4), p.rows - 1);
-        *reinterpret_cast<float4 *>(x_lds + (tid >> 4) * STRIDE + 4 * (tid & 15)) =
+#pragma unroll
+    for (int t = 0; t < RELPROJ_TILES; ++t) {
+        const long long row = min(row_base + 16 * t + (tid >> 4), p.rows - 1);
+        *reinterpret_cast<float4 *>(x_lds[t] + (tid >> 4) * STRIDE + 4 * (tid & 15)) =
             *reinterpret_cast<const float4 *>(p.x + row * 64 + 4 * (tid & 15));
     }
-    // A operands: lane (i, kk) holds W[16 wave + i][4 s + kk]
+    // A operands: lane (i, kk) holds W[16 wave + i][4 s + kk]; a lane reads its weight row as 16-byte pieces and keeps
+    // element kk of each
     float a0[16], a2[16];
+    {
+        const float4 *r0 = reinterpret_cast<const float4 *>(w0 + (16 * wave + i16) * 64);
+        const float4 *r2 = reinterpret_cast<const float4 *>(w2 + (16 * wave + i16) * 64);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        a0[s] = w0[(16 * wave + i16) * 64 + 4 * s + kk];
-        a2[s] = w2[(16 * wave + i16) * 64 + 4 * s + kk];
+        for (int s = 0; s < 16; ++s) {
+            const float4 v0 = r0[s], v2 = r2[s];
+            a0[s] = kk == 0 ? v0.x : (kk == 1 ? v0.y : (kk == 2 ? v0.z : v0.w));
+            a2[s] = kk == 0 ? v2.x : (kk == 1 ? v2.y : (kk == 2 ? v2.z : v2.w));
+        }
     }
     const int f0 = 16 * wave + 4 * kk;   // D: lane l, reg r -> feature 16 wave + 4 (l >> 4) + r of tile row l & 15
     float b0v[4], b2v[4];
@@ -365,22 +374,38 @@ __global__ void __launch_bounds__(256) relation_projection_kernel(const RelProjP
         b2v[r] = p.b2[layer * 64 + f0 + r];
     }
     __syncthreads();
-    f32x4 d;
+    // the RELPROJ_TILES chains are independent: interleaved, they fill the 40-cycle latency of a dependent 16x16x4
+    f32x4 d[RELPROJ_TILES];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) d[r] = 0.f;
+    for (int t = 0; t < RELPROJ_TILES; ++t)
 #pragma unroll
-    for (int s = 0; s < 16; ++s) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], x_lds[i16 * STRIDE + 4 * s + kk], d, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) d[t][r] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) h_lds[i16 * STRIDE + f0 + r] = fmaxf(d[r] + b0v[r], 0.f);
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int t = 0; t < RELPROJ_TILES; ++t)
+            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], x_lds[t][i16 * STRIDE + 4 * s + kk], d[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < RELPROJ_TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h_lds[t][i16 * STRIDE + f0 + r] = fmaxf(d[t][r] + b0v[r], 0.f);
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) d[r] = 0.f;
+    for (int t = 0; t < RELPROJ_TILES; ++t)
 #pragma unroll
-    for (int s = 0; s < 16; ++s) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s], h_lds[i16 * STRIDE + 4 * s + kk], d, 0, 0, 0);
-    const long long row = row0 + i16;
-    if (row < p.rows)
-        *reinterpret_cast<float4 *>(p.out + ((size_t)layer * p.rows + row) * 64 + f0) =
-            make_float4(d[0] + b2v[0], d[1] + b2v[1], d[2] + b2v[2], d[3] + b2v[3]);
+        for (int r = 0; r < 4; ++r) d[t][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int t = 0; t < RELPROJ_TILES; ++t)
+            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s], h_lds[t][i16 * STRIDE + 4 * s + kk], d[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < RELPROJ_TILES; ++t) {
+        const long long row = row_base + 16 * t + i16;
+        if (row < p.rows)
+            *reinterpret_cast<float4 *>(p.out + ((size_t)layer * p.rows + row) * 64 + f0) =
+                make_float4(d[t][0] + b2v[0], d[t][1] + b2v[1], d[t][2] + b2v[2], d[t][3] + b2v[3]);
+    }
 }
 
 static int grid_for(long long ntile, int waves_per_block, int blocks_per_cu = 2) {
@@ -559,7 +584,7 @@ int32_t ultra_relation_projection(const void *x, const void *w0, const void *b0,
     p.out = (float *)out;
     p.rows = rows;
     p.n_layer = n_layer;
-    const dim3 grid((unsigned)((rows + 15) / 16), (unsigned)n_layer);
+    const dim3 grid((unsigned)((rows + 16 * RELPROJ_TILES - 1) / (16 * RELPROJ_TILES)), (unsigned)n_layer);
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
     hipLaunchKernelGGL(relation_projection_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
     hipError_t e = hipGetLastError();

@@ -80,8 +80,12 @@ __global__ void __launch_bounds__(256) dense_order_layer_kernel(const DenseOrder
             st.x[q] = *reinterpret_cast<const float *>(xcol + (uint32_t)j * x_row_bytes);
         }
     };
-    Stage cur, nxt;
-    fetch(0, cur);
+    // three stages (48 source columns, ~1,900 cycles of chain) in flight: one wave per SIMD has nothing else to hide an
+    // L2 round trip behind
+    Stage st0, st1, st2;
+    fetch(0, st0);
+    fetch(1, st1);
+    fetch(2, st2);
     const float relv = kk < p.n_rel ? p.rel[(long long)outer * p.rel_so + (long long)kk * p.rel_sr + c0 + i16] : 0.f;
 
     // the tile's own x rows (update input and residual), the update weights of this wave's feature tile and the small
@@ -117,8 +121,7 @@ __global__ void __launch_bounds__(256) dense_order_layer_kernel(const DenseOrder
     f32x4 acc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = 0.f;
-    for (int jc = 0; jc < p.n_jc; ++jc) {
-        fetch(jc + 1, nxt);   // (the last round re-reads itself: harmless)
+    const auto chain = [&](const Stage &cur) {
         const uint32_t aw[4] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w};
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -126,7 +129,16 @@ __global__ void __launch_bounds__(256) dense_order_layer_kernel(const DenseOrder
             const float b = relv * cur.x[q];          // the message, rounded on its own like rspmm.cpp:67
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
         }
-        cur = nxt;
+    };
+    for (int jc = 0; jc < p.n_jc; jc += 3) {   // (rounds past the end re-read the last stage: harmless, never chained)
+        chain(st0);
+        fetch(jc + 3, st0);
+        if (jc + 1 >= p.n_jc) break;
+        chain(st1);
+        fetch(jc + 4, st1);
+        if (jc + 2 >= p.n_jc) break;
+        chain(st2);
+        fetch(jc + 5, st2);
     }
 
     // ---- phase 2: + boundary (layers.py:199-200), aggregate tile and x tile to LDS ----

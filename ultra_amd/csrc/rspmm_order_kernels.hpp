@@ -80,12 +80,16 @@ __device__ __forceinline__ U load_uniform(const U *ptr) {
 }
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-// Loads that sit behind a branch defeat the compiler's vmcnt bookkeeping at the join (it must assume the shorter
-// queue and drains everything), so the walks below issue every load unconditionally: the record streams are padded
-// (ORDER_PAD entries past the last edge are readable), lanes past the end of their row read the NEXT rows' records
-// -- valid node / relation ids -- and their products are discarded by the step predicate.
+// A load that sits behind a branch which re-joins the main path defeats the compiler's vmcnt bookkeeping (at the join
+// it must assume the shorter queue and drains everything).  The walks below therefore never skip a load on a path that
+// re-joins: every "is there more?" test either issues the next chunk's loads and carries on, or finishes the walk on
+// its own exit path.  The record streams are padded (ORDER_PAD entries past the last edge are readable).
 
 // ---- group items: four rows per wave, each walked sequentially by one 16-lane group ----
+// Records come 8 steps at a time (lane l16 holds the record of step base + (l16 & 7)), requested a whole round before
+// use and broadcast inside the group with ds_swizzle; source rows are gathered one 4-step chunk ahead of the chunk
+// being reduced, so 8 rows per lane are in flight.  Steps a group does not have (its row is shorter than the unit's
+// longest) gather row 0 -- an L1 hit -- and are discarded by the step predicate.
 template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED>
 __device__ __forceinline__ Pack<T, 4> walk_row_in_order(const OrderParams &p, const int begin, const int cnt, const int nsteps,
                                                         const int nfull, const int l16, const char *xbase, const char *relbase,
@@ -95,12 +99,29 @@ __device__ __forceinline__ Pack<T, 4> walk_row_in_order(const OrderParams &p, co
     using V = typename VecOf<T, 4>::type;
     V acc = V(nary_zero<T, SUM>());
     const T *wt = reinterpret_cast<const T *>(p.w);
-    const int2 *recs = reinterpret_cast<const int2 *>(p.rec) + begin + l16;
-    const int32_t *perm = p.perm + begin + l16;
+    const int l8 = l16 & 7;
+    const int2 *recs = reinterpret_cast<const int2 *>(p.rec) + begin + l8;
+    const int32_t *perm = p.perm + begin + l8;
 
-    struct Records {   // this lane holds the record of step (batch base + l16) of its group's row
+    struct Records {   // this lane holds the record of step (round base + l8) of its group's row
         int c, t;
         T w;
+    };
+    // raw = as loaded (a step past the row's end holds a neighbouring row's record); promote() masks those to node 0
+    const auto load_records = [&](const int k0, int &pm) {
+        Records r;
+        const int2 ct = recs[k0];
+        r.c = ct.x, r.t = ct.y, r.w = T(1);
+        if (WEIGHTED) {
+            r.w = wt[pm];           // pm: original edge id, requested one round earlier (w[perm[.]] is a dependent load)
+            pm = perm[k0 + 8];
+        }
+        return r;
+    };
+    const auto promote = [&](const Records &raw, const int k0) {
+        Records r = raw;
+        r.c = (k0 + l8 < cnt) ? raw.c : 0;
+        return r;
     };
     struct Fetched {   // one chunk = 4 consecutive steps
         int t[4];
@@ -156,44 +177,30 @@ __device__ __forceinline__ Pack<T, 4> walk_row_in_order(const OrderParams &p, co
     };
 
     if (nsteps > 0) {
-        Records cur, nxt;
-        int pm = 0;   // WEIGHTED: original edge id of the record two batches ahead (w[perm[.]] is a dependent load)
-        {
-            const int2 a = recs[0], b = recs[16];
-            cur.c = a.x, cur.t = a.y, nxt.c = b.x, nxt.t = b.y;
-            cur.w = nxt.w = T(1);
-            if (WEIGHTED) {
-                const int pa = perm[0], pb = perm[16];
-                pm = perm[32];
-                cur.w = wt[pa];
-                nxt.w = wt[pb];
-            }
-        }
+        int pm = 0;
+        if (WEIGHTED) pm = perm[0];
+        Records nxt_raw = load_records(0, pm);
+        Records cur = promote(nxt_raw, 0);
+        nxt_raw = load_records(8, pm);
         Fetched fa, fb;
         fetch(StepTag<0>{}, fa, cur);
-        // Steady state: the gathers of chunk i + 1 are issued before chunk i is reduced (8 source rows in flight per
-        // lane).  Two exits per 16-step batch, straight-line code between them; a walk that ends inside a half reduces
-        // the rest of it under the step predicate and leaves one chunk of speculative gathers behind.
-        for (int kb = 0;; kb += 16) {
-            fetch(StepTag<4>{}, fb, cur);
-            reduce(fa, kb);
-            fetch(StepTag<8>{}, fa, cur);
-            reduce(fb, kb + 4);
-            if (kb + 8 >= nsteps) break;
-            fetch(StepTag<12>{}, fb, cur);
-            reduce(fa, kb + 8);
-            cur = nxt;
-            {
-                const int2 b = recs[kb + 32];       // requested a whole batch before its first use
-                nxt.c = b.x, nxt.t = b.y;
-                if (WEIGHTED) {
-                    nxt.w = wt[pm];
-                    pm = perm[kb + 48];
-                }
+        for (int kb = 0;; kb += 8) {
+            if (kb + 4 < nsteps) {
+                fetch(StepTag<4>{}, fb, cur);
+                reduce(fa, kb);
+            } else {
+                compute(std::true_type{}, fa, kb);
+                break;
             }
-            fetch(StepTag<0>{}, fa, cur);
-            reduce(fb, kb + 12);
-            if (kb + 16 >= nsteps) break;
+            if (kb + 8 < nsteps) {
+                cur = promote(nxt_raw, kb + 8);
+                nxt_raw = load_records(kb + 16, pm);       // requested a whole round before its first use
+                fetch(StepTag<0>{}, fa, cur);
+                reduce(fb, kb + 4);
+            } else {
+                compute(std::true_type{}, fb, kb + 4);
+                break;
+            }
         }
     }
     return to_pack<T, 4>(acc);

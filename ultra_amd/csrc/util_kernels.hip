@@ -11,10 +11,25 @@
 
 namespace ultra {
 
+// Streaming copy, 16 B per lane: eight loads in flight per lane before the first store (one wave keeps 8 KiB moving), the
+// grid strides in 8-chunk blocks so that a wave's eight requests are eight consecutive 1-KiB lines.
 __global__ void __launch_bounds__(256) stream_copy_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst,
                                                           long long n16) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x)
-        dst[i] = src[i];
+    constexpr int U = 8;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 *s4 = reinterpret_cast<const f4 *>(src);
+    f4 *d4 = reinterpret_cast<f4 *>(dst);
+    const long long stride = (long long)gridDim.x * blockDim.x * U;
+    long long base = ((long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) * U + (threadIdx.x & 63);
+    for (; base + (U - 1) * 64 < n16; base += stride) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(s4 + base + u * 64);
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(v[u], d4 + base + u * 64);
+    }
+    for (int u = 0; u < U; ++u)       // ragged tail of the last block
+        if (base + u * 64 < n16) dst[base + u * 64] = src[base + u * 64];
 }
 
 // out[b, n, :] = (n == rows[b]) ? values[b, :] (or 1 when values == NULL) : 0 -- the NBFNet boundary condition
