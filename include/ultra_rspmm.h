@@ -125,6 +125,11 @@ int32_t ultra_plan_create(ultra_plan **plan, const int64_t *edge_index_host, con
 /* Copy the plan arrays to the current HIP device (idempotent). */
 int32_t ultra_plan_upload(ultra_plan *plan);
 int32_t ultra_plan_destroy(ultra_plan *plan);
+/* delta = +1 / -1: a captured hipGraph starts / stops referencing this plan's device arrays.  While pinned, a call that
+ * would have to re-allocate one of the plan's scratch buffers (general-walk plans only: per-call weights in sorted order,
+ * partial sums of split rows) fails with ULTRA_ERR_INVALID instead of freeing memory the graph still reads.
+ * ULTRA_PLAN_EXACT_ORDER plans own no scratch. */
+int32_t ultra_plan_pin(ultra_plan *plan, int32_t delta);
 int32_t ultra_plan_get_info(const ultra_plan *plan, ultra_plan_info *info);
 
 /* Host-side introspection (tests, tooling): copies array `which` into dst, returns element count via *count. */

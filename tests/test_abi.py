@@ -77,3 +77,38 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libultra_amd.so"))
     with pytest.raises(ImportError, match="no CPU or PyTorch fallback"):
         _lib._load()
+
+
+def test_torch_binding_has_the_reference_extension_surface():
+    """The pybind11 module `rspmm` (csrc/torch_binding/rspmm.cpp, a shim over the C ABI) exports the names of
+    /root/reference/ultra/rspmm/source/rspmm.cpp:256-283 with the same Tensor signatures -- checked against the
+    reference's own compiled module (oracle/_ref) where that is present -- so the unchanged wrapper
+    ultra/rspmm/rspmm.py can load it.  No GPU needed: the engine library is opened lazily, CPU calls raise."""
+    import torch
+    from ultra_amd import build
+    mod = build.load_torch_binding()
+    sig = {}
+    for s in ("add", "min", "max"):
+        for m in ("mul", "add"):
+            for d, n_arg, ret in (("forward", 5, "torch.Tensor"),
+                                  ("backward", 7, "tuple[torch.Tensor, torch.Tensor, torch.Tensor]")):
+                for dev in ("cpu", "cuda"):
+                    name = "rspmm_%s_%s_%s_%s" % (s, m, d, dev)
+                    fn = getattr(mod, name)
+                    doc = fn.__doc__.splitlines()[0]
+                    assert doc.count("torch.Tensor") >= n_arg, doc
+                    assert doc.split("->")[1].strip().replace("Tuple", "tuple") == ret, doc
+                    sig[name] = doc.split("(", 1)[1]
+    from oracle import build_ref
+    if build_ref.available():
+        ref = build_ref.load()
+        ref_names = sorted(n for n in dir(ref) if n.startswith("rspmm_"))
+        assert ref_names == sorted(n for n in sig if n.endswith("_cpu"))          # built without CUDA_OP: the 12 cpu exports
+        for n in ref_names:
+            assert getattr(ref, n).__doc__.splitlines()[0].split("(", 1)[1].replace("Tuple", "tuple") == sig[n].replace("Tuple", "tuple")
+            assert sig[n] == sig[n.replace("_cpu", "_cuda")]
+    x = torch.zeros(3, 4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        mod.rspmm_add_mul_forward_cpu(torch.zeros(2, 0, dtype=torch.long), torch.zeros(0, dtype=torch.long), torch.zeros(0), x, x)
+    with pytest.raises(RuntimeError, match="same GPU"):      # reference: checkAllSameGPU (rspmm.cu:225)
+        mod.rspmm_add_mul_forward_cuda(torch.zeros(2, 0, dtype=torch.long), torch.zeros(0, dtype=torch.long), torch.zeros(0), x, x)

@@ -90,3 +90,37 @@ def test_graph_replay_stays_correct_when_interleaved_with_eager_work(dev):
     a = ueval.evaluate(model, data, batch_size=8, max_triples=256, use_graph=True)
     b = ueval.evaluate(model, data, batch_size=8, max_triples=256, use_graph=False)
     assert a == b
+
+
+def test_graph_survives_plan_cache_eviction_and_weight_updates(dev):
+    """A captured forward holds raw pointers into its plans and into cached weight stacks: it keeps (and pins) the plans
+    while the LRU plan cache turns over, and re-captures when a parameter is updated in place."""
+    from tests.test_oracle_model import load_golden
+    from ultra_amd import models, rspmm, synthetic, tasks
+    from ultra_amd.graph import GraphedForward
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    data = synthetic.make_kg(num_node=2000, num_triple=16000, num_relation_base=9, num_test=64, seed=7).to(dev)
+    model = models.Ultra(**cfg)
+    model.load_state_dict(state)
+    model = model.to(dev).eval()
+    t_batch, _ = tasks.all_negative(data, data.target_triples[:8])
+    with torch.no_grad():
+        graphed = GraphedForward(model, data, t_batch)
+        want = model(data, t_batch).clone()
+        assert torch.equal(graphed(t_batch), want)
+        # 40 other graphs push every plan of `data` out of the 16-entry cache (and their Plan objects are released)
+        for seed in range(40):
+            other = synthetic.make_kg(num_node=50, num_triple=200, num_relation_base=2, num_test=8, seed=100 + seed,
+                                      relation_graph=False).to(dev)
+            rspmm.get_plan(other.edge_index, other.edge_type, 50, 4).forward(
+                torch.randn(4, 64, device=dev), torch.randn(50, 64, device=dev))
+        torch.cuda.synchronize()
+        assert all(p not in rspmm.cached_plans() for p in graphed._pinned)
+        assert torch.equal(graphed(t_batch), want)
+        # an optimizer-style in-place update: the replay must see the new weights (re-capture), not the cached stacks
+        for prm in model.entity_model.layers[0].relation_projection.parameters():
+            prm.mul_(1.05)
+        model.entity_model.mlp[0].weight.add_(0.01)
+        fresh = model(data, t_batch).clone()
+        assert not torch.equal(fresh, want)
+        assert torch.equal(graphed(t_batch), fresh)

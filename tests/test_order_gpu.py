@@ -275,3 +275,34 @@ def test_dense_order_layer_matches_rspmm_plus_update(dev, residual, layer_norm, 
         want = want + x
     scale = want.abs().max().item()
     assert (got - want).abs().max().item() <= 2e-5 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("sum,mul", list(itertools.product(SUMS, MULS)))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("surface", ["ctypes", "pybind"])
+def test_all_twelve_reference_exports(dev, sum, mul, dtype, surface):
+    """rspmm_<sum>_<mul>_{forward,backward}_cuda (rspmm.h:63-105) -- through the ctypes namespace ultra_amd.rspmm.rspmm and
+    through the pybind11 module `rspmm` -- against the oracle: forward bit for bit (the stateless entries build
+    reference-order plans), gradients to 1e-4 relative (rspmm.cpp:77-119 accumulates under mutexes: no order to match)."""
+    from ultra_amd import build, rspmm as R_
+    ns = R_.rspmm if surface == "ctypes" else build.load_torch_binding()
+    case = CASES[1]
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    rel, x, w = helpers.features(N, R, 64, E, dtype=dtype, seed=3)
+    sei, set_, sw, _ = rspmm_oracle.sort_edges(ei, et, w)
+    d = lambda t: t.to(dev)
+    want = rspmm_oracle.rspmm_forward(sei, set_, sw, rel, x, sum=sum, mul=mul)
+    got = getattr(ns, "rspmm_%s_%s_forward_cuda" % (sum, mul))(d(sei), d(set_), d(sw), d(rel), d(x)).cpu()
+    assert torch.equal(got, want)
+    g = torch.Generator().manual_seed(9)
+    og = torch.randn(want.shape, generator=g, dtype=torch.float64).to(dtype)
+    wg, rg, xg = rspmm_oracle.rspmm_backward(sei, set_, sw, rel, x, want, og, sum=sum, mul=mul)
+    gwg, grg, gxg = getattr(ns, "rspmm_%s_%s_backward_cuda" % (sum, mul))(d(sei), d(set_), d(sw), d(rel), d(x), d(want), d(og))
+    tol = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=1e-9, atol=1e-9)
+    torch.testing.assert_close(gxg.cpu(), xg, **tol)
+    torch.testing.assert_close(grg.cpu(), rg, **tol)
+    torch.testing.assert_close(gwg.cpu(), wg, **tol)
+    if surface == "pybind":
+        with pytest.raises(RuntimeError, match="Expect sorted"):
+            ns.rspmm_add_mul_forward_cuda(d(ei), d(et), d(w), d(rel), d(x))

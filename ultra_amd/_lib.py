@@ -78,6 +78,7 @@ def _load():
     lib.ultra_plan_create.argtypes = [ctypes.POINTER(vp), vp, vp, i64, i64, i64, i64, ctypes.POINTER(PlanOpts)]
     lib.ultra_plan_upload.argtypes = [vp]
     lib.ultra_plan_destroy.argtypes = [vp]
+    lib.ultra_plan_pin.argtypes = [vp, i32]
     lib.ultra_plan_get_info.argtypes = [vp, ctypes.POINTER(PlanInfo)]
     lib.ultra_plan_export.argtypes = [vp, i32, vp, i64, ctypes.POINTER(i64)]
     lib.ultra_rspmm_forward.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp]

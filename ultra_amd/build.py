@@ -71,5 +71,47 @@ def build(force=False, verbose=False):
     return LIB
 
 
+BINDING_SRC = os.path.join(CSRC, "torch_binding", "rspmm.cpp")
+BINDING = os.path.join(LIB_DIR, "rspmm.so")
+
+
+def build_torch_binding(force=False):
+    """The pybind11 module `rspmm` (the reference extension's names and Tensor signatures, rspmm.cpp:256-283) as a shim
+    over libultra_amd.so: g++ against torch's headers, no device code.  Output: ultra_amd/lib/rspmm.so."""
+    import sysconfig
+
+    import torch
+    from torch.utils import cpp_extension as ce
+    hdr = os.path.join(INCLUDE, "ultra_rspmm.h")
+    if not force and os.path.exists(BINDING) and os.path.getmtime(BINDING) >= max(os.path.getmtime(BINDING_SRC), os.path.getmtime(hdr)):
+        return BINDING
+    os.makedirs(LIB_DIR, exist_ok=True)
+    inc = []
+    for p in ce.include_paths() + [sysconfig.get_paths()["include"], "/opt/rocm/include"]:
+        inc += ["-isystem", p]
+    libdir = ce.library_paths()[0]
+    cmd = ["g++", "-std=c++17", "-O2", "-shared", "-fPIC", "-w", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=rspmm", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)] + inc + [
+           BINDING_SRC, "-o", BINDING, "-L" + libdir, "-Wl,-rpath," + libdir,
+           "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_python", "-ldl"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("torch binding build failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return BINDING
+
+
+def load_torch_binding():
+    """import the built `rspmm` module (torch must be imported first)."""
+    import importlib.util
+
+    import torch  # noqa: F401
+    spec = importlib.util.spec_from_file_location("rspmm", build_torch_binding())
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_torch_binding(force="--force" in sys.argv))

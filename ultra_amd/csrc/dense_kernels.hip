@@ -19,6 +19,7 @@
 
 #include "../../include/ultra_rspmm.h"
 #include "plan.hpp"
+#include "device_scope.hpp"
 #include "torch_math.hpp"
 
 namespace ultra {
@@ -433,6 +434,7 @@ extern "C" {
 int32_t ultra_conv_update(const void *x, const void *agg, const void *weight, const void *bias, const void *ln_weight,
                           const void *ln_bias, void *out, int64_t rows, int32_t input_dim, int32_t output_dim, float eps,
                           int32_t flags, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream);
     if (input_dim != 64 || output_dim != 64) {
         set_error("ultra_conv_update: only input_dim = output_dim = 64 is built (the ULTRA checkpoints' shape)");
         return ULTRA_ERR_UNSUPPORTED;
@@ -484,6 +486,7 @@ static int check_query_bias(const void *qbias, const void *query, const void *b1
 int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1, const void *qbias, const void *query,
                       const void *b1, const void *w2, const void *b2, void *score, int64_t batch, int64_t num_node,
                       int64_t n_cand, int32_t hidden_dim, int32_t feature_dim, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream);
     if (hidden_dim != 64 || feature_dim != 128) {
         set_error("ultra_readout: only hidden_dim = 64, feature_dim = 128 is built (the ULTRA checkpoints' shape)");
         return ULTRA_ERR_UNSUPPORTED;
@@ -526,6 +529,7 @@ int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const in
                             const void *qbias, const void *query, const void *b1, const void *w2, const void *b2, void *score,
                             int64_t batch, int64_t num_node, int64_t n_cand, int32_t hidden_dim, int32_t feature_dim,
                             void *stream) {
+    ULTRA_DEVICE_SCOPE(stream);
     if (hidden_dim != 64 || feature_dim != 128) {
         set_error("ultra_readout_batch: only hidden_dim = 64, feature_dim = 128 is built (the ULTRA checkpoints' shape)");
         return ULTRA_ERR_UNSUPPORTED;
@@ -566,6 +570,7 @@ int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const in
 
 int32_t ultra_relation_projection(const void *x, const void *w0, const void *b0, const void *w2, const void *b2, void *out,
                                   int64_t rows, int32_t n_layer, int32_t dim, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream);
     if (dim != 64) {
         set_error("ultra_relation_projection: only dim = 64 is built (the ULTRA checkpoints' shape)");
         return ULTRA_ERR_UNSUPPORTED;

@@ -117,6 +117,7 @@ struct ultra_plan {
     std::vector<int32_t> h_row, h_col, h_type;
 
     bool on_device = false;
+    int32_t pinned = 0;     // > 0: a captured hipGraph holds this plan's device pointers -- scratch buffers must not move
     ultra::DevicePlan d;
 
     // backward plans (built on first use):

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "device_scope.hpp"
 #include "layer0_kernels.hpp"
 #include "rspmm_bwd_kernels.hpp"
 #include "rspmm_kernels.hpp"
@@ -84,9 +85,14 @@ static int upload_array(V **dst, const std::vector<V> &src) {
 }
 
 static int upload_plan(ultra_plan *p) {
-    if (p->on_device) return ULTRA_OK;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
+    if (p->on_device) {
+        if (p->d.device != dev)
+            return invalid("the plan was uploaded to device " + std::to_string(p->d.device) + " but this call runs on device " +
+                           std::to_string(dev) + " (operands / stream of another GPU): build one plan per device");
+        return ULTRA_OK;
+    }
     int rc;
     if (p->flags & ULTRA_PLAN_DENSE) {
         if ((rc = upload_array(&p->d.a_frag, p->a_frag))) return rc;
@@ -177,8 +183,11 @@ static void free_device(ultra_plan *p) {
     p->on_device = false;
 }
 
-static int ensure_scratch(void **buf, size_t *have, size_t need) {
+static int ensure_scratch(void **buf, size_t *have, size_t need, const ultra_plan *owner = nullptr) {
     if (need <= *have) return ULTRA_OK;
+    if (owner && owner->pinned > 0 && *buf)
+        return invalid("this plan's scratch buffer is referenced by a captured hipGraph (ultra_plan_pin) and the call needs a "
+                       "larger one: use a separate plan, or release the graph first");
     if (*buf) HIP_TRY(hipFree(*buf));  // implicit device sync: no in-flight kernel still reads it
     *buf = nullptr;
     *have = 0;
@@ -364,7 +373,7 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
 
     // per-call edge weights -> sorted order
     if (w && p->num_edge > 0) {
-        if ((rc = ensure_scratch(&p->d.w_sorted, &p->d.w_sorted_bytes, (size_t)p->num_edge * esz))) return rc;
+        if ((rc = ensure_scratch(&p->d.w_sorted, &p->d.w_sorted_bytes, (size_t)p->num_edge * esz, p))) return rc;
         const int blocks = (int)std::min<int64_t>((p->num_edge + 255) / 256, 4096);
         if (dtype == ULTRA_F32)
             hipLaunchKernelGGL(permute_weight_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float *)w,
@@ -376,7 +385,7 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
         fp.w_sorted = p->d.w_sorted;
     }
     if (p->n_slot > 0) {
-        if ((rc = ensure_scratch(&p->d.partial, &p->d.partial_bytes, (size_t)p->n_slot * n_outer * row_len * esz)))
+        if ((rc = ensure_scratch(&p->d.partial, &p->d.partial_bytes, (size_t)p->n_slot * n_outer * row_len * esz, p)))
             return rc;
         fp.partial = p->d.partial;
     }
@@ -686,7 +695,10 @@ static int stateless_plan(ultra_plan **plan, const int64_t *ei_dev, const int64_
             }
         }
     }
-    return ultra_plan_create(plan, ei.data(), et.data(), E, N, N, R, nullptr);
+    ultra_plan_opts opts;
+    std::memset(&opts, 0, sizeof(opts));
+    opts.flags = ULTRA_PLAN_EXACT_ORDER;      // the reference's summation order (rspmm.cpp:61-72)
+    return ultra_plan_create(plan, ei.data(), et.data(), E, N, N, R, &opts);
 }
 
 }  // namespace ultra
@@ -706,6 +718,14 @@ int32_t ultra_plan_upload(ultra_plan *plan) {
     return upload_plan(plan);
 }
 
+int32_t ultra_plan_pin(ultra_plan *plan, int32_t delta) {
+    if (!plan) return invalid("plan is NULL");
+    plan->pinned += delta;
+    if (plan->tplan) plan->tplan->pinned += delta;
+    if (plan->rplan) plan->rplan->pinned += delta;
+    return ULTRA_OK;
+}
+
 int32_t ultra_plan_destroy(ultra_plan *plan) {
     if (!plan) return ULTRA_OK;
     if (plan->tplan) ultra_plan_destroy(plan->tplan);
@@ -718,6 +738,7 @@ int32_t ultra_plan_destroy(ultra_plan *plan) {
 int32_t ultra_rspmm_forward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype, const void *edge_weight_dev,
                             const ultra_mat *relation, const ultra_mat *input, const ultra_mat *boundary,
                             const ultra_mat *output, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream);
     if (mul < 0 || mul > 1) return invalid("unknown mul code");
     return forward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, boundary, output,
                         reinterpret_cast<hipStream_t>(stream));
@@ -726,6 +747,7 @@ int32_t ultra_rspmm_forward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t 
 int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t mul, int32_t dtype, const void *edge_weight_dev,
                                   const ultra_mat *relation, const ultra_mat *input, const int64_t *point_rows_dev,
                                   const ultra_mat *point_values, const ultra_mat *output, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream);
     if (mul < 0 || mul > 1) return invalid("unknown mul code");
     if (!point_rows_dev || !point_values) return invalid("ultra_rspmm_forward_point: NULL point boundary");
     return forward_impl(plan, ULTRA_SUM_ADD, mul, dtype, edge_weight_dev, relation, input, point_values, output,
@@ -735,6 +757,7 @@ int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t mul, int32_t dtype, 
 int32_t ultra_rspmm_forward_onehot(ultra_plan *plan, int32_t dtype, const void *edge_weight_dev,
                                    const ultra_mat *relation, const ultra_mat *input, const int64_t *src_rows_dev,
                                    const ultra_mat *boundary, const ultra_mat *output, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream);
     return forward_onehot_impl(plan, dtype, edge_weight_dev, relation, input, src_rows_dev, boundary, output,
                                reinterpret_cast<hipStream_t>(stream));
 }
@@ -742,6 +765,7 @@ int32_t ultra_rspmm_forward_onehot(ultra_plan *plan, int32_t dtype, const void *
 int32_t ultra_nbf_layer0(ultra_plan *plan, const void *edge_weight_dev, const ultra_mat *relation, const int64_t *src_rows_dev,
                          const void *src_values_dev, const void *weight, const void *bias, const void *ln_weight,
                          const void *ln_bias, float eps, int32_t flags, const ultra_mat *output, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream);
     return layer0_impl(plan, edge_weight_dev, relation, src_rows_dev, src_values_dev, weight, bias, ln_weight, ln_bias, eps,
                        flags, output, reinterpret_cast<hipStream_t>(stream));
 }
@@ -749,6 +773,7 @@ int32_t ultra_nbf_layer0(ultra_plan *plan, const void *edge_weight_dev, const ul
 int32_t ultra_nbf_dense_layer(ultra_plan *plan, const ultra_mat *relation, const ultra_mat *input, const ultra_mat *boundary,
                               const int64_t *point_rows_dev, const void *weight, const void *bias, const void *ln_weight,
                               const void *ln_bias, float eps, int32_t flags, const ultra_mat *output, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream);
     if (!plan) return invalid("plan is NULL");
     (void)hipGetLastError();
     if (!output || !output->ptr || !weight) return invalid("ultra_nbf_dense_layer: NULL operand");
@@ -773,6 +798,7 @@ int32_t ultra_rspmm_backward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t
                              const ultra_mat *relation, const ultra_mat *input, const ultra_mat *output,
                              const ultra_mat *output_grad, void *weight_grad_dev, const ultra_mat *relation_grad,
                              const ultra_mat *input_grad, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream);
     return backward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, output, output_grad, weight_grad_dev,
                          relation_grad, input_grad, reinterpret_cast<hipStream_t>(stream));
 }
@@ -781,6 +807,7 @@ int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, in
                                   const void *edge_weight_dev, const ultra_mat *relation, const ultra_mat *input,
                                   const ultra_mat *boundary, const int64_t *point_rows_dev, const ultra_mat *output,
                                   void *stream, int32_t warmup, int32_t iters, float *ms_per_call, float *ms_main_kernel) {
+    ULTRA_DEVICE_SCOPE(stream);
     if (mul < 0 || mul > 1) return invalid("unknown mul code");
     const auto once = [&]() {
         return forward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, boundary, output,
@@ -895,6 +922,7 @@ int32_t ultra_get_tuning(ultra_tuning *t) {
         const int64_t *edge_index_dev, const int64_t *edge_type_dev, const void *edge_weight_dev,                    \
         const void *relation_dev, const void *input_dev, void *output_dev, int64_t num_edge, int64_t num_node,       \
         int64_t num_relation, int64_t dim, int32_t dtype, void *stream) {                                            \
+        ULTRA_DEVICE_SCOPE(stream);                                                                                  \
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);                                                       \
         ultra_plan *plan = nullptr;                                                                                  \
         int rc = stateless_plan(&plan, edge_index_dev, edge_type_dev, num_edge, num_node, num_relation, s);         \
@@ -911,6 +939,7 @@ int32_t ultra_get_tuning(ultra_tuning *t) {
         const void *relation_dev, const void *input_dev, const void *output_dev, const void *output_grad_dev,        \
         void *weight_grad_dev, void *relation_grad_dev, void *input_grad_dev, int64_t num_edge, int64_t num_node,    \
         int64_t num_relation, int64_t dim, int32_t dtype, void *stream) {                                            \
+        ULTRA_DEVICE_SCOPE(stream);                                                                                  \
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);                                                       \
         ultra_plan *plan = nullptr;                                                                                  \
         int rc = stateless_plan(&plan, edge_index_dev, edge_type_dev, num_edge, num_node, num_relation, s);         \

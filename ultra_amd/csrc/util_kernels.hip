@@ -8,6 +8,7 @@
 
 #include "../../include/ultra_rspmm.h"
 #include "plan.hpp"
+#include "device_scope.hpp"
 
 namespace ultra {
 
@@ -118,6 +119,7 @@ __global__ void __launch_bounds__(256) onehot_rows_kernel(float4 *__restrict__ o
 
 extern "C" int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void *values, int64_t batch, int64_t num_node,
                                      int64_t dim, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream);
     if (!out || !rows || batch < 0 || num_node < 0 || dim <= 0 || (dim & 3)) {
         ultra::set_error("ultra_onehot_rows: NULL operand or dim not a multiple of 4");
         return ULTRA_ERR_INVALID;
@@ -141,6 +143,7 @@ extern "C" int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void 
 extern "C" int32_t ultra_query_boundary(void *out, void *query_out, const int64_t *rows, const void *table,
                                         const int64_t *pick, int64_t batch, int64_t num_node, int64_t table_rows, int64_t dim,
                                         const void *w1, const void *b1, void *qbias_out, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream);
     if (!query_out || !rows || !table || !pick || batch < 0 || num_node <= 0 || table_rows <= 0 || dim <= 0 || (dim & 3)) {
         ultra::set_error("ultra_query_boundary: NULL operand, empty graph or dim not a multiple of 4");
         return ULTRA_ERR_INVALID;
@@ -163,6 +166,7 @@ extern "C" int32_t ultra_query_boundary(void *out, void *query_out, const int64_
 }
 
 extern "C" int32_t ultra_stream_copy(void *dst, const void *src, int64_t bytes, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream);
     if (!dst || !src || bytes < 0 || (bytes & 15)) {
         ultra::set_error("ultra_stream_copy: NULL pointer or size not a multiple of 16");
         return ULTRA_ERR_INVALID;

@@ -11,8 +11,9 @@ from ._lib import check, lib
 CONV_LAYER_NORM, CONV_RELU, CONV_RESIDUAL = 1, 2, 4
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(t):
+    """The current HIP stream of the operand's device (the C entry points make that device current for the launch)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
 def conv_update_supported(layer, input, update):
@@ -37,7 +38,7 @@ def conv_update(layer, input, update, residual):
                                 bias.data_ptr() if bias is not None else None,
                                 ln.weight.data_ptr() if ln is not None else None,
                                 ln.bias.data_ptr() if ln is not None else None,
-                                out.data_ptr(), rows, 64, 64, float(ln.eps) if ln is not None else 1e-5, flags, _stream()))
+                                out.data_ptr(), rows, 64, 64, float(ln.eps) if ln is not None else 1e-5, flags, _stream(x)))
     return out
 
 
@@ -72,12 +73,12 @@ def readout(model, hidden, query, t_index, qbias=None):
     _keep_qb, _keep_q, qargs = _query_bias_args(mlp, query, qbias)
     hidden = hidden.contiguous()
     batch, num_node = hidden.shape[:2]
-    t_index = t_index.contiguous()
+    t_index = t_index.to(torch.int64).contiguous()      # the kernel reads int64 ids (an int32 batch would be misread)
     n_cand = t_index.shape[1]
     score = torch.empty(batch, n_cand, dtype=hidden.dtype, device=hidden.device)
     check(lib.ultra_readout(hidden.data_ptr(), t_index.data_ptr(), w1.data_ptr(), *qargs,
                             mlp[2].weight.data_ptr(), mlp[2].bias.data_ptr(), score.data_ptr(), batch, num_node, n_cand,
-                            64, 128, _stream()))
+                            64, 128, _stream(hidden)))
     return score
 
 
@@ -90,7 +91,7 @@ def batch_prologue(batch, num_direct_rel):
     side = torch.empty(bs, dtype=torch.int32, device=batch.device)
     valid = torch.empty(bs, dtype=torch.int32, device=batch.device)
     check(lib.ultra_batch_prologue(batch.data_ptr(), bs, n_cand, int(num_direct_rel), h0.data_ptr(), r0.data_ptr(),
-                                   side.data_ptr(), valid.data_ptr(), _stream()))
+                                   side.data_ptr(), valid.data_ptr(), _stream(batch)))
     return batch, h0, r0, side, valid
 
 
@@ -105,7 +106,7 @@ def readout_batch(model, hidden, query, batch, side, qbias=None):
     score = torch.empty(bs, n_cand, dtype=hidden.dtype, device=hidden.device)
     check(lib.ultra_readout_batch(hidden.data_ptr(), batch.data_ptr(), side.data_ptr(), w1.data_ptr(), *qargs,
                                   mlp[2].weight.data_ptr(), mlp[2].bias.data_ptr(), score.data_ptr(), bs, num_node, n_cand,
-                                  64, 128, _stream()))
+                                  64, 128, _stream(hidden)))
     return score
 
 
@@ -121,7 +122,7 @@ def onehot_boundary(index, values, num_node, dim):
     index = index.to(torch.int64).contiguous()
     values = values.contiguous() if values is not None else None     # (kept referenced until the launch is enqueued)
     check(lib.ultra_onehot_rows(out.data_ptr(), index.data_ptr(), values.data_ptr() if values is not None else None, batch,
-                                num_node, dim, _stream()))
+                                num_node, dim, _stream(out)))
     return out
 
 
@@ -146,7 +147,7 @@ def query_boundary(h_index, relation_representations, r_index, num_node, readout
     pick = r_index.to(torch.int64).contiguous()
     check(lib.ultra_query_boundary(boundary.data_ptr() if materialize else None, query.data_ptr(), rows.data_ptr(),
                                    table.data_ptr(), pick.data_ptr(), bs, num_node, num_rel,
-                                   dim, w1, b1, qbias.data_ptr() if qbias is not None else None, _stream()))
+                                   dim, w1, b1, qbias.data_ptr() if qbias is not None else None, _stream(table)))
     return boundary, query, qbias
 
 
@@ -157,5 +158,5 @@ def relation_projection(x, w0, b0, w2, b2):
     n_layer = w0.shape[0]
     out = torch.empty((n_layer,) + tuple(x.shape), dtype=torch.float32, device=x.device)
     check(lib.ultra_relation_projection(x.data_ptr(), w0.data_ptr(), b0.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-                                        out.data_ptr(), rows, n_layer, 64, _stream()))
+                                        out.data_ptr(), rows, n_layer, 64, _stream(x)))
     return out

@@ -16,7 +16,7 @@ import math
 import torch
 
 from . import distributed as udist
-from . import tasks
+from . import models, tasks
 
 
 def metrics_from_rankings(ranking, num_negative, metric_names):
@@ -71,7 +71,8 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
                 from .graph import GraphedForward
                 try:
                     graphed = GraphedForward(model, test_data, t_batch)
-                except RuntimeError:       # model outside the fused inference path: stay eager
+                except models.NotOnFusedPath:       # model outside the fused inference path: stay eager
+                    torch.cuda.synchronize()
                     use_graph = False
             if graphed is not None:
                 t_pred = graphed(t_batch).clone()

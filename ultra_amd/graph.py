@@ -1,13 +1,21 @@
 """hipGraph capture of the inference forward.
 
-The forward of one batch is ~30 short launches (layer-0 kernels, 5 rspmm + fix-ups + updates on the entity
-graph, 5 fused relation-graph layers, prologue, projections, readout); on a static graph with a fixed batch shape
+The forward of one batch is ~30 short launches (layer-0 kernels, 5 rspmm + updates on the entity graph, 5 fused
+relation-graph layers, prologue, projections, readout); on a static graph with a fixed batch shape
 the launch sequence never changes, so it is captured once into a HIP graph (torch.cuda.CUDAGraph drives
 hipStreamBeginCapture / hipGraphLaunch) and replayed: one host call per forward instead of ~30.  Our kernels are enqueued on
-torch's current stream, which is the capturing stream during capture; plans, scratch buffers and the
+torch's current stream, which is the capturing stream during capture; plans, schedules and the
 LDS opt-in are created by the eager warm-up runs, so nothing allocates inside the captured region.
+
+What the captured graph points at stays alive and in place for as long as the GraphedForward does:
+  * the aggregation plans its launches used are held (and pinned: ultra_plan_pin) -- the plan cache is an LRU and
+    would otherwise free device arrays the graph still reads once enough other graphs have been seen;
+  * the model's parameters are watched: the forward caches stacked copies of some weights (relation projections), so a
+    parameter update (optimizer step, load_state_dict) makes the next call re-capture instead of replaying stale values.
 """
 import torch
+
+from . import rspmm
 
 
 class GraphedForward(object):
@@ -17,21 +25,47 @@ class GraphedForward(object):
         assert example_batch.is_cuda, "graph capture needs GPU tensors"
         self.model = model
         self.data = data
+        self.warmup = warmup
         self.static_batch = example_batch.clone()
+        self._pinned = []
+        self._capture()
+
+    def _param_state(self):
+        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+
+    def _release(self):
+        for plan in self._pinned:
+            plan.pin(-1)
+        self._pinned = []
+
+    def _capture(self):
+        model, data = self.model, self.data
+        self._release()
         model.eval()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.no_grad(), torch.cuda.stream(side):
-            for _ in range(warmup):
-                model(data, self.static_batch)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        # thread-local capture mode: helper threads of the process (RCCL's watchdog polls events) must not be able to
-        # invalidate the capture; everything captured here is enqueued by this thread
-        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.static_out = model(data, self.static_batch)
+        with torch.cuda.device(self.static_batch.device):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.no_grad(), torch.cuda.stream(side):
+                for _ in range(self.warmup):
+                    model(data, self.static_batch)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._pinned = rspmm.cached_plans()       # every plan the warm-up touched is in the cache right now
+            for plan in self._pinned:
+                plan.pin(+1)
+            self.graph = torch.cuda.CUDAGraph()
+            # thread-local capture mode: helper threads of the process (RCCL's watchdog polls events) must not be able to
+            # invalidate the capture; everything captured here is enqueued by this thread
+            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.static_out = model(data, self.static_batch)
         self.valid = getattr(model.entity_model, "_pending_valid", None) if hasattr(model, "entity_model") else None
+        self._params = self._param_state()
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
 
     def _load_input(self, batch):
         """batch -> the graph's input buffer.  A plain 16-byte streaming kernel: the runtime's device-to-device memcpy
@@ -42,7 +76,7 @@ class GraphedForward(object):
             import ctypes
             from ._lib import check, lib
             check(lib.ultra_stream_copy(self.static_batch.data_ptr(), batch.data_ptr(), nbytes,
-                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                                        ctypes.c_void_p(torch.cuda.current_stream(batch.device).cuda_stream)))
         else:
             self.static_batch.copy_(batch, non_blocking=True)
 
@@ -50,6 +84,8 @@ class GraphedForward(object):
         if batch.shape != self.static_batch.shape:
             raise ValueError("GraphedForward was captured for batch shape %s, got %s"
                              % (tuple(self.static_batch.shape), tuple(batch.shape)))
+        if self._param_state() != self._params:       # weights changed since the capture: the cached stacks are stale
+            self._capture()
         self._load_input(batch)
         self.graph.replay()
         if check and self.valid is not None:

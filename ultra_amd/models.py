@@ -19,6 +19,11 @@ from . import dense, layers, tasks
 PROLOGUE_FAST_PATH = True
 
 
+class NotOnFusedPath(RuntimeError):
+    """Raised when a hipGraph capture reaches a forward that is outside the fused inference path (the only thing the
+    evaluation loop falls back to eager launches for -- HIP errors, out-of-memory and engine errors propagate)."""
+
+
 def index_to_mask(index, size):
     mask = torch.zeros(size, dtype=torch.bool, device=index.device)
     mask[index] = True
@@ -317,8 +322,8 @@ class EntityNBFNet(BaseNBFNet):
         if batch.is_cuda and torch.cuda.is_current_stream_capturing():
             # the generic path goes through torch reductions / memsets whose captured nodes were seen to go stale
             # when replays interleave with eager work (ROCm 7.2); only the fused inference path is graph-captured
-            raise RuntimeError("hipGraph capture is supported for the fused inference path only "
-                               "(64-d hidden, no concat_hidden, eval mode, no_grad)")
+            raise NotOnFusedPath("hipGraph capture is supported for the fused inference path only "
+                                 "(64-d hidden, no concat_hidden, eval mode, no_grad)")
         # One reduction tells, per row, whether heads / tails / relations are constant along the candidates:
         # it drives the head->tail conversion (base_nbfnet.py:82) AND replaces the two asserts of models.py:196-197
         # (two host syncs in the middle of the forward there; here the flag is checked after the whole forward has

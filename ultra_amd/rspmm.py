@@ -27,8 +27,9 @@ module = sys.modules[__name__]
 _DTYPES = {torch.float32: _lib.F32, torch.float64: _lib.F64}
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(t):
+    """The current HIP stream of the operand's device (the C entry points make that device current for the launch)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
 def _require_gpu(*tensors):
@@ -138,6 +139,12 @@ class Plan(object):
                 pass
             self._h = None
 
+    def pin(self, delta=1):
+        """A captured hipGraph starts (+1) / stops (-1) referencing this plan's device arrays (twins included)."""
+        for p in (self, self.typed, self.dense):
+            if p is not None and getattr(p, "_h", None):
+                check(lib.ultra_plan_pin(p._h, int(delta)))
+
     def info(self):
         info = _lib.PlanInfo()
         check(lib.ultra_plan_get_info(self._h, ctypes.byref(info)))
@@ -211,10 +218,10 @@ class Plan(object):
             _require_gpu(rows, vals)
             vals, mv = as_mat(vals)
             check(lib.ultra_rspmm_forward_point(self._h, _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel), ctypes.byref(mx),
-                                                rows.data_ptr(), ctypes.byref(mv), ctypes.byref(mout), _stream()))
+                                                rows.data_ptr(), ctypes.byref(mv), ctypes.byref(mout), _stream(input)))
             return out
         check(lib.ultra_rspmm_forward(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
-                                      ctypes.byref(mx), mb, ctypes.byref(mout), _stream()))
+                                      ctypes.byref(mx), mb, ctypes.byref(mout), _stream(input)))
         return out
 
     def forward_onehot(self, relation, input, src_rows, edge_weight=None, boundary=None):
@@ -243,7 +250,7 @@ class Plan(object):
             edge_weight = edge_weight.contiguous()
             w = edge_weight.data_ptr()
         check(lib.ultra_rspmm_forward_onehot(self._h, dt, w, ctypes.byref(mrel), ctypes.byref(mx), src_rows.data_ptr(), mb,
-                                             ctypes.byref(mout), _stream()))
+                                             ctypes.byref(mout), _stream(input)))
         return out
 
     def fused_layer(self, relation, input, linear, layer_norm=None, relu=True, residual=False, boundary=None, point=None):
@@ -278,7 +285,7 @@ class Plan(object):
                                         layer_norm.weight.data_ptr() if layer_norm is not None else None,
                                         layer_norm.bias.data_ptr() if layer_norm is not None else None,
                                         float(layer_norm.eps) if layer_norm is not None else 1e-5, flags, ctypes.byref(mout),
-                                        _stream()))
+                                        _stream(input)))
         return out
 
     def layer0(self, relation, src_rows, src_values, linear, layer_norm=None, relu=True, residual=False, edge_weight=None):
@@ -302,7 +309,7 @@ class Plan(object):
                                    layer_norm.weight.data_ptr() if layer_norm is not None else None,
                                    layer_norm.bias.data_ptr() if layer_norm is not None else None,
                                    float(layer_norm.eps) if layer_norm is not None else 1e-5, flags, ctypes.byref(mout),
-                                   _stream()))
+                                   _stream(relation)))
         return out
 
     def backward(self, relation, input, output, output_grad, edge_weight=None, need_weight_grad=False, sum="add",
@@ -328,7 +335,7 @@ class Plan(object):
             wg = wgrad.data_ptr()
         check(lib.ultra_rspmm_backward(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
                                        ctypes.byref(mx), ctypes.byref(mo), ctypes.byref(mog), wg, ctypes.byref(mrg),
-                                       ctypes.byref(mxg), _stream()))
+                                       ctypes.byref(mxg), _stream(input)))
         return wgrad, rgrad, xgrad
 
     def forward_timed(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", warmup=3, iters=20,
@@ -361,7 +368,7 @@ class Plan(object):
         w = edge_weight.data_ptr() if edge_weight is not None else None
         ms, ms_kernel = ctypes.c_float(), ctypes.c_float()
         check(lib.ultra_rspmm_forward_timed(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
-                                            ctypes.byref(mx), mb, rows_ptr, ctypes.byref(mout), _stream(), warmup, iters,
+                                            ctypes.byref(mx), mb, rows_ptr, ctypes.byref(mout), _stream(input), warmup, iters,
                                             ctypes.byref(ms), ctypes.byref(ms_kernel)))
         self.last_main_kernel_ms = ms_kernel.value
         return ms.value, out
@@ -401,6 +408,11 @@ def get_plan(edge_index, edge_type, num_node, num_relation):
 
 def clear_plan_cache():
     _PLAN_CACHE.clear()
+
+
+def cached_plans():
+    """The Plan objects currently held by the cache (a hipGraph capture pins the ones its launches used)."""
+    return [entry[0] for entry in _PLAN_CACHE.values()]
 
 
 class _PlanRSPMM(autograd.Function):
@@ -519,7 +531,7 @@ class _ReferenceExports(object):
             rel, x = relation.contiguous(), input.contiguous()
             out = torch.empty_like(x)
             check(fn(ei.data_ptr(), et.data_ptr(), ew.data_ptr(), rel.data_ptr(), x.data_ptr(), out.data_ptr(),
-                     ei.shape[1], x.shape[0], rel.shape[0], x.shape[1], dt, _stream()))
+                     ei.shape[1], x.shape[0], rel.shape[0], x.shape[1], dt, _stream(input)))
             return out
         return forward
 
@@ -536,7 +548,7 @@ class _ReferenceExports(object):
             wg, rg, xg = torch.zeros_like(ew), torch.zeros_like(rel), torch.zeros_like(x)
             check(fn(ei.data_ptr(), et.data_ptr(), ew.data_ptr(), rel.data_ptr(), x.data_ptr(), o.data_ptr(),
                      og.data_ptr(), wg.data_ptr(), rg.data_ptr(), xg.data_ptr(), ei.shape[1], x.shape[0],
-                     rel.shape[0], x.shape[1], dt, _stream()))
+                     rel.shape[0], x.shape[1], dt, _stream(input)))
             return wg, rg, xg
         return backward
 

@@ -166,7 +166,7 @@ def filtered_ranking(data, batch, pred, mode="tail"):
     num_neg = torch.empty_like(rank)
     check(lib.ultra_filtered_rank(pred.data_ptr(), pos.data_ptr(), ptr.data_ptr(), index.data_ptr(),
                                   pred.shape[0], pred.shape[1], rank.data_ptr(), num_neg.data_ptr(),
-                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                                  ctypes.c_void_p(torch.cuda.current_stream(pred.device).cuda_stream)))
     return rank, num_neg
 
 
