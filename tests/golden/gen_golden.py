@@ -12,6 +12,8 @@ the shipped checkpoints.  Outputs (small, committed):
   ultra_50g_model.pt        ckpts/ultra_50g.pth["model"]
   model_<ckpt>_<aggr>.pt    a seeded small KG, its reference relation graph, all-negative batches, reference
                             scores for tail and head batches, filter masks and rankings
+  query_nbfnet_ultra_3g.pt  QueryNBFNet (models.py:212-275) on dense initial node features
+  relation_projection_ultra_3g.pt   RelationProjection (ultraquery.py:245-277) with and without its threshold
 """
 import os
 import sys
@@ -124,9 +126,52 @@ def gen_query_nbfnet():
     print("query_nbfnet", tuple(score.shape))
 
 
+def gen_relation_projection():
+    """RelationProjection (ultra/ultraquery.py:245-277): fuzzy set of head entities x query relation -> fuzzy set of tails.
+    ultra/ultraquery.py pulls in the whole query stack (datasets, torch_scatter composites) at import, so only the
+    class's own source is executed -- read from the reference file where it lies, nothing is copied into the repo --
+    around the reference's Ultra(RelNBFNet, QueryNBFNet) with the ultra_3g weights."""
+    from torch import nn
+    from torch.nn import functional as F
+    from torch_geometric.data import Data
+    from ultra import tasks as ref_tasks
+    from ultra.models import Ultra
+    from ultra_amd import synthetic
+
+    src = open(os.path.join(REF, "ultra", "ultraquery.py")).read()
+    ns = {"torch": torch, "nn": nn, "F": F}
+    exec(src[src.index("class RelationProjection"):src.index("class SymbolicTraversal")], ns)
+    state = torch.load(os.path.join(HERE, "ultra_3g_model.pt"))
+    kg = synthetic.make_kg(num_node=150, num_triple=1000, num_relation_base=5, num_test=8, seed=13, relation_graph=False)
+    data = Data(edge_index=kg.edge_index, edge_type=kg.edge_type, num_nodes=kg.num_nodes, num_relations=kg.num_relations)
+    data = ref_tasks.build_relation_graph(data)
+    cfg = synthetic.default_model_cfg()
+    ent_cfg = dict(cfg["entity_model_cfg"])
+    ent_cfg["class"] = "QueryNBFNet"
+    model = Ultra(rel_model_cfg=dict(cfg["rel_model_cfg"]), entity_model_cfg=ent_cfg)
+    model.load_state_dict(state)
+    model.eval()
+    g = torch.Generator().manual_seed(23)
+    r_index = torch.tensor([2, 0, 9, 5])
+    h_prob = torch.rand(4, kg.num_nodes, generator=g) * (torch.rand(4, kg.num_nodes, generator=g) < 0.15)
+    out = {}
+    with torch.no_grad():
+        for thr in (0.0, 0.3):
+            out[thr] = ns["RelationProjection"](model, threshold=thr)(data, h_prob, r_index)
+    torch.save(dict(edge_index=data.edge_index, edge_type=data.edge_type, num_nodes=data.num_nodes,
+                    num_relations=data.num_relations, rel_edge_index=data.relation_graph.edge_index,
+                    rel_edge_type=data.relation_graph.edge_type, h_prob=h_prob, r_index=r_index,
+                    t_prob=out[0.0], t_prob_thr03=out[0.3]), os.path.join(HERE, "relation_projection_ultra_3g.pt"))
+    print("relation_projection", tuple(out[0.0].shape), float((out[0.0] - out[0.3]).abs().max()))
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden generation needs the reference checkout at /root/reference"
     torch.manual_seed(0)     # negative_sampling draws from the global generator
+    if "--only-relation-projection" in sys.argv:
+        gen_relation_projection()
+        sys.exit(0)
     gen_rspmm()
     gen_models()
     gen_query_nbfnet()
+    gen_relation_projection()

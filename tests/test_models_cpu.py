@@ -66,3 +66,19 @@ def test_fast_path_switches_default_on():
     from ultra_amd import layers, models
     assert layers.ONEHOT_FAST_PATH and layers.POINT_BOUNDARY_FAST_PATH and layers.FUSED_DENSE_LAYER
     assert models.PROLOGUE_FAST_PATH
+
+
+def test_relation_projection_has_the_reference_interface():
+    """ultra/ultraquery.py:245-277: RelationProjection(model, threshold=0.0).forward(graph, h_prob, r_index)."""
+    import inspect
+
+    from ultra_amd import models, synthetic
+    from ultra_amd.ultraquery import RelationProjection
+    cfg = synthetic.default_model_cfg()
+    cfg["entity_model_cfg"]["class"] = "QueryNBFNet"
+    model = models.Ultra(**cfg)
+    proj = RelationProjection(model, threshold=0.25)
+    assert proj.model is model and proj.threshold == 0.25
+    assert list(inspect.signature(RelationProjection.__init__).parameters) == ["self", "model", "threshold"]
+    assert list(inspect.signature(proj.forward).parameters) == ["graph", "h_prob", "r_index"]
+    assert {k for k in proj.state_dict()} == {"model." + k for k in model.state_dict()}

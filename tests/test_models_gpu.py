@@ -358,3 +358,28 @@ def test_sparse_relation_graph_takes_the_edge_walk(dev):
         got_t, got_h = model(data, t_batch.to(dev)).cpu(), model(data, h_batch.to(dev)).cpu()
     assert rspmm.get_plan(data.relation_graph.edge_index, data.relation_graph.edge_type, rg.num_nodes, 4).dense is None
     assert (got_t - want_t).abs().max().item() <= 1e-4 and (got_h - want_h).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("threshold,key", [(0.0, "t_prob"), (0.3, "t_prob_thr03")])
+def test_relation_projection_matches_reference_golden(dev, threshold, key):
+    """RelationProjection (ultraquery.py:245-277) against the output of the reference class itself (executed from the
+    reference file by tests/golden/gen_golden.py around the reference's Ultra(RelNBFNet, QueryNBFNet))."""
+    import os
+
+    from ultra_amd.data import Data
+    from ultra_amd.ultraquery import RelationProjection
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "relation_projection_ultra_3g.pt"))
+    state = torch.load(os.path.join(os.path.dirname(__file__), "golden", "ultra_3g_model.pt"))
+    rel_graph = Data(edge_index=g["rel_edge_index"], edge_type=g["rel_edge_type"], num_nodes=g["num_relations"],
+                     num_relations=4)
+    data = Data(edge_index=g["edge_index"], edge_type=g["edge_type"], num_nodes=g["num_nodes"],
+                num_relations=g["num_relations"], relation_graph=rel_graph).to(dev)
+    cfg = synthetic.default_model_cfg()
+    cfg["entity_model_cfg"]["class"] = "QueryNBFNet"
+    model = models.Ultra(**cfg)
+    model.load_state_dict(state)
+    proj = RelationProjection(model.to(dev).eval(), threshold=threshold)
+    with torch.no_grad():
+        got = proj(data, g["h_prob"].to(dev), g["r_index"].to(dev)).cpu()
+    assert got.shape == g[key].shape
+    assert (got - g[key]).abs().max().item() <= 1e-5, (got - g[key]).abs().max().item()

@@ -83,16 +83,11 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
         else:
             t_pred = model(test_data, t_batch)
             h_pred = model(test_data, h_batch)
-        if t_pred.is_cuda:
-            # fused filtered rank: no (bs, N) masks (tasks.py:94-141 in one kernel per direction)
-            t_rank, t_neg = tasks.filtered_ranking(filt, batch, t_pred, mode="tail")
-            h_rank, h_neg = tasks.filtered_ranking(filt, batch, h_pred, mode="head")
-        else:
-            t_mask, h_mask = tasks.strict_negative_mask(filt, batch)
-            pos_h, pos_t, _ = batch.t()
-            t_rank = tasks.compute_ranking(t_pred, pos_t, t_mask)
-            h_rank = tasks.compute_ranking(h_pred, pos_h, h_mask)
-            t_neg, h_neg = t_mask.sum(dim=-1), h_mask.sum(dim=-1)
+        # filtered rank of the positives and their number of negatives (tasks.py:94-141): one fused kernel per direction
+        # on the GPU (no (bs, N) masks); the mask-based formulation of the reference with the same interface elsewhere
+        rank_fn = tasks.filtered_ranking if t_pred.is_cuda else tasks.filtered_ranking_masks
+        t_rank, t_neg = rank_fn(filt, batch, t_pred, mode="tail")
+        h_rank, h_neg = rank_fn(filt, batch, h_pred, mode="head")
         is_tail = torch.ones_like(t_rank)
         rows.append(torch.stack([t_rank, t_neg, is_tail], dim=-1))
         rows.append(torch.stack([h_rank, h_neg, torch.zeros_like(is_tail)], dim=-1))

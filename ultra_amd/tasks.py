@@ -170,6 +170,15 @@ def filtered_ranking(data, batch, pred, mode="tail"):
     return rank, num_neg
 
 
+def filtered_ranking_masks(data, batch, pred, mode="tail"):
+    """filtered_ranking() in the reference's own formulation -- strict_negative_mask + compute_ranking
+    (tasks.py:94-141) -- for tensors on any device; the fused kernel is tested against it."""
+    t_mask, h_mask = strict_negative_mask(data, batch)
+    mask = t_mask if mode == "tail" else h_mask
+    pos = batch[:, 1] if mode == "tail" else batch[:, 0]
+    return compute_ranking(pred, pos, mask), mask.sum(dim=-1)
+
+
 def build_relation_graph(graph, node_chunk=1 << 16):
     """Relation graph of a KG that already contains inverse edges: nodes are relation ids, an edge
     (r1, r2) of type hh / tt / ht / th exists iff some entity is a head (h) or tail (t) of r1 and of
