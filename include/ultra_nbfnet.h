@@ -106,6 +106,27 @@ int32_t ultra_filtered_rank(const void *score, const int64_t *pos_index, const i
                             const int64_t *known_index, int64_t batch, int64_t n_cand, int64_t *rank_out,
                             int64_t *num_negative_out, void *stream);
 
+/*
+ * Relation graph of a knowledge graph (/root/reference/ultra/tasks.py:144-199) on the GPU, as bit matrices.
+ *   edge_index (2, num_edge) int64 [head; tail], edge_type (num_edge) int64 -- inverse edges already included;
+ *   W = (num_relation + 31) / 32 words per bit row.
+ * ultra_relation_graph_bits:  hbits / tbits (num_node * W words, ZEROED by the caller) receive, per entity, the set of
+ *   relations it is head / tail of; adj (4 * num_relation * W words, zeroed) the four adjacency bit matrices
+ *   [hh | tt | ht | th] (row = r1, bit = r2; tasks.py:186-189); row_counts (4 * num_relation int64) the edges per (type, row).
+ * ultra_relation_graph_emit:  with row_offsets = the exclusive prefix sum of row_counts (type-major, row-minor) and
+ *   total_edges their sum, writes the relation graph's edge_index (2, total_edges) / edge_type (total_edges) in the
+ *   reference's order (hh, tt, ht, th blocks, each sorted by (row, col)).
+ * ultra_relation_graph_dense_adjacency:  the same matrices as the byte adjacency of the reference-order layer kernel
+ *   (ultra_nbf_dense_layer with ULTRA_LAYER_REFERENCE_ORDER): a_ex_out = ceil(R/16)^2 * 1024 bytes, layout
+ *   [row tile 16][col chunk 16][lane = row % 16 + 16 type][col % 16] -- plan format straight from the device.
+ */
+int32_t ultra_relation_graph_bits(const int64_t *edge_index_dev, const int64_t *edge_type_dev, int64_t num_edge, int64_t num_node,
+                                  int64_t num_relation, void *hbits_dev, void *tbits_dev, void *adj_dev, int64_t *row_counts_dev,
+                                  void *stream);
+int32_t ultra_relation_graph_emit(const void *adj_dev, const int64_t *row_offsets_dev, int64_t num_relation, int64_t total_edges,
+                                  int64_t *edge_index_out_dev, int64_t *edge_type_out_dev, void *stream);
+int32_t ultra_relation_graph_dense_adjacency(const void *adj_dev, int64_t num_relation, void *a_ex_out_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

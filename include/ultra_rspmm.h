@@ -144,6 +144,8 @@ typedef enum {
     ULTRA_ARR_DENSE = 7      /* uint8 [row_tile][type_chunk][kgroup (padded to a multiple of 20)][lane 0..63][tl 0..tc-1][q 0..3], in 4-byte words
                                 (ULTRA_PLAN_DENSE only; tc = 1, 2, 4 for num_relation 1, 2, >= 3): multiplicity of edge
                                 (row = 32 row_tile + lane % 32, type = tc type_chunk + tl, col = 8 kgroup + 2 q + lane / 32) */
+    , ULTRA_ARR_DENSE_ORDER = 8   /* uint8 [row_tile16][col_chunk16][lane = row % 16 + 16 type][col % 16], in 4-byte words: the 0 / 1
+                                     adjacency of the reference-order layer kernel (ULTRA_PLAN_DENSE plans with dense_order_bytes > 0) */
 } ultra_plan_array;
 int32_t ultra_plan_export(const ultra_plan *plan, int32_t which, void *dst_host, int64_t capacity_elems, int64_t *count);
 

@@ -124,3 +124,48 @@ def test_graph_survives_plan_cache_eviction_and_weight_updates(dev):
         fresh = model(data, t_batch).clone()
         assert not torch.equal(fresh, want)
         assert torch.equal(graphed(t_batch), fresh)
+
+
+def test_relation_graph_builder_matches_reference_golden(dev):
+    """csrc/relgraph.hip against the relation graph the reference built (tests/golden/model_*.pt hold
+    tasks.build_relation_graph's output for their KG): same edges, same order."""
+    import os
+    from ultra_amd import tasks
+    from ultra_amd.data import Data
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "model_ultra_3g_sum.pt"))
+    data = Data(edge_index=g["edge_index"], edge_type=g["edge_type"], num_nodes=g["num_nodes"], num_relations=g["num_relations"]).to(dev)
+    tasks.build_relation_graph(data)
+    assert torch.equal(data.relation_graph.edge_index.cpu(), g["rel_edge_index"])
+    assert torch.equal(data.relation_graph.edge_type.cpu(), g["rel_edge_type"])
+
+
+@pytest.mark.parametrize("shape", ["fb15k237", "wn18rr"])
+def test_relation_graph_builder_at_dataset_shape_and_plan_format(dev, shape):
+    """Edge for edge equal to the torch formulation on the CPU (itself pinned to the reference golden in tests/test_tasks.py);
+    the device-built byte adjacency equals the one the host plan builder derives from the edge list; wall time printed
+    beside the reference's 5.9 s (SURVEY.md section 8f-3, FB15k237 shape on 8 CPU cores)."""
+    import time
+    from ultra_amd import _lib, rspmm, synthetic, tasks
+    cpu = synthetic.make_kg(**synthetic.SHAPES[shape], seed=1234, relation_graph=False)
+    t0 = time.perf_counter()
+    tasks.build_relation_graph(cpu)
+    t_cpu = time.perf_counter() - t0
+    gpu = cpu.to(dev)
+    gpu.relation_graph = None
+    tasks.build_relation_graph(gpu)          # warm-up (module load)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tasks.build_relation_graph(gpu)
+    torch.cuda.synchronize()
+    t_gpu = time.perf_counter() - t0
+    rg = gpu.relation_graph
+    print("%s: relation graph %d nodes, %d edges; GPU %.2f ms, torch-on-CPU %.0f ms" %
+          (shape, rg.num_nodes, rg.edge_index.shape[1], 1e3 * t_gpu, 1e3 * t_cpu))
+    assert torch.equal(rg.edge_index.cpu(), cpu.relation_graph.edge_index)
+    assert torch.equal(rg.edge_type.cpu(), cpu.relation_graph.edge_type)
+    # plan format from the device
+    dense = rspmm.Plan(cpu.relation_graph.edge_index, cpu.relation_graph.edge_type, rg.num_nodes, 4, exact_order=True).dense
+    if dense is not None:
+        want = dense.export(_lib.ARR_DENSE_ORDER)
+        got = tasks.relation_graph_dense_adjacency(rg.adjacency_bits).cpu()
+        assert torch.equal(got, want)

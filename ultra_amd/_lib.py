@@ -31,6 +31,7 @@ PLAN_DENSE = 4
 LAYER_REFERENCE_ORDER = 8
 DENSE_MAX_IN_ROW = 1024
 ARR_DENSE = 7
+ARR_DENSE_ORDER = 8
 
 
 class UltraMat(ctypes.Structure):
@@ -101,6 +102,9 @@ def _load():
     lib.ultra_plan_schedule_info.argtypes = [vp, i32, ctypes.POINTER(ScheduleInfo)]
     lib.ultra_order_trace.argtypes = [vp]
     lib.ultra_plan_schedule_export.argtypes = [vp, i32, i32, vp, i64, ctypes.POINTER(i64)]
+    lib.ultra_relation_graph_bits.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp, vp, vp]
+    lib.ultra_relation_graph_emit.argtypes = [vp, vp, i64, i64, vp, vp, vp]
+    lib.ultra_relation_graph_dense_adjacency.argtypes = [vp, i64, vp, vp]
     lib.ultra_set_tuning.argtypes = [ctypes.POINTER(Tuning)]
     lib.ultra_get_tuning.argtypes = [ctypes.POINTER(Tuning)]
     for s in ("add", "min", "max"):

@@ -410,6 +410,7 @@ int32_t ultra_plan_export(const ultra_plan *p, int32_t which, void *dst, int64_t
         case ULTRA_ARR_SPLIT_ROW: src = p->split_row.data(); n = (int64_t)p->split_row.size(); break;
         case ULTRA_ARR_SPLIT_PTR: src = p->split_ptr.data(); n = (int64_t)p->split_ptr.size(); break;
         case ULTRA_ARR_DENSE: src = p->a_frag.data(); n = (int64_t)p->a_frag.size() / 4; break;
+        case ULTRA_ARR_DENSE_ORDER: src = p->a_ex.data(); n = (int64_t)p->a_ex.size() / 4; break;
         default: set_error("ultra_plan_export: unknown array id"); return ULTRA_ERR_INVALID;
     }
     *count = n;

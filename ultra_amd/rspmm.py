@@ -171,7 +171,7 @@ class Plan(object):
         check(lib.ultra_plan_export(self._h, which, None, 0, ctypes.byref(n)))
         out = torch.empty(n.value, dtype=torch.int32)
         check(lib.ultra_plan_export(self._h, which, out.data_ptr(), n.value, ctypes.byref(n)))
-        return out.view(torch.uint8) if which == _lib.ARR_DENSE else out
+        return out.view(torch.uint8) if which in (_lib.ARR_DENSE, _lib.ARR_DENSE_ORDER) else out
 
     # ---- kernels ----
     def forward(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", out=None, point=None):

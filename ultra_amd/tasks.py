@@ -179,6 +179,56 @@ def filtered_ranking_masks(data, batch, pred, mode="tail"):
     return compute_ranking(pred, pos, mask), mask.sum(dim=-1)
 
 
+def relation_graph_bits(graph):
+    """(adj, row_counts): the four adjacency bit matrices [hh | tt | ht | th] of graph's relation graph, shape
+    (4, num_relations, W) int32 words, and the edges per (type, row) -- built by the HIP kernels of csrc/relgraph.hip."""
+    import ctypes
+    from ._lib import check, lib
+    ei, et = graph.edge_index.to(torch.int64).contiguous(), graph.edge_type.to(torch.int64).contiguous()
+    n, r = int(graph.num_nodes), int(graph.num_relations)
+    w = (r + 31) // 32
+    dev = ei.device
+    hbits = torch.zeros(n * w, dtype=torch.int32, device=dev)
+    tbits = torch.zeros(n * w, dtype=torch.int32, device=dev)
+    adj = torch.zeros(4, r, w, dtype=torch.int32, device=dev)
+    counts = torch.empty(4 * r, dtype=torch.int64, device=dev)
+    check(lib.ultra_relation_graph_bits(ei.data_ptr(), et.data_ptr(), ei.shape[1], n, r, hbits.data_ptr(), tbits.data_ptr(),
+                                        adj.data_ptr(), counts.data_ptr(),
+                                        ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return adj, counts
+
+
+def build_relation_graph_gpu(graph):
+    """build_relation_graph for a graph resident on the GPU: bit-matrix kernels instead of the reference's four sparse
+    products (tasks.py:186-189); relation_graph.edge_index / edge_type equal the reference's element for element.  The
+    bit matrices stay attached (relation_graph.adjacency_bits) for consumers that want plan format without the edge list."""
+    import ctypes
+    from ._lib import check, lib
+    adj, counts = relation_graph_bits(graph)
+    r = int(graph.num_relations)
+    offsets = torch.cumsum(counts, 0) - counts
+    total = int(counts.sum())
+    dev = adj.device
+    edge_index = torch.empty(2, total, dtype=torch.int64, device=dev)
+    edge_type = torch.empty(total, dtype=torch.int64, device=dev)
+    check(lib.ultra_relation_graph_emit(adj.data_ptr(), offsets.data_ptr(), r, total, edge_index.data_ptr(), edge_type.data_ptr(),
+                                        ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    graph.relation_graph = Data(edge_index=edge_index, edge_type=edge_type, num_nodes=r, num_relations=4, adjacency_bits=adj)
+    return graph
+
+
+def relation_graph_dense_adjacency(adj):
+    """The byte adjacency of the reference-order layer kernel (plan.hpp `a_ex`) from the bit matrices, on the device."""
+    import ctypes
+    from ._lib import check, lib
+    r = adj.shape[1]
+    nt = (r + 15) // 16
+    out = torch.empty(nt * nt * 1024, dtype=torch.uint8, device=adj.device)
+    check(lib.ultra_relation_graph_dense_adjacency(adj.contiguous().data_ptr(), r, out.data_ptr(),
+                                                   ctypes.c_void_p(torch.cuda.current_stream(adj.device).cuda_stream)))
+    return out
+
+
 def build_relation_graph(graph, node_chunk=1 << 16):
     """Relation graph of a KG that already contains inverse edges: nodes are relation ids, an edge
     (r1, r2) of type hh / tt / ht / th exists iff some entity is a head (h) or tail (t) of r1 and of
@@ -188,6 +238,8 @@ def build_relation_graph(graph, node_chunk=1 << 16):
     edge_index, edge_type = graph.edge_index, graph.edge_type
     num_nodes, num_rels = graph.num_nodes, graph.num_relations
     device = edge_index.device
+    if edge_index.is_cuda:
+        return build_relation_graph_gpu(graph)
     counts = [torch.zeros(num_rels, num_rels, device=device) for _ in range(4)]
     key_h = torch.unique(edge_index[0] * num_rels + edge_type)
     key_t = torch.unique(edge_index[1] * num_rels + edge_type)
