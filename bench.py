@@ -288,6 +288,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch the forward eagerly instead of replaying its hipGraph")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes of the roofline block")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the fine-tuning steps of the `secondary` block")
     ap.add_argument("--pmc-target", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -489,6 +490,19 @@ def main():
                                              "re-associated, nn.Linear / nn.LayerNorm still in torch's order"}}
             finally:
                 rspmm.set_plan_defaults()
+    if rank == 0 and world == 1 and not launched and not args.no_secondary:
+        # ---- BASELINE.json config 5 (fine-tuning): fwd + bwd + AdamW per step, beside the headline ----
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import secondary_bench
+        del model, data
+        rspmm.clear_plan_cache()
+        torch.cuda.empty_cache()
+        out["secondary"] = {
+            "fine_tune": [secondary_bench.train_case("fb15k237"), secondary_bench.train_case("yago310")],
+            "note": "one optimisation step of script/run.py:40-90 (strict negatives, train()-mode forward with the batch's own "
+                    "edges dropped, self-adversarial BCE, backward, AdamW) on synthetic graphs of the named shapes; batch 8 x "
+                    "(1 + 256 negatives).  rspmm forward / backward and the layer update (forward and backward) run on the HIP "
+                    "engine; 10 timed steps after 3 warm-up steps"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or launched:

@@ -31,6 +31,22 @@ int32_t ultra_conv_update(const void *x, const void *agg, const void *weight, co
                           int32_t flags, void *stream);
 
 /*
+ * Backward of ultra_conv_update for the fine-tuning path (autograd of /root/reference/ultra/layers.py:233-240; in the
+ * reference: cat, addmm, native_layer_norm, relu and add nodes).  Nothing but x and agg has to be kept from the forward:
+ * the pre-activation is recomputed on the matrix cores.
+ *     grad_x, grad_agg (rows, 64); grad_weight (64, 128); grad_bias / grad_ln_weight / grad_ln_bias (64) may be NULL.
+ * `flags` as in the forward.  workspace: ultra_conv_update_backward_workspace(rows) bytes of device memory (the
+ * pre-activation gradient and the per-workgroup partial sums; combined in a fixed order -- no atomics, gradients are
+ * reproducible run to run).  Gradients OVERWRITE their destinations.
+ */
+int64_t ultra_conv_update_backward_workspace(int64_t rows);
+int32_t ultra_conv_update_backward(const void *x, const void *agg, const void *grad_out, const void *weight, const void *bias,
+                                   const void *ln_weight, const void *ln_bias, void *grad_x, void *grad_agg, void *grad_weight,
+                                   void *grad_bias, void *grad_ln_weight, void *grad_ln_bias, void *workspace,
+                                   int64_t workspace_bytes, int64_t rows, int32_t input_dim, int32_t output_dim, float eps,
+                                   int32_t flags, void *stream);
+
+/*
  * Readout of EntityNBFNet.forward (/root/reference/ultra/models.py:166-170, 202-209):
  *     feature = cat[hidden, query]; score = mlp.2( relu( mlp.0( feature.gather(t_index) ) ) )
  * The query half of mlp.0 is constant per sample:
@@ -68,6 +84,17 @@ int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const in
  */
 int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void *values, int64_t batch, int64_t num_node, int64_t dim,
                           void *stream);
+
+/*
+ * Dynamic edge dropout of the training step (/root/reference/ultra/base_nbfnet.py:54-77) as a 0/1 vector instead of a
+ * filtered copy of the graph: keep[e] = 0 where edge e equals one of the listed (easy) edges, else 1.  Edges are compared
+ * through the mixed-radix key of the reference's edge_match (tasks.py:7-39): key = (head * num_node + tail) * num_rel +
+ * type, or head * num_node + tail when type == NULL (`remove_one_hop`).  easy_key_sorted: the n_easy <= 8192 keys of the
+ * edges to drop, ascending (duplicates allowed).  keep: (num_edge) fp32.
+ */
+int32_t ultra_edge_keep_mask(const int64_t *head, const int64_t *tail, const int64_t *type, int64_t num_edge,
+                             const int64_t *easy_key_sorted, int64_t n_easy, int64_t num_node, int64_t num_rel, void *keep,
+                             void *stream);
 
 /*
  * Boundary condition of EntityNBFNet (/root/reference/ultra/models.py:131-141) with the query gather fused:

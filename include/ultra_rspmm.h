@@ -160,6 +160,18 @@ int32_t ultra_rspmm_forward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t 
                             const ultra_mat *boundary, const ultra_mat *output, void *stream);
 
 /*
+ * ultra_rspmm_forward with the weight stream read as a 0/1 KEEP MASK (dtype-typed, original edge order): an edge
+ * with keep == 0 is absent from the graph for this call.  Under `add` that equals a zero weight; under `min` / `max` a
+ * zero weight would still enter the reduction with the value 0, an absent edge does not.  This is the reference's
+ * training-time edge dropout (/root/reference/ultra/base_nbfnet.py:54-77) without a filtered copy of the graph: the plan
+ * of the static graph serves every batch.  ultra_rspmm_backward needs no twin: with 0/1 weights its min / max rule
+ * (operator.cuh:62-64) already gives dropped edges a zero gradient.
+ */
+int32_t ultra_rspmm_forward_masked(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype, const void *edge_keep_dev,
+                                   const ultra_mat *relation, const ultra_mat *input, const ultra_mat *boundary,
+                                   const ultra_mat *output, void *stream);
+
+/*
  * Forward with a POINT boundary: the NBFNet boundary condition (/root/reference/ultra/models.py:59-66, 135-141) is zero
  * except for one row per outer slice, so `update + boundary` (/root/reference/ultra/layers.py:199-200) only touches that
  * row.  point_values: (n_outer, 1, row_len) -- n_row == 1 -- is added to output row point_rows[outer]; nothing of size

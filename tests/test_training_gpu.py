@@ -1,0 +1,216 @@
+"""The fine-tuning path (BASELINE.json config 5) on the GPU: the fused layer-update backward against torch autograd of the
+plain op chain (layers.py:233-240), edge dropout as a keep mask against the reference's filtered graph
+(base_nbfnet.py:54-77), and a whole training step."""
+import pytest
+import torch
+from torch.nn import functional as F
+
+from tests.test_oracle_model import load_golden
+from ultra_amd import dense, layers, models, rspmm, synthetic, tasks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def plain_update(x, agg, w, b, g, beta, eps, ln, relu, residual):
+    out = F.linear(torch.cat([x, agg], dim=-1), w, b)
+    if ln:
+        out = F.layer_norm(out, (64,), g, beta, eps)
+    if relu:
+        out = F.relu(out)
+    return out + x if residual else out
+
+
+@pytest.mark.parametrize("rows", [1, 5, 32, 1000, 14541 * 8])
+@pytest.mark.parametrize("ln,relu,residual", [(True, True, True), (True, True, False), (False, True, True), (True, False, False),
+                                               (False, False, False)])
+def test_conv_update_backward_matches_autograd(dev, rows, ln, relu, residual):
+    """Gradients of the fused node vs autograd of the plain chain in fp64 (what both fp32 paths approximate); the fused
+    fp32 gradient may not be further from it than a few times torch's own fp32 chain."""
+    if rows > 1000 and not (ln and relu and residual):
+        pytest.skip("the large shape runs the ULTRA configuration only")
+    gen = torch.Generator().manual_seed(rows * 8 + ln * 4 + relu * 2 + residual)
+    x = torch.randn(rows, 64, generator=gen)
+    agg = torch.randn(rows, 64, generator=gen) * 3
+    w = torch.randn(64, 128, generator=gen) / 11
+    b = torch.randn(64, generator=gen) / 10
+    g = 1 + torch.randn(64, generator=gen) / 10
+    beta = torch.randn(64, generator=gen) / 10
+    gout = torch.randn(rows, 64, generator=gen)
+    eps = 1e-5
+
+    def run(dtype, device, fused):
+        leaves = [t.clone().to(device=device, dtype=dtype).requires_grad_() for t in (x, agg, w, b, g, beta)]
+        if fused:
+            flags = (1 if ln else 0) | (2 if relu else 0) | (4 if residual else 0)
+            out = dense.ConvUpdateFunction.apply(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4] if ln else None,
+                                                 leaves[5] if ln else None, eps, flags)
+        else:
+            out = plain_update(*leaves, eps, ln, relu, residual)
+        out.backward(gout.to(device=device, dtype=dtype))
+        return out.detach().cpu().double(), [t.grad.cpu().double() if t.grad is not None else None for t in leaves]
+
+    out64, g64 = run(torch.float64, "cpu", False)
+    out32, g32 = run(torch.float32, dev, False)
+    outf, gf = run(torch.float32, dev, True)
+    assert (outf - out64).abs().max().item() <= 2e-5 * max(1.0, out64.abs().max().item())
+    for name, a, r32, r64 in zip(("x", "agg", "weight", "bias", "ln_weight", "ln_bias"), gf, g32, g64):
+        if r64 is None or (not ln and name.startswith("ln_")):
+            assert a is None or not ln
+            continue
+        scale = max(r64.abs().max().item(), 1e-6)
+        err = (a - r64).abs().max().item()
+        err_torch = (r32 - r64).abs().max().item()
+        assert err <= 4 * err_torch + 2e-5 * scale, "%s: |fused - fp64| = %g, |torch fp32 - fp64| = %g (scale %g)" % (
+            name, err, err_torch, scale)
+
+
+def test_conv_update_backward_is_deterministic(dev):
+    gen = torch.Generator().manual_seed(5)
+    x, agg, gout = (torch.randn(50000, 64, generator=gen).to(dev) for _ in range(3))
+    w = (torch.randn(64, 128, generator=gen) / 11).to(dev)
+    vec = [torch.randn(64, generator=gen).to(dev) for _ in range(3)]
+    grads = []
+    for _ in range(2):
+        leaves = [t.clone().requires_grad_() for t in (x, agg, w, *vec)]
+        dense.ConvUpdateFunction.apply(*leaves, 1e-5, 7).backward(gout)
+        grads.append([t.grad.clone() for t in leaves])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)         # partial sums are combined in a fixed order: no atomics
+
+
+def test_layer_update_uses_the_fused_node_under_grad(dev):
+    layer = layers.GeneralizedRelationalConv(64, 64, 10, 64, "distmult", "sum", layer_norm=True, activation="relu",
+                                             project_relations=True).to(dev)
+    x = torch.randn(3, 77, 64, device=dev, requires_grad=True)
+    agg = torch.randn(3, 77, 64, device=dev, requires_grad=True)
+    out = layer.update(agg, x, residual=True)
+    assert type(out.grad_fn).__name__ == "ConvUpdateFunctionBackward"
+    want = plain_update(x, agg, layer.linear.weight, layer.linear.bias, layer.layer_norm.weight, layer.layer_norm.bias,
+                        layer.layer_norm.eps, True, True, True)
+    assert torch.allclose(out, want, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("one_hop", [False, True])
+def test_edge_keep_mask_matches_edge_match(dev, one_hop):
+    data = synthetic.make_kg(num_node=500, num_triple=6000, num_relation_base=7, num_test=16, seed=11).to(dev)
+    model = models.EntityNBFNet(64, [64] * 2, remove_one_hop=one_hop)
+    batch = torch.stack([data.edge_index[0, :6], data.edge_index[1, :6], data.edge_type[:6]], dim=-1)
+    torch.manual_seed(1)
+    neg = tasks.negative_sampling(data, batch, 300, strict=True)         # 6 * 2 * 301 = 3612 easy edges
+    h, t, r = neg.unbind(-1)
+    want = model.easy_edge_mask(data, h, t, r)
+    got = model.easy_edge_keep(data, h, t, r)
+    assert got.dtype == torch.float32 and torch.equal(got.bool(), want)
+    assert 0 < int((~want).sum()) < data.num_edges
+    # beyond the kernel's key table: the torch path serves
+    big = neg.repeat(1, 6, 1)
+    h, t, r = big.unbind(-1)
+    assert h.numel() * 2 > dense.EDGE_KEEP_MAX_EASY
+    assert torch.equal(model.easy_edge_keep(data, h, t, r).bool(), want)
+
+
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("sum", ["add", "min", "max"])
+@pytest.mark.parametrize("mul", ["mul", "add"])
+def test_masked_forward_equals_the_filtered_graph(dev, exact, sum, mul):
+    """An edge with keep == 0 is ABSENT: same output as the reference's filtered copy of the graph (bit for bit with
+    reference-order plans and for min / max, where the order of the reduction does not matter)."""
+    gen = torch.Generator().manual_seed(3)
+    n, e, r, bs = 400, 9000, 6, 3
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    ei[0, :700] = 7                                        # a hub row (chain path of the reference-order kernels)
+    et = torch.randint(0, r, (e,), generator=gen)
+    keep = torch.rand(e, generator=gen) > 0.3
+    keep[ei[0] == 11] = False                              # a row that loses every edge
+    rel = torch.randn(bs, r, 64, generator=gen).to(dev)
+    x = torch.randn(bs, n, 64, generator=gen).relu().to(dev)          # exact zeros: 0-weight and absent differ under max
+    full = rspmm.Plan(ei, et, n, r, exact_order=exact)
+    part = rspmm.Plan(ei[:, keep], et[keep], n, r, exact_order=exact)
+    got = full.forward(rel, x, edge_weight=keep.float().to(dev), sum=sum, mul=mul, keep=True)
+    want = part.forward(rel, x, sum=sum, mul=mul)
+    if exact or sum != "add":
+        assert torch.equal(got, want)
+    else:
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-4)
+    if sum != "add":
+        weighted = full.forward(rel, x, edge_weight=keep.float().to(dev), sum=sum, mul=mul)      # zero WEIGHTS: value 0 enters
+        assert not torch.equal(weighted, want)
+
+
+@pytest.mark.parametrize("sum", ["add", "max"])
+def test_masked_backward_equals_the_filtered_graph(dev, sum):
+    gen = torch.Generator().manual_seed(4)
+    n, e, r, bs = 300, 5000, 5, 2
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    et = torch.randint(0, r, (e,), generator=gen)
+    keep = torch.rand(e, generator=gen) > 0.25
+    rel0 = torch.randn(bs, r, 64, generator=gen)
+    x0 = torch.randn(bs, n, 64, generator=gen)
+    gout = torch.randn(bs, n, 64, generator=gen).to(dev)
+    full = rspmm.Plan(ei, et, n, r)
+    part = rspmm.Plan(ei[:, keep], et[keep], n, r)
+
+    def grads(plan, w, keep_flag):
+        rel, x = rel0.clone().to(dev).requires_grad_(), x0.clone().to(dev).requires_grad_()
+        rspmm.plan_rspmm(plan, rel, x, w, sum=sum, mul="mul", keep=keep_flag).backward(gout)
+        return rel.grad, x.grad
+
+    got = grads(full, keep.float().to(dev), True)
+    want = grads(part, None, False)
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * b.abs().max().item())
+
+
+def test_fused_boundary_gradient(dev):
+    gen = torch.Generator().manual_seed(6)
+    n, e, r, bs = 200, 3000, 4, 2
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    et = torch.randint(0, r, (e,), generator=gen)
+    plan = rspmm.Plan(ei, et, n, r)
+    leaves = [t.to(dev).requires_grad_() for t in (torch.randn(bs, r, 64, generator=gen), torch.randn(bs, n, 64, generator=gen),
+                                                    torch.randn(bs, n, 64, generator=gen))]
+    gout = torch.randn(bs, n, 64, generator=gen).to(dev)
+    rspmm.plan_rspmm(plan, leaves[0], leaves[1], boundary=leaves[2]).backward(gout)
+    fused = [t.grad.clone() for t in leaves]
+    for t in leaves:
+        t.grad = None
+    (rspmm.plan_rspmm(plan, leaves[0], leaves[1]) + leaves[2]).backward(gout)
+    for a, t in zip(fused, leaves):
+        assert torch.equal(a, t.grad)
+
+
+@pytest.mark.parametrize("aggr", ["sum", "max"])
+def test_training_forward_equals_the_filtered_graph(dev, aggr):
+    """model.train(): the batch's own edges are dropped through the keep mask; same scores as the reference's route
+    (remove_easy_edges, base_nbfnet.py:54-77: a filtered copy of the graph) and no plan is built per batch."""
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    cfg = {k: dict(v) for k, v in cfg.items()}
+    cfg["entity_model_cfg"]["aggregate_func"] = aggr
+    data = synthetic.make_kg(num_node=300, num_triple=2500, num_relation_base=5, num_test=16, seed=8).to(dev)
+    model = models.Ultra(**cfg)
+    model.load_state_dict(state)
+    model = model.to(dev).train()
+    batch = torch.stack([data.edge_index[0, :4], data.edge_index[1, :4], data.edge_type[:4]], dim=-1)
+    torch.manual_seed(0)
+    neg = tasks.negative_sampling(data, batch, 16, strict=True)
+    out = model(data, neg)
+    n_plans = len(rspmm.cached_plans())
+    loss = F.binary_cross_entropy_with_logits(out, torch.zeros_like(out))
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    out2 = model(data, tasks.negative_sampling(data, batch.flip(0), 16, strict=True))       # another batch: same plans
+    assert len(rspmm.cached_plans()) == n_plans and out2.shape == out.shape
+    # the reference's route on the same batch
+    h, t, r = neg.unbind(-1)
+    filtered = model.entity_model.remove_easy_edges(data, h, t, r)
+    assert filtered.edge_index.shape[1] < data.num_edges
+    model.eval()
+    with torch.no_grad():
+        want = model(filtered, neg)
+    assert torch.allclose(out.detach(), want, atol=2e-5, rtol=1e-5)

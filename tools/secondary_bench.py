@@ -43,13 +43,15 @@ def forward_case(shape, aggr, ckpt, bs=8):
         with torch.no_grad():
             model(data, t_batch)
     dt = timeit(step, 3, 20)
-    print(json.dumps({"case": "forward all-tail", "shape": shape, "aggregate": aggr, "weights": ckpt, "batch": bs,
-                      "ms_per_forward": 1e3 * dt, "triples_per_s": bs * data.num_nodes / dt, "launch": "eager"}), flush=True)
+    return {"case": "forward all-tail", "shape": shape, "aggregate": aggr, "weights": ckpt, "batch": bs,
+            "ms_per_forward": 1e3 * dt, "triples_per_s": bs * data.num_nodes / dt, "launch": "eager"}
 
 
-def train_case(shape, bs=8, num_negative=256):
+def train_case(shape, bs=8, num_negative=256, aggr="sum"):
+    """One fine-tuning step as script/run.py:40-90 runs it: strict negative sampling, forward in train() mode (the
+    batch's own edges dropped), self-adversarial BCE, backward, AdamW."""
     data = synthetic.make_kg(**synthetic.SHAPES[shape], seed=1234).to(dev)
-    model = load_model("sum", "ultra_50g").train()
+    model = load_model(aggr, "ultra_50g").train()
     opt = torch.optim.AdamW(model.parameters(), lr=5e-4)          # config/transductive/inference.yaml:34-36
     triples = torch.stack([data.edge_index[0], data.edge_index[1], data.edge_type], dim=-1)[: data.num_edges // 2]
     state = {"i": 0}
@@ -71,13 +73,12 @@ def train_case(shape, bs=8, num_negative=256):
         loss.backward()
         opt.step()
     dt = timeit(step, 3, 10)
-    print(json.dumps({"case": "fine-tune step fwd+bwd+AdamW", "shape": shape, "batch": bs, "num_negative": num_negative,
-                      "ms_per_step": 1e3 * dt, "samples_per_s": bs / dt}), flush=True)
+    return {"case": "fine-tune step fwd+bwd+AdamW", "shape": shape, "N": data.num_nodes, "E": data.num_edges,
+            "aggregate": aggr, "batch": bs, "num_negative": num_negative, "ms_per_step": 1e3 * dt, "samples_per_s": bs / dt}
 
 
 if __name__ == "__main__":
-    forward_case("codex_l", "max", "ultra_50g")
-    forward_case("codex_l", "sum", "ultra_50g")
-    forward_case("wn18rr", "sum", "ultra_3g", bs=4)
-    train_case("fb15k237")
-    train_case("yago310")
+    for case in (lambda: forward_case("codex_l", "max", "ultra_50g"), lambda: forward_case("codex_l", "sum", "ultra_50g"),
+                 lambda: forward_case("wn18rr", "sum", "ultra_3g", bs=4), lambda: train_case("fb15k237"),
+                 lambda: train_case("yago310"), lambda: train_case("fb15k237", aggr="max")):
+        print(json.dumps(case()), flush=True)

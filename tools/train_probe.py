@@ -2,4 +2,6 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import secondary_bench as sb
-sb.train_case("fb15k237")
+import json
+import sys as _sys
+print(json.dumps(sb.train_case(_sys.argv[1] if len(_sys.argv) > 1 else "fb15k237")))

@@ -83,6 +83,7 @@ def _load():
     lib.ultra_plan_get_info.argtypes = [vp, ctypes.POINTER(PlanInfo)]
     lib.ultra_plan_export.argtypes = [vp, i32, vp, i64, ctypes.POINTER(i64)]
     lib.ultra_rspmm_forward.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp]
+    lib.ultra_rspmm_forward_masked.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp]
     lib.ultra_rspmm_forward_onehot.argtypes = [vp, i32, vp, matp, matp, vp, matp, matp, vp]
     lib.ultra_rspmm_forward_point.argtypes = [vp, i32, i32, vp, matp, matp, vp, matp, matp, vp]
     lib.ultra_nbf_dense_layer.argtypes = [vp, matp, matp, matp, vp, vp, vp, vp, vp, ctypes.c_float, i32, matp, vp]
@@ -91,6 +92,10 @@ def _load():
     lib.ultra_rspmm_forward_timed.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, vp, matp, vp, i32, i32,
                                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     lib.ultra_conv_update.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, ctypes.c_float, i32, vp]
+    lib.ultra_conv_update_backward_workspace.argtypes = [i64]
+    lib.ultra_conv_update_backward_workspace.restype = i64
+    lib.ultra_conv_update_backward.argtypes = [vp] * 14 + [i64, i64, i32, i32, ctypes.c_float, i32, vp]
+    lib.ultra_edge_keep_mask.argtypes = [vp, vp, vp, i64, vp, i64, i64, i64, vp, vp]
     lib.ultra_readout.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
     lib.ultra_stream_copy.argtypes = [vp, vp, i64, vp]
     lib.ultra_filtered_rank.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]

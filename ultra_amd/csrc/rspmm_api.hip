@@ -59,6 +59,8 @@ static ultra_tuning g_tuning = {0, 0, -1, -1, 0, {0, 0, 0}};
 static thread_local hipEvent_t g_ev_before = nullptr, g_ev_after = nullptr;
 // measurement hook: per-workgroup clock trace of the order kernel (ultra_order_trace)
 static thread_local long long *g_order_trace = nullptr;
+// set by ultra_rspmm_forward_masked around its launch: the weight stream is a 0/1 keep mask (weigh(), rspmm_kernels.hpp)
+static thread_local int g_keep_mode = 0;
 
 static int hip_fail(hipError_t e, const char *what) {
     set_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -302,6 +304,7 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
     fp.unit_w = w ? 0 : 1;
     fp.packed_on = p->packed_ok ? 1 : 0;
     fp.has_bnd = bnd ? 1 : 0;
+    fp.keep_mode = (w && g_keep_mode) ? 1 : 0;
     if ((p->flags & ULTRA_PLAN_TYPE_RUNS) && !(p->flags & ULTRA_PLAN_EXACT_ORDER)) {
         if (!(sum == ULTRA_SUM_ADD && mul == BIN_MUL)) {
             set_error("a ULTRA_PLAN_TYPE_RUNS plan serves add_mul only (distributivity)");
@@ -353,6 +356,7 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
             op.num_rel = fp.num_rel;
             op.has_bnd = fp.has_bnd;
             op.has_chain = p->n_chain > 0 ? 1 : 0;
+            op.keep_mode = fp.keep_mode;
             op.x_row_bytes = fp.x_row_bytes, op.rel_row_bytes = fp.rel_row_bytes;
             op.trace = g_order_trace;
             const size_t lds = (rel_lds ? rel_bytes : 0) + ring_bytes;
@@ -465,7 +469,9 @@ static int ensure_backward_plans(ultra_plan *p) {
     std::memset(&o, 0, sizeof(o));
     o.seg_len = p->seg_len;
     o.g_max = p->g_max;
-    o.flags = p->flags;
+    // The backward sums are scatter-adds in the reference (atomicAdd on the GPU, rspmm.cu:153-214): no summation order
+    // to reproduce, so the transposed plans are always the re-associating kind (split hub rows, balanced units).
+    o.flags = p->flags & ~ULTRA_PLAN_EXACT_ORDER;
     if (!p->tplan)
         p->tplan = build_plan(p->h_col.data(), p->h_row.data(), p->h_type.data(), p->num_edge, p->num_in, p->num_out,
                               p->num_rel, &o, false);
@@ -742,6 +748,19 @@ int32_t ultra_rspmm_forward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t 
     if (mul < 0 || mul > 1) return invalid("unknown mul code");
     return forward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, boundary, output,
                         reinterpret_cast<hipStream_t>(stream));
+}
+
+int32_t ultra_rspmm_forward_masked(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype, const void *edge_keep_dev,
+                                   const ultra_mat *relation, const ultra_mat *input, const ultra_mat *boundary,
+                                   const ultra_mat *output, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream);
+    if (mul < 0 || mul > 1) return invalid("unknown mul code");
+    if (!edge_keep_dev) return invalid("ultra_rspmm_forward_masked: edge_keep is NULL");
+    g_keep_mode = 1;
+    const int rc = forward_impl(plan, sum, mul, dtype, edge_keep_dev, relation, input, boundary, output,
+                                reinterpret_cast<hipStream_t>(stream));
+    g_keep_mode = 0;
+    return rc;
 }
 
 int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t mul, int32_t dtype, const void *edge_weight_dev,

@@ -73,6 +73,7 @@ struct FwdParams {
     int32_t num_rel, num_in;
     int32_t type_bits;
     int32_t unit_w, packed_on, has_bnd;
+    int32_t keep_mode;           // the weight stream is a 0/1 keep mask: a dropped edge is absent (matters for min / max)
     int32_t smod, nparts;
     uint32_t x_row_bytes, rel_row_bytes;   // row strides in bytes (each operand slice is < 4 GiB)
 };
@@ -115,6 +116,15 @@ __device__ __forceinline__ T binary(T rel, T x) {  // operator.cuh:15,29
     if (MUL == BIN_ADD) return rel + x;
     if (MUL == BIN_LHS) return rel;
     return x;
+}
+
+// Edge weight applied to a message (rspmm.cpp:68).  keep_mode: the weights are a 0/1 keep mask and a dropped edge must
+// be ABSENT -- under min / max that is the identity of the reduction, not the value 0 a zero weight would produce
+// (edge dropout of base_nbfnet.py:54-77 without rebuilding the graph); under add the two coincide.
+template <typename T, int SUM, typename V>
+__device__ __forceinline__ V weigh(const V y, const T w, const int keep_mode) {
+    if (SUM != ULTRA_SUM_ADD && keep_mode) return w != T(0) ? y : V(nary_zero<T, SUM>());
+    return y * V(w);
 }
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -283,7 +293,7 @@ __device__ __forceinline__ Pack<T, VEC> walk_edges(const FwdParams &p, const int
             const V xx = (MUL != BIN_LHS) ? to_vec<T, VEC>(f.xv[q]) : V(T(0));
             // TYPED items hold edges of ONE relation: sum the sources, multiply by rel[type] once at the end
             V y = TYPED ? xx : binary_vec<V, MUL>(rr, xx);
-            if (!UNITW) y = y * V(f.w[q]);
+            if (!UNITW) y = weigh<T, SUM>(y, f.w[q], p.keep_mode);
             const V cand = nary_vec<V, SUM>(acc, y);
             if (PRED)
                 acc = (kbase + q < cnt) ? cand : acc;

@@ -46,6 +46,7 @@ struct OrderParams {
     long long out_stride_outer, out_stride_row;
     int32_t n_outer, row_len, spans_per_outer, n_span;
     int32_t num_rel, has_bnd, has_chain;
+    int32_t keep_mode;        // weights are a 0/1 keep mask (see weigh(), rspmm_kernels.hpp)
     int32_t smod, nparts;
     uint32_t x_row_bytes, rel_row_bytes;
     long long *trace;         // measurement hook (NULL in production): per workgroup {start, chains done, end} shader clocks
@@ -161,7 +162,7 @@ __device__ __forceinline__ Pack<T, 4> walk_row_in_order(const OrderParams &p, co
             const V rr = (MUL != BIN_RHS) ? to_vec<T, 4>(rv[q]) : V(T(0));
             const V xx = (MUL != BIN_LHS) ? to_vec<T, 4>(f.xv[q]) : V(T(0));
             V y = binary_vec<V, MUL>(rr, xx);
-            if (WEIGHTED) y = V(f.w[q]) * y;            // w * x, rspmm.cpp:68
+            if (WEIGHTED) y = weigh<T, SUM>(y, f.w[q], p.keep_mode);   // w * x, rspmm.cpp:68
             const V cand = nary_vec<V, SUM>(acc, y);
             if (PRED)
                 acc = (kbase + q < cnt) ? cand : acc;
@@ -416,7 +417,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                     const V rr = (MUL != BIN_RHS) ? to_vec<T, 4>(rv) : V(T(0));
                     const V xx = (MUL != BIN_LHS) ? to_vec<T, 4>(xq[J]) : V(T(0));
                     V y = binary_vec<V, MUL>(rr, xx);
-                    if (WEIGHTED) y = V(rx[J].w) * y;
+                    if (WEIGHTED) y = weigh<T, SUM>(y, rx[J].w, p.keep_mode);
                     *reinterpret_cast<P *>(ring + ((size_t)((it - c0) & 1) * CHAIN_SLOTS + slot) * SPAN + l16 * 4) = to_pack<T, 4>(y);
                     // refill this pipeline stage: source row of chunk it + D, record of chunk it + 2 D
                     rx[J] = rq[J];

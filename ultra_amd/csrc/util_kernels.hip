@@ -115,6 +115,32 @@ __global__ void __launch_bounds__(256) onehot_rows_kernel(float4 *__restrict__ o
     }
 }
 
+// keep[e] = 0 where edge e = (head, tail[, type]) equals one of the listed (easy) edges, else 1: the 0/1 vector that
+// replaces the graph copy of base_nbfnet.py:54-77 (edge_match + boolean indexing) -- the graph, and with it the plan,
+// stays static across training batches.  Edges are compared through the mixed-radix key (head * N + tail) * R + type the
+// reference's edge_match uses (tasks.py:7-39); the easy keys arrive sorted and sit in LDS, one binary search per edge.
+constexpr int EASY_MAX = 8192;
+__global__ void __launch_bounds__(256) edge_keep_mask_kernel(const long long *head, const long long *tail, const long long *type,
+                                                             long long num_edge, const long long *easy_key, int n_easy,
+                                                             long long num_node, long long num_rel, float *keep) {
+    __shared__ long long lds_key[EASY_MAX];
+    for (int i = threadIdx.x; i < n_easy; i += blockDim.x) lds_key[i] = easy_key[i];
+    __syncthreads();
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < num_edge; e += (long long)gridDim.x * blockDim.x) {
+        long long key = head[e] * num_node + tail[e];
+        if (type) key = key * num_rel + type[e];
+        int lo = 0, hi = n_easy;          // first position with lds_key[pos] >= key
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (lds_key[mid] < key)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        keep[e] = (lo < n_easy && lds_key[lo] == key) ? 0.f : 1.f;
+    }
+}
+
 }  // namespace ultra
 
 extern "C" int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void *values, int64_t batch, int64_t num_node,
@@ -179,6 +205,32 @@ extern "C" int32_t ultra_stream_copy(void *dst, const void *src, int64_t bytes, 
                        (const float4 *)src, (float4 *)dst, n16);
     if (hipGetLastError() != hipSuccess) {
         ultra::set_error("stream_copy_kernel launch failed");
+        return ULTRA_ERR_HIP;
+    }
+    return ULTRA_OK;
+}
+
+extern "C" int32_t ultra_edge_keep_mask(const int64_t *head, const int64_t *tail, const int64_t *type, int64_t num_edge,
+                                        const int64_t *easy_key_sorted, int64_t n_easy, int64_t num_node, int64_t num_rel,
+                                        void *keep, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream);
+    if (!head || !tail || !keep || num_edge < 0 || n_easy < 0 || (n_easy > 0 && !easy_key_sorted) || num_node <= 0 ||
+        (type && num_rel <= 0)) {
+        ultra::set_error("ultra_edge_keep_mask: NULL operand or empty key space");
+        return ULTRA_ERR_INVALID;
+    }
+    if (n_easy > ultra::EASY_MAX) {
+        ultra::set_error("ultra_edge_keep_mask: more than 8192 edges to match");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    if (num_edge == 0) return ULTRA_OK;
+    (void)hipGetLastError();   // drop any stale error left by other users of the runtime
+    const unsigned blocks = (unsigned)((num_edge + 255) / 256 < 2048 ? (num_edge + 255) / 256 : 2048);
+    hipLaunchKernelGGL(ultra::edge_keep_mask_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const long long *)head, (const long long *)tail, (const long long *)type, (long long)num_edge,
+                       (const long long *)easy_key_sorted, (int)n_easy, (long long)num_node, (long long)num_rel, (float *)keep);
+    if (hipGetLastError() != hipSuccess) {
+        ultra::set_error("edge_keep_mask_kernel launch failed");
         return ULTRA_ERR_HIP;
     }
     return ULTRA_OK;

@@ -17,29 +17,90 @@ def _stream(t):
 
 
 def conv_update_supported(layer, input, update):
+    """The fused update kernels serve the ULTRA shape (64 -> 64, fp32); with gradients enabled through
+    ConvUpdateFunction (forward kernel + ultra_conv_update_backward)."""
     return (input.is_cuda and input.dtype == torch.float32 and update.dtype == torch.float32
             and layer.input_dim == 64 and layer.output_dim == 64 and layer.linear.in_features == 128
             and update.shape[-1] == 64 and (layer.activation is None or layer.activation is F.relu)
-            and not (torch.is_grad_enabled() and (input.requires_grad or update.requires_grad
-                                                  or layer.linear.weight.requires_grad)))
+            and input.numel() > 0
+            and (layer.layer_norm is None or (layer.layer_norm.elementwise_affine and layer.layer_norm.bias is not None)))
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _conv_update_forward(x, agg, weight, bias, ln_w, ln_b, eps, flags):
+    out = torch.empty_like(x)
+    check(lib.ultra_conv_update(x.data_ptr(), agg.data_ptr(), weight.data_ptr(), _ptr(bias), _ptr(ln_w), _ptr(ln_b),
+                                out.data_ptr(), x.numel() // 64, 64, 64, eps, flags, _stream(x)))
+    return out
+
+
+class ConvUpdateFunction(torch.autograd.Function):
+    """out = [x +] relu(LayerNorm(W . cat[x, agg] + b)) as ONE autograd node (the reference builds five: cat, addmm,
+    native_layer_norm, relu, add -- layers.py:233-240).  Saves x and agg only; the backward recomputes the
+    pre-activation on the matrix cores (csrc/conv_update_bwd.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, agg, weight, bias, ln_w, ln_b, eps, flags):
+        x, agg, weight = x.contiguous(), agg.contiguous(), weight.contiguous()
+        ctx.eps, ctx.flags = eps, flags
+        ctx.save_for_backward(x, agg, weight, bias, ln_w, ln_b)
+        return _conv_update_forward(x, agg, weight, bias, ln_w, ln_b, eps, flags)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, agg, weight, bias, ln_w, ln_b = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        rows = x.numel() // 64
+        gx, gagg, gw = torch.empty_like(x), torch.empty_like(agg), torch.empty_like(weight)
+        gb = torch.empty_like(bias) if bias is not None else None
+        gln_w = torch.empty_like(ln_w) if ln_w is not None else None
+        gln_b = torch.empty_like(ln_b) if ln_b is not None else None
+        nbytes = lib.ultra_conv_update_backward_workspace(rows)
+        work = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+        check(lib.ultra_conv_update_backward(x.data_ptr(), agg.data_ptr(), grad_out.data_ptr(), weight.data_ptr(), _ptr(bias),
+                                             _ptr(ln_w), _ptr(ln_b), gx.data_ptr(), gagg.data_ptr(), gw.data_ptr(), _ptr(gb),
+                                             _ptr(gln_w), _ptr(gln_b), work.data_ptr(), nbytes, rows, 64, 64, ctx.eps,
+                                             ctx.flags, _stream(x)))
+        return gx, gagg, gw, gb, gln_w, gln_b, None, None
 
 
 def conv_update(layer, input, update, residual):
     """out = [input +] relu(layer_norm(linear(cat[input, update]))) for (..., 64) fp32 GPU tensors."""
-    x = input.contiguous()
-    agg = update.contiguous()
-    out = torch.empty_like(x)
-    rows = x.numel() // 64
     flags = (CONV_LAYER_NORM if layer.layer_norm is not None else 0) | (CONV_RELU if layer.activation is not None else 0) \
         | (CONV_RESIDUAL if residual else 0)
     ln = layer.layer_norm
-    bias = layer.linear.bias
-    check(lib.ultra_conv_update(x.data_ptr(), agg.data_ptr(), layer.linear.weight.data_ptr(),
-                                bias.data_ptr() if bias is not None else None,
-                                ln.weight.data_ptr() if ln is not None else None,
-                                ln.bias.data_ptr() if ln is not None else None,
-                                out.data_ptr(), rows, 64, 64, float(ln.eps) if ln is not None else 1e-5, flags, _stream(x)))
-    return out
+    eps = float(ln.eps) if ln is not None else 1e-5
+    args = (input, update, layer.linear.weight, layer.linear.bias, ln.weight if ln is not None else None,
+            ln.bias if ln is not None else None)
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in args):
+        return ConvUpdateFunction.apply(*args, eps, flags)
+    return _conv_update_forward(input.contiguous(), update.contiguous(), layer.linear.weight, layer.linear.bias, args[4],
+                                args[5], eps, flags)
+
+
+EDGE_KEEP_MAX_EASY = 8192
+
+
+def edge_keep_mask(edge_index, edge_type, easy_edge, num_node, num_relation, dtype=torch.float32):
+    """keep[e] = 0 where graph edge e equals one of the columns of easy_edge ((3, M): heads, tails, types; (2, M) with
+    edge_type=None: heads, tails), else 1 -- the edge dropout of base_nbfnet.py:54-77 as a 0/1 vector: one small sort of
+    the M easy keys and one kernel over the edges, instead of sorting the graph's edge keys every batch."""
+    assert edge_index.dtype == torch.int64 and edge_index.is_cuda
+    edge_index = edge_index.contiguous()
+    head, tail = edge_index[0], edge_index[1]
+    easy_edge = easy_edge.to(torch.int64)
+    key = easy_edge[0] * int(num_node) + easy_edge[1]
+    if edge_type is not None:
+        edge_type = edge_type.contiguous()
+        key = key * int(num_relation) + easy_edge[2]
+    key = key.sort()[0].contiguous()
+    keep = torch.empty(edge_index.shape[1], dtype=torch.float32, device=edge_index.device)
+    check(lib.ultra_edge_keep_mask(head.data_ptr(), tail.data_ptr(), _ptr(edge_type), edge_index.shape[1], key.data_ptr(),
+                                   key.numel(), int(num_node), int(num_relation), keep.data_ptr(), _stream(keep)))
+    return keep if dtype == torch.float32 else keep.to(dtype)
 
 
 def readout_supported(model, hidden):

@@ -117,10 +117,11 @@ class GeneralizedRelationalConv(nn.Module):
         return self._forward_impl(input, query, boundary, edge_index, edge_type, size, edge_weight, residual=False)
 
     def _forward_impl(self, input, query, boundary, edge_index, edge_type, size, edge_weight=None, residual=False,
-                      relation=None, onehot_rows=None):
+                      relation=None, onehot_rows=None, edge_keep=False):
         """forward() plus the option to fuse the caller's residual `hidden + layer_input` (models.py:158-160),
-        to take this layer's relation features precomputed by the caller, and to be told that `input` is zero
-        outside row onehot_rows[b] of every sample (the layer-0 boundary condition, models.py:139-141)."""
+        to take this layer's relation features precomputed by the caller, to be told that `input` is zero
+        outside row onehot_rows[b] of every sample (the layer-0 boundary condition, models.py:139-141), and that
+        `edge_weight` is a 0/1 keep mask (edge_keep=True: edges with 0 are absent, base_nbfnet.py:54-77)."""
         batch_size = len(query)
 
         if relation is None:
@@ -129,7 +130,7 @@ class GeneralizedRelationalConv(nn.Module):
         # the kernel then skips the weight stream instead of multiplying by 1.
         return self.propagate(input=input, relation=relation, boundary=boundary, edge_index=edge_index,
                               edge_type=edge_type, size=size, edge_weight=edge_weight, residual=residual,
-                              onehot_rows=onehot_rows)
+                              onehot_rows=onehot_rows, edge_keep=edge_keep)
 
     def _relation_for(self, query, batch_size):
         if self.dependent:
@@ -158,8 +159,11 @@ class GeneralizedRelationalConv(nn.Module):
         return plan.layer0(relation, point.rows, point.values, self.linear, self.layer_norm,
                            relu=self.activation is not None, residual=residual, edge_weight=edge_weight)
 
-    def propagate(self, edge_index, size=None, residual=False, onehot_rows=None, **kwargs):
+    def propagate(self, edge_index, size=None, residual=False, onehot_rows=None, edge_keep=False, **kwargs):
         edge_weight = kwargs["edge_weight"]
+        if edge_keep and (self.message_func == "rotate" or self.aggregate_func in ("mean", "pna")):
+            # paths whose degree normalisation / unfused scatter need the edges really gone: the caller removes them
+            raise RuntimeError("edge_keep masks serve sum / min / max aggregation of TransE / DistMult messages")
         if isinstance(kwargs["boundary"], PointBoundary) and (
                 (edge_weight is not None and edge_weight.requires_grad) or self.message_func == "rotate"
                 or self.aggregate_func != "sum" or not kwargs["input"].is_cuda
@@ -176,7 +180,7 @@ class GeneralizedRelationalConv(nn.Module):
             return fused
         out = self.message_and_aggregate(edge_index, kwargs["input"], kwargs["relation"], kwargs["boundary"],
                                          kwargs["edge_type"], edge_weight, edge_index[1], num_node,
-                                         onehot_rows=onehot_rows)
+                                         onehot_rows=onehot_rows, edge_keep=edge_keep)
         return self.update(out, kwargs["input"], residual=residual)
 
     def _fused_dense_layer(self, edge_index, kwargs, num_node, residual, onehot_rows):
@@ -246,7 +250,7 @@ class GeneralizedRelationalConv(nn.Module):
 
     # ---- fused path ----
     def message_and_aggregate(self, edge_index, input, relation, boundary, edge_type, edge_weight, index, dim_size,
-                              onehot_rows=None):
+                              onehot_rows=None, edge_keep=False):
         """(batch, N, d) in, (batch, N, d') out.  Aggregates into edge_index[0] from edge_index[1]
         (the fused kernel's direction, rspmm.cpp:143-145) -- not the unfused path's direction."""
         batch_size, num_node = input.shape[:2]
@@ -254,11 +258,13 @@ class GeneralizedRelationalConv(nn.Module):
             mul = self.message2mul[self.message_func]
         else:
             raise ValueError("Unknown message function `%s`" % self.message_func)
-        plan = rspmm.get_plan(edge_index, edge_type, num_node, relation.shape[1])
         if edge_weight is not None and not torch.is_floating_point(edge_weight):
             edge_weight = edge_weight.to(input.dtype)
         needs_grad = torch.is_grad_enabled() and (input.requires_grad or relation.requires_grad or
                                                    boundary.requires_grad)
+        # a differentiable call (training step) takes the re-associating plan: its backward is a scatter-add and its
+        # result feeds a stochastic optimiser step -- there is no reference summation order to reproduce
+        plan = rspmm.get_plan(edge_index, edge_type, num_node, relation.shape[1], exact_order=False if needs_grad else None)
 
         point = None
         if isinstance(boundary, PointBoundary):     # (propagate() only lets it through for the fused sum path)
@@ -268,13 +274,14 @@ class GeneralizedRelationalConv(nn.Module):
             if point is not None:
                 return plan.forward(rel, x, edge_weight=edge_weight, sum=sum, mul=mul, point=point)
             if needs_grad:
-                out = rspmm.plan_rspmm(plan, rel, x, edge_weight, sum=sum, mul=mul)
+                if sum == "add":      # boundary added in the kernel's epilogue; its gradient is the output gradient
+                    return rspmm.plan_rspmm(plan, rel, x, edge_weight, sum=sum, mul=mul, boundary=fuse_boundary,
+                                            keep=edge_keep)
+                out = rspmm.plan_rspmm(plan, rel, x, edge_weight, sum=sum, mul=mul, keep=edge_keep)
                 if fuse_boundary is None:
                     return out
-                if sum == "add":
-                    return out + fuse_boundary
                 return torch.max(out, fuse_boundary) if sum == "max" else torch.min(out, fuse_boundary)
-            return plan.forward(rel, x, edge_weight=edge_weight, boundary=fuse_boundary, sum=sum, mul=mul)
+            return plan.forward(rel, x, edge_weight=edge_weight, boundary=fuse_boundary, sum=sum, mul=mul, keep=edge_keep)
 
         if self.aggregate_func in ("mean", "pna"):
             # layers.py:193 -- PyG's `index` is edge_index[1]

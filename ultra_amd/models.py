@@ -69,6 +69,19 @@ class BaseNBFNet(nn.Module):
         index = tasks.edge_match(edge_index, easy_edge)[0]
         return ~index_to_mask(index, data.num_edges)
 
+    def easy_edge_keep(self, data, h_index, t_index, r_index, dtype=torch.float32):
+        """easy_edge_mask as the 0/1 float vector the rspmm kernels read (dense.edge_keep_mask: one kernel on the GPU)."""
+        h_index_ext = torch.cat([h_index, t_index], dim=-1)
+        t_index_ext = torch.cat([t_index, h_index], dim=-1)
+        r_index_ext = torch.cat([r_index, r_index + data.num_relations // 2], dim=-1)
+        rows = [h_index_ext, t_index_ext] + ([] if self.remove_one_hop else [r_index_ext])
+        easy_edge = torch.stack(rows).flatten(1)
+        if (data.edge_index.is_cuda and data.edge_index.dtype == torch.int64
+                and easy_edge.shape[1] <= dense.EDGE_KEEP_MAX_EASY):
+            return dense.edge_keep_mask(data.edge_index, None if self.remove_one_hop else data.edge_type, easy_edge,
+                                        data.num_nodes, data.num_relations, dtype)
+        return self.easy_edge_mask(data, h_index, t_index, r_index).to(dtype)
+
     def remove_easy_edges(self, data, h_index, t_index, r_index=None):
         # dynamic edge dropout of the training triples and their inverses (base_nbfnet.py:54-77)
         h_index_ext = torch.cat([h_index, t_index], dim=-1)
@@ -97,7 +110,7 @@ class BaseNBFNet(nn.Module):
         return new_h_index, new_t_index, new_r_index
 
     def _propagate_layers(self, data, layer_input, query, boundary, separate_grad=False, relations=None,
-                          edge_weight=None, onehot_rows=None):
+                          edge_weight=None, onehot_rows=None, edge_keep=False):
         """The Bellman-Ford loop shared by every model (models.py:72-80, 150-163, 233-246).
         `relations`: optional per-layer relation features computed up front (EntityNBFNet batches the six
         relation_projection MLPs, which all read the same relation representations).
@@ -132,7 +145,8 @@ class BaseNBFNet(nn.Module):
             hidden = layer._forward_impl(layer_input, query, boundary, data.edge_index, data.edge_type, size,
                                          edge_weight, residual=residual,
                                          relation=None if relations is None else relations[i],
-                                         onehot_rows=onehot_rows if i == 0 else None)
+                                         onehot_rows=onehot_rows if i == 0 else None,
+                                         edge_keep=edge_keep and not separate_grad)
             hiddens.append(hidden)
             edge_weights.append(edge_weight)
             layer_input = hidden
@@ -218,7 +232,7 @@ class EntityNBFNet(BaseNBFNet):
         mlp.append(nn.Linear(feature_dim, 1))
         self.mlp = nn.Sequential(*mlp)
 
-    def _bellmanford_hidden(self, data, h_index, r_index, separate_grad=False, edge_weight=None):
+    def _bellmanford_hidden(self, data, h_index, r_index, separate_grad=False, edge_weight=None, edge_keep=False):
         batch_size = len(r_index)
         # query = representation of each sample's query relation, scattered to its head node
         fused = (dense.boundary_supported(h_index, self.query) and self.query.dim() == 3
@@ -242,7 +256,7 @@ class EntityNBFNet(BaseNBFNet):
             boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
         hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad,
                                                        relations=self._project_relations_batched(),
-                                                       edge_weight=edge_weight, onehot_rows=h_index)
+                                                       edge_weight=edge_weight, onehot_rows=h_index, edge_keep=edge_keep)
         return hiddens, edge_weights, query
 
     def _project_relations_batched(self):
@@ -295,16 +309,13 @@ class EntityNBFNet(BaseNBFNet):
 
         edge_weight = None
         if self.training:
-            if self.aggregate_func in ("sum", "mean") and self.message_func in ("distmult", "transe"):
-                # Edge dropout without touching the graph: a 0/1 edge weight removes the batch's own edges from a
-                # SUM exactly (w * message = 0), so the cached plan of the static graph keeps serving every batch.
-                # (mean divides by the static degree in the reference only after its own edge removal -> keep the
-                # reference behaviour there; max/min need the edges really gone.)
-                if self.aggregate_func == "sum":
-                    edge_weight = self.easy_edge_mask(data, h_index, t_index, r_index).to(relation_representations.dtype)
-                else:
-                    data = self.remove_easy_edges(data, h_index, t_index, r_index)
+            if self.aggregate_func in ("sum", "min", "max") and self.message_func in ("distmult", "transe"):
+                # Edge dropout without touching the graph: a 0/1 keep vector over the static edge list (one kernel), read
+                # by the rspmm kernels as "edge absent" -- so the cached plan of the static graph serves every batch
+                # (the reference filters the edge list, base_nbfnet.py:54-77, and re-sorts it inside every rspmm call).
+                edge_weight = self.easy_edge_keep(data, h_index, t_index, r_index, relation_representations.dtype)
             else:
+                # mean / pna normalise by the degree AFTER the removal, rotate runs the unfused scatter path
                 data = self.remove_easy_edges(data, h_index, t_index, r_index)
 
         shape = h_index.shape
@@ -335,7 +346,8 @@ class EntityNBFNet(BaseNBFNet):
                                      torch.where(is_t_neg, r_index, r_index + num_direct_rel))
         valid = ((same[:, 0] | same[:, 1]) & same[:, 2]).all()
 
-        hiddens, _, query = self._bellmanford_hidden(data, h_index[:, 0], r_index[:, 0], edge_weight=edge_weight)
+        hiddens, _, query = self._bellmanford_hidden(data, h_index[:, 0], r_index[:, 0], edge_weight=edge_weight,
+                                                     edge_keep=edge_weight is not None)
         if dense.readout_supported(self, hiddens[-1]):
             # gather + cat[hidden, query] + MLP in one MFMA kernel (nothing of size (bs, N, 128) is materialised)
             score = dense.readout(self, hiddens[-1], query, t_index, qbias=self._qbias).view(shape)

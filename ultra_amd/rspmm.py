@@ -174,9 +174,12 @@ class Plan(object):
         return out.view(torch.uint8) if which in (_lib.ARR_DENSE, _lib.ARR_DENSE_ORDER) else out
 
     # ---- kernels ----
-    def forward(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", out=None, point=None):
+    def forward(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", out=None, point=None,
+                keep=False):
         """point=(rows, values): a boundary that is zero except row rows[o] of outer slice o, where it is values[o]
-        (the NBFNet boundary condition) -- added to that row only, sum aggregate only; excludes `boundary`."""
+        (the NBFNet boundary condition) -- added to that row only, sum aggregate only; excludes `boundary`.
+        keep=True: `edge_weight` is a 0/1 keep mask -- an edge with 0 is absent from the graph for this call
+        (ultra_rspmm_forward_masked; differs from a zero weight under min / max only)."""
         if point is not None:
             if boundary is not None or sum != "add":
                 raise RuntimeError("a point boundary excludes `boundary` and serves the sum aggregate only")
@@ -185,7 +188,7 @@ class Plan(object):
             twin = self._twin_for(sum, mul, edge_weight, input, relation, boundary, out)
         if twin is not None:
             return twin.forward(relation, input, edge_weight=edge_weight, boundary=boundary, sum=sum, mul=mul, out=out,
-                                point=point)
+                                point=point, keep=keep)
         _require_gpu(relation, input, edge_weight, boundary)
         dt = _dtype_code(*([relation, input] + ([edge_weight] if edge_weight is not None else [])
                            + ([boundary] if boundary is not None else [])))
@@ -220,8 +223,9 @@ class Plan(object):
             check(lib.ultra_rspmm_forward_point(self._h, _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel), ctypes.byref(mx),
                                                 rows.data_ptr(), ctypes.byref(mv), ctypes.byref(mout), _stream(input)))
             return out
-        check(lib.ultra_rspmm_forward(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
-                                      ctypes.byref(mx), mb, ctypes.byref(mout), _stream(input)))
+        entry = lib.ultra_rspmm_forward_masked if (keep and w is not None and sum != "add") else lib.ultra_rspmm_forward
+        check(entry(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
+                    ctypes.byref(mx), mb, ctypes.byref(mout), _stream(input)))
         return out
 
     def forward_onehot(self, relation, input, src_rows, edge_weight=None, boundary=None):
@@ -389,16 +393,20 @@ def set_plan_defaults(seg_len=0, g_max=0, exact_order=True, type_runs="auto", de
     _PLAN_CACHE.clear()
 
 
-def get_plan(edge_index, edge_type, num_node, num_relation):
+def get_plan(edge_index, edge_type, num_node, num_relation, exact_order=None):
+    """The cached plan of a graph.  exact_order=None: the default kind (set_plan_defaults; reference summation order);
+    False: the re-associating kind, whatever the default -- what the models' training step asks for (its forward feeds a
+    scatter-add backward and a stochastic optimiser step: no summation order to reproduce there)."""
+    defaults = _plan_defaults if exact_order is None else dict(_plan_defaults, exact_order=bool(exact_order))
     key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), tuple(edge_index.stride()),
            edge_type.data_ptr(), edge_type._version, tuple(edge_type.shape), str(edge_index.device),
-           int(num_node), int(num_relation))
+           int(num_node), int(num_relation), defaults["exact_order"])
     hit = _PLAN_CACHE.get(key)
     if hit is not None:
         plan, ei_ref, et_ref = hit
         _PLAN_CACHE.move_to_end(key)
         return plan
-    plan = Plan(edge_index, edge_type, num_node, num_relation, **_plan_defaults)
+    plan = Plan(edge_index, edge_type, num_node, num_relation, **defaults)
     # the tensors are kept alive with the plan so a recycled data_ptr can never alias a stale entry
     _PLAN_CACHE[key] = (plan, edge_index, edge_type)
     while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
@@ -419,8 +427,12 @@ class _PlanRSPMM(autograd.Function):
     """autograd node shared by every (sum, mul) pair; the graph plan rides along as a non-tensor arg."""
 
     @staticmethod
-    def forward(ctx, plan, sum, mul, edge_weight, relation, input):
-        output = plan.forward(relation, input, edge_weight=edge_weight, sum=sum, mul=mul)
+    def forward(ctx, plan, sum, mul, edge_weight, relation, input, boundary=None, keep=False):
+        """boundary (sum == "add" only): added in the kernel's epilogue (layers.py:199-200), its gradient is the output
+        gradient itself.  keep: `edge_weight` is a 0/1 keep mask (Plan.forward)."""
+        if boundary is not None and sum != "add":
+            raise RuntimeError("the fused boundary of the differentiable rspmm serves the sum aggregate only")
+        output = plan.forward(relation, input, edge_weight=edge_weight, boundary=boundary, sum=sum, mul=mul, keep=keep)
         ctx.plan, ctx.sum, ctx.mul = plan, sum, mul
         ctx.save_for_backward(edge_weight, relation, input, output)   # rspmm.py:25
         return output
@@ -429,10 +441,12 @@ class _PlanRSPMM(autograd.Function):
     def backward(ctx, output_grad):
         edge_weight, relation, input, output = ctx.saved_tensors
         need_w = ctx.needs_input_grad[3]
+        output_grad = output_grad.contiguous()
         weight_grad, relation_grad, input_grad = ctx.plan.backward(
-            relation, input, output, output_grad.contiguous(), edge_weight=edge_weight, need_weight_grad=need_w,
+            relation, input, output, output_grad, edge_weight=edge_weight, need_weight_grad=need_w,
             sum=ctx.sum, mul=ctx.mul)
-        return None, None, None, weight_grad, relation_grad, input_grad   # rspmm.py:35
+        boundary_grad = output_grad if ctx.needs_input_grad[6] else None
+        return None, None, None, weight_grad, relation_grad, input_grad, boundary_grad, None   # rspmm.py:35
 
 
 def _check_args(edge_index, edge_type, edge_weight, relation, input):
@@ -501,9 +515,9 @@ def generalized_rspmm(edge_index, edge_type, edge_weight, relation, input, sum="
     return _PlanRSPMM.apply(plan, sum, mul, edge_weight, relation, input)
 
 
-def plan_rspmm(plan, relation, input, edge_weight=None, sum="add", mul="mul"):
+def plan_rspmm(plan, relation, input, edge_weight=None, sum="add", mul="mul", boundary=None, keep=False):
     """Differentiable rspmm on an explicit plan; accepts batch-major (batch, N, d) operands."""
-    return _PlanRSPMM.apply(plan, sum, mul, edge_weight, relation, input)
+    return _PlanRSPMM.apply(plan, sum, mul, edge_weight, relation, input, boundary, keep)
 
 
 class _ReferenceExports(object):

@@ -73,9 +73,12 @@ def strict_negative_mask(data, batch):
     masks = []
     # tails of every (h, r) in the graph, then heads of every (t, r)
     for known, anchor, answer_row, positive in ((0, pos_h, 1, pos_t), (1, pos_t, 0, pos_h)):
-        keyed = torch.stack([data.edge_index[known], data.edge_type])
         query = torch.stack([anchor, pos_r])
-        edge_id, count = edge_match(keyed, query)
+        # the sorted key index of the static graph is built once and reused by every batch (the reference re-sorts the
+        # whole edge list inside each edge_match call, tasks.py:25-26)
+        index = _key_index("strict%d" % known, (data.edge_index, data.edge_type),
+                           lambda known=known: EdgeKeyIndex(torch.stack([data.edge_index[known], data.edge_type])))
+        edge_id, count = edge_match(None, query, index=index)
         truth = data.edge_index[answer_row, edge_id]
         sample = torch.arange(len(count), device=batch.device).repeat_interleave(count)
         mask = torch.ones(len(count), data.num_nodes, dtype=torch.bool, device=batch.device)
