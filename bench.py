@@ -389,7 +389,18 @@ def main():
 
     elapsed = timed_run(make_forward(), world > 1 or launched)
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    per_rank = None
+    if world > 1 or launched:
+        # per-rank consistency: every rank scores the SAME probe batch on its own GPU (its own plan upload, its own capture);
+        # the digests and the ranks' own clocks are gathered over RCCL and compared on rank 0
+        with torch.no_grad():
+            probe = model(data, tasks.all_negative(data, triples[:bs])[0]).double()
+        digest = torch.stack([probe.sum(), probe.abs().max(), probe[:, ::97].sum(), el[0]])
+        gathered = [torch.empty_like(digest) for _ in range(dist.get_world_size())]
+        dist.all_gather(gathered, digest)
+        g = torch.stack(gathered).cpu()
+        per_rank = {"ms_per_step": [1e3 * v / args.steps for v in g[:, 3].tolist()],
+                    "probe_scores_identical": bool((g[:, :3] == g[0, :3]).all())}
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
     triples_per_s = world * bs * N * args.steps / elapsed
@@ -406,6 +417,7 @@ def main():
                    "summation_order": "reference (rspmm.cpp:61-72 sequential per row; nn.Linear / nn.LayerNorm in torch's CPU order)",
                    "launch": "eager" if args.no_graph else "hipGraph replay of the captured forward",
                    "rccl_world_size": dist.get_world_size() if (world > 1 or launched) else 1,
+                   "per_rank": per_rank,
                    "parallelism": "query-shard x%d + RCCL all-gather of scores" % world if world > 1 else "single GPU"},
     }
 
@@ -499,6 +511,7 @@ def main():
         torch.cuda.empty_cache()
         out["secondary"] = {
             "fine_tune": [secondary_bench.train_case("fb15k237"), secondary_bench.train_case("yago310")],
+            "sparse_relation_graph": secondary_bench.sparse_relation_case("fb15k237", fill=0.12),
             "note": "one optimisation step of script/run.py:40-90 (strict negatives, train()-mode forward with the batch's own "
                     "edges dropped, self-adversarial BCE, backward, AdamW) on synthetic graphs of the named shapes; batch 8 x "
                     "(1 + 256 negatives).  rspmm forward / backward and the layer update (forward and backward) run on the HIP "

@@ -49,17 +49,23 @@ int32_t ultra_conv_update_backward(const void *x, const void *agg, const void *g
 /*
  * Readout of EntityNBFNet.forward (/root/reference/ultra/models.py:166-170, 202-209):
  *     feature = cat[hidden, query]; score = mlp.2( relu( mlp.0( feature.gather(t_index) ) ) )
- * The query half of mlp.0 is constant per sample:
- *     qbias[b] = mlp.0.weight[:, 64:] . query[b] + mlp.0.bias            (batch, 128)
- * either passed pre-folded (qbias != NULL), or computed inside the kernel from query (batch, 64) and b1 = mlp.0.bias
- * (qbias == NULL; batch <= 32, ULTRA_ERR_UNSUPPORTED beyond).
- * hidden (batch, num_node, 64) contiguous; t_index (batch, n_cand) int64 node ids or NULL for
- * all-tail (n_cand == num_node, identity); w1 = mlp.0.weight (128, 128) row-major; w2 = mlp.2.weight (128); b2 = mlp.2.bias (1);
- * score (batch, n_cand).
+ * in the reference's operation order: mlp.0 = one k-ascending fmaf chain per hidden unit over the 64 node features and
+ * then the 64 query features, bias added after the chain (the concatenated feature is never materialised: the query half
+ * of the chain reads query[sample]); mlp.2 = nn.Linear(128, 1), a GEMV on the reference's CPU path whose association of
+ * the 128 products belongs to the host BLAS and is passed in as a PROGRAM (order_dev, int32 words on the device;
+ * ultra_amd/host_order.py recovers it from the BLAS of the running process):
+ *     [n_stage, then per stage: L (lanes, power of two <= 16), carry (0/1), then per lane: n, k_0 .. k_{n-1}]
+ *     lane p: v = (p == 0 && carry) ? previous stage's result : 0;  v = fma(hid[k], w2[k], v) for its k in order
+ *             (an element written k + 256: v = v + fl(hid[k] * w2[k]), for host code that does not fuse);
+ *     fold: v[p] += v[p + L/2]; v[p] += v[p + L/4]; ...; stage result v[0];  score = last result + b2.
+ * order_dev == NULL: one chain, k ascending.  Every product of every stage must appear exactly once.
+ * hidden (batch, num_node, 64) contiguous; query (batch, 64); t_index (batch, n_cand) int64 node ids or NULL for
+ * all-tail (n_cand == num_node, identity); w1 = mlp.0.weight (128, 128) row-major, b1 = mlp.0.bias (128);
+ * w2 = mlp.2.weight (128); b2 = mlp.2.bias (1); score (batch, n_cand).
  */
-int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1, const void *qbias, const void *query,
-                      const void *b1, const void *w2, const void *b2, void *score, int64_t batch, int64_t num_node,
-                      int64_t n_cand, int32_t hidden_dim, int32_t feature_dim, void *stream);
+int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1, const void *query, const void *b1,
+                      const void *w2, const void *b2, const int32_t *order_dev, int64_t order_len, void *score, int64_t batch,
+                      int64_t num_node, int64_t n_cand, int32_t hidden_dim, int32_t feature_dim, void *stream);
 
 /*
  * Batch prologue of EntityNBFNet.forward (/root/reference/ultra/models.py:190-197 with
@@ -72,10 +78,10 @@ int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1
  */
 int32_t ultra_batch_prologue(const int64_t *triples, int64_t batch, int64_t n_cand, int64_t num_direct_rel, int64_t *h0,
                              int64_t *r0, int32_t *side, int32_t *valid, void *stream);
-int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const int32_t *side, const void *w1,
-                            const void *qbias, const void *query, const void *b1, const void *w2, const void *b2, void *score,
-                            int64_t batch, int64_t num_node, int64_t n_cand, int32_t hidden_dim, int32_t feature_dim,
-                            void *stream);
+int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const int32_t *side, const void *w1, const void *query,
+                            const void *b1, const void *w2, const void *b2, const int32_t *order_dev, int64_t order_len,
+                            void *score, int64_t batch, int64_t num_node, int64_t n_cand, int32_t hidden_dim,
+                            int32_t feature_dim, void *stream);
 
 /*
  * The NBFNet boundary condition (/root/reference/ultra/models.py:59-66, 135-141): out (batch, num_node, dim) fp32,
@@ -105,7 +111,8 @@ int32_t ultra_edge_keep_mask(const int64_t *head, const int64_t *tail, const int
  * ultra_rspmm_forward_point / ultra_nbf_layer0.
  * Optionally (w1, b1, qbias_out all non-NULL) the same launch also emits the readout's per-sample bias
  *     qbias_out[b, f] = b1[f] + sum_k w1[f, dim + k] * query_out[b, k]      w1 (2 dim, 2 dim) = mlp.0.weight, f < 2 dim
- * i.e. the `qbias` operand of ultra_readout / ultra_readout_batch.
+ * (a per-sample folding of the readout's query half; the readout kernels of ABI 4 run the chain through the query
+ * themselves and no longer take it).
  */
 int32_t ultra_query_boundary(void *out, void *query_out, const int64_t *rows, const void *table, const int64_t *pick,
                              int64_t batch, int64_t num_node, int64_t table_rows, int64_t dim, const void *w1, const void *b1,

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_ABI_VERSION 3
+#define ULTRA_ABI_VERSION 4
 
 typedef enum {
     ULTRA_OK = 0,

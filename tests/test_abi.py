@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
 def test_host_entry_points_without_gpu():
     from ultra_amd import _lib
     lib = _lib.lib
-    assert lib.ultra_abi_version() == 3
+    assert lib.ultra_abi_version() == 4
     assert lib.ultra_device_count() >= 0
     t = _lib.Tuning()
     assert lib.ultra_get_tuning(ctypes.byref(t)) == 0
@@ -63,7 +63,7 @@ def test_dense_entry_points_validate_shapes():
     lib = _lib.lib
     rc = lib.ultra_conv_update(None, None, None, None, None, None, None, 10, 32, 64, 1e-5, 0, None)
     assert rc == _lib.ULTRA_ERR_UNSUPPORTED
-    rc = lib.ultra_readout(None, None, None, None, None, None, None, None, None, 1, 10, 10, 32, 64, None)
+    rc = lib.ultra_readout(None, None, None, None, None, None, None, None, 0, None, 1, 10, 10, 32, 64, None)
     assert rc == _lib.ULTRA_ERR_UNSUPPORTED
     rc = lib.ultra_relation_projection(None, None, None, None, None, None, 10, 6, 32, None)
     assert rc == _lib.ULTRA_ERR_UNSUPPORTED

@@ -6,12 +6,13 @@ order): Ultra.forward on the GPU against oracle/ultra_oracle_model.py with the r
     config 2  ultra_3g,  FB15k237 shape, batch 8   (distmult + sum: the headline)
     config 3  ultra_50g, CoDEx-L shape,  batch 8   (max aggregate)
 
-Gates: scores within 1e-5 (north_star asks 1e-4; the hidden states are bit-equal, only the readout's last 128 -> 1
-product -- MKL GEMV order on the CPU side -- differs); rankings from tasks.compute_ranking identical, where "identical"
-tolerates exactly the reference's own near-ties: a GPU rank may differ only if moving the positive's REFERENCE score by
-<= 2 * max|gpu - reference| reproduces it (on these synthetic graphs most positives sit in the bulk of unreachable
-nodes whose scores agree to the last bits).  Strict equality is asserted for the max-aggregate config, whose scores
-are spread out."""
+Gates: north_star asks scores within 1e-4 and identical rankings.  Every operation of the forward follows the reference's
+order (rspmm.cpp's sequential row sums, torch's nn.Linear / nn.LayerNorm arithmetic, the host BLAS's association for the
+readout's last product -- ultra_amd/host_order.py), so where that association was recovered from this host's BLAS the
+test asserts what is then true: >= 99.9 % of the scores BIT-EQUAL (the BLAS may sum a few trailing rows of each thread's
+share with a remainder kernel), max difference <= 1e-5, and strictly identical rankings.  On a host whose BLAS tree is
+outside the recognised family (sequential fallback) the gates are 1e-5 and rankings identical up to the reference's own
+near-ties: a GPU rank may differ only if moving the positive's REFERENCE score by <= 2 * max|gpu - reference| reproduces it."""
 import os
 
 import pytest
@@ -58,7 +59,7 @@ def test_scores_and_rankings_at_baseline_size(dev, name, ckpt, shape, bs, aggr, 
     model = model.to(dev).eval()
     gdata = data.to(dev)
     fn = ultra_oracle_model.reference_rspmm_fn()
-    worst_diff, strict, outside, total = 0.0, 0, 0, 0
+    worst_diff, strict, outside, total, equal, count = 0.0, 0, 0, 0, 0, 0
     for b in range(n_batch):
         batch = data.target_triples[b * bs:(b + 1) * bs]
         t_batch, h_batch = tasks.all_negative(data, batch)
@@ -70,16 +71,21 @@ def test_scores_and_rankings_at_baseline_size(dev, name, ckpt, shape, bs, aggr, 
                 got = model(gdata, cand.to(dev)).cpu()
             diff = (got - want).abs().max().item()
             worst_diff = max(worst_diff, diff)
+            equal += int((got == want).sum())
+            count += got.numel()
             r_got = tasks.compute_ranking(got, pos, mask)
             r_want = tasks.compute_ranking(want, pos, mask)
             best, worst = _tie_band(want, pos, mask, 2 * diff)
             strict += int((r_got != r_want).sum())
             outside += int(((r_got < best) | (r_got > worst)).sum())
             total += len(pos)
-    msg = "%s: max |gpu - reference| = %.3g, %d of %d rankings differ, %d outside the reference's ties" % (
-        name, worst_diff, strict, total, outside)
+    msg = "%s: max |gpu - reference| = %.3g, %.4f %% of the scores bit-equal, %d of %d rankings differ, %d outside the " \
+          "reference's ties" % (name, worst_diff, 100.0 * equal / count, strict, total, outside)
     print(msg)
     assert worst_diff <= 1e-5, msg
     assert outside == 0, msg
-    if aggr == "max":
+    from ultra_amd import host_order
+    if aggr == "max" or host_order.readout_stages(128)[1].startswith("host BLAS"):
         assert strict == 0, msg
+    if host_order.readout_stages(128)[1].startswith("host BLAS"):
+        assert equal >= 0.999 * count, msg

@@ -75,7 +75,7 @@ def test_conv_update_asymmetric_weight_layout(dev):
 
 
 @pytest.mark.parametrize("bs,n,cand", [(1, 40, None), (3, 100, None), (8, 14541, None), (4, 300, 9), (2, 50, 257),
-                                       (32, 70, None), (33, 70, None), (70, 20, 5)])     # > 32 samples: query bias by GEMM
+                                       (32, 70, None), (33, 70, None), (70, 20, 5)])
 def test_readout_matches_torch(dev, bs, n, cand):
     from ultra_amd import dense, models, synthetic
     torch.manual_seed(bs)

@@ -1,8 +1,8 @@
 """The dense kernels of the layer follow the REFERENCE'S OPERATION ORDER (csrc/torch_math.hpp): nn.Linear as one
 k-ascending fmaf chain per output with the bias added last, nn.LayerNorm as eight Welford accumulators merged in
 order.  torch's CPU kernels compute exactly that (tests/test_torch_math.py), so the GPU results must equal
-torch-on-CPU BIT FOR BIT -- layer outputs, hidden states after all six layers, everything up to the readout MLP
-(whose last 128 -> 1 product goes through MKL's GEMV, an order we do not reproduce: scores agree to ~1e-6)."""
+torch-on-CPU BIT FOR BIT -- layer outputs, hidden states after all six layers, and the readout MLP, whose last
+128 -> 1 product is summed in the association of the host BLAS (ultra_amd/host_order.py probes it)."""
 import pytest
 import torch
 from torch import nn
@@ -140,3 +140,34 @@ def test_hidden_states_equal_the_reference_flow_bitwise(dev):
             (hiddens[-1].cpu() - want_hidden).abs().max().item())
         assert torch.equal(query.cpu(), captured["feature"][:, 0, 64:])
         assert (got - want).abs().max().item() <= 5e-6
+
+
+@pytest.mark.parametrize("bs,n,cand", [(8, 14541, None), (3, 500, 257), (1, 40, None)])
+def test_readout_equals_torch_cpu_bitwise(dev, bs, n, cand):
+    """score = mlp.2(relu(mlp.0(cat[hidden, query]))): mlp.0 as one k-ascending chain through both halves of the
+    concatenated feature, mlp.2 in the host BLAS's association.  The kernel equals the restatement bit for bit on every
+    row; torch itself equals it on all rows but the handful its BLAS sums with a remainder kernel."""
+    import numpy as np
+    from oracle import torch_math_oracle as tm
+    from ultra_amd import dense, host_order, models, synthetic
+    torch.manual_seed(7 + bs)
+    net = models.EntityNBFNet(**{k: v for k, v in synthetic.default_model_cfg()["entity_model_cfg"].items() if k != "class"})
+    g = torch.Generator().manual_seed(n)
+    hidden = torch.randn(bs, n, 64, generator=g).relu()
+    query = torch.randn(bs, 64, generator=g)
+    t_index = torch.arange(n).unsqueeze(0).expand(bs, -1).contiguous() if cand is None \
+        else torch.randint(0, n, (bs, cand), generator=g)
+    with torch.no_grad():
+        feature = torch.cat([hidden, query.unsqueeze(1).expand(-1, n, -1)], dim=-1)
+        feature = feature.gather(1, t_index.unsqueeze(-1).expand(-1, -1, 128))
+        want_torch = net.mlp(feature).squeeze(-1)
+        hid = tm.linear(feature, net.mlp[0].weight, net.mlp[0].bias).relu().reshape(-1, 128)
+        stages, source = host_order.readout_stages(128)
+        last = host_order.emulate(stages, hid.numpy(), net.mlp[2].weight[0].numpy()).astype(np.float64)
+        restated = torch.from_numpy((last + float(net.mlp[2].bias)).astype(np.float32)).view_as(want_torch)
+        gnet = net.to(dev)
+        got = dense.readout(gnet, hidden.to(dev), query.to(dev), t_index.to(dev)).cpu()
+    assert source.startswith("host BLAS"), source
+    assert torch.equal(got, restated)
+    same = (got == want_torch).float().mean().item()
+    assert same >= 0.995 and (got - want_torch).abs().max().item() <= 4e-6, same

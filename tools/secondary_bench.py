@@ -47,6 +47,31 @@ def forward_case(shape, aggr, ckpt, bs=8):
             "ms_per_forward": 1e3 * dt, "triples_per_s": bs * data.num_nodes / dt, "launch": "eager"}
 
 
+def sparse_relation_case(shape="fb15k237", fill=0.12, bs=8):
+    """The headline forward with the relation graph thinned to `fill` of its (row, type, col) cells (uniform sample of its
+    edges): below plan.DENSE_MIN_FILL the relation model leaves the byte-adjacency kernels and runs on the edge-list
+    plans like the entity model (reference-order kernels + update kernel)."""
+    from ultra_amd import graph as ugraph
+    from ultra_amd.data import Data
+    data = synthetic.make_kg(**synthetic.SHAPES[shape], seed=1234)
+    rg = data.relation_graph
+    R = data.num_relations
+    keep = torch.randperm(rg.edge_index.shape[1], generator=torch.Generator().manual_seed(7))[: int(fill * R * R * 4)]
+    keep = keep.sort()[0]
+    data.relation_graph = Data(edge_index=rg.edge_index[:, keep], edge_type=rg.edge_type[keep], num_nodes=rg.num_nodes,
+                               num_relations=rg.num_relations)
+    data = data.to(dev)
+    model = load_model("sum", "ultra_3g").eval()
+    t_batch, _ = tasks.all_negative(data, data.target_triples[:bs])
+    fwd = ugraph.GraphedForward(model, data, t_batch)
+    dt = timeit(lambda: fwd(t_batch), 3, 20)
+    from ultra_amd import rspmm as _rspmm
+    plan = _rspmm.get_plan(data.relation_graph.edge_index, data.relation_graph.edge_type, R, 4)
+    return {"case": "forward all-tail, thinned relation graph", "shape": shape, "batch": bs, "relation_graph_edges": int(keep.numel()),
+            "relation_graph_fill": keep.numel() / (R * R * 4.0), "dense_format_plan": plan.dense is not None,
+            "ms_per_forward": 1e3 * dt, "triples_per_s": bs * data.num_nodes / dt, "launch": "hipGraph replay"}
+
+
 def train_case(shape, bs=8, num_negative=256, aggr="sum"):
     """One fine-tuning step as script/run.py:40-90 runs it: strict negative sampling, forward in train() mode (the
     batch's own edges dropped), self-adversarial BCE, backward, AdamW."""
@@ -80,5 +105,5 @@ def train_case(shape, bs=8, num_negative=256, aggr="sum"):
 if __name__ == "__main__":
     for case in (lambda: forward_case("codex_l", "max", "ultra_50g"), lambda: forward_case("codex_l", "sum", "ultra_50g"),
                  lambda: forward_case("wn18rr", "sum", "ultra_3g", bs=4), lambda: train_case("fb15k237"),
-                 lambda: train_case("yago310"), lambda: train_case("fb15k237", aggr="max")):
+                 lambda: train_case("yago310"), lambda: train_case("fb15k237", aggr="max"), sparse_relation_case):
         print(json.dumps(case()), flush=True)

@@ -96,12 +96,12 @@ def _load():
     lib.ultra_conv_update_backward_workspace.restype = i64
     lib.ultra_conv_update_backward.argtypes = [vp] * 14 + [i64, i64, i32, i32, ctypes.c_float, i32, vp]
     lib.ultra_edge_keep_mask.argtypes = [vp, vp, vp, i64, vp, i64, i64, i64, vp, vp]
-    lib.ultra_readout.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
+    lib.ultra_readout.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, i32, i32, vp]
     lib.ultra_stream_copy.argtypes = [vp, vp, i64, vp]
     lib.ultra_filtered_rank.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
     lib.ultra_onehot_rows.argtypes = [vp, vp, vp, i64, i64, i64, vp]
     lib.ultra_batch_prologue.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp]
-    lib.ultra_readout_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
+    lib.ultra_readout_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, i32, i32, vp]
     lib.ultra_query_boundary.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp]
     lib.ultra_relation_projection.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]
     lib.ultra_plan_schedule_info.argtypes = [vp, i32, ctypes.POINTER(ScheduleInfo)]
@@ -122,7 +122,7 @@ def _load():
 
 
 lib = _load()
-if lib.ultra_abi_version() != 3:
+if lib.ultra_abi_version() != 4:
     raise ImportError("ultra_amd: libultra_amd.so ABI version mismatch")
 
 

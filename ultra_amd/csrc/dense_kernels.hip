@@ -1,8 +1,7 @@
 // Dense epilogues of the NBFNet layer on the MI355X matrix cores (f32-in / f32-accumulate MFMA).
 //
 //   ultra_conv_update : out = [+x] relu( LayerNorm( W . [x ; agg] + b ) )        layers.py:233-240 (+ models.py:158-160)
-//   ultra_readout     : score = w2 . relu( W1[:, :d] . h[t] + qb[sample] ) + b2  models.py:202-209 with the query half of
-//                       the concatenated feature folded into a per-sample bias qb = W1[:, d:] . query + b1
+//   ultra_readout     : score = w2 . relu( W1 . [h[t] ; query] + b1 ) + b2      models.py:166-170, 202-209
 //
 // Both are skinny GEMMs (K = 128 / 64, N = 64 / 128) over M = batch * num_node rows, i.e. HBM/L2-bound
 // epilogues: one wave owns 32 data rows and computes the TRANSPOSED product D[feature][row] with
@@ -219,53 +218,61 @@ struct ReadoutParams {
     const int64_t *t_index;  // (batch, n_cand) node ids, or NULL = identity (all-tail)
     const int64_t *triples;  // alternative to t_index: the raw (batch, n_cand, 3) [h, t, r] batch ...
     const int32_t *side;     // ... with side[b] = 1 -> candidates are the tails (column 1), 0 -> the heads (column 0)
-    const float *w1;         // (128, 128) row-major; only the first 64 input columns are used here
-    const float *qbias;      // (batch, 128) = W1[:, 64:] . query + b1, or NULL: computed here from ...
-    const float *query;      // ... query (batch, 64) and
-    const float *b1;         // ... mlp.0.bias (128); batch <= READOUT_MAX_INLINE_BATCH then
-    const float *w2;         // (128)
+    const float *w1;         // (128, 128) row-major = mlp.0.weight
+    const float *query;      // (batch, 64): the second half of the concatenated feature (models.py:166-170)
+    const float *b1;         // (128) = mlp.0.bias
+    const float *w2;         // (128) = mlp.2.weight
     const float *b2;         // (1) = mlp.2.bias
+    const int32_t *order;    // summation program of the last product (READOUT_ORDER_MAX words at most), or NULL
+    int order_len;
     float *score;            // (batch, n_cand)
     long long batch, num_node, n_cand;
 };
 
-constexpr int READOUT_MAX_INLINE_BATCH = 32;
+constexpr int READOUT_ORDER_MAX = 384;    // 1 + stages * (2 + lanes) + 128 elements
+constexpr int READOUT_HID_STRIDE = 129;   // floats per row of the hidden tile in LDS: a lane reads ITS row, bank = row + k
 
-__global__ void __launch_bounds__(512, 2) readout_kernel(const ReadoutParams p) {
-    // [tile m (4)][i (8)][lane][q] : W1[32 m + (lane & 31)][8 i + 4 (lane >> 5) + q]
-    __shared__ __attribute__((aligned(16))) float lds_w[4 * 8 * 64 * 4];
-    __shared__ float lds_w2[128];
-    __shared__ float lds_qb[READOUT_MAX_INLINE_BATCH * 128];
+// score = mlp.2( relu( mlp.0( cat[hidden[t], query] ) ) ) in the reference's operation order:
+//   mlp.0 (nn.Linear 128 -> 128): one k-ascending fmaf chain per hidden unit over the 64 node features and then the 64
+//   query features, bias added after the chain (torch_math.hpp) -- v_mfma_f32_32x32x2_f32 fed consecutive k pairs; the
+//   query half needs no loads from the big tensors, its B operand is query[sample][k];
+//   mlp.2 (nn.Linear 128 -> 1): a GEMV on the reference's CPU path, whose association of the 128 products is a property
+//   of the host BLAS.  It arrives as a program (ultra_amd/host_order.py): stages of L lanes, lane p an fma chain over its
+//   element list (lane 0 of a later stage continues from the previous stage's value; an element flagged + 256 is added
+//   as a rounded product instead of fused), lanes folded v[p] += v[p + L/2],
+//   v[p] += v[p + L/4], ...; bias last.  The hidden tile passes through LDS so that one lane walks one row's program.
+__global__ void __launch_bounds__(256) readout_kernel(const ReadoutParams p) {
+    // [tile m (4)][i (16)][lane] float4 : W1[32 m + (lane & 31)][2 s + (lane >> 5)], s = 4 i + {0, 2, 1, 3}[q] (see swap32)
+    __shared__ __attribute__((aligned(16))) float lds_w[4 * 16 * 64 * 4];
+    __shared__ float lds_hid[4][32 * READOUT_HID_STRIDE];
+    __shared__ float lds_lane[4][16 * 32];
+    __shared__ float lds_w2[128], lds_b1[128];
+    __shared__ int lds_order[READOUT_ORDER_MAX];
     const int tid = threadIdx.x;
-    if (!p.qbias) {
-        // the query half of mlp.0 (models.py:166-170 concatenates query to every node feature): one 64-term dot
-        // product per (sample, hidden unit), computed by every workgroup for itself instead of a GEMM launch
-        for (int idx = tid; idx < (int)p.batch * 128; idx += blockDim.x) {
-            const int b = idx >> 7, f = idx & 127;
-            const float4 *wr = reinterpret_cast<const float4 *>(p.w1 + f * 128 + 64);
-            const float4 *qr = reinterpret_cast<const float4 *>(p.query + b * 64);
-            float acc = p.b1[f];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float4 w = wr[k], q = qr[k];
-                acc += w.x * q.x;
-                acc += w.y * q.y;
-                acc += w.z * q.z;
-                acc += w.w * q.w;
-            }
-            lds_qb[idx] = acc;
-        }
-    }
-    for (int idx4 = tid; idx4 < 4 * 8 * 64; idx4 += blockDim.x) {
-        const int l = idx4 & 63, i = (idx4 >> 6) & 7, m = idx4 >> 9;
+    for (int idx4 = tid; idx4 < 4 * 16 * 64; idx4 += blockDim.x) {
+        const int l = idx4 & 63, i = (idx4 >> 6) & 15, m = idx4 >> 10;
+        const float *wr = p.w1 + (32 * m + (l & 31)) * 128 + 8 * i;
+        const float4 w0 = *reinterpret_cast<const float4 *>(wr), w1 = *reinterpret_cast<const float4 *>(wr + 4);
+        const bool odd = (l >> 5) != 0;
         reinterpret_cast<float4 *>(lds_w)[idx4] =
-            *reinterpret_cast<const float4 *>(p.w1 + (32 * m + (l & 31)) * 128 + 8 * i + 4 * (l >> 5));
+            make_float4(odd ? w0.y : w0.x, odd ? w1.y : w1.x, odd ? w0.w : w0.z, odd ? w1.w : w1.z);
     }
-    if (tid < 128) lds_w2[tid] = p.w2[tid];
+    if (tid < 128) {
+        lds_w2[tid] = p.w2[tid];
+        lds_b1[tid] = p.b1[tid];
+    }
+    if (p.order) {
+        for (int i = tid; i < p.order_len; i += blockDim.x) lds_order[i] = p.order[i];
+    } else {
+        // default: one chain, k ascending
+        for (int i = tid; i < 4 + 128; i += blockDim.x) lds_order[i] = i == 0 ? 1 : (i == 1 ? 1 : (i == 2 ? 0 : (i == 3 ? 128 : i - 4)));
+    }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const float4 *w4 = reinterpret_cast<const float4 *>(lds_w);
+    float *hid = lds_hid[wave];
+    float *lv = lds_lane[wave];
     const long long total = p.batch * p.n_cand;
     const long long ntile = (total + 31) / 32;
     const int wpb = blockDim.x >> 6;
@@ -284,6 +291,11 @@ __global__ void __launch_bounds__(512, 2) readout_kernel(const ReadoutParams p) 
         float4 bh[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) bh[i] = hr[2 * i + h];
+        // the query half: element 2 s + h of the k pairs s = 4 i, 4 i + 2, 4 i + 1, 4 i + 3 (the layout swap32 produces)
+        const float *qr = p.query + b * 64 + h;
+        float4 bq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bq[i] = make_float4(qr[8 * i], qr[8 * i + 4], qr[8 * i + 2], qr[8 * i + 6]);
         f32x16 acc[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -291,35 +303,70 @@ __global__ void __launch_bounds__(512, 2) readout_kernel(const ReadoutParams p) 
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
         float4 a[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) a[m] = w4[(m * 8 + 0) * 64 + lane];
+        for (int m = 0; m < 4; ++m) a[m] = w4[(m * 16 + 0) * 64 + lane];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 16; ++i) {
+            float4 bb;
+            if (i < 8) {
+                bb = bh[i];
+                swap32(bb.x, bb.y);
+                swap32(bb.z, bb.w);
+            } else {
+                bb = bq[i - 8];
+            }
             float4 an[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) an[m] = (i + 1 < 8) ? w4[(m * 8 + i + 1) * 64 + lane] : a[m];
+            for (int m = 0; m < 4; ++m) an[m] = (i + 1 < 16) ? w4[(m * 16 + i + 1) * 64 + lane] : a[m];
+            // k ascending: s = 4 i, 4 i + 1, 4 i + 2, 4 i + 3; the four hidden-unit tiles are independent chains
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, bh[i].x, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, bh[i].y, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, bh[i].z, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, bh[i].w, acc[m], 0, 0, 0);
-            }
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, bb.x, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, bb.z, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, bb.y, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, bb.w, acc[m], 0, 0, 0);
 #pragma unroll
             for (int m = 0; m < 4; ++m) a[m] = an[m];
             __builtin_amdgcn_sched_barrier(0);
         }
-        const float *qb = p.qbias ? p.qbias + b * 128 : lds_qb + b * 128;
-        float s = 0.f;
+        // hidden activation of the 32 rows -> LDS (row-major; the lane pair (j, h) holds all 128 units of row j)
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int f = feat_of(m, r, h);
-                const float hid = fmaxf(acc[m][r] + qb[f], 0.f);
-                s += hid * lds_w2[f];
+                hid[j * READOUT_HID_STRIDE + f] = fmaxf(acc[m][r] + lds_b1[f], 0.f);
             }
-        s += __shfl_xor(s, 32);
-        if (valid && h == 0) p.score[row] = s + p.b2[0];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (h == 0) {
+            const float *hrow = hid + j * READOUT_HID_STRIDE;
+            int pc = 1;
+            float s = 0.f;
+            const int n_stage = lds_order[0];
+            for (int st = 0; st < n_stage; ++st) {
+                const int L = lds_order[pc], carry = lds_order[pc + 1];
+                pc += 2;
+                for (int q = 0; q < L; ++q) {
+                    const int n = lds_order[pc++];
+                    float v = (q == 0 && carry) ? s : 0.f;
+                    for (int e = 0; e < n; ++e) {
+                        const int word = lds_order[pc++];
+                        const int k = word & 255;
+                        // (bit 8: the host code rounds this product before adding it)
+                        v = (word & 256) ? v + hrow[k] * lds_w2[k] : __builtin_fmaf(hrow[k], lds_w2[k], v);
+                    }
+                    lv[q * 32 + j] = v;
+                }
+                for (int half = L >> 1; half >= 1; half >>= 1)
+                    for (int q = 0; q < half; ++q) lv[q * 32 + j] = lv[q * 32 + j] + lv[(q + half) * 32 + j];
+                s = lv[j];
+            }
+            if (valid) p.score[row] = s + p.b2[0];
+        }
+        __builtin_amdgcn_wave_barrier();      // the next tile overwrites the hidden tile
     }
 }
 
@@ -470,102 +517,73 @@ int32_t ultra_conv_update(const void *x, const void *agg, const void *weight, co
     return ULTRA_OK;
 }
 
-static int check_query_bias(const void *qbias, const void *query, const void *b1, int64_t batch) {
-    if (qbias) return ULTRA_OK;
-    if (!query || !b1) {
-        set_error("ultra_readout: pass qbias, or query and b1");
+static int launch_readout(ReadoutParams &p, const void *hidden, const void *w1, const void *query, const void *b1,
+                          const void *w2, const void *b2, const int32_t *order, int64_t order_len, void *score, int64_t batch,
+                          int64_t num_node, int64_t n_cand, int32_t hidden_dim, int32_t feature_dim, void *stream, const char *who) {
+    if (hidden_dim != 64 || feature_dim != 128) {
+        set_error(std::string(who) + ": only hidden_dim = 64, feature_dim = 128 is built (the ULTRA checkpoints' shape)");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    if (!hidden || !w1 || !query || !b1 || !w2 || !b2 || !score || batch < 0 || n_cand < 0) {
+        set_error(std::string(who) + ": NULL operand");
         return ULTRA_ERR_INVALID;
     }
-    if (batch > READOUT_MAX_INLINE_BATCH) {
-        set_error("ultra_readout: the in-kernel query bias serves batch <= 32; pass a precomputed qbias beyond");
-        return ULTRA_ERR_UNSUPPORTED;
+    if (order && (order_len < 5 || order_len > READOUT_ORDER_MAX)) {
+        set_error(std::string(who) + ": summation program longer than 384 words (or empty)");
+        return ULTRA_ERR_INVALID;
+    }
+    if (batch * n_cand == 0) return ULTRA_OK;
+    p.hidden = (const float *)hidden;
+    p.w1 = (const float *)w1;
+    p.query = (const float *)query;
+    p.b1 = (const float *)b1;
+    p.w2 = (const float *)w2;
+    p.b2 = (const float *)b2;
+    p.order = order;
+    p.order_len = (int)order_len;
+    p.score = (float *)score;
+    p.batch = batch;
+    p.num_node = num_node;
+    p.n_cand = n_cand;
+    const long long ntile = (batch * n_cand + 31) / 32;
+    const int grid = grid_for(ntile, 4, 1);      // 4 waves per workgroup, one workgroup per CU (138 KB of LDS)
+    (void)hipGetLastError();   // drop any stale error left by other users of the runtime
+    hipLaunchKernelGGL(readout_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error(std::string("readout_kernel launch: ") + hipGetErrorString(e));
+        return ULTRA_ERR_HIP;
     }
     return ULTRA_OK;
 }
 
-int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1, const void *qbias, const void *query,
-                      const void *b1, const void *w2, const void *b2, void *score, int64_t batch, int64_t num_node,
-                      int64_t n_cand, int32_t hidden_dim, int32_t feature_dim, void *stream) {
+int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1, const void *query, const void *b1,
+                      const void *w2, const void *b2, const int32_t *order_dev, int64_t order_len, void *score, int64_t batch,
+                      int64_t num_node, int64_t n_cand, int32_t hidden_dim, int32_t feature_dim, void *stream) {
     ULTRA_DEVICE_SCOPE(stream);
-    if (hidden_dim != 64 || feature_dim != 128) {
-        set_error("ultra_readout: only hidden_dim = 64, feature_dim = 128 is built (the ULTRA checkpoints' shape)");
-        return ULTRA_ERR_UNSUPPORTED;
-    }
-    if (!hidden || !w1 || !w2 || !b2 || !score || batch < 0 || n_cand < 0) {
-        set_error("ultra_readout: NULL operand");
-        return ULTRA_ERR_INVALID;
-    }
-    if (int rc = check_query_bias(qbias, query, b1, batch)) return rc;
-    if (batch * n_cand == 0) return ULTRA_OK;
     ReadoutParams p;
-    p.query = (const float *)query;
-    p.b1 = (const float *)b1;
-    p.hidden = (const float *)hidden;
     p.t_index = t_index;
     p.triples = nullptr;
     p.side = nullptr;
-    p.w1 = (const float *)w1;
-    p.qbias = (const float *)qbias;
-    p.w2 = (const float *)w2;
-    p.b2 = (const float *)b2;
-    p.score = (float *)score;
-    p.batch = batch;
-    p.num_node = num_node;
-    p.n_cand = n_cand;
-    const long long ntile = (batch * n_cand + 31) / 32;
-    const int threads = ntile >= 2048 ? 512 : 256;   // as in ultra_conv_update
-    const int grid = grid_for(ntile, threads / 64, threads == 512 ? 1 : 2);
-    (void)hipGetLastError();   // drop any stale error left by other users of the runtime
-    hipLaunchKernelGGL(readout_kernel, dim3(grid), dim3(threads), 0, reinterpret_cast<hipStream_t>(stream), p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        set_error(std::string("readout_kernel launch: ") + hipGetErrorString(e));
-        return ULTRA_ERR_HIP;
-    }
-    return ULTRA_OK;
+    return launch_readout(p, hidden, w1, query, b1, w2, b2, order_dev, order_len, score, batch, num_node, n_cand, hidden_dim,
+                          feature_dim, stream, "ultra_readout");
 }
 
-int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const int32_t *side, const void *w1,
-                            const void *qbias, const void *query, const void *b1, const void *w2, const void *b2, void *score,
-                            int64_t batch, int64_t num_node, int64_t n_cand, int32_t hidden_dim, int32_t feature_dim,
-                            void *stream) {
+int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const int32_t *side, const void *w1, const void *query,
+                            const void *b1, const void *w2, const void *b2, const int32_t *order_dev, int64_t order_len,
+                            void *score, int64_t batch, int64_t num_node, int64_t n_cand, int32_t hidden_dim,
+                            int32_t feature_dim, void *stream) {
     ULTRA_DEVICE_SCOPE(stream);
-    if (hidden_dim != 64 || feature_dim != 128) {
-        set_error("ultra_readout_batch: only hidden_dim = 64, feature_dim = 128 is built (the ULTRA checkpoints' shape)");
-        return ULTRA_ERR_UNSUPPORTED;
-    }
-    if (!hidden || !triples || !side || !w1 || !w2 || !b2 || !score || batch < 0 || n_cand < 0) {
+    if (!triples || !side) {
         set_error("ultra_readout_batch: NULL operand");
         return ULTRA_ERR_INVALID;
     }
-    if (int rc = check_query_bias(qbias, query, b1, batch)) return rc;
-    if (batch * n_cand == 0) return ULTRA_OK;
     ReadoutParams p;
-    p.query = (const float *)query;
-    p.b1 = (const float *)b1;
-    p.hidden = (const float *)hidden;
     p.t_index = nullptr;
     p.triples = triples;
     p.side = side;
-    p.w1 = (const float *)w1;
-    p.qbias = (const float *)qbias;
-    p.w2 = (const float *)w2;
-    p.b2 = (const float *)b2;
-    p.score = (float *)score;
-    p.batch = batch;
-    p.num_node = num_node;
-    p.n_cand = n_cand;
-    const long long ntile = (batch * n_cand + 31) / 32;
-    const int threads = ntile >= 2048 ? 512 : 256;   // as in ultra_conv_update
-    const int grid = grid_for(ntile, threads / 64, threads == 512 ? 1 : 2);
-    (void)hipGetLastError();   // drop any stale error left by other users of the runtime
-    hipLaunchKernelGGL(readout_kernel, dim3(grid), dim3(threads), 0, reinterpret_cast<hipStream_t>(stream), p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        set_error(std::string("readout_kernel launch: ") + hipGetErrorString(e));
-        return ULTRA_ERR_HIP;
-    }
-    return ULTRA_OK;
+    return launch_readout(p, hidden, w1, query, b1, w2, b2, order_dev, order_len, score, batch, num_node, n_cand, hidden_dim,
+                          feature_dim, stream, "ultra_readout_batch");
 }
 
 int32_t ultra_relation_projection(const void *x, const void *w0, const void *b0, const void *w2, const void *b2, void *out,

@@ -109,37 +109,38 @@ def readout_supported(model, hidden):
             and len(mlp) == 3 and isinstance(mlp[0], torch.nn.Linear) and isinstance(mlp[1], torch.nn.ReLU)
             and isinstance(mlp[2], torch.nn.Linear) and mlp[0].in_features == 128 and mlp[0].out_features == 128
             and mlp[2].out_features == 1 and mlp[0].bias is not None and mlp[2].bias is not None
+            and mlp[0].weight.is_contiguous()
             and not (torch.is_grad_enabled() and (hidden.requires_grad or mlp[0].weight.requires_grad)))
 
 
-INLINE_QUERY_BIAS_MAX_BATCH = 32     # readout kernels fold the query half of mlp.0 themselves up to this batch size
+_ORDER_CACHE = {}
 
 
-def _query_bias_args(mlp, query, qbias=None):
-    """(qbias, query, b1) pointers for the readout kernels: a bias computed upstream (query_boundary), else in-kernel
-    for small batches, one GEMM beyond."""
-    if qbias is not None:
-        return qbias, query, (qbias.data_ptr(), None, None)
-    if query.shape[0] <= INLINE_QUERY_BIAS_MAX_BATCH:
-        query = query.contiguous()
-        return None, query, (None, query.data_ptr(), mlp[0].bias.data_ptr())
-    qbias = F.linear(query, mlp[0].weight[:, 64:], mlp[0].bias).contiguous()      # (batch, 128)
-    return qbias, query, (qbias.data_ptr(), None, None)
+def readout_order(device):
+    """The summation program of the readout's last product on `device` (host_order.readout_program: the association the
+    host BLAS uses for nn.Linear(128, 1), probed once per process), as an int32 tensor."""
+    key = str(device)
+    if key not in _ORDER_CACHE:
+        from . import host_order
+        prog, _source = host_order.readout_program(128)
+        _ORDER_CACHE[key] = torch.tensor(prog, dtype=torch.int32, device=device)
+    return _ORDER_CACHE[key]
 
 
-def readout(model, hidden, query, t_index, qbias=None):
-    """score[b, i] = mlp(cat[hidden[b, t_index[b, i]], query[b]]) without materialising the concatenation."""
+def readout(model, hidden, query, t_index, order=None):
+    """score[b, i] = mlp(cat[hidden[b, t_index[b, i]], query[b]]) without materialising the concatenation, in the
+    reference's operation order (csrc/dense_kernels.hip: readout_kernel)."""
     mlp = model.mlp
-    w1 = mlp[0].weight
-    _keep_qb, _keep_q, qargs = _query_bias_args(mlp, query, qbias)
     hidden = hidden.contiguous()
+    query = query.contiguous()
     batch, num_node = hidden.shape[:2]
     t_index = t_index.to(torch.int64).contiguous()      # the kernel reads int64 ids (an int32 batch would be misread)
     n_cand = t_index.shape[1]
+    order = readout_order(hidden.device) if order is None else order
     score = torch.empty(batch, n_cand, dtype=hidden.dtype, device=hidden.device)
-    check(lib.ultra_readout(hidden.data_ptr(), t_index.data_ptr(), w1.data_ptr(), *qargs,
-                            mlp[2].weight.data_ptr(), mlp[2].bias.data_ptr(), score.data_ptr(), batch, num_node, n_cand,
-                            64, 128, _stream(hidden)))
+    check(lib.ultra_readout(hidden.data_ptr(), t_index.data_ptr(), mlp[0].weight.data_ptr(), query.data_ptr(),
+                            mlp[0].bias.data_ptr(), mlp[2].weight.data_ptr(), mlp[2].bias.data_ptr(), order.data_ptr(),
+                            order.numel(), score.data_ptr(), batch, num_node, n_cand, 64, 128, _stream(hidden)))
     return score
 
 
@@ -156,18 +157,19 @@ def batch_prologue(batch, num_direct_rel):
     return batch, h0, r0, side, valid
 
 
-def readout_batch(model, hidden, query, batch, side, qbias=None):
+def readout_batch(model, hidden, query, batch, side, order=None):
     """readout() with the candidate node read straight from the raw (bs, n_cand, 3) batch."""
     mlp = model.mlp
-    w1 = mlp[0].weight
-    _keep_qb, _keep_q, qargs = _query_bias_args(mlp, query, qbias)
     hidden = hidden.contiguous()
+    query = query.contiguous()
     bs, num_node = hidden.shape[:2]
     n_cand = batch.shape[1]
+    order = readout_order(hidden.device) if order is None else order
     score = torch.empty(bs, n_cand, dtype=hidden.dtype, device=hidden.device)
-    check(lib.ultra_readout_batch(hidden.data_ptr(), batch.data_ptr(), side.data_ptr(), w1.data_ptr(), *qargs,
-                                  mlp[2].weight.data_ptr(), mlp[2].bias.data_ptr(), score.data_ptr(), bs, num_node, n_cand,
-                                  64, 128, _stream(hidden)))
+    check(lib.ultra_readout_batch(hidden.data_ptr(), batch.data_ptr(), side.data_ptr(), mlp[0].weight.data_ptr(),
+                                  query.data_ptr(), mlp[0].bias.data_ptr(), mlp[2].weight.data_ptr(), mlp[2].bias.data_ptr(),
+                                  order.data_ptr(), order.numel(), score.data_ptr(), bs, num_node, n_cand, 64, 128,
+                                  _stream(hidden)))
     return score
 
 

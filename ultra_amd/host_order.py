@@ -1,0 +1,268 @@
+"""Summation order of the readout's last product, taken from the host BLAS.
+
+EntityNBFNet's readout ends in nn.Linear(feature_dim, 1) (models.py:208): one dot product of 128 terms per candidate.
+On the reference's CPU path that is an MKL GEMV whose association of the 128 products depends on the machine -- 16-lane
+AVX-512 accumulators with a masked tail on an Intel Xeon, four strided SSE-style chains on an AMD EPYC (both observed with
+the same torch build).  Scores only reproduce the reference bit for bit -- and rankings at near-ties -- if the GPU adds the
+products in the same association, so the readout kernel takes the association as DATA (a small program) and this module
+recovers it from the BLAS the process itself links:
+
+  probe_tree(K)          the summation tree of F.linear(x, w) for w of shape (1, K), by probing: a row with x_i = 1,
+                         x_j = -1, x_k = 2^-30 (all else 0, w = 1) gives 2^-30 iff i and j are added before k joins them
+                         ((1 + 2^-30) rounds to 1 in fp32).  O(K^2) probe rows per tree level, ~1 s for K = 128.
+  tree_to_stages(tree)   the tree in the form the kernel executes: a sequence of STAGES; a stage has L lanes (L a power of
+                         two), lane p runs a chain  acc = fma(h[k], w[k], acc)  (or acc + fl(h[k] w[k]) where the host
+                         code does not fuse) over its element list starting from 0 (lane 0 of a later stage: from the
+                         previous stage's result), then the lanes are folded
+                         v[p] += v[p + L/2], v[p] += v[p + L/4], ...  Raises ValueError for trees outside this family.
+  emulate(stages, x, w)  numpy restatement of what the kernel does (tests; validation against torch on this host).
+  readout_program(K)     the validated program of this host as an int32 list (cached), or the k-ascending single chain
+                         when the host's tree is outside the family or ULTRA_READOUT_ORDER=sequential.
+
+Only the association is taken from the host; every product and sum is an fp32 operation on the GPU.
+"""
+import os
+import warnings
+
+import numpy as np
+import torch
+
+TINY = 2.0 ** -30
+PROBE_ROWS = 8192
+
+
+def _run_queries(qs, K):
+    out = []
+    w = torch.ones(1, K)
+    for s in range(0, len(qs), PROBE_ROWS):
+        chunk = qs[s:s + PROBE_ROWS]
+        x = torch.zeros(PROBE_ROWS, K)
+        idx = torch.tensor(chunk, dtype=torch.long)
+        r = torch.arange(len(chunk))
+        x[r, idx[:, 0]] = 1.0
+        x[r, idx[:, 1]] = -1.0
+        x[r, idx[:, 2]] = TINY
+        y = torch.nn.functional.linear(x, w)[:, 0]
+        out += (y[:len(chunk)] != 0).tolist()
+    return out
+
+
+def probe_tree(K=128):
+    """Nested pairs over 0..K-1: (a, b) = a and b are added; leaves are products h[k] * w[k]."""
+
+    def solve(leaves):
+        if len(leaves) == 1:
+            return leaves[0]
+        if len(leaves) == 2:
+            return (leaves[0], leaves[1])
+        a, rest = leaves[0], leaves[1:]
+        qs = [(a, j, k) for j in rest for k in rest if j != k]
+        res = iter(_run_queries(qs, K))
+        below = {(j, k): next(res) for j in rest for k in rest if j != k}     # LCA(a, j) strictly below LCA(a, k)
+        level = {j: sum(1 for k in rest if k != j and below[(k, j)]) for j in rest}
+        groups = {}
+        for j in rest:
+            groups.setdefault(level[j], []).append(j)
+        node = a
+        for lv in sorted(groups):
+            node = (node, solve(groups[lv]))
+        return node
+
+    return solve(list(range(K)))
+
+
+def _as_tuple(t):
+    return t if isinstance(t, int) else (_as_tuple(t[0]), _as_tuple(t[1]))
+
+
+def _leaves(t):
+    return [t] if isinstance(t, int) else _leaves(t[0]) + _leaves(t[1])
+
+
+def annotate(tree, K=128):
+    """The probed tree with every join that involves a single product marked as fused or not:
+    ('f', acc, k): fma(h[k], w[k], acc) -- the product of leaf k is not rounded on its own; ('a', left, right): an fp32
+    add of two finished values.  Probe: w = 1 + 2^-12 everywhere, x_a = -(1 + 2^-12), x_b = 1 + 2^-12: the products are
+    -+(1 + 2^-11 + 2^-24), which round to -+(1 + 2^-11); the row sums to +2^-24 if b is fused onto a value holding a's
+    rounded product, -2^-24 the other way round, 0 if both products are rounded before they are added."""
+    tree = _as_tuple(tree)
+    nodes = []
+
+    def collect(t):
+        if isinstance(t, int):
+            return
+        a, b = t
+        if isinstance(a, int) or isinstance(b, int):
+            nodes.append(t)
+        collect(a)
+        collect(b)
+
+    collect(tree)
+    w = torch.full((1, K), 1.0 + 2.0 ** -12)
+    x = torch.zeros(max(len(nodes), 1), K)
+    for r, (a, b) in enumerate(nodes):
+        if isinstance(b, int):
+            acc_leaf, leaf = _leaves(a)[0], b
+        else:
+            acc_leaf, leaf = _leaves(b)[0], a
+        x[r, acc_leaf] = -(1.0 + 2.0 ** -12)
+        x[r, leaf] = 1.0 + 2.0 ** -12
+    pad = torch.zeros(max(PROBE_ROWS - x.shape[0], 0), K)
+    y = torch.nn.functional.linear(torch.cat([x, pad]), w)[:len(nodes), 0].tolist()
+    verdict = {id(n): v for n, v in zip(nodes, y)}
+
+    def build(t):
+        if isinstance(t, int):
+            return t
+        a, b = t
+        v = verdict.get(id(t), 0.0)
+        if isinstance(b, int) and v > 0:
+            return ("f", build(a), b)
+        if isinstance(b, int) and v < 0 and isinstance(a, int):
+            return ("f", b, a)
+        if isinstance(a, int) and v > 0:
+            return ("f", build(b), a)
+        if isinstance(a, int) and v < 0 and isinstance(b, int):
+            return ("f", a, b)
+        return ("a", build(a), build(b))
+
+    return build(tree)
+
+
+UNFUSED = 256      # flag on an element of a lane: v = v + fl(h[k] * w[k]) instead of v = fma(h[k], w[k], v)
+
+
+def _is_fold(node):
+    return not isinstance(node, int) and node[0] == "a" and not isinstance(node[1], int) and not isinstance(node[2], int)
+
+
+def tree_to_stages(annotated):
+    """[(L, carry, [lane element lists])] from the first stage to the last, for an annotate()d tree.  An element is the
+    product index k, + UNFUSED where the product is rounded before it is added.  Adding a single rounded product to a lane
+    is the same arithmetic whether one calls it a chain step or a fold with a one-element lane; it is parsed as a step."""
+    stages = []
+    t = annotated
+    while t is not None:
+        lanes, depth = {}, [0]
+
+        def walk(node, level, lane):
+            if _is_fold(node):
+                # addition commutes: the operand holding the smallest product index (the side a carried value lives on)
+                # keeps the lane, the other one sits `1 << level` lanes away
+                first, second = sorted((node[1], node[2]), key=lambda c: min(_leaves_annotated(c)))
+                walk(first, level + 1, lane)
+                walk(second, level + 1, lane | (1 << level))
+                return
+            depth[0] = max(depth[0], level)
+            lanes[lane] = node
+
+        walk(t, 0, 0)
+        L = 1 << depth[0]
+        if L > 16:
+            raise ValueError("more than 16 lanes")
+        carry, lists = None, []
+        for p in range(L):
+            elems, node = [], lanes.get(p)
+            while node is not None:
+                if isinstance(node, int):
+                    elems.append(node)              # first product of a lane: fma onto +0 = the rounded product
+                    node = None
+                elif node[0] == "f":
+                    elems.append(node[2])
+                    node = node[1]
+                elif isinstance(node[2], int):
+                    elems.append(node[2] + UNFUSED)
+                    node = node[1]
+                elif isinstance(node[1], int):
+                    elems.append(node[1] + UNFUSED)
+                    node = node[2]
+                else:                               # a fold below a chain: the value carried in from the previous stage
+                    if p != 0 or carry is not None:
+                        raise ValueError("a carried value outside lane 0")
+                    carry, node = node, None
+            lists.append(elems[::-1])
+        stages.append((L, carry is not None, lists))
+        t = carry
+    stages.reverse()
+    covered = sorted(k & 255 for _, _, lists in stages for lane in lists for k in lane)
+    if stages[0][1] or covered != sorted(_leaves_annotated(annotated)):
+        raise ValueError("stages do not cover every product exactly once")
+    return stages
+
+
+def _leaves_annotated(t):
+    return [t] if isinstance(t, int) else _leaves_annotated(t[1]) + _leaves_annotated(t[2])
+
+
+def stages_to_program(stages):
+    """int32 words for the kernel: [n_stage, then per stage: L, carry, then per lane: n, k_0 .. k_{n-1}]."""
+    prog = [len(stages)]
+    for L, carry, lists in stages:
+        prog += [L, 1 if carry else 0]
+        for lane in lists:
+            prog += [len(lane)] + list(lane)
+    return prog
+
+
+def sequential_stages(K=128):
+    return [(1, False, [list(range(K))])]
+
+
+def emulate(stages, x, w):
+    """What the readout kernel computes for y = x @ w (x (M, K), w (K,)): fp32, the fma chains and folds of `stages`."""
+    x64, w64 = np.asarray(x, dtype=np.float64), np.asarray(w, dtype=np.float64)
+
+    def r32(a):
+        return a.astype(np.float32).astype(np.float64)
+
+    s = np.zeros(x64.shape[0])
+    for L, carry, lists in stages:
+        v = []
+        for p, elems in enumerate(lists):
+            acc = s if (p == 0 and carry) else np.zeros(x64.shape[0])
+            for e in elems:
+                k = e & 255
+                if e & UNFUSED:
+                    acc = r32(r32(x64[:, k] * w64[k]) + acc)
+                else:
+                    acc = r32(x64[:, k] * w64[k] + acc)       # fp32 fma: the 48-bit product is exact in fp64
+            v.append(acc)
+        half = L >> 1
+        while half >= 1:
+            for p in range(half):
+                v[p] = r32(v[p] + v[p + half])
+            half >>= 1
+        s = v[0]
+    return s.astype(np.float32)
+
+
+_CACHE = {}
+
+
+def readout_stages(K=128):
+    """The stages of this host's F.linear(x, (1, K)) (validated against torch on random rows), or the sequential chain."""
+    if K in _CACHE:
+        return _CACHE[K]
+    mode = os.environ.get("ULTRA_READOUT_ORDER", "host")
+    stages, source = sequential_stages(K), "sequential"
+    if mode == "host":
+        try:
+            cand = tree_to_stages(annotate(probe_tree(K), K))
+            g = torch.Generator().manual_seed(0)
+            x, w = torch.randn(4096, K, generator=g), torch.randn(1, K, generator=g)
+            want = torch.nn.functional.linear(x, w)[:, 0].numpy()
+            match = float((emulate(cand, x.numpy(), w[0].numpy()) == want).mean())
+            if match >= 0.99:            # (the BLAS sums a few trailing rows of each thread's share with another kernel)
+                stages, source = cand, "host BLAS (probed; %.2f %% of 4096 random rows bit-equal)" % (100 * match)
+            else:
+                warnings.warn("ultra_amd: probed GEMV order reproduces only %.1f %% of rows; using the sequential chain"
+                              % (100 * match))
+        except ValueError as exc:
+            warnings.warn("ultra_amd: host GEMV order not recognised (%s); using the sequential chain" % exc)
+    _CACHE[K] = (stages, source)
+    return _CACHE[K]
+
+
+def readout_program(K=128):
+    stages, source = readout_stages(K)
+    return stages_to_program(stages), source

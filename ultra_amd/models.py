@@ -237,18 +237,13 @@ class EntityNBFNet(BaseNBFNet):
         # query = representation of each sample's query relation, scattered to its head node
         fused = (dense.boundary_supported(h_index, self.query) and self.query.dim() == 3
                  and self.query.shape[0] == batch_size and self.query.shape[-1] == self.dims[0])
-        self._qbias = None
         if fused and layers.POINT_BOUNDARY_FAST_PATH and not torch.is_grad_enabled():
-            # gather the query rows (+ the readout's per-sample bias); the boundary stays in closed form
-            _, query, self._qbias = dense.query_boundary(
-                h_index, self.query, r_index, data.num_nodes, materialize=False,
-                readout_mlp=self.mlp if not self.concat_hidden else None)
+            # gather the query rows; the boundary stays in closed form
+            _, query, _ = dense.query_boundary(h_index, self.query, r_index, data.num_nodes, materialize=False)
             boundary = layers.PointBoundary(h_index, query, data.num_nodes)
         elif fused:
-            # gather + scatter (+ the readout's per-sample bias), one kernel
-            boundary, query, self._qbias = dense.query_boundary(
-                h_index, self.query, r_index, data.num_nodes,
-                readout_mlp=self.mlp if not torch.is_grad_enabled() and not self.concat_hidden else None)
+            # gather + scatter, one kernel
+            boundary, query, _ = dense.query_boundary(h_index, self.query, r_index, data.num_nodes)
         else:
             query = self.query[torch.arange(batch_size, device=r_index.device), r_index]
             index = h_index.unsqueeze(-1).expand_as(query)
@@ -326,7 +321,7 @@ class EntityNBFNet(BaseNBFNet):
             batch_c, h0, r0, side, valid = dense.batch_prologue(batch, data.num_relations // 2)
             hiddens, _, query = self._bellmanford_hidden(data, h0, r0)
             if dense.readout_supported(self, hiddens[-1]):
-                score = dense.readout_batch(self, hiddens[-1], query, batch_c, side, qbias=self._qbias).view(shape)
+                score = dense.readout_batch(self, hiddens[-1], query, batch_c, side).view(shape)
                 self._check_valid(valid)
                 return score
             # (shape not covered by the fused readout: fall through to the generic path below)
@@ -350,7 +345,7 @@ class EntityNBFNet(BaseNBFNet):
                                                      edge_keep=edge_weight is not None)
         if dense.readout_supported(self, hiddens[-1]):
             # gather + cat[hidden, query] + MLP in one MFMA kernel (nothing of size (bs, N, 128) is materialised)
-            score = dense.readout(self, hiddens[-1], query, t_index, qbias=self._qbias).view(shape)
+            score = dense.readout(self, hiddens[-1], query, t_index).view(shape)
             self._check_valid(valid)
             return score
         node_query = query.unsqueeze(1).expand(-1, data.num_nodes, -1)
