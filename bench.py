@@ -322,7 +322,7 @@ def main():
     if world > 1:
         dist.barrier()
     from ultra_amd import distributed as udist
-    from ultra_amd import models, rspmm, synthetic, tasks
+    from ultra_amd import host_order, models, rspmm, synthetic, tasks
 
     shape = synthetic.SHAPES[args.shape]
     data_cpu = synthetic.make_kg(**shape, seed=1234)
@@ -414,7 +414,8 @@ def main():
                                "(N=%d, E=%d, R=%d), distmult+sum rspmm, batch %d queries/GPU, query-sharded"
                                % (args.shape, N, data.num_edges, data.num_relations, bs),
                    "batch_per_gpu": bs, "triples_per_step_per_gpu": bs * N, "weights": weights,
-                   "summation_order": "reference (rspmm.cpp:61-72 sequential per row; nn.Linear / nn.LayerNorm in torch's CPU order)",
+                   "summation_order": "reference (rspmm.cpp:61-72 sequential per row; nn.Linear / nn.LayerNorm in torch's CPU order; "
+                                      "readout GEMV: %s)" % host_order.readout_stages(128)[1],
                    "launch": "eager" if args.no_graph else "hipGraph replay of the captured forward",
                    "rccl_world_size": dist.get_world_size() if (world > 1 or launched) else 1,
                    "per_rank": per_rank,
@@ -481,9 +482,12 @@ def main():
                              "max_abs_err_reference_fp32_vs_fp64": (ref_score.double() - truth).abs().max().item(),
                              "rank_mismatches_gpu_vs_fp64": int((r_gpu != r_true).sum()),
                              "rank_mismatches_reference_fp32_vs_fp64": int((r_cpu != r_true).sum()),
-                             "note": "hidden states after all layers equal the reference flow bit for bit "
-                                     "(tests/test_torch_order_gpu.py); what is left is the readout MLP's last 128 -> 1 product "
-                                     "(MKL GEMV order on the CPU side)"}
+                             "scores_bit_equal": int((got == ref_score).sum()), "scores": got.numel(),
+                             "readout_order": host_order.readout_stages(128)[1],
+                             "note": "every operation of the forward follows the reference's order (rspmm.cpp row sums, torch's "
+                                     "nn.Linear / nn.LayerNorm arithmetic, the host BLAS's association for the readout's last "
+                                     "product, probed by ultra_amd/host_order.py); the host BLAS may sum a few trailing rows of "
+                                     "each thread's share with a remainder kernel"}
             # ---- the re-associating plans (round 1's timed path), same command: throughput and parity beside the timed mode ----
             rspmm.set_plan_defaults(exact_order=False)
             try:

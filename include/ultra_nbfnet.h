@@ -52,9 +52,11 @@ int32_t ultra_conv_update_backward(const void *x, const void *agg, const void *g
  * in the reference's operation order: mlp.0 = one k-ascending fmaf chain per hidden unit over the 64 node features and
  * then the 64 query features, bias added after the chain (the concatenated feature is never materialised: the query half
  * of the chain reads query[sample]); mlp.2 = nn.Linear(128, 1), a GEMV on the reference's CPU path whose association of
- * the 128 products belongs to the host BLAS and is passed in as a PROGRAM (order_dev, int32 words on the device;
+ * the 128 products belongs to the host BLAS and is passed in as a PROGRAM (order_dev, at most 640 int32 words on the device;
  * ultra_amd/host_order.py recovers it from the BLAS of the running process):
- *     [n_stage, then per stage: L (lanes, power of two <= 16), carry (0/1), then per lane: n, k_0 .. k_{n-1}]
+ *     [n_stage, then one header per stage: L (lanes, power of two <= 16), carry (0/1), (offset_p, groups_p) for p < L,
+ *      then the element area]: lane p's elements start at word offset_p (a multiple of 4) and fill groups_p groups of
+ *     eight, the last one padded with the element 128, which multiplies zeros
  *     lane p: v = (p == 0 && carry) ? previous stage's result : 0;  v = fma(hid[k], w2[k], v) for its k in order
  *             (an element written k + 256: v = v + fl(hid[k] * w2[k]), for host code that does not fuse);
  *     fold: v[p] += v[p + L/2]; v[p] += v[p + L/4]; ...; stage result v[0];  score = last result + b2.

@@ -54,7 +54,8 @@ def test_parse_four_unfused_strided_chains_with_a_scalar_prologue():
     x, w = random_operands()
     assert np.array_equal(ho.emulate(stages, x, w), eval_tree(tree, x, w).astype(np.float32))
     prog = ho.stages_to_program(stages)
-    assert prog[:3] == [1, 4, 0] and len(prog) == 3 + 4 + 128
+    assert prog[:5] == [1, 4, 0, 12, 5] and prog[5:7] == [52, 4] and len(prog) == 12 + 40 + 3 * 32
+    assert prog[12:16] == [0, 1 + ho.UNFUSED, 2 + ho.UNFUSED, 3 + ho.UNFUSED] and prog[12 + 35] == ho.PAD
 
 
 def test_parse_sixteen_fused_lanes_plus_a_masked_tail():
@@ -97,7 +98,7 @@ def test_host_blas_order_is_recovered_and_reproduces_torch(monkeypatch):
         # the BLAS sums the last few rows of every thread's share with a remainder kernel: everything else is bit-equal
         assert (got == want).mean() >= 0.995 and np.abs(got - want).max() <= 4e-6 * np.abs(want).max()
     prog, _ = ho.readout_program(128)
-    assert prog[0] == len(stages) and len(prog) <= 384
+    assert prog[0] == len(stages) and len(prog) <= 640
 
 
 def test_sequential_order_on_request(monkeypatch):

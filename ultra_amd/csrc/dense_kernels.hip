@@ -229,7 +229,7 @@ struct ReadoutParams {
     long long batch, num_node, n_cand;
 };
 
-constexpr int READOUT_ORDER_MAX = 384;    // 1 + stages * (2 + lanes) + 128 elements
+constexpr int READOUT_ORDER_MAX = 640;    // 1 + stages * (2 + lanes) + the 128 elements, each lane padded to groups of 8
 constexpr int READOUT_HID_STRIDE = 129;   // floats per row of the hidden tile in LDS: a lane reads ITS row, bank = row + k
 
 // score = mlp.2( relu( mlp.0( cat[hidden[t], query] ) ) ) in the reference's operation order:
@@ -241,13 +241,13 @@ constexpr int READOUT_HID_STRIDE = 129;   // floats per row of the hidden tile i
 //   element list (lane 0 of a later stage continues from the previous stage's value; an element flagged + 256 is added
 //   as a rounded product instead of fused), lanes folded v[p] += v[p + L/2],
 //   v[p] += v[p + L/4], ...; bias last.  The hidden tile passes through LDS so that one lane walks one row's program.
-__global__ void __launch_bounds__(256) readout_kernel(const ReadoutParams p) {
+__global__ void __launch_bounds__(512) readout_kernel(const ReadoutParams p) {
     // [tile m (4)][i (16)][lane] float4 : W1[32 m + (lane & 31)][2 s + (lane >> 5)], s = 4 i + {0, 2, 1, 3}[q] (see swap32)
     __shared__ __attribute__((aligned(16))) float lds_w[4 * 16 * 64 * 4];
-    __shared__ float lds_hid[4][32 * READOUT_HID_STRIDE];
-    __shared__ float lds_lane[4][16 * 32];
-    __shared__ float lds_w2[128], lds_b1[128];
-    __shared__ int lds_order[READOUT_ORDER_MAX];
+    __shared__ float lds_hid[8][16 * READOUT_HID_STRIDE];     // per wave: 16 rows at a time (two passes per tile)
+    __shared__ float lds_lane[8][16 * 16];
+    __shared__ float lds_w2[136], lds_b1[128];      // w2[128 ..] = 0: the program's padding element
+    __shared__ __attribute__((aligned(16))) int lds_order[READOUT_ORDER_MAX];
     const int tid = threadIdx.x;
     for (int idx4 = tid; idx4 < 4 * 16 * 64; idx4 += blockDim.x) {
         const int l = idx4 & 63, i = (idx4 >> 6) & 15, m = idx4 >> 10;
@@ -257,15 +257,14 @@ __global__ void __launch_bounds__(256) readout_kernel(const ReadoutParams p) {
         reinterpret_cast<float4 *>(lds_w)[idx4] =
             make_float4(odd ? w0.y : w0.x, odd ? w1.y : w1.x, odd ? w0.w : w0.z, odd ? w1.w : w1.z);
     }
-    if (tid < 128) {
-        lds_w2[tid] = p.w2[tid];
-        lds_b1[tid] = p.b1[tid];
-    }
+    if (tid < 136) lds_w2[tid] = tid < 128 ? p.w2[tid] : 0.f;
+    if (tid < 128) lds_b1[tid] = p.b1[tid];
     if (p.order) {
         for (int i = tid; i < p.order_len; i += blockDim.x) lds_order[i] = p.order[i];
     } else {
-        // default: one chain, k ascending
-        for (int i = tid; i < 4 + 128; i += blockDim.x) lds_order[i] = i == 0 ? 1 : (i == 1 ? 1 : (i == 2 ? 0 : (i == 3 ? 128 : i - 4)));
+        // default: one chain, k ascending: [1 stage | 1 lane, no carry, (offset 8, 16 groups) | pad | 0 .. 127]
+        for (int i = tid; i < 8 + 128; i += blockDim.x)
+            lds_order[i] = i >= 8 ? i - 8 : (i == 0 || i == 1 ? 1 : (i == 3 ? 8 : (i == 4 ? 16 : 0)));
     }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
@@ -276,10 +275,11 @@ __global__ void __launch_bounds__(256) readout_kernel(const ReadoutParams p) {
     const long long total = p.batch * p.n_cand;
     const long long ntile = (total + 31) / 32;
     const int wpb = blockDim.x >> 6;
-    for (long long tile = (long long)blockIdx.x * wpb + wave; tile < ntile; tile += (long long)gridDim.x * wpb) {
+    // operands of a tile: the candidate's hidden row (16-byte chunks 2 i + h) and its sample's query row, as element
+    // 2 s + h of the k pairs s = 4 i, 4 i + 2, 4 i + 1, 4 i + 3 (the layout swap32 produces)
+    const auto load_tile = [&](const long long tile, float4 (&bh)[8], float4 (&bq)[8]) {
         const long long row = tile * 32 + j;
-        const bool valid = row < total;
-        const long long rowc = valid ? row : total - 1;
+        const long long rowc = row < total ? row : total - 1;
         const long long b = rowc / p.n_cand;
         const long long c = rowc - b * p.n_cand;
         long long node = c;
@@ -288,14 +288,20 @@ __global__ void __launch_bounds__(256) readout_kernel(const ReadoutParams p) {
         else if (p.t_index)
             node = p.t_index[rowc];
         const float4 *hr = reinterpret_cast<const float4 *>(p.hidden + (b * p.num_node + node) * 64);
-        float4 bh[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) bh[i] = hr[2 * i + h];
-        // the query half: element 2 s + h of the k pairs s = 4 i, 4 i + 2, 4 i + 1, 4 i + 3 (the layout swap32 produces)
         const float *qr = p.query + b * 64 + h;
-        float4 bq[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) bq[i] = make_float4(qr[8 * i], qr[8 * i + 4], qr[8 * i + 2], qr[8 * i + 6]);
+    };
+    const long long tstride = (long long)gridDim.x * wpb;
+    long long tile = (long long)blockIdx.x * wpb + wave;
+    float4 bh[8], bq[8];
+    if (tile < ntile) load_tile(tile, bh, bq);
+    for (; tile < ntile; tile += tstride) {
+        // the next tile's operands are requested before the 256 matrix instructions of this one
+        float4 bhn[8], bqn[8];
+        load_tile(tile + tstride < ntile ? tile + tstride : tile, bhn, bqn);
         f32x16 acc[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -330,43 +336,74 @@ __global__ void __launch_bounds__(256) readout_kernel(const ReadoutParams p) {
             for (int m = 0; m < 4; ++m) a[m] = an[m];
             __builtin_amdgcn_sched_barrier(0);
         }
-        // hidden activation of the 32 rows -> LDS (row-major; the lane pair (j, h) holds all 128 units of row j)
+        // hidden activation -> LDS, 16 rows at a time (row-major; the lane pair (j, h) holds all 128 units of row j), then
+        // the program: hardware lane = (row of the pass, sub); the four subs take the program's lanes q = sub, sub + 4, ...
+        // (independent chains), sub 0 folds them and carries the stage's value into the next stage.
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            if ((j >> 4) == pass) {
+                const int jr = j & 15;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int f = feat_of(m, r, h);
-                hid[j * READOUT_HID_STRIDE + f] = fmaxf(acc[m][r] + lds_b1[f], 0.f);
+                    for (int r = 0; r < 16; ++r) {
+                        const int f = feat_of(m, r, h);
+                        hid[jr * READOUT_HID_STRIDE + f] = fmaxf(acc[m][r] + lds_b1[f], 0.f);
+                    }
+                if (h == 0) hid[jr * READOUT_HID_STRIDE + 128] = 0.f;       // the padding element
             }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (h == 0) {
-            const float *hrow = hid + j * READOUT_HID_STRIDE;
-            int pc = 1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int pr = lane & 15, sub = lane >> 4;
+            const float *hrow = hid + pr * READOUT_HID_STRIDE;
+            int hdr = 1;
             float s = 0.f;
             const int n_stage = lds_order[0];
             for (int st = 0; st < n_stage; ++st) {
-                const int L = lds_order[pc], carry = lds_order[pc + 1];
-                pc += 2;
-                for (int q = 0; q < L; ++q) {
-                    const int n = lds_order[pc++];
+                const int L = lds_order[hdr], carry = lds_order[hdr + 1];
+                for (int q = sub; q < L; q += 4) {
+                    const int off = lds_order[hdr + 2 + 2 * q], groups = lds_order[hdr + 3 + 2 * q];
                     float v = (q == 0 && carry) ? s : 0.f;
-                    for (int e = 0; e < n; ++e) {
-                        const int word = lds_order[pc++];
-                        const int k = word & 255;
-                        // (bit 8: the host code rounds this product before adding it)
-                        v = (word & 256) ? v + hrow[k] * lds_w2[k] : __builtin_fmaf(hrow[k], lds_w2[k], v);
+                    // eight elements at a time: their indices, then their operands, arrive together; only the eight
+                    // dependent fp32 operations of the chain are serial
+                    for (int g = 0; g < groups; ++g) {
+                        const int4 w0 = *reinterpret_cast<const int4 *>(lds_order + off + 8 * g);
+                        const int4 w1 = *reinterpret_cast<const int4 *>(lds_order + off + 8 * g + 4);
+                        const int word[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                        float hv[8], wv[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            hv[e] = hrow[word[e] & 255];
+                            wv[e] = lds_w2[word[e] & 255];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)      // (bit 8: the host code rounds this product before adding it)
+                            v = (word[e] & 256) ? v + hv[e] * wv[e] : __builtin_fmaf(hv[e], wv[e], v);
                     }
-                    lv[q * 32 + j] = v;
+                    lv[q * 16 + pr] = v;
                 }
-                for (int half = L >> 1; half >= 1; half >>= 1)
-                    for (int q = 0; q < half; ++q) lv[q * 32 + j] = lv[q * 32 + j] + lv[(q + half) * 32 + j];
-                s = lv[j];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (sub == 0) {
+                    for (int half = L >> 1; half >= 1; half >>= 1)
+                        for (int q = 0; q < half; ++q) lv[q * 16 + pr] = lv[q * 16 + pr] + lv[(q + half) * 16 + pr];
+                    s = lv[pr];
+                }
+                hdr += 2 + 2 * L;
             }
-            if (valid) p.score[row] = s + p.b2[0];
+            const long long prow = tile * 32 + 16 * pass + pr;
+            if (sub == 0 && prow < total) p.score[prow] = s + p.b2[0];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();      // the next pass / tile overwrites the hidden rows
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __builtin_amdgcn_wave_barrier();      // the next tile overwrites the hidden tile
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bh[i] = bhn[i];
+            bq[i] = bqn[i];
+        }
     }
 }
 
@@ -529,7 +566,7 @@ static int launch_readout(ReadoutParams &p, const void *hidden, const void *w1, 
         return ULTRA_ERR_INVALID;
     }
     if (order && (order_len < 5 || order_len > READOUT_ORDER_MAX)) {
-        set_error(std::string(who) + ": summation program longer than 384 words (or empty)");
+        set_error(std::string(who) + ": summation program longer than 640 words (or empty)");
         return ULTRA_ERR_INVALID;
     }
     if (batch * n_cand == 0) return ULTRA_OK;
@@ -546,9 +583,9 @@ static int launch_readout(ReadoutParams &p, const void *hidden, const void *w1, 
     p.num_node = num_node;
     p.n_cand = n_cand;
     const long long ntile = (batch * n_cand + 31) / 32;
-    const int grid = grid_for(ntile, 4, 1);      // 4 waves per workgroup, one workgroup per CU (138 KB of LDS)
+    const int grid = grid_for(ntile, 8, 1);      // 8 waves per workgroup, one workgroup per CU (140 KB of LDS)
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
-    hipLaunchKernelGGL(readout_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(readout_kernel, dim3(grid), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error(std::string("readout_kernel launch: ") + hipGetErrorString(e));

@@ -194,14 +194,24 @@ def _leaves_annotated(t):
     return [t] if isinstance(t, int) else _leaves_annotated(t[1]) + _leaves_annotated(t[2])
 
 
+PAD = 128          # padding element of the kernel's program: h[128] = w[128] = 0, fma(0, 0, v) = v
+
+
 def stages_to_program(stages):
-    """int32 words for the kernel: [n_stage, then per stage: L, carry, then per lane: n, k_0 .. k_{n-1}]."""
-    prog = [len(stages)]
+    """int32 words for the kernel:
+        [n_stage] then one header per stage: [L, carry, (offset_p, groups_p) for p < L], then the element area.
+    offset_p: word index (a multiple of 4) of lane p's elements; groups_p: its element count in groups of eight, the
+    last group padded with PAD (the kernel reads eight elements at a time, lanes of a stage run in parallel)."""
+    header_words = 1 + sum(2 + 2 * L for L, _, _ in stages)
+    base = (header_words + 3) // 4 * 4
+    prog, area = [len(stages)], []
     for L, carry, lists in stages:
         prog += [L, 1 if carry else 0]
         for lane in lists:
-            prog += [len(lane)] + list(lane)
-    return prog
+            groups = (len(lane) + 7) // 8
+            prog += [base + len(area), groups]
+            area += list(lane) + [PAD] * (8 * groups - len(lane))
+    return prog + [0] * (base - len(prog)) + area
 
 
 def sequential_stages(K=128):

@@ -512,7 +512,7 @@ def generalized_rspmm(edge_index, edge_type, edge_weight, relation, input, sum="
                          % (sum, mul))
     _check_args(edge_index, edge_type, edge_weight, relation, input)
     plan = get_plan(edge_index, edge_type, input.shape[0], relation.shape[0])
-    return _PlanRSPMM.apply(plan, sum, mul, edge_weight, relation, input)
+    return _PlanRSPMM.apply(plan, sum, mul, edge_weight, relation, input, None, False)
 
 
 def plan_rspmm(plan, relation, input, edge_weight=None, sum="add", mul="mul", boundary=None, keep=False):
