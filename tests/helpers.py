@@ -107,9 +107,16 @@ def emulate_plan_forward(plan, relation, input, edge_weight=None, boundary=None,
         emit(row, slot, acc)
         seen_rows.add(int(row))
     for k, row in enumerate(split_row):
-        acc = np.full(D, _zero(sum, dtype), dtype=dtype)
-        for s in range(split_ptr[k], split_ptr[k + 1]):
-            acc = _nary(sum, acc, partial[s]).astype(dtype)
+        # rspmm_fixup_kernel: 16 slot lanes sum the partials s, s + 16, ... in order; the lane sums are folded 0 .. 15
+        lanes = []
+        for s in range(16):
+            acc = np.full(D, _zero(sum, dtype), dtype=dtype)
+            for sl in range(split_ptr[k] + s, split_ptr[k + 1], 16):
+                acc = _nary(sum, acc, partial[sl]).astype(dtype)
+            lanes.append(acc)
+        acc = lanes[0]
+        for s in range(1, 16):
+            acc = _nary(sum, acc, lanes[s]).astype(dtype)
         if boundary is not None:
             acc = _nary(sum, acc, boundary.numpy()[row]).astype(dtype)
         out[row] = acc

@@ -444,7 +444,7 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
         xp.row_len = fp.row_len;
         xp.has_bnd = fp.has_bnd;
         const long long total = (long long)xp.n_split * n_outer * (row_len / VEC);
-        const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+        const int blocks = (int)std::min<long long>((total + 15) / 16, 16384);      // 16 output vectors per workgroup
 #define ULTRA_FIX(T_, V_)                                                                                          \
     switch (sum) {                                                                                                \
         case 0: hipLaunchKernelGGL((rspmm_fixup_kernel<T_, V_, 0>), dim3(blocks), dim3(256), 0, stream, xp); break; \

@@ -499,14 +499,21 @@ __global__ void __launch_bounds__(1024) rspmm_fwd_kernel(const FwdParams p) {
     }
 }
 
-// Combines the partial results of split rows in slot order and applies the boundary epilogue.
+// Combines the partial results of split rows and applies the boundary epilogue.  A workgroup handles 16 output vectors
+// with 16 slot lanes each: slot lane s sums the row's partials s, s + 16, s + 32, ... in order, the 16 lane sums are folded
+// 0, 1, ..., 15 -- a fixed association (deterministic, no atomics), wide enough for relation-major plans whose rows hold
+// hundreds of slots (tests/helpers.py: emulate_plan_forward restates it).
+constexpr int FIXUP_SLOT_LANES = 16;
 template <typename T, int VEC, int SUM>
 __global__ void __launch_bounds__(256) rspmm_fixup_kernel(const FixupParams p) {
     using P = Pack<T, VEC>;
+    __shared__ P lds[FIXUP_SLOT_LANES][16];
+    const int v = threadIdx.x & 15, s = threadIdx.x >> 4;
     const int vec_per_row = p.row_len / VEC;
     const long long total = (long long)p.n_split * p.n_outer * vec_per_row;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
+    for (long long base = blockIdx.x * 16ll; base < total; base += gridDim.x * 16ll) {
+        const bool ok = base + v < total;
+        const long long i = ok ? base + v : total - 1;
         const int dv = (int)(i % vec_per_row);
         const long long r2 = i / vec_per_row;
         const int outer = (int)(r2 % p.n_outer);
@@ -517,32 +524,42 @@ __global__ void __launch_bounds__(256) rspmm_fixup_kernel(const FixupParams p) {
         P acc;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc.v[e] = nary_zero<T, SUM>();
-        // slot order is the summation order (deterministic); eight partials are in flight at a time so a
-        // hub row with dozens of slots does not serialise on memory latency
-        for (int sb = s0; sb < s1; sb += 8) {
-            P v[8];
+        // four partials in flight per thread
+        for (int sb = s0 + s; sb < s1; sb += 4 * FIXUP_SLOT_LANES) {
+            P pv[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int sl = sb + u < s1 ? sb + u : s1 - 1;
-                v[u] = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.partial) +
-                                                    ((long long)sl * p.n_outer + outer) * p.row_len + d0);
+            for (int u = 0; u < 4; ++u) {
+                const int sl = sb + u * FIXUP_SLOT_LANES < s1 ? sb + u * FIXUP_SLOT_LANES : sb;
+                pv[u] = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.partial) +
+                                                     ((long long)sl * p.n_outer + outer) * p.row_len + d0);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (sb + u < s1) {
+            for (int u = 0; u < 4; ++u) {
+                if (sb + u * FIXUP_SLOT_LANES < s1) {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc.v[e] = nary<T, SUM>(acc.v[e], v[u].v[e]);
+                    for (int e = 0; e < VEC; ++e) acc.v[e] = nary<T, SUM>(acc.v[e], pv[u].v[e]);
                 }
             }
         }
-        if (p.has_bnd && (!p.bnd_rows || p.bnd_rows[outer] == row)) {
-            const P b = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.bnd.ptr) +
-                                                     outer * p.bnd.stride_outer + (long long)row * p.bnd.stride_row + d0);
+        lds[s][v] = acc;
+        __syncthreads();
+        if (s == 0 && ok) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc.v[e] = nary<T, SUM>(acc.v[e], b.v[e]);
+            for (int q = 1; q < FIXUP_SLOT_LANES; ++q) {
+                const P o = lds[q][v];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc.v[e] = nary<T, SUM>(acc.v[e], o.v[e]);
+            }
+            if (p.has_bnd && (!p.bnd_rows || p.bnd_rows[outer] == row)) {
+                const P b = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.bnd.ptr) +
+                                                         outer * p.bnd.stride_outer + (long long)row * p.bnd.stride_row + d0);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc.v[e] = nary<T, SUM>(acc.v[e], b.v[e]);
+            }
+            T *dst = reinterpret_cast<T *>(p.out) + outer * p.out_stride_outer + (long long)row * p.out_stride_row + d0;
+            *reinterpret_cast<P *>(dst) = acc;
         }
-        T *dst = reinterpret_cast<T *>(p.out) + outer * p.out_stride_outer + (long long)row * p.out_stride_row + d0;
-        *reinterpret_cast<P *>(dst) = acc;
+        __syncthreads();
     }
 }
 
