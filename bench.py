@@ -145,6 +145,10 @@ def _run_pmc_pass(counters, timeout=240):
         files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
         if r.returncode != 0 or not files:
             raise RuntimeError("rocprofv3 pass failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
+        keep = os.environ.get("ULTRA_BENCH_PMC_KEEP")       # raw per-dispatch counters, for profiles/
+        if keep:
+            os.makedirs(keep, exist_ok=True)
+            shutil.copy(files[0], os.path.join(keep, "_".join(counters) + "_counter_collection.csv"))
         out = {c: {"copy": [], "kernel": []} for c in counters}
         for row in csv.DictReader(open(files[0])):
             c = row["Counter_Name"]
