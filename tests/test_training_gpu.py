@@ -185,7 +185,7 @@ def test_fused_boundary_gradient(dev):
         assert torch.equal(a, t.grad)
 
 
-@pytest.mark.parametrize("aggr", ["sum", "max"])
+@pytest.mark.parametrize("aggr", ["sum", "max", "mean", "pna"])
 def test_training_forward_equals_the_filtered_graph(dev, aggr):
     """model.train(): the batch's own edges are dropped through the keep mask; same scores as the reference's route
     (remove_easy_edges, base_nbfnet.py:54-77: a filtered copy of the graph) and no plan is built per batch."""
@@ -193,8 +193,10 @@ def test_training_forward_equals_the_filtered_graph(dev, aggr):
     cfg = {k: dict(v) for k, v in cfg.items()}
     cfg["entity_model_cfg"]["aggregate_func"] = aggr
     data = synthetic.make_kg(num_node=300, num_triple=2500, num_relation_base=5, num_test=16, seed=8).to(dev)
+    torch.manual_seed(3)
     model = models.Ultra(**cfg)
-    model.load_state_dict(state)
+    if aggr != "pna":                      # (pna's update layer has its own shape: random weights there)
+        model.load_state_dict(state)
     model = model.to(dev).train()
     batch = torch.stack([data.edge_index[0, :4], data.edge_index[1, :4], data.edge_type[:4]], dim=-1)
     torch.manual_seed(0)
@@ -213,4 +215,4 @@ def test_training_forward_equals_the_filtered_graph(dev, aggr):
     model.eval()
     with torch.no_grad():
         want = model(filtered, neg)
-    assert torch.allclose(out.detach(), want, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(out.detach(), want, atol=(2e-4 if aggr == "pna" else 2e-5), rtol=1e-4)

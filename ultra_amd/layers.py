@@ -161,9 +161,9 @@ class GeneralizedRelationalConv(nn.Module):
 
     def propagate(self, edge_index, size=None, residual=False, onehot_rows=None, edge_keep=False, **kwargs):
         edge_weight = kwargs["edge_weight"]
-        if edge_keep and (self.message_func == "rotate" or self.aggregate_func in ("mean", "pna")):
-            # paths whose degree normalisation / unfused scatter need the edges really gone: the caller removes them
-            raise RuntimeError("edge_keep masks serve sum / min / max aggregation of TransE / DistMult messages")
+        if edge_keep and self.message_func == "rotate":
+            # the unfused scatter path needs the edges really gone: the caller removes them
+            raise RuntimeError("edge_keep masks serve the fused TransE / DistMult path")
         if isinstance(kwargs["boundary"], PointBoundary) and (
                 (edge_weight is not None and edge_weight.requires_grad) or self.message_func == "rotate"
                 or self.aggregate_func != "sum" or not kwargs["input"].is_cuda
@@ -284,8 +284,14 @@ class GeneralizedRelationalConv(nn.Module):
             return plan.forward(rel, x, edge_weight=edge_weight, boundary=fuse_boundary, sum=sum, mul=mul, keep=edge_keep)
 
         if self.aggregate_func in ("mean", "pna"):
-            # layers.py:193 -- PyG's `index` is edge_index[1]
-            degree_out = (torch.bincount(index, minlength=dim_size).to(input.dtype) + 1).view(1, -1, 1)
+            # layers.py:193 -- PyG's `index` is edge_index[1]; under a keep mask the degree counts the kept edges only
+            # (what bincount gives on the reference's filtered copy of the graph, base_nbfnet.py:54-77)
+            if edge_keep and edge_weight is not None:
+                degree_out = torch.zeros(dim_size, dtype=input.dtype, device=input.device).index_add_(
+                    0, index, edge_weight.detach().to(input.dtype))
+            else:
+                degree_out = torch.bincount(index, minlength=dim_size).to(input.dtype)
+            degree_out = (degree_out + 1).view(1, -1, 1)
 
         if (ONEHOT_FAST_PATH and onehot_rows is not None and not needs_grad and self.aggregate_func == "sum"
                 and mul == "mul" and input.is_cuda and point is None):

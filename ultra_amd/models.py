@@ -304,13 +304,14 @@ class EntityNBFNet(BaseNBFNet):
 
         edge_weight = None
         if self.training:
-            if self.aggregate_func in ("sum", "min", "max") and self.message_func in ("distmult", "transe"):
+            if self.aggregate_func in ("sum", "min", "max", "mean", "pna") and self.message_func in ("distmult", "transe"):
                 # Edge dropout without touching the graph: a 0/1 keep vector over the static edge list (one kernel), read
                 # by the rspmm kernels as "edge absent" -- so the cached plan of the static graph serves every batch
-                # (the reference filters the edge list, base_nbfnet.py:54-77, and re-sorts it inside every rspmm call).
+                # (the reference filters the edge list, base_nbfnet.py:54-77, and re-sorts it inside every rspmm call);
+                # mean / pna take their degree from the same vector (layers.message_and_aggregate).
                 edge_weight = self.easy_edge_keep(data, h_index, t_index, r_index, relation_representations.dtype)
             else:
-                # mean / pna normalise by the degree AFTER the removal, rotate runs the unfused scatter path
+                # rotate runs the unfused scatter path: the reference's filtered copy of the graph
                 data = self.remove_easy_edges(data, h_index, t_index, r_index)
 
         shape = h_index.shape
