@@ -1,51 +1,17 @@
-"""Recovers the summation tree the host BLAS uses for y = x @ w.T with ONE output column (nn.Linear(K, 1): the readout's
-last product, models.py:208), by probing: a row with x_i = 1, x_j = -1, x_k = 2^-30 (everything else 0, w = 1) gives
-2^-30 iff i and j are added together before k joins them -- (1 + 2^-30) rounds to 1 in fp32.  O(K^2) probes per tree level,
-one F.linear call per 8192 probes.  Prints the tree as nested pairs and writes it as JSON.
+"""Prints the summation tree the host BLAS uses for y = x @ w.T with ONE output column (nn.Linear(K, 1): the readout's last
+product, models.py:208), the stage program the readout kernel would run for it, and how much of torch it reproduces.
+CPU only (ultra_amd/host_order.py does the probing).
 
-    python tools/gemv_order_probe.py [K=128] [rows per call=8192] [out.json]
+    python tools/gemv_order_probe.py [K=128] [out.json]
 """
 import json
+import os
 import sys
 
 import torch
 
-K = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-MROWS = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-OUT = sys.argv[3] if len(sys.argv) > 3 else "gemv_tree.json"
-w = torch.ones(1, K)
-TINY = 2.0 ** -30
-
-
-def run_queries(qs):
-    out = []
-    for s in range(0, len(qs), MROWS):
-        chunk = qs[s:s + MROWS]
-        x = torch.zeros(MROWS, K)
-        for r, (i, j, k) in enumerate(chunk):
-            x[r, i], x[r, j], x[r, k] = 1.0, -1.0, TINY
-        y = torch.nn.functional.linear(x, w)[:, 0]
-        out += [bool(v != 0) for v in y[:len(chunk)].tolist()]
-    return out
-
-
-def solve(leaves):
-    if len(leaves) == 1:
-        return leaves[0]
-    if len(leaves) == 2:
-        return (leaves[0], leaves[1])
-    a, rest = leaves[0], leaves[1:]
-    qs = [(a, j, k) for j in rest for k in rest if j != k]
-    res = iter(run_queries(qs))
-    below = {(j, k): next(res) for j in rest for k in rest if j != k}          # LCA(a, j) strictly below LCA(a, k)
-    level = {j: sum(1 for k in rest if k != j and below[(k, j)]) for j in rest}
-    groups = {}
-    for j in rest:
-        groups.setdefault(level[j], []).append(j)
-    node = a
-    for lv in sorted(groups):
-        node = (node, solve(groups[lv]))
-    return node
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ultra_amd import host_order as ho  # noqa: E402
 
 
 def show(t):
@@ -53,7 +19,21 @@ def show(t):
 
 
 if __name__ == "__main__":
-    print(torch.__config__.parallel_info().splitlines()[0:3], file=sys.stderr)
-    tree = solve(list(range(K)))
+    K = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    print(torch.__config__.parallel_info().splitlines()[1].strip(), file=sys.stderr)
+    tree = ho.probe_tree(K)
     print(show(tree))
-    json.dump(tree, open(OUT, "w"))
+    if len(sys.argv) > 2:
+        json.dump(tree, open(sys.argv[2], "w"))
+    try:
+        stages = ho.tree_to_stages(ho.annotate(tree, K))
+    except ValueError as exc:
+        sys.exit("outside the lanes-and-fold family: %s" % exc)
+    for L, carry, lists in stages:
+        print("stage: %d lanes%s, elements per lane %s, unfused steps %d"
+              % (L, " (lane 0 continues from the previous stage)" if carry else "", [len(l) for l in lists],
+                 sum(1 for l in lists for k in l if k & ho.UNFUSED)))
+    g = torch.Generator().manual_seed(0)
+    x, w = torch.randn(8192, K, generator=g), torch.randn(1, K, generator=g)
+    same = (ho.emulate(stages, x.numpy(), w[0].numpy()) == torch.nn.functional.linear(x, w)[:, 0].numpy()).mean()
+    print("program vs torch on 8192 random rows: %.3f %% bit-equal" % (100 * same))
