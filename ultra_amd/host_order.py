@@ -28,22 +28,38 @@ import numpy as np
 import torch
 
 TINY = 2.0 ** -30
-PROBE_ROWS = 8192
+PROBE_ROWS = 8192      # rows per probing call
+PROBE_SPARE = 64       # ... of which the last ones stay empty: a BLAS sums the trailing rows of a call with a remainder kernel
+
+
+class _single_thread(object):
+    """Probing calls run on one thread: with several, every thread's share of the rows ends in remainder rows that follow
+    another association, and probes landing there would contradict the others."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        torch.set_num_threads(1)
+
+    def __exit__(self, *exc):
+        torch.set_num_threads(self.n)
+
 
 
 def _run_queries(qs, K):
     out = []
     w = torch.ones(1, K)
-    for s in range(0, len(qs), PROBE_ROWS):
-        chunk = qs[s:s + PROBE_ROWS]
-        x = torch.zeros(PROBE_ROWS, K)
-        idx = torch.tensor(chunk, dtype=torch.long)
-        r = torch.arange(len(chunk))
-        x[r, idx[:, 0]] = 1.0
-        x[r, idx[:, 1]] = -1.0
-        x[r, idx[:, 2]] = TINY
-        y = torch.nn.functional.linear(x, w)[:, 0]
-        out += (y[:len(chunk)] != 0).tolist()
+    cap = PROBE_ROWS - PROBE_SPARE
+    with _single_thread():
+        for s in range(0, len(qs), cap):
+            chunk = qs[s:s + cap]
+            x = torch.zeros(PROBE_ROWS, K)
+            idx = torch.tensor(chunk, dtype=torch.long)
+            r = torch.arange(len(chunk))
+            x[r, idx[:, 0]] = 1.0
+            x[r, idx[:, 1]] = -1.0
+            x[r, idx[:, 2]] = TINY
+            y = torch.nn.functional.linear(x, w)[:, 0]
+            out += (y[:len(chunk)] != 0).tolist()
     return out
 
 
@@ -107,8 +123,9 @@ def annotate(tree, K=128):
             acc_leaf, leaf = _leaves(b)[0], a
         x[r, acc_leaf] = -(1.0 + 2.0 ** -12)
         x[r, leaf] = 1.0 + 2.0 ** -12
-    pad = torch.zeros(max(PROBE_ROWS - x.shape[0], 0), K)
-    y = torch.nn.functional.linear(torch.cat([x, pad]), w)[:len(nodes), 0].tolist()
+    pad = torch.zeros(max(PROBE_ROWS - x.shape[0], PROBE_SPARE), K)
+    with _single_thread():
+        y = torch.nn.functional.linear(torch.cat([x, pad]), w)[:len(nodes), 0].tolist()
     verdict = {id(n): v for n, v in zip(nodes, y)}
 
     def build(t):
