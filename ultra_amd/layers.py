@@ -197,56 +197,53 @@ class GeneralizedRelationalConv(nn.Module):
         return plan.fused_layer(relation, input, self.linear, self.layer_norm, relu=self.activation is not None,
                                 residual=residual, boundary=None if point is not None else boundary, point=point)
 
-    # ---- unfused path: PyG semantics (gather edge_index[0], scatter to edge_index[1]; layers.py:135-181) ----
+    # ---- unfused path: gather edge_index[0], scatter to edge_index[1] -- PyG's direction (layers.py:135-181) ----
     def _propagate_unfused(self, edge_index, size, input, relation, boundary, edge_type, edge_weight):
-        dim_size = size[1] if size is not None else input.shape[1]
+        num_target = size[1] if size is not None else input.shape[1]
         if edge_weight is None:
             edge_weight = torch.ones(edge_index.shape[1], device=input.device, dtype=input.dtype)
-        input_j = input.index_select(self.node_dim, edge_index[0])
-        message = self.message(input_j, relation, boundary, edge_type)
-        out = self.aggregate(message, edge_weight, edge_index[1], dim_size)
-        return self.update(out, input)
+        message = self.message(input.index_select(self.node_dim, edge_index[0]), relation, boundary, edge_type)
+        return self.update(self.aggregate(message, edge_weight, edge_index[1], num_target), input)
+
+    @staticmethod
+    def _combine(message_func, source, relation):
+        """One message per edge from its source state and relation feature (layers.py:138-151)."""
+        if message_func == "transe":
+            return source + relation
+        if message_func == "distmult":
+            return source * relation
+        if message_func == "rotate":         # complex product on (real | imaginary) halves
+            s_re, s_im = source.chunk(2, dim=-1)
+            r_re, r_im = relation.chunk(2, dim=-1)
+            return torch.cat([s_re * r_re - s_im * r_im, s_re * r_im + s_im * r_re], dim=-1)
+        raise ValueError("Unknown message function `%s`" % message_func)
 
     def message(self, input_j, relation, boundary, edge_type):
-        relation_j = relation.index_select(self.node_dim, edge_type)
-
-        if self.message_func == "transe":
-            message = input_j + relation_j
-        elif self.message_func == "distmult":
-            message = input_j * relation_j
-        elif self.message_func == "rotate":
-            x_j_re, x_j_im = input_j.chunk(2, dim=-1)
-            r_j_re, r_j_im = relation_j.chunk(2, dim=-1)
-            message_re = x_j_re * r_j_re - x_j_im * r_j_im
-            message_im = x_j_re * r_j_im + x_j_im * r_j_re
-            message = torch.cat([message_re, message_im], dim=-1)
-        else:
-            raise ValueError("Unknown message function `%s`" % self.message_func)
-
-        # boundary condition as self-loop messages
-        return torch.cat([message, boundary], dim=self.node_dim)
+        edges = self._combine(self.message_func, input_j, relation.index_select(self.node_dim, edge_type))
+        # the boundary condition rides along as one self-loop message per node (layers.py:153-155)
+        return torch.cat([edges, boundary], dim=self.node_dim)
 
     def aggregate(self, input, edge_weight, index, dim_size):
-        index = torch.cat([index, torch.arange(dim_size, device=input.device)])
-        edge_weight = torch.cat([edge_weight, torch.ones(dim_size, device=input.device, dtype=edge_weight.dtype)])
-        edge_weight = edge_weight.view(1, -1, 1)
+        # the self-loop messages appended by message(): target = the node itself, weight 1
+        loops = torch.arange(dim_size, device=input.device)
+        index = torch.cat([index, loops])
+        weight = torch.cat([edge_weight, torch.ones(dim_size, device=input.device, dtype=edge_weight.dtype)]).view(1, -1, 1)
+        weighted = input * weight
+        if self.aggregate_func != "pna":
+            return _scatter(weighted, index, dim_size, self.aggregate_func)
+        degree = torch.bincount(index, minlength=dim_size).to(input.dtype).view(1, -1, 1)
+        return self._pna(_scatter(weighted, index, dim_size, "mean"), _scatter(input ** 2 * weight, index, dim_size, "mean"),
+                         _scatter(weighted, index, dim_size, "max"), _scatter(weighted, index, dim_size, "min"), degree)
 
-        if self.aggregate_func == "pna":
-            mean = _scatter(input * edge_weight, index, dim_size, "mean")
-            sq_mean = _scatter(input ** 2 * edge_weight, index, dim_size, "mean")
-            max = _scatter(input * edge_weight, index, dim_size, "max")
-            min = _scatter(input * edge_weight, index, dim_size, "min")
-            std = (sq_mean - mean ** 2).clamp(min=self.eps).sqrt()
-            features = torch.cat([mean.unsqueeze(-1), max.unsqueeze(-1), min.unsqueeze(-1), std.unsqueeze(-1)], dim=-1)
-            features = features.flatten(-2)
-            degree_out = torch.bincount(index, minlength=dim_size).to(input.dtype).unsqueeze(0).unsqueeze(-1)
-            scale = degree_out.log()
-            scale = scale / scale.mean()
-            scales = torch.cat([torch.ones_like(scale), scale, 1 / scale.clamp(min=1e-2)], dim=-1)
-            output = (features.unsqueeze(-1) * scales.unsqueeze(-2)).flatten(-2)
-        else:
-            output = _scatter(input * edge_weight, index, dim_size, self.aggregate_func)
-        return output
+    def _pna(self, mean, sq_mean, maximum, minimum, degree):
+        """Principal neighbourhood aggregation (layers.py:165-179, 208-226): [mean, max, min, std] x [1, s, 1 / s] with
+        s = log(degree) / mean(log(degree)); (batch, node, 12 d) in the reference's feature order."""
+        std = (sq_mean - mean ** 2).clamp(min=self.eps).sqrt()
+        stats = torch.stack([mean, maximum, minimum, std], dim=-1).flatten(-2)      # (batch, node, 4 d), statistic fastest
+        scale = degree.log()
+        scale = scale / scale.mean()
+        scalers = torch.cat([torch.ones_like(scale), scale, 1 / scale.clamp(min=1e-2)], dim=-1)      # (1, node, 3)
+        return (stats.unsqueeze(-1) * scalers.unsqueeze(-2)).flatten(-2)
 
     # ---- fused path ----
     def message_and_aggregate(self, edge_index, input, relation, boundary, edge_type, edge_weight, index, dim_size,
@@ -304,19 +301,11 @@ class GeneralizedRelationalConv(nn.Module):
         elif self.aggregate_func == "max":
             update = agg("max", fuse_boundary=boundary)
         elif self.aggregate_func == "pna":
-            sum = agg("add")
-            sq_sum = agg("add", rel=relation ** 2, x=input ** 2)
-            max = agg("max", fuse_boundary=boundary)
-            min = agg("min", fuse_boundary=boundary)
-            mean = (sum + boundary) / degree_out
-            sq_mean = (sq_sum + boundary ** 2) / degree_out
-            std = (sq_mean - mean ** 2).clamp(min=self.eps).sqrt()
-            features = torch.cat([mean.unsqueeze(-1), max.unsqueeze(-1), min.unsqueeze(-1), std.unsqueeze(-1)], dim=-1)
-            features = features.flatten(-2)   # (batch, node, dim * 4)
-            scale = degree_out.log()
-            scale = scale / scale.mean()
-            scales = torch.cat([torch.ones_like(scale), scale, 1 / scale.clamp(min=1e-2)], dim=-1)   # (1, node, 3)
-            update = (features.unsqueeze(-1) * scales.unsqueeze(-2)).flatten(-2)
+            # four rspmm calls: sum and sum of squares (relation and input squared: (r x)^2 = r^2 x^2), max, min
+            total = agg("add")
+            sq_total = agg("add", rel=relation ** 2, x=input ** 2)
+            update = self._pna((total + boundary) / degree_out, (sq_total + boundary ** 2) / degree_out,
+                               agg("max", fuse_boundary=boundary), agg("min", fuse_boundary=boundary), degree_out)
         else:
             raise ValueError("Unknown aggregation function `%s`" % self.aggregate_func)
         return update
