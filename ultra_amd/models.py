@@ -55,50 +55,37 @@ class BaseNBFNet(nn.Module):
         self.activation = activation
         self.num_mlp_layers = num_mlp_layer
 
+    # ---- dynamic edge dropout of the training step (base_nbfnet.py:54-77): the batch's own triples and their inverses ----
+    def _easy_edges(self, data, h_index, t_index, r_index):
+        """Rows [heads; tails(; types)] of the edges to drop: every (h, t, r) of the batch and its inverse (t, h, r + R/2);
+        with `remove_one_hop` every edge between the two nodes whatever its type."""
+        heads = torch.cat([h_index, t_index], dim=-1)
+        tails = torch.cat([t_index, h_index], dim=-1)
+        if self.remove_one_hop:
+            return torch.stack([heads, tails]).flatten(1)
+        types = torch.cat([r_index, r_index + data.num_relations // 2], dim=-1)
+        return torch.stack([heads, tails, types]).flatten(1)
+
     def easy_edge_mask(self, data, h_index, t_index, r_index=None):
         """True for the edges base_nbfnet.py:54-77 keeps, False for the batch's own (h, t[, r]) edges and inverses."""
-        h_index_ext = torch.cat([h_index, t_index], dim=-1)
-        t_index_ext = torch.cat([t_index, h_index], dim=-1)
-        r_index_ext = torch.cat([r_index, r_index + data.num_relations // 2], dim=-1)
-        if self.remove_one_hop:
-            edge_index = data.edge_index
-            easy_edge = torch.stack([h_index_ext, t_index_ext]).flatten(1)
-        else:
-            edge_index = torch.cat([data.edge_index, data.edge_type.unsqueeze(0)])
-            easy_edge = torch.stack([h_index_ext, t_index_ext, r_index_ext]).flatten(1)
-        index = tasks.edge_match(edge_index, easy_edge)[0]
-        return ~index_to_mask(index, data.num_edges)
+        graph = data.edge_index if self.remove_one_hop else torch.cat([data.edge_index, data.edge_type.unsqueeze(0)])
+        dropped = tasks.edge_match(graph, self._easy_edges(data, h_index, t_index, r_index))[0]
+        return ~index_to_mask(dropped, data.num_edges)
 
     def easy_edge_keep(self, data, h_index, t_index, r_index, dtype=torch.float32):
         """easy_edge_mask as the 0/1 float vector the rspmm kernels read (dense.edge_keep_mask: one kernel on the GPU)."""
-        h_index_ext = torch.cat([h_index, t_index], dim=-1)
-        t_index_ext = torch.cat([t_index, h_index], dim=-1)
-        r_index_ext = torch.cat([r_index, r_index + data.num_relations // 2], dim=-1)
-        rows = [h_index_ext, t_index_ext] + ([] if self.remove_one_hop else [r_index_ext])
-        easy_edge = torch.stack(rows).flatten(1)
-        if (data.edge_index.is_cuda and data.edge_index.dtype == torch.int64
-                and easy_edge.shape[1] <= dense.EDGE_KEEP_MAX_EASY):
-            return dense.edge_keep_mask(data.edge_index, None if self.remove_one_hop else data.edge_type, easy_edge,
+        easy = self._easy_edges(data, h_index, t_index, r_index)
+        if data.edge_index.is_cuda and data.edge_index.dtype == torch.int64 and easy.shape[1] <= dense.EDGE_KEEP_MAX_EASY:
+            return dense.edge_keep_mask(data.edge_index, None if self.remove_one_hop else data.edge_type, easy,
                                         data.num_nodes, data.num_relations, dtype)
         return self.easy_edge_mask(data, h_index, t_index, r_index).to(dtype)
 
     def remove_easy_edges(self, data, h_index, t_index, r_index=None):
-        # dynamic edge dropout of the training triples and their inverses (base_nbfnet.py:54-77)
-        h_index_ext = torch.cat([h_index, t_index], dim=-1)
-        t_index_ext = torch.cat([t_index, h_index], dim=-1)
-        r_index_ext = torch.cat([r_index, r_index + data.num_relations // 2], dim=-1)
-        if self.remove_one_hop:
-            edge_index = data.edge_index
-            easy_edge = torch.stack([h_index_ext, t_index_ext]).flatten(1)
-        else:
-            edge_index = torch.cat([data.edge_index, data.edge_type.unsqueeze(0)])
-            easy_edge = torch.stack([h_index_ext, t_index_ext, r_index_ext]).flatten(1)
-        index = tasks.edge_match(edge_index, easy_edge)[0]
-        mask = ~index_to_mask(index, data.num_edges)
-
+        """The reference's route: a filtered copy of the graph (only the unfused `rotate` path still needs it)."""
+        keep = self.easy_edge_mask(data, h_index, t_index, r_index)
         data = copy.copy(data)
-        data.edge_index = data.edge_index[:, mask]
-        data.edge_type = data.edge_type[mask]
+        data.edge_index = data.edge_index[:, keep]
+        data.edge_type = data.edge_type[keep]
         return data
 
     def negative_sample_to_tail(self, h_index, t_index, r_index, num_direct_rel):
