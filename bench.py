@@ -266,6 +266,15 @@ def measure_roofline(dev, use_pmc=True):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def ranking_metrics(rank):
+    """MRR / Hits@k of a vector of ranks (script/run.py:188-213), to 6 digits."""
+    r = rank.double()
+    out = {"mrr": round((1 / r).mean().item(), 6)}
+    for k in (1, 3, 10):
+        out["hits@%d" % k] = round((r <= k).double().mean().item(), 6)
+    return out
+
+
 def tie_band_mismatches(ref_score, got_rank, pos, mask, band):
     """Rankings that differ from the reference's by more than its own near-ties allow.  With |gpu - reference| <= d on
     every score, `gpu_pos <= gpu_c` is certain when ref_c >= ref_pos + 2 d and impossible when ref_c < ref_pos - 2 d: the
@@ -467,6 +476,29 @@ def main():
                                            "cannot be imported here; the restatement is pinned to it by tests/golden (recorded from the "
                                            "unchanged reference modules).  Survey container (8 vCPU Xeon 2.1 GHz), unchanged reference "
                                            "Ultra.forward: 910 ms per forward = 0.128 M triples/s (SURVEY.md section 6)."}
+            # op level: the reference kernel on the identical pre-sorted tensors, min of 3 after a warm-up
+            try:
+                from oracle import build_ref, rspmm_oracle
+                if build_ref.available():
+                    ref_mod = build_ref.load()
+                    gen = torch.Generator().manual_seed(0)
+                    ei_s, et_s, ew_s, _ = rspmm_oracle.sort_edges(data_cpu.edge_index, data_cpu.edge_type,
+                                                                   torch.ones(data_cpu.num_edges))
+                    rel_cpu = torch.randn(data_cpu.num_relations, bs * 64, generator=gen)
+                    x_cpu = torch.randn(N, bs * 64, generator=gen)
+                    op_ms = {}
+                    for name in ("rspmm_add_mul_forward_cpu", "rspmm_max_mul_forward_cpu"):
+                        f = getattr(ref_mod, name)
+                        f(ei_s, et_s, ew_s, rel_cpu, x_cpu)
+                        best = float("inf")
+                        for _ in range(3):
+                            t0 = time.perf_counter()
+                            f(ei_s, et_s, ew_s, rel_cpu, x_cpu)
+                            best = min(best, time.perf_counter() - t0)
+                        op_ms[name] = 1e3 * best
+                    out["cpu_baseline"]["reference_kernel_ms"] = op_ms
+            except Exception as exc:       # the op-level figure is context only
+                out["cpu_baseline"]["reference_kernel_ms"] = "unavailable: %s" % exc
             with torch.no_grad():
                 got = model(data, t_batch_cpu.to(dev)).cpu()
             # fp64 run of the same oracle: the value both fp32 implementations approximate
@@ -487,6 +519,7 @@ def main():
                              "rank_mismatches_gpu_vs_fp64": int((r_gpu != r_true).sum()),
                              "rank_mismatches_reference_fp32_vs_fp64": int((r_cpu != r_true).sum()),
                              "scores_bit_equal": int((got == ref_score).sum()), "scores": got.numel(),
+                             "metrics_gpu": ranking_metrics(r_gpu), "metrics_reference": ranking_metrics(r_cpu),
                              "readout_order": host_order.readout_stages(128)[1],
                              "note": "every operation of the forward follows the reference's order (rspmm.cpp row sums, torch's "
                                      "nn.Linear / nn.LayerNorm arithmetic, the host BLAS's association for the readout's last "
