@@ -89,6 +89,7 @@ def edge_keep_mask(edge_index, edge_type, easy_edge, num_node, num_relation, dty
     edge_type=None: heads, tails), else 1 -- the edge dropout of base_nbfnet.py:54-77 as a 0/1 vector: one small sort of
     the M easy keys and one kernel over the edges, instead of sorting the graph's edge keys every batch."""
     assert edge_index.dtype == torch.int64 and edge_index.is_cuda
+    assert int(num_node) ** 2 * max(int(num_relation), 1) < 2 ** 63, "edge key overflows int64"      # (tasks.py:19, same bound)
     edge_index = edge_index.contiguous()
     head, tail = edge_index[0], edge_index[1]
     easy_edge = easy_edge.to(torch.int64)
