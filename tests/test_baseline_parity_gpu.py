@@ -5,6 +5,7 @@ order): Ultra.forward on the GPU against oracle/ultra_oracle_model.py with the r
     config 1  ultra_3g,  WN18RR shape,   batch 4   (sum aggregate; the reference's CPU-runnable plumbing case)
     config 2  ultra_3g,  FB15k237 shape, batch 8   (distmult + sum: the headline)
     config 3  ultra_50g, CoDEx-L shape,  batch 8   (max aggregate)
+    config 5  ultra_50g, YAGO3-10 shape, batch 8   (sum aggregate; the forward of the fine-tuning configuration)
 
 Gates: north_star asks scores within 1e-4 and identical rankings.  Every operation of the forward follows the reference's
 order (rspmm.cpp's sequential row sums, torch's nn.Linear / nn.LayerNorm arithmetic, the host BLAS's association for the
@@ -29,6 +30,7 @@ CONFIGS = [
     ("config1_wn18rr", "ultra_3g", "wn18rr", 4, "sum", 4),
     ("config2_fb15k237", "ultra_3g", "fb15k237", 8, "sum", 4),
     ("config3_codex_l", "ultra_50g", "codex_l", 8, "max", 2),
+    ("config5_yago310_forward", "ultra_50g", "yago310", 8, "sum", 1),       # the fine-tuning config's graph, forward only
 ]
 
 
