@@ -64,21 +64,31 @@ __global__ void __launch_bounds__(256) dense_order_layer_kernel(const DenseOrder
     const int c0 = 16 * wave;
 
     // ---- phase 1 operands: all requested before anything waits ----
-    const uint4 *ap = p.a_ex + (size_t)rt * p.n_jc * 64 + lane;
-    const char *xcol = reinterpret_cast<const char *>(xo + c0 + i16);   // B operand: lane (kk, n) reads x[j][c0 + n]
+    // One wave per SIMD: whatever the wave does between two matrix instructions of the chain stalls the chain.  The fetch
+    // of a stage is therefore pure load issue: a uniform (scalar) base per stage + per-lane byte offsets computed once
+    // (global_load v, v_off, s[base]) -- no multiplies, no clamps in the loop.  Only the last stage can touch columns past
+    // n_in (their adjacency bytes are 0); it has its own, clamped offsets.
+    const uint4 *ap = p.a_ex + (size_t)rt * p.n_jc * 64;
+    const char *xbase = reinterpret_cast<const char *>(xo);
     const uint32_t x_row_bytes = (uint32_t)p.x_sr * 4u;
+    const uint32_t lane_bytes = (uint32_t)(c0 + i16) * 4u;       // B operand: lane (kk, n) reads x[j][c0 + n]
+    uint32_t voff[16], voff_last[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        voff[q] = (uint32_t)q * x_row_bytes + lane_bytes;
+        voff_last[q] = (uint32_t)min(16 * (p.n_jc - 1) + q, p.n_in - 1) * x_row_bytes + lane_bytes;
+    }
     struct Stage {
         uint4 a;
         float x[16];
     };
     const auto fetch = [&](const int jc, Stage &st) {
-        const int jcc = min(jc, p.n_jc - 1);
-        st.a = ap[(size_t)jcc * 64];
+        const bool last = jc >= p.n_jc - 1;                                   // uniform
+        const int jcc = last ? p.n_jc - 1 : jc;
+        st.a = ap[(size_t)jcc * 64 + lane];
+        const char *sbase = xbase + (last ? 0u : (uint32_t)jcc * 16u * x_row_bytes);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int j = min(16 * jcc + q, p.n_in - 1);   // columns past n_in: adjacency bytes are 0 there
-            st.x[q] = *reinterpret_cast<const float *>(xcol + (uint32_t)j * x_row_bytes);
-        }
+        for (int q = 0; q < 16; ++q) st.x[q] = *reinterpret_cast<const float *>(sbase + (last ? voff_last[q] : voff[q]));
     };
     // three stages (48 source columns, ~1,900 cycles of chain) in flight: one wave per SIMD has nothing else to hide an
     // L2 round trip behind
@@ -121,8 +131,11 @@ __global__ void __launch_bounds__(256) dense_order_layer_kernel(const DenseOrder
     f32x4 acc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = 0.f;
-    const auto chain = [&](const Stage &cur) {
-        const uint32_t aw[4] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w};
+    const auto chain = [&](const Stage &cur, const int jc) {
+        // (stages past the graph chain zeros: fma(0, b, acc) = acc exactly -- rounds have no conditional exit, which
+        // would be a join where the compiler stops counting outstanding loads and drains the queue)
+        const uint32_t m = jc < p.n_jc ? 0xffffffffu : 0u;
+        const uint32_t aw[4] = {cur.a.x & m, cur.a.y & m, cur.a.z & m, cur.a.w & m};
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const float a = byte_of(aw[q >> 2], q & 3);
@@ -130,14 +143,12 @@ __global__ void __launch_bounds__(256) dense_order_layer_kernel(const DenseOrder
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
         }
     };
-    for (int jc = 0; jc < p.n_jc; jc += 3) {   // (rounds past the end re-read the last stage: harmless, never chained)
-        chain(st0);
+    for (int jc = 0; jc < p.n_jc; jc += 3) {
+        chain(st0, jc);
         fetch(jc + 3, st0);
-        if (jc + 1 >= p.n_jc) break;
-        chain(st1);
+        chain(st1, jc + 1);
         fetch(jc + 4, st1);
-        if (jc + 2 >= p.n_jc) break;
-        chain(st2);
+        chain(st2, jc + 2);
         fetch(jc + 5, st2);
     }
 
