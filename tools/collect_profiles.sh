@@ -4,6 +4,7 @@
 #                                                                    judged command, 1-process torchrun line
 #   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh B r2'   secondary cases, fine-tune kernel stats, kernel probes,
 #                                                                    evaluation protocol speed
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh C r2'   SQ / TCC counter passes over tools/pmc_target.py
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 part="${1:-A}"
@@ -19,6 +20,17 @@ if [ "$part" = "A" ]; then
     find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} "$OUT/${R}_bench_kernel_stats.csv" \;
     timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
         bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/${R}_bench_torchrun1.json" 2>> "$OUT/bench.err"
+elif [ "$part" = "C" ]; then
+    # SQ / TCC counter passes over tools/pmc_target.py (separate passes, no other trace domain)
+    i=0
+    for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
+               "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY" \
+               "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE"; do
+        i=$((i + 1))
+        (cd /tmp && timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_sq$i -o run -- \
+            python "$OLDPWD/tools/pmc_target.py" > /dev/null 2>&1)
+    done
+    python tools/summarize_pmc.py $(find /tmp/pmc_sq1 /tmp/pmc_sq2 /tmp/pmc_sq3 -name "*counter_collection.csv" | sort) > "$OUT/${R}_pmc_sq.txt" 2>&1
 else
     timeout 600 python tools/secondary_bench.py > "$OUT/${R}_secondary.jsonl" 2> "$OUT/secondary.err"
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -o run -- \
