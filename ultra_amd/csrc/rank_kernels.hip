@@ -51,16 +51,23 @@ __global__ void __launch_bounds__(256) filtered_rank_kernel(const float *__restr
 //   h0[b], r0[b] = source node and query relation of the row after that conversion;
 //   valid[b] = the row really shares its source node and its relation (the reference's two asserts), per row:
 //              no initialisation pass / memset node is needed (hipGraph friendly).
-__global__ void __launch_bounds__(1024) batch_prologue_kernel(const int64_t *__restrict__ batch, long long n_cand,
-                                                             long long num_direct_rel, int64_t *h0, int64_t *r0,
-                                                             int32_t *side, int32_t *valid) {
-    const int b = blockIdx.x;
+// PROLOGUE_SPLIT workgroups scan one row of the batch each (a single workgroup per row left 248 CUs idle: 7-11 us for
+// 2.8 MB).  They meet in `scratch` (4 ints per row: violations of h / t / r uniformity, arrival ticket): the last
+// workgroup to arrive writes the row's results and puts the four ints back to zero, so the buffer needs zeroing once at
+// allocation and never inside a captured graph.
+constexpr int PROLOGUE_SPLIT = 16;
+__global__ void __launch_bounds__(256) batch_prologue_kernel(const int64_t *__restrict__ batch, long long n_cand,
+                                                            long long num_direct_rel, int64_t *h0, int64_t *r0,
+                                                            int32_t *side, int32_t *valid, int32_t *scratch) {
+    const int b = blockIdx.y, part = blockIdx.x;
     const int64_t *row = batch + (long long)b * n_cand * 3;
     const int64_t fh = row[0], ft = row[1], fr = row[2];
     int same_h = 1, same_t = 1, same_r = 1;
-    // 4 candidates (12 independent loads) in flight per thread: one workgroup scans a whole row of the batch
-    long long i = threadIdx.x;
-    for (; i + 3 * (long long)blockDim.x < n_cand; i += 4 * (long long)blockDim.x) {
+    const long long per = (n_cand + PROLOGUE_SPLIT - 1) / PROLOGUE_SPLIT;
+    const long long lo = part * per, hi = lo + per < n_cand ? lo + per : n_cand;
+    // 4 candidates (12 independent loads) in flight per thread
+    long long i = lo + threadIdx.x;
+    for (; i + 3 * (long long)blockDim.x < hi; i += 4 * (long long)blockDim.x) {
         int64_t v[4][3];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -73,41 +80,46 @@ __global__ void __launch_bounds__(1024) batch_prologue_kernel(const int64_t *__r
             same_r &= (v[u][2] == fr);
         }
     }
-    for (; i < n_cand; i += blockDim.x) {
+    for (; i < hi; i += blockDim.x) {
         same_h &= (row[3 * i] == fh);
         same_t &= (row[3 * i + 1] == ft);
         same_r &= (row[3 * i + 2] == fr);
     }
-    __shared__ int flags[3];
-    if (threadIdx.x == 0) flags[0] = flags[1] = flags[2] = 1;
+    int32_t *sc = scratch + 4 * b;
+    const bool wave_h = __all(same_h), wave_t = __all(same_t), wave_r = __all(same_r);
+    if ((threadIdx.x & 63) == 0) {
+        if (!wave_h) atomicAdd(&sc[0], 1);
+        if (!wave_t) atomicAdd(&sc[1], 1);
+        if (!wave_r) atomicAdd(&sc[2], 1);
+    }
+    __threadfence();
     __syncthreads();
-    if (!__all(same_h)) { if ((threadIdx.x & 63) == 0) atomicAnd(&flags[0], 0); }
-    if (!__all(same_t)) { if ((threadIdx.x & 63) == 0) atomicAnd(&flags[1], 0); }
-    if (!__all(same_r)) { if ((threadIdx.x & 63) == 0) atomicAnd(&flags[2], 0); }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int tail_row = flags[0];     // base_nbfnet.py:82 is_t_neg
+    if (threadIdx.x == 0 && atomicAdd(&sc[3], 1) == PROLOGUE_SPLIT - 1) {
+        const int bad_h = atomicAdd(&sc[0], 0), bad_t = atomicAdd(&sc[1], 0), bad_r = atomicAdd(&sc[2], 0);
+        const int tail_row = bad_h == 0;     // base_nbfnet.py:82 is_t_neg
         side[b] = tail_row;
         h0[b] = tail_row ? fh : ft;
         r0[b] = tail_row ? fr : fr + num_direct_rel;
-        valid[b] = ((flags[0] | flags[1]) & flags[2]) ? 1 : 0;
+        valid[b] = ((bad_h == 0 || bad_t == 0) && bad_r == 0) ? 1 : 0;
+        sc[0] = sc[1] = sc[2] = sc[3] = 0;      // ready for the next launch (or graph replay)
     }
 }
 
 }  // namespace ultra
 
 extern "C" int32_t ultra_batch_prologue(const int64_t *batch, int64_t batch_size, int64_t n_cand, int64_t num_direct_rel,
-                                        int64_t *h0, int64_t *r0, int32_t *side, int32_t *valid, void *stream) {
+                                        int64_t *h0, int64_t *r0, int32_t *side, int32_t *valid, int32_t *scratch,
+                                        void *stream) {
     ULTRA_DEVICE_SCOPE(stream);
-    if (!batch || !h0 || !r0 || !side || !valid || batch_size < 0 || n_cand <= 0) {
+    if (!batch || !h0 || !r0 || !side || !valid || !scratch || batch_size < 0 || n_cand <= 0) {
         ultra::set_error("ultra_batch_prologue: NULL operand or empty candidate set");
         return ULTRA_ERR_INVALID;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (batch_size == 0) return ULTRA_OK;
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
-    hipLaunchKernelGGL(ultra::batch_prologue_kernel, dim3((unsigned)batch_size), dim3(1024), 0, s, batch, (long long)n_cand,
-                       (long long)num_direct_rel, h0, r0, side, valid);
+    hipLaunchKernelGGL(ultra::batch_prologue_kernel, dim3(ultra::PROLOGUE_SPLIT, (unsigned)batch_size), dim3(256), 0, s, batch, (long long)n_cand,
+                       (long long)num_direct_rel, h0, r0, side, valid, scratch);
     if (hipGetLastError() != hipSuccess) {
         ultra::set_error("batch_prologue_kernel launch failed");
         return ULTRA_ERR_HIP;

@@ -145,16 +145,32 @@ def readout(model, hidden, query, t_index, order=None):
     return score
 
 
+_PROLOGUE_SCRATCH = {}
+
+
+def _prologue_scratch(device, bs):
+    """The meeting point of the prologue's workgroups: zero on entry, left zero on exit.  One per device, allocated by the
+    first (eager) call so that a later hipGraph capture finds it in place; prologues of one device are expected on one
+    stream at a time (the C entry takes the buffer as an argument for callers that need more)."""
+    key = str(device)
+    buf = _PROLOGUE_SCRATCH.get(key)
+    if buf is None or buf.numel() < 4 * bs:
+        buf = torch.zeros(4 * max(bs, 256), dtype=torch.int32, device=device)
+        _PROLOGUE_SCRATCH[key] = buf
+    return buf
+
+
 def batch_prologue(batch, num_direct_rel):
     """(h0, r0, side, valid) of a (bs, n_cand, 3) GPU batch in one kernel (models.py:190-197, base_nbfnet.py:79-86)."""
     batch = batch.contiguous()
     bs, n_cand = batch.shape[:2]
+    scratch = _prologue_scratch(batch.device, bs)
     h0 = torch.empty(bs, dtype=torch.long, device=batch.device)
     r0 = torch.empty_like(h0)
     side = torch.empty(bs, dtype=torch.int32, device=batch.device)
     valid = torch.empty(bs, dtype=torch.int32, device=batch.device)
     check(lib.ultra_batch_prologue(batch.data_ptr(), bs, n_cand, int(num_direct_rel), h0.data_ptr(), r0.data_ptr(),
-                                   side.data_ptr(), valid.data_ptr(), _stream(batch)))
+                                   side.data_ptr(), valid.data_ptr(), scratch.data_ptr(), _stream(batch)))
     return batch, h0, r0, side, valid
 
 
