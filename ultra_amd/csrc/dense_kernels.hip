@@ -230,7 +230,7 @@ struct ReadoutParams {
 };
 
 constexpr int READOUT_ORDER_MAX = 640;    // 1 + stages * (2 + lanes) + the 128 elements, each lane padded to groups of 8
-constexpr int READOUT_HID_STRIDE = 129;   // floats per row of the hidden tile in LDS: a lane reads ITS row, bank = row + k
+constexpr int READOUT_HID_STRIDE = 132;   // floats per row of the hidden tile in LDS (16-byte aligned rows; element 128 = padding)
 
 // score = mlp.2( relu( mlp.0( cat[hidden[t], query] ) ) ) in the reference's operation order:
 //   mlp.0 (nn.Linear 128 -> 128): one k-ascending fmaf chain per hidden unit over the 64 node features and then the 64
@@ -244,9 +244,9 @@ constexpr int READOUT_HID_STRIDE = 129;   // floats per row of the hidden tile i
 __global__ void __launch_bounds__(512) readout_kernel(const ReadoutParams p) {
     // [tile m (4)][i (16)][lane] float4 : W1[32 m + (lane & 31)][2 s + (lane >> 5)], s = 4 i + {0, 2, 1, 3}[q] (see swap32)
     __shared__ __attribute__((aligned(16))) float lds_w[4 * 16 * 64 * 4];
-    __shared__ float lds_hid[8][16 * READOUT_HID_STRIDE];     // per wave: 16 rows at a time (two passes per tile)
+    __shared__ __attribute__((aligned(16))) float lds_hid[8][16 * READOUT_HID_STRIDE];     // per wave: 16 rows at a time (two passes per tile)
     __shared__ float lds_lane[8][16 * 16];
-    __shared__ float lds_w2[136], lds_b1[128];      // w2[128 ..] = 0: the program's padding element
+    __shared__ __attribute__((aligned(16))) float lds_w2[136], lds_b1[128];      // w2[128 ..] = 0: the program's padding element
     __shared__ __attribute__((aligned(16))) int lds_order[READOUT_ORDER_MAX];
     const int tid = threadIdx.x;
     for (int idx4 = tid; idx4 < 4 * 16 * 64; idx4 += blockDim.x) {
@@ -343,12 +343,16 @@ __global__ void __launch_bounds__(512) readout_kernel(const ReadoutParams p) {
         for (int pass = 0; pass < 2; ++pass) {
             if ((j >> 4) == pass) {
                 const int jr = j & 15;
+                // registers 4 g .. 4 g + 3 of a tile hold four consecutive hidden units: 16-byte stores
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int f = feat_of(m, r, h);
-                        hid[jr * READOUT_HID_STRIDE + f] = fmaxf(acc[m][r] + lds_b1[f], 0.f);
+                    for (int g = 0; g < 4; ++g) {
+                        const int f = feat_of(m, 4 * g, h);
+                        const float4 bb = *reinterpret_cast<const float4 *>(lds_b1 + f);
+                        *reinterpret_cast<float4 *>(hid + jr * READOUT_HID_STRIDE + f) =
+                            make_float4(fmaxf(acc[m][4 * g + 0] + bb.x, 0.f), fmaxf(acc[m][4 * g + 1] + bb.y, 0.f),
+                                        fmaxf(acc[m][4 * g + 2] + bb.z, 0.f), fmaxf(acc[m][4 * g + 3] + bb.w, 0.f));
                     }
                 if (h == 0) hid[jr * READOUT_HID_STRIDE + 128] = 0.f;       // the padding element
             }
