@@ -170,5 +170,7 @@ def test_readout_equals_torch_cpu_bitwise(dev, bs, n, cand):
     assert torch.equal(got, restated)           # the kernel executes the program exactly, whatever the program is
     same = (got == want_torch).float().mean().item()
     assert (got - want_torch).abs().max().item() <= 4e-6
-    if source.startswith("host BLAS"):          # (a host whose BLAS tree is outside the family runs the ascending chain)
+    # torch itself: all rows but the few its BLAS sums with a remainder kernel at the end of each thread's share (a host whose
+    # tree is outside the family runs the ascending chain: closeness only)
+    if source.startswith("host BLAS") and got.numel() >= 100000:
         assert same >= 0.995, same
