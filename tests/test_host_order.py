@@ -92,12 +92,15 @@ def test_host_blas_order_is_recovered_and_reproduces_torch(monkeypatch):
     if not source.startswith("host BLAS"):
         pytest.skip("this host's BLAS sums nn.Linear(128, 1) outside the lanes-and-fold family: the ascending chain is used")
     g = torch.Generator().manual_seed(1)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 4))      # few shares: few remainder rows (see below)
     for rows in (4096, 116328):
         x, w, b = torch.randn(rows, 128, generator=g), torch.randn(1, 128, generator=g), torch.randn(1, generator=g)
         want = torch.nn.functional.linear(x, w, b)[:, 0].numpy()
         got = (ho.emulate(stages, x.numpy(), w[0].numpy()).astype(np.float64) + float(b)).astype(np.float32)
         # the BLAS sums the last few rows of every thread's share with a remainder kernel: everything else is bit-equal
         assert (got == want).mean() >= 0.995 and np.abs(got - want).max() <= 4e-6 * np.abs(want).max()
+    torch.set_num_threads(threads)
     prog, _ = ho.readout_program(128)
     assert prog[0] == len(stages) and len(prog) <= 640
 
