@@ -273,8 +273,8 @@ typedef struct {
 } ultra_schedule_info;
 int32_t ultra_plan_schedule_info(ultra_plan *plan, int32_t nparts, ultra_schedule_info *info);
 /* The schedule's arrays (tests, tooling): which = 0 chunk_ptr [nparts + 1], 1 unit_ptr [nparts + 1], 2 unit ids (a unit =
- * group items n_chain_row + 4 u .. + 3 of ULTRA_ARR_ITEM), 3 chunks as {row, begin, count, flags} quadruples (flags: 1 first,
- * 2 last chunk of its row).  Workgroup q of a span walks chunks [chunk_ptr[q], chunk_ptr[q + 1]) then its units. */
+ * group items n_chain_row + 4 u .. + 3 of ULTRA_ARR_ITEM), 3 chunks as {row, begin, count, flags} quadruples (flags: bit 0 first,
+ * bit 1 last chunk of its row; a first chunk also holds the row's edge count in flags >> 2).  Workgroup q of a span walks chunks [chunk_ptr[q], chunk_ptr[q + 1]) then its units. */
 int32_t ultra_plan_schedule_export(ultra_plan *plan, int32_t nparts, int32_t which, int32_t *dst_host, int64_t capacity_elems,
                                    int64_t *count);
 

@@ -1,0 +1,369 @@
+"""Generator of ultra_amd/csrc/rspmm_order_asm.hpp: the two software-pipelined inner loops of the reference-order
+rspmm kernel (fp32, unit weights, relation slice in LDS) as gfx950 assembly.
+
+    python tools/gen_order_asm.py            # rewrites ultra_amd/csrc/rspmm_order_asm.hpp
+
+Why assembly.  Both loops keep vector-memory loads in flight ACROSS loop iterations (source rows requested one or two
+chunks before they are summed).  hipcc handles that badly in two ways (ROCm 7.2, read off the ISA): its vmcnt
+bookkeeping gives up at the back-edge (`s_waitcnt vmcnt(0)` at the top of every round: the queue is drained before the
+next requests go out) and it rotates loop-carried load destinations through register copies, each of which waits for
+the load it copies.  Issuing the loads as `asm volatile` from C++ does not help: the compiler then copies (or spills)
+registers whose load has not landed.  Inside one asm statement the registers, the issue order and every wait count are
+fixed by this file:
+
+  * loads of one wave return in issue order, so `s_waitcnt vmcnt(N)` means "everything but the N youngest requests has
+    landed"; every count below is derived from the issue sequence noted beside it;
+  * all in-flight destinations are clobber registers of the statement (v64..v127): the compiler keeps nothing there
+    across it, and every path out of the statement ends in vmcnt(0);
+  * the arithmetic is the C++ path's: v_pk_mul_f32 / v_pk_add_f32 (or v_min / v_max) per message in sorted edge
+    order, one accumulator per output element -- bit-identical to rspmm.cpp:61-72.
+
+The generated header is committed; this script is its source.
+"""
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("ULTRA_GEN_OUT") or os.path.join(os.path.dirname(HERE), "ultra_amd", "csrc", "rspmm_order_asm.hpp")
+
+BINOPS = {0: "v_pk_mul_f32", 1: "v_pk_add_f32"}            # BIN_MUL, BIN_ADD (operator.cuh:15,29)
+IDENT = {0: "0", 1: "0x7f7fffff", 2: "0xff7fffff"}          # add: 0, min: +FLT_MAX, max: -FLT_MAX (operator.cuh:43-80)
+
+
+def vr(lo, n=1):
+    return "v%d" % lo if n == 1 else "v[%d:%d]" % (lo, lo + n - 1)
+
+
+class Asm:
+    def __init__(self):
+        self.lines = []
+
+    def __call__(self, text, comment=None):
+        self.lines.append((text, comment))
+
+    def label(self, name):
+        self.lines.append((name + ":", None))
+
+    def render(self, indent="        "):
+        out = []
+        for text, comment in self.lines:
+            c = ("   // " + comment) if comment else ""
+            out.append('%s"%s\\n"%s' % (indent, text, c))
+        return "\n".join(out)
+
+
+def nary(a, sum_code, acc, x):
+    """acc[0..3] (+)= x[0..3] under the current exec mask"""
+    if sum_code == 0:
+        a("v_pk_add_f32 %s, %s, %s" % (vr(acc, 2), vr(acc, 2), vr(x, 2)))
+        a("v_pk_add_f32 %s, %s, %s" % (vr(acc + 2, 2), vr(acc + 2, 2), vr(x + 2, 2)))
+    else:
+        op = "v_min_f32_e32" if sum_code == 1 else "v_max_f32_e32"
+        for e in range(4):
+            a("%s %s, %s, %s" % (op, vr(acc + e), vr(acc + e), vr(x + e)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# group walk: one 16-lane group per row, four rows per wave; two 4-step chunks of source rows + one round of records
+# in flight.  Register map (clobbers):
+#   v64..v79   chunk A source rows (4 x 16 B)    v96..v99    LDS addresses of chunk A's relation rows
+#   v80..v95   chunk B source rows               v100..v103  ... of chunk B's
+#   v126:127   records of the round after the current one (in flight)
+#   v108/v109  current round's col / type (lane l holds step l % 8)
+#   v110..v113 broadcast cols / gather offsets while a chunk is requested; third relation row while one is summed
+#   v114..v121 first / second relation row       v104..v107  fourth relation row (v104:105: round 0's records in the prologue)
+#   v122..v125 the accumulator
+WALK_CLOBBER_LO, WALK_CLOBBER_HI = 64, 127
+RV = (114, 118, 110, 104)
+
+
+def walk_fetch(a, xb, tb, J):
+    for q in range(4):
+        a("ds_swizzle_b32 v%d, v108 offset:swizzle(BROADCAST,16,%d)" % (110 + q, J + q))
+    for q in range(4):
+        a("ds_swizzle_b32 v%d, v109 offset:swizzle(BROADCAST,16,%d)" % (tb + q, J + q))
+    for q in range(4):
+        a("s_waitcnt lgkmcnt(%d)" % (7 - q))
+        a("v_mad_u32_u24 v%d, v%d, %%[xrb], %%[lb]" % (110 + q, 110 + q))
+        a("global_load_dwordx4 %s, v%d, %%[xb]" % (vr(xb + 4 * q, 4), 110 + q))
+    a("s_waitcnt lgkmcnt(0)")
+    for q in range(4):
+        a("v_lshl_add_u32 v%d, v%d, 8, %%[lds]" % (tb + q, tb + q))
+
+
+def walk_rel_reads(a, tb):
+    """the chunk's four relation rows: requested BEFORE the wait for its source rows, so that they land under it"""
+    for q in range(4):
+        a("ds_read_b128 %s, v%d" % (vr(RV[q], 4), tb + q))
+
+
+def walk_compute(a, xb, consts, binop, sum_code, first_step, tag):
+    """acc (+)= rel[t] (x) x for the chunk's four steps, in step order.  Step q of the chunk is step first_step + q of the
+    round; when every row of the unit still has the whole chunk (uniform test against nfull) the sums run unmasked,
+    otherwise step q is live in the lanes with consts[q] < rem (exec mask)."""
+    a("s_add_i32 %%[t1], %%[kb], %d" % (first_step + 4))
+    a("s_cmp_le_i32 %[t1], %[nf]")
+    a("s_cbranch_scc0 .Lwalk_masked_%s_%%=" % tag)
+    for q in range(4):
+        a("s_waitcnt lgkmcnt(%d)" % (3 - q))
+        x = xb + 4 * q
+        a("%s %s, %s, %s" % (binop, vr(x, 2), vr(RV[q], 2), vr(x, 2)))
+        a("%s %s, %s, %s" % (binop, vr(x + 2, 2), vr(RV[q] + 2, 2), vr(x + 2, 2)))
+        nary(a, sum_code, 122, x)
+    a("s_branch .Lwalk_summed_%s_%%=" % tag)
+    a.label(".Lwalk_masked_%s_%%=" % tag)
+    for q in range(4):
+        a("s_waitcnt lgkmcnt(%d)" % (3 - q))
+        x = xb + 4 * q
+        a("%s %s, %s, %s" % (binop, vr(x, 2), vr(RV[q], 2), vr(x, 2)))
+        a("%s %s, %s, %s" % (binop, vr(x + 2, 2), vr(RV[q] + 2, 2), vr(x + 2, 2)))
+        a("v_cmpx_lt_i32_e32 vcc, %d, %%[rem]" % consts[q])
+        nary(a, sum_code, 122, x)
+        a("s_mov_b64 exec, %[ex]")
+    a.label(".Lwalk_summed_%s_%%=" % tag)
+
+
+def gen_walk(sum_code, mul_code, rec_policy):
+    a = Asm()
+    binop = BINOPS[mul_code]
+    A, B, TA, TB = 64, 80, 96, 100
+    a("s_mov_b64 %[ex], exec")
+    a("s_mov_b32 %[kb], 0")
+    for e in range(4):
+        a("v_mov_b32_e32 v%d, %s" % (122 + e, IDENT[sum_code]))
+    a("global_load_dwordx2 v[104:105], %%[roff], %%[rb]%s" % rec_policy, "records of round 0")
+    a("global_load_dwordx2 v[126:127], %%[roff], %%[rb] offset:64%s" % rec_policy, "records of round 1")
+    a("v_add_u32_e32 %[roff], 0x80, %[roff]")
+    a("s_waitcnt vmcnt(1)", "in flight: [r0, r1] -> r0")
+    a("v_cmp_lt_i32_e32 vcc, %[l8], %[rem]")
+    a("v_cndmask_b32_e32 v108, 0, v104, vcc", "steps past the row's end gather node 0 (and are masked out of the sum)")
+    a("v_mov_b32_e32 v109, v105")
+    walk_fetch(a, A, TA, 0)                                        # in flight: [r1, A x 4]
+    a.label(".Lwalk_loop_%=")
+    a("s_add_i32 %[t0], %[kb], 4")
+    a("s_cmp_lt_i32 %[t0], %[ns]")
+    a("s_cbranch_scc0 .Lwalk_last_a_%=")
+    walk_fetch(a, B, TB, 4)                                        # [r', A x 4, B x 4]
+    walk_rel_reads(a, TA)
+    a("s_waitcnt vmcnt(4)", "[r', A x 4, B x 4] -> r', A")
+    walk_compute(a, A, (0, 1, 2, 3), binop, sum_code, 0, "a")
+    a("s_add_i32 %[t0], %[kb], 8")
+    a("s_cmp_lt_i32 %[t0], %[ns]")
+    a("s_cbranch_scc0 .Lwalk_last_b_%=")
+    a("v_add_u32_e32 %[rem], -8, %[rem]", "rem = cnt - (kb + 8)")
+    a("v_cmp_lt_i32_e32 vcc, %[l8], %[rem]")
+    a("v_cndmask_b32_e32 v108, 0, v126, vcc")
+    a("v_mov_b32_e32 v109, v127")
+    a("global_load_dwordx2 v[126:127], %%[roff], %%[rb]%s" % rec_policy, "records of round kb / 8 + 2: a whole round before their first use")
+    a("v_add_u32_e32 %[roff], 64, %[roff]")
+    walk_fetch(a, A, TA, 0)                                        # [B x 4, r'', A x 4]
+    walk_rel_reads(a, TB)
+    a("s_waitcnt vmcnt(5)", "[B x 4, r'', A x 4] -> B")
+    walk_compute(a, B, (-4, -3, -2, -1), binop, sum_code, 4, "b")  # (rem already moved on by 8)
+    a("s_mov_b32 %[kb], %[t0]")
+    a("s_branch .Lwalk_loop_%=")
+    a.label(".Lwalk_last_a_%=")
+    walk_rel_reads(a, TA)
+    a("s_waitcnt vmcnt(0)")
+    walk_compute(a, A, (0, 1, 2, 3), binop, sum_code, 0, "la")
+    a("s_branch .Lwalk_done_%=")
+    a.label(".Lwalk_last_b_%=")
+    walk_rel_reads(a, TB)
+    a("s_waitcnt vmcnt(0)")
+    walk_compute(a, B, (4, 5, 6, 7), binop, sum_code, 4, "lb")
+    a.label(".Lwalk_done_%=")
+    for e in range(4):
+        a("v_mov_b32_e32 %%[o%d], v%d" % (e, 122 + e))
+    return a
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# chain producers: 16-lane group `slot` of waves 1..15 computes message `slot` of every 60-edge chunk of the workgroup's
+# chunk list and parks it (transposed, see CHAIN_QUADS in rspmm_order_kernels.hpp) in the ring half of the chunk.
+# Per lane and chunk k three requests go through the vector-memory queue, D chunks apart: B_k (the chunk's first edge,
+# from its descriptor), R_k (this slot's record) and G_k (the record's source row).  Register map (clobbers):
+#   v64..v95   xq[j]  source row of the chunk in stage j        v96..v111  rq[j]  record (col, type) of the chunk D further on
+#   v112..v119 tq[j]  LDS address of the relation row of xq[j]  v56..v63   bq[j]  first edge of the chunk 2 D further on
+#   v120..v123, v52..v55, v48..v51, v44..v47  relation row -> message -> transposed message, one set per chunk, rotating:
+#                          while message i is parked, message i + 1 is multiplied and transposed and the relation row
+#                          of chunk i + 2 is on its way
+#   v124, v125 gather / record offsets    v126 ring address of this chunk    v127 descriptor offset of the last B request
+# Descriptors are read with vector loads on purpose: a scalar load shares lgkmcnt with the LDS traffic and returns out of
+# order, so every LDS wait behind it would have to be lgkmcnt(0) -- one scalar-cache round trip per chunk on the
+# critical path (measured: 800 cycles per chunk with per-chunk s_loads).  The descriptor list is readable CHUNK_PAD
+# (>= 3 D) entries past its end (plan.cpp), so no index is clamped; a prefetch past the end requests edge 0 or a
+# neighbouring workgroup's chunk -- valid addresses whose data nobody consumes.
+PROD_D = 8
+PROD_CLOBBER_LO, PROD_CLOBBER_HI = 44, 127
+RING_HALF_BYTES = 15 * 64 * 16
+
+
+def gen_producer(mul_code, rec_policy):
+    a = Asm()
+    D = PROD_D
+    binop = BINOPS[mul_code]
+    SETS = (120, 52, 48, 44)   # four 4-register sets: relation row -> message -> transposed message, rotating per chunk
+
+    def xq(j):
+        return 64 + 4 * (j % D)
+
+    def rq(j):
+        return 96 + 2 * (j % D)
+
+    def tq(j):
+        return 112 + (j % D)
+
+    def bq(j):
+        return 56 + (j % D)
+
+    def begin_request_imm(j, k):
+        a("global_load_dword v%d, v127, %%[chunks] offset:%d" % (bq(j), 16 * k + 4), "B_%d: Chunk::begin" % k)
+
+    def rec_request(j):
+        a("v_lshl_add_u32 v125, v%d, 3, %%[slot8]" % bq(j))
+        a("global_load_dwordx2 %s, v125, %%[rb]%s" % (vr(rq(j), 2), rec_policy))
+
+    def row_request(j):
+        a("v_lshl_add_u32 v%d, v%d, 8, %%[lds]" % (tq(j), rq(j) + 1))
+        a("v_mad_u32_u24 v124, v%d, %%[xrb], %%[lb]" % rq(j))
+        a("global_load_dwordx4 %s, v124, %%[xb]" % vr(xq(j), 4))
+
+    def prepare(k):
+        """message of chunk k (stage k % D, set k % 4, whose relation row is already there) -> transposed, in registers;
+        then the stage is refilled and the relation row of chunk k + 1 is requested"""
+        m = SETS[k % 4]
+        # chunk k needs G_k, R_k+D and B_k+2D: all three went out when chunk k - D was prepared (or in the prologue in the
+        # same order), G first, and every later preparation appended three requests -> 3 (D - 1) requests are younger.
+        if not os.environ.get("ULTRA_GEN_PROD_NOWAIT"):   # (measurement builds: what the step costs without the wait; results are wrong)
+            a("s_waitcnt vmcnt(%d)" % (3 * (D - 1)))
+        x = xq(k)
+        a("%s %s, %s, %s" % (binop, vr(m, 2), vr(m, 2), vr(x, 2)))
+        a("%s %s, %s, %s" % (binop, vr(m + 2, 2), vr(m + 2, 2), vr(x + 2, 2)))
+        a("s_nop 1", "VALU write -> v_permlane*_swap read: 2 wait states")
+        a("v_permlane32_swap_b32_e32 v%d, v%d" % (m, m + 2))
+        a("v_permlane32_swap_b32_e32 v%d, v%d" % (m + 1, m + 3))
+        a("s_nop 1")
+        a("v_permlane16_swap_b32_e32 v%d, v%d" % (m, m + 1))
+        a("v_permlane16_swap_b32_e32 v%d, v%d" % (m + 2, m + 3))
+        row_request(k)                                               # G_k+D
+        rec_request(k)                                               # R_k+2D
+        a("v_add_u32_e32 v127, 16, v127")
+        a("global_load_dword v%d, v127, %%[chunks]" % bq(k), "B_k+3D")
+        a("ds_read_b128 %s, v%d" % (vr(SETS[(k + 1) % 4], 4), tq(k + 1)), "relation row of the next chunk")
+
+    a("s_mov_b32 %[i], 0")
+    a("s_mov_b32 %[half], 0")
+    a("v_mov_b32_e32 v127, 0")
+    for j in range(D):
+        begin_request_imm(j, j)                                      # B_0 .. B_D-1
+    a("s_waitcnt vmcnt(0)")
+    for j in range(D):
+        rec_request(j)                                               # R_0 .. R_D-1
+        begin_request_imm(j, D + j)                                  # B_D .. B_2D-1
+    a("s_waitcnt vmcnt(0)")
+    for j in range(D):
+        row_request(j)                                               # G_j
+        rec_request(j)                                               # R_D+j
+        begin_request_imm(j, 2 * D + j)                              # B_2D+j      sequence: G_0 R_D B_2D G_1 R_D+1 B_2D+1 ...
+    a("v_mov_b32_e32 v127, 0x%x" % (16 * (3 * D - 1) + 4), "descriptor offset of chunk 3 D - 1")
+    a("ds_read_b128 %s, v%d" % (vr(SETS[0], 4), tq(0)), "relation row of chunk 0")
+    a("s_waitcnt lgkmcnt(0)")
+    prepare(0)
+    a("s_waitcnt lgkmcnt(0)")
+    a.label(".Lprod_loop_%=")
+    for J in range(D):
+        # step i (i % D = J): park message i -- prepared during the previous step, so the write goes out right behind the
+        # barrier and the LDS works on it while message i + 1 is prepared; then barrier i.  (A message past the last chunk
+        # is prepared from prefetched, valid data and never parked.)
+        a("v_add_u32_e32 v126, %[half], %[ring]")
+        a("ds_write_b128 v126, %s" % vr(SETS[J % 4], 4))
+        a("s_xor_b32 %%[half], %%[half], %d" % RING_HALF_BYTES)
+        prepare(J + 1)
+        a("s_add_i32 %[i], %[i], 1")
+        a("s_waitcnt lgkmcnt(0)")
+        a("s_barrier")
+        a("s_cmp_ge_i32 %[i], %[n]")
+        a("s_cbranch_scc1 .Lprod_done_%=")
+    a("s_branch .Lprod_loop_%=")
+    a.label(".Lprod_done_%=")
+    a("s_waitcnt vmcnt(0)", "requests past the last chunk: nobody consumes them")
+    return a
+
+
+def clobbers(lo, hi):
+    return ", ".join('"v%d"' % r for r in range(lo, hi + 1))
+
+
+HEADER = '''// GENERATED by tools/gen_order_asm.py -- do not edit; edit the generator and re-run it.
+//
+// The two software-pipelined inner loops of rspmm_order_kernel (fp32, unit weights, relation slice in LDS) as gfx950
+// assembly: see the generator's docstring for why these are not left to the compiler and for how every wait count
+// follows from the issue order.  Arithmetic and summation order are those of the C++ paths (walk_row_in_order and the
+// producer lambda in rspmm_order_kernels.hpp), i.e. rspmm.cpp:61-72's.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace ultra {
+
+#ifndef ULTRA_REC_NT
+#define ULTRA_REC_NT 0   // 1: nt (streaming) policy on the record stream -- measured slower: in-order return puts its longer latency in front of the gathers
+#endif
+
+'''
+
+
+def main():
+    parts = [HEADER]
+    parts.append("// group walk: returns the four sums of this lane; rem = the row's edge count, roff = byte offset of the lane's\n"
+                 "// first record ((begin + lane % 8) * 8), l8 = lane % 8, lb = lane's byte offset inside a source row, lds = LDS byte\n"
+                 "// address of the lane's part of relation row 0, ns / nf = steps of the unit's longest / shortest row (ns > 0, wave-uniform)\n"
+                 "template <int SUM, int MUL>\n"
+                 "__device__ __forceinline__ void order_walk_asm(float (&o)[4], int rem, uint32_t roff, const int l8, const uint32_t lb,\n"
+                 "                                               const uint32_t lds, const int ns, const int nf, const char *xb,\n"
+                 "                                               const char *rb, const uint32_t xrb) {\n"
+                 "    int kb, t0, t1;\n    unsigned long long ex;\n")
+    first = True
+    for sum_code in (0, 1, 2):
+        for mul_code in (0, 1):
+            for nt in (1, 0):
+                a = gen_walk(sum_code, mul_code, " nt" if nt else "")
+                cond = "SUM == %d && MUL == %d && ULTRA_REC_NT == %d" % (sum_code, mul_code, nt)
+                parts.append("    %sif constexpr (%s) {\n" % ("" if first else "else ", cond))
+                first = False
+                parts.append("        asm volatile(\n" + a.render("            ") + "\n")
+                parts.append('            : [o0] "=v"(o[0]), [o1] "=v"(o[1]), [o2] "=v"(o[2]), [o3] "=v"(o[3]), [rem] "+v"(rem), [roff] "+v"(roff),\n'
+                             '              [kb] "=&s"(kb), [t0] "=&s"(t0), [t1] "=&s"(t1), [ex] "=&s"(ex)\n'
+                             '            : [l8] "v"(l8), [lb] "v"(lb), [lds] "v"(lds), [ns] "s"(ns), [nf] "s"(nf), [xb] "s"(xb), [rb] "s"(rb),\n'
+                             '              [xrb] "s"(xrb)\n'
+                             '            : "memory", "vcc", "scc", %s);\n' % clobbers(WALK_CLOBBER_LO, WALK_CLOBBER_HI))
+                parts.append("    }\n")
+    parts.append("}\n\n")
+
+    parts.append("// chain producers: `n` chunks from descriptor `chunks` on (Chunk = 16 B, begin at +4), one s_barrier per chunk;\n"
+                 "// slot8 = 8 * slot, ring = LDS byte address of this lane's 16 B in ring half 0 ((quad * 64 + lane) * 16 past the ring)\n"
+                 "template <int MUL>\n"
+                 "__device__ __forceinline__ void order_produce_asm(const int n, const void *chunks, const uint32_t slot8, const uint32_t lb,\n"
+                 "                                                  const uint32_t lds, const uint32_t ring, const char *xb, const char *rb,\n"
+                 "                                                  const uint32_t xrb) {\n"
+                 "    int i, half;\n")
+    first = True
+    for mul_code in (0, 1):
+        for nt in (1, 0):
+            a = gen_producer(mul_code, " nt" if nt else "")
+            cond = "MUL == %d && ULTRA_REC_NT == %d" % (mul_code, nt)
+            parts.append("    %sif constexpr (%s) {\n" % ("" if first else "else ", cond))
+            first = False
+            parts.append("        asm volatile(\n" + a.render("            ") + "\n")
+            parts.append('            : [i] "=&s"(i), [half] "=&s"(half)\n'
+                         '            : [n] "s"(n), [chunks] "s"(chunks), [slot8] "v"(slot8), [lb] "v"(lb), [lds] "v"(lds), [ring] "v"(ring),\n'
+                         '              [xb] "s"(xb), [rb] "s"(rb), [xrb] "s"(xrb)\n'
+                         '            : "memory", "scc", %s);\n' % clobbers(PROD_CLOBBER_LO, PROD_CLOBBER_HI))
+            parts.append("    }\n")
+    parts.append("}\n\n}  // namespace ultra\n")
+    with open(OUT, "w") as f:
+        f.write("".join(parts))
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()

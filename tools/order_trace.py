@@ -32,12 +32,13 @@ def main():
     n_chain = plan.info()["n_chain_row"]
     ms, _ = plan.forward_timed(rel, x, point=point, warmup=3, iters=20)
     print("time per call %.4f ms" % ms)
-    trace = torch.zeros(grid * 3, dtype=torch.int64, device=dev)
+    trace = torch.zeros(grid * 4, dtype=torch.int64, device=dev)   # (+ grid spare words for measurement builds)
     _lib.check(_lib.lib.ultra_order_trace(trace.data_ptr()))
     plan.forward(rel, x, point=point)
     torch.cuda.synchronize()
     _lib.check(_lib.lib.ultra_order_trace(None))
-    t = trace.cpu().view(grid, 3)
+    extra = trace[grid * 3:].cpu()
+    t = trace[:grid * 3].cpu().view(grid, 3)
     t0 = t[:, 0].min()
     rows = []
     for b in range(grid):
@@ -47,11 +48,11 @@ def main():
         ch_rows = int((chunks[chunk_ptr[part]:chunk_ptr[part + 1], 3] & 1).sum())
         us = units[unit_ptr[part]:unit_ptr[part + 1]].long()
         steps = int(items[n_chain + 4 * us, 2].sum()) if len(us) else 0
-        rows.append((b, part, int(t[b, 0] - t0), int(t[b, 1] - t[b, 0]), int(t[b, 2] - t[b, 1]), nch, ch_edges, ch_rows, len(us), steps))
+        rows.append((b, part, int(t[b, 0] - t0), int(t[b, 1] - t[b, 0]), int(t[b, 2] - t[b, 1]), nch, ch_edges, ch_rows, len(us), steps, int(extra[b])))
     rows.sort(key=lambda r: -(r[3] + r[4]))
-    print("block part start chain_cyc unit_cyc | chunks chain_edges chain_rows units unit_steps")
+    print("block part start chain_cyc unit_cyc | chunks chain_edges chain_rows units unit_steps extra")
     for r in rows[:12] + rows[-6:]:
-        print("%5d %4d %6d %9d %8d | %6d %11d %10d %5d %10d" % r)
+        print("%5d %4d %6d %9d %8d | %6d %11d %10d %5d %10d %8d" % r)
     tot = torch.tensor([[r[3], r[4], r[5], r[6], r[7], r[8], r[9]] for r in rows], dtype=torch.float64)
     # least squares: chain_cyc ~ a * edges + b * chunks + c * rows ; unit_cyc ~ d * steps / 16 ... per workgroup
     A = tot[:, [3, 2, 4]]

@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libultra_amd.so")
+# ULTRA_AMD_LIB: another build of the same sources (kernel A/B measurements, tools/build_variant.py)
+LIB_PATH = os.environ.get("ULTRA_AMD_LIB") or os.path.join(HERE, "lib", "libultra_amd.so")
 
 ULTRA_OK = 0
 ULTRA_ERR_INVALID = 1

@@ -298,8 +298,10 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
             const Item &it = p->items[(size_t)c];
             for (int32_t pos = 0; pos < it.len; pos += CHAIN_SLOTS) {
                 const int32_t cnt = std::min<int32_t>(CHAIN_SLOTS, it.len - pos);
+                // (a row's first chunk also carries the row's length: the consumer wave reads one descriptor per row)
                 s->chunks.push_back(Chunk{it.row, it.begin + pos, cnt,
-                                          (pos == 0 ? CHUNK_FIRST : 0) | (pos + cnt == it.len ? CHUNK_LAST : 0)});
+                                          (pos == 0 ? (CHUNK_FIRST | (it.len << CHUNK_LEN_SHIFT)) : 0) |
+                                              (pos + cnt == it.len ? CHUNK_LAST : 0)});
             }
         }
         s->chunk_ptr[(size_t)q + 1] = (int32_t)s->chunks.size();
@@ -308,6 +310,9 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
         s->max_cost = std::max(s->max_cost, load[(size_t)q]);
         s->mean_cost += load[(size_t)q] / nparts;
     }
+    // the chain producers request descriptors a fixed number of chunks ahead without a bounds test: readable, harmless
+    // entries (edge 0) behind the last chunk
+    for (int k = 0; k < CHUNK_PAD; ++k) s->chunks.push_back(Chunk{0, 0, 0, 0});
     return s;
 }
 

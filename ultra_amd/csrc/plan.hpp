@@ -33,10 +33,11 @@ struct Item {
 // park it in an LDS ring, one consumer wave adds the parked messages in sorted edge order -- the reference's
 // sequential summation order (rspmm.cpp:61-72) without a 9,000-step walk by a single lane group.
 struct Chunk {
-    int32_t row, begin, count, flags;   // flags: CHUNK_FIRST / CHUNK_LAST chunk of its row
+    int32_t row, begin, count, flags;   // flags: CHUNK_FIRST / CHUNK_LAST chunk of its row; a first chunk: | row length << 2
 };
-enum { CHUNK_FIRST = 1, CHUNK_LAST = 2 };
+enum { CHUNK_FIRST = 1, CHUNK_LAST = 2, CHUNK_LEN_SHIFT = 2 };
 constexpr int CHAIN_SLOTS = 60;          // producer groups of a 1024-thread workgroup (15 waves x 4)
+constexpr int CHUNK_PAD = 32;           // descriptors readable behind a schedule's last chunk (>= 3 x the producers' depth)
 constexpr int ORDER_PAD = 128;           // the device record / perm streams are readable this many entries past the last edge
 
 // Static work assignment of one launch geometry: `nparts` workgroups share the items of a span.  Built on first use

@@ -882,7 +882,7 @@ int32_t ultra_plan_schedule_info(ultra_plan *plan, int32_t nparts, ultra_schedul
     if (!(plan->flags & ULTRA_PLAN_EXACT_ORDER)) return invalid("schedules belong to ULTRA_PLAN_EXACT_ORDER plans");
     Schedule *s = build_schedule(plan, nparts);
     info->nparts = nparts;
-    info->n_chunk = (int64_t)s->chunks.size();
+    info->n_chunk = (int64_t)s->chunk_ptr.back();   // (the array carries CHUNK_PAD readable entries behind the last chunk)
     info->n_unit = (int64_t)s->units.size();
     info->max_cost = s->max_cost;
     info->mean_cost = s->mean_cost;
@@ -907,7 +907,7 @@ int32_t ultra_plan_schedule_export(ultra_plan *plan, int32_t nparts, int32_t whi
         case 0: src = s->chunk_ptr.data(), n = (int64_t)s->chunk_ptr.size(); break;
         case 1: src = s->unit_ptr.data(), n = (int64_t)s->unit_ptr.size(); break;
         case 2: src = s->units.data(), n = (int64_t)s->units.size(); break;
-        case 3: src = reinterpret_cast<const int32_t *>(s->chunks.data()), n = (int64_t)s->chunks.size() * 4; break;
+        case 3: src = reinterpret_cast<const int32_t *>(s->chunks.data()), n = (int64_t)s->chunk_ptr.back() * 4; break;
         default: delete s; return invalid("ultra_plan_schedule_export: unknown array id");
     }
     *count = n;

@@ -24,12 +24,16 @@
 #pragma once
 
 #include "rspmm_kernels.hpp"
+#include "rspmm_order_asm.hpp"
 
 #pragma clang fp contract(off)
 
 namespace ultra {
 
 constexpr int ORDER_THREADS = 1024;
+#ifndef ULTRA_CHAIN_PRIO
+#define ULTRA_CHAIN_PRIO 1
+#endif
 static_assert(CHAIN_SLOTS == 4 * (ORDER_THREADS / 64 - 1), "one ring slot per producer group");
 
 struct OrderParams {
@@ -71,7 +75,6 @@ __device__ __forceinline__ double bcast16(double v) {
 
 template <int J>
 using StepTag = std::integral_constant<int, J>;
-
 // Read-only schedule data addressed by a wave-uniform index: loaded through the constant address space so that it
 // comes in over the scalar cache (s_load) -- off the vector-memory counter, whose in-order bookkeeping would otherwise
 // make a descriptor prefetch drain the gathers queued behind it.
@@ -101,8 +104,10 @@ __device__ __forceinline__ Pack<T, 4> walk_row_in_order(const OrderParams &p, co
     V acc = V(nary_zero<T, SUM>());
     const T *wt = reinterpret_cast<const T *>(p.w);
     const int l8 = l16 & 7;
-    const int2 *recs = reinterpret_cast<const int2 *>(p.rec) + begin + l8;
-    const int32_t *perm = p.perm + begin + l8;
+    // record / permutation streams: uniform base + 32-bit per-lane offset (no 64-bit address pair to keep alive)
+    const char *rec_base = reinterpret_cast<const char *>(p.rec);
+    const char *perm_base = reinterpret_cast<const char *>(p.perm);
+    const uint32_t first = (uint32_t)(begin + l8);
 
     struct Records {   // this lane holds the record of step (round base + l8) of its group's row
         int c, t;
@@ -111,11 +116,11 @@ __device__ __forceinline__ Pack<T, 4> walk_row_in_order(const OrderParams &p, co
     // raw = as loaded (a step past the row's end holds a neighbouring row's record); promote() masks those to node 0
     const auto load_records = [&](const int k0, int &pm) {
         Records r;
-        const int2 ct = recs[k0];
+        const int2 ct = *reinterpret_cast<const int2 *>(rec_base + (first + (uint32_t)k0) * 8u);
         r.c = ct.x, r.t = ct.y, r.w = T(1);
         if (WEIGHTED) {
             r.w = wt[pm];           // pm: original edge id, requested one round earlier (w[perm[.]] is a dependent load)
-            pm = perm[k0 + 8];
+            pm = *reinterpret_cast<const int32_t *>(perm_base + (first + (uint32_t)k0 + 8u) * 4u);
         }
         return r;
     };
@@ -179,7 +184,7 @@ __device__ __forceinline__ Pack<T, 4> walk_row_in_order(const OrderParams &p, co
 
     if (nsteps > 0) {
         int pm = 0;
-        if (WEIGHTED) pm = perm[0];
+        if (WEIGHTED) pm = *reinterpret_cast<const int32_t *>(perm_base + first * 4u);
         Records nxt_raw = load_records(0, pm);
         Records cur = promote(nxt_raw, 0);
         nxt_raw = load_records(8, pm);
@@ -207,46 +212,111 @@ __device__ __forceinline__ Pack<T, 4> walk_row_in_order(const OrderParams &p, co
     return to_pack<T, 4>(acc);
 }
 
-// ---- consumer side of a chain chunk ----
-// The adds form one dependent chain per lane -- the serial part of the whole kernel; the LDS reads do not depend on it.
-// A full chunk is taken in two halves of CHAIN_HALF messages: the reads of a half are in flight while the previous
-// half is added, and the second half of chunk i is added behind barrier i + 1 (its values are in registers by then),
-// so the chain only ever waits for the barrier.
-constexpr int CHAIN_HALF = CHAIN_SLOTS / 2;
+// The configurations whose two pipelined loops run as hand-scheduled assembly (rspmm_order_asm.hpp): fp32, unit
+// weights, relation slice in LDS, mul / add messages -- the inference path.  Everything else takes the C++ loops below.
+#ifndef ULTRA_ORDER_ASM
+#define ULTRA_ORDER_ASM 1
+#endif
+#ifndef ULTRA_DBG_CHAIN
+#define ULTRA_DBG_CHAIN 0
+#endif
+#ifndef ULTRA_ASM_WALK
+#define ULTRA_ASM_WALK 1
+#endif
+#ifndef ULTRA_ASM_PRODUCE
+#define ULTRA_ASM_PRODUCE 1
+#endif
+template <typename T, int MUL, bool REL_LDS, bool WEIGHTED>
+struct OrderAsm {
+    static constexpr bool value =
+        ULTRA_ORDER_ASM && std::is_same<T, float>::value && REL_LDS && !WEIGHTED && (MUL == BIN_MUL || MUL == BIN_ADD);
+};
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
+}
 
-template <typename T, int N>
-__device__ __forceinline__ void ring_read(T (&v)[N], const T *ring_lane) {
-#pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = ring_lane[k * 64];
+// ---- chain rows: ring layout and the consumer's reads ----
+// A chunk's CHAIN_SLOTS messages sit in the ring as CHAIN_QUADS quads; quad q holds, for each of the span's 64 elements,
+// the FOUR messages 4 q .. 4 q + 3 next to each other (16 B for fp32): [half][quad][lane][4].  The consumer lane reads
+// four links of its chain with one ds_read_b128 -- one LDS instruction per four dependent adds instead of one per
+// add (a wave issues roughly one instruction per four cycles, so with a read per add the reads, not the adds, paced
+// the chain).  The producers hold a message as four consecutive elements per lane (16-lane group g of wave 1 + q holds
+// message 4 q + g); a 4 x 4 transpose across the wave's four lane rows (two v_permlane32_swap + two v_permlane16_swap
+// per 32-bit word) turns that into "lane (g, l16) holds element 4 l16 + g of messages 4 q .. 4 q + 3", which is
+// stored with one conflict-free 16-byte write at [quad][lane].  Consumer lane c therefore owns element
+// chain_element(c) = 4 (c % 16) + c / 16 of the span.
+constexpr int CHAIN_QUADS = CHAIN_SLOTS / 4;
+constexpr int CHAIN_QA = (CHAIN_QUADS + 1) / 2;    // quads read right behind the barrier ...
+constexpr int CHAIN_QB = CHAIN_QUADS - CHAIN_QA;   // ... and quads read in the shadow of the first half's adds
+static_assert(CHAIN_SLOTS % 4 == 0, "whole quads");
+
+__device__ __forceinline__ int chain_element(const int lane) { return 4 * (lane & 15) + (lane >> 4); }
+
+// rows of 16 lanes: (a0 a1 a2 a3), (b0 b1 b2 b3) -> (a0 a1 b0 b1), (a2 a3 b2 b3)
+__device__ __forceinline__ void swap_rows32(uint32_t &a, uint32_t &b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0], b = r[1];
 }
-template <typename T, int SUM, int N>
-__device__ __forceinline__ T chain_add(T acc, const T (&v)[N]) {
-#pragma unroll
-    for (int k = 0; k < N; ++k) acc = nary<T, SUM>(acc, v[k]);
-    return acc;
+// (a0 a1 a2 a3), (b0 b1 b2 b3) -> (a0 b0 a2 b2), (a1 b1 a3 b3)
+__device__ __forceinline__ void swap_rows16(uint32_t &a, uint32_t &b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0], b = r[1];
 }
-// acc (+)= v[0..N) while the next half is requested: the reads issue in the shadow of the dependent adds
-template <typename T, int SUM, int N>
-__device__ __forceinline__ T chain_add_and_read(T acc, const T (&v)[N], T (&next)[N], const T *ring_lane) {
+// y[e] of lane row g  <-  y[g] of lane row e   (g, e = 0..3; same lane % 16)
+template <typename T>
+__device__ __forceinline__ void transpose_lane_rows(typename VecOf<T, 4>::type &y) {
+    constexpr int W = sizeof(T) / 4;   // 32-bit words per element
+    uint32_t w[4][W];
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        next[k] = ring_lane[k * 64];
-        acc = nary<T, SUM>(acc, v[k]);
+    for (int e = 0; e < 4; ++e) {
+        const T v = y[e];
+        __builtin_memcpy(w[e], &v, sizeof(T));
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        swap_rows32(w[0][k], w[2][k]);
+        swap_rows32(w[1][k], w[3][k]);
+        swap_rows16(w[0][k], w[1][k]);
+        swap_rows16(w[2][k], w[3][k]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        T v;
+        __builtin_memcpy(&v, w[e], sizeof(T));
+        y[e] = v;
+    }
+}
+
+template <typename V, int N>
+__device__ __forceinline__ void ring_read(V (&v)[N], const V *ring_lane) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = ring_lane[q * 64];
+}
+// the dependent chain: 4 N links
+template <typename T, int SUM, typename V, int N>
+__device__ __forceinline__ T chain_add(T acc, const V (&v)[N]) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = nary<T, SUM>(acc, v[q][e]);
     }
     return acc;
 }
-template <typename T, int SUM>
-__device__ __forceinline__ T consume_partial(T acc, const T *ring_lane, const int count) {
-    int k = 0;
-    for (; k + 4 <= count; k += 4) {
-        const T v0 = ring_lane[(k + 0) * 64], v1 = ring_lane[(k + 1) * 64], v2 = ring_lane[(k + 2) * 64],
-                v3 = ring_lane[(k + 3) * 64];
-        acc = nary<T, SUM>(acc, v0);
-        acc = nary<T, SUM>(acc, v1);
-        acc = nary<T, SUM>(acc, v2);
-        acc = nary<T, SUM>(acc, v3);
+// the first `count` links of quads [Q0, Q0 + N) of a chunk (count is wave-uniform)
+template <typename T, int SUM, typename V, int N>
+__device__ __forceinline__ T chain_add_partial(T acc, const V (&v)[N], const int q0, const int count) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        const int left = count - 4 * (q0 + q);
+        if (left >= 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = nary<T, SUM>(acc, v[q][e]);
+        } else if (left > 0) {
+            acc = nary<T, SUM>(acc, v[q][0]);
+            if (left > 1) acc = nary<T, SUM>(acc, v[q][1]);
+            if (left > 2) acc = nary<T, SUM>(acc, v[q][2]);
+        }
     }
-    for (; k < count; ++k) acc = nary<T, SUM>(acc, ring_lane[k * 64]);
     return acc;
 }
 
@@ -263,8 +333,6 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
     const int lane = tid & 63;
     const int wave = rfl(tid >> 6);
     constexpr int nwave = ORDER_THREADS / 64;
-    const int grp = lane >> 4;
-    const int l16 = lane & 15;
     const int part = blockIdx.x / p.smod;
     if (part >= p.nparts) return;
     const T *wt = reinterpret_cast<const T *>(p.w);
@@ -273,167 +341,233 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
     for (int span = blockIdx.x % p.smod; span < p.n_span; span += p.smod) {
         const int outer = span / p.spans_per_outer;
         const int inner = span - outer * p.spans_per_outer;
-        const int d0 = inner * SPAN + l16 * 4;
-        const bool dvalid = d0 < p.row_len;
-        const int d0c = dvalid ? d0 : 0;
         const char *xbase = reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.x.ptr) + outer * p.x.stride_outer);
         const char *relbase =
             reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.rel.ptr) + outer * p.rel.stride_outer);
-        const uint32_t lane_bytes = (uint32_t)d0c * (uint32_t)sizeof(T);
         const long long bnd_row = p.bnd_rows ? p.bnd_rows[outer] : -1;   // (stride_row of a point boundary is 0)
-        const T *lds_rel_lane = lds_rel + l16 * 4;
+        // Per-lane geometry of the span, derived from the lane id.  Each phase derives its own copy from an opaque lane id:
+        // values computed once at the top would stay live through the chain phase (whose consumer holds 60 registers of
+        // ring data) and come back from scratch in every unit of the walk.
+        struct LaneGeom {
+            int grp, l16, d0;
+            bool dvalid;
+            uint32_t lane_bytes;
+            const T *lds_rel_lane;
+        };
+        const auto lane_geom = [&]() {
+            int l = lane;
+            asm volatile("" : "+v"(l));
+            LaneGeom g;
+            g.grp = l >> 4, g.l16 = l & 15;
+            g.d0 = inner * SPAN + g.l16 * 4;
+            g.dvalid = g.d0 < p.row_len;
+            g.lane_bytes = (uint32_t)(g.dvalid ? g.d0 : 0) * (uint32_t)sizeof(T);
+            g.lds_rel_lane = lds_rel + g.l16 * 4;
+            return g;
+        };
 
         if (REL_LDS && MUL != BIN_RHS) {
             __syncthreads();  // readers of the previous span are done with the LDS image
+            // (the staging addresses are recomputed per span: hoisted out of the span loop they would stay live through
+            // the walks below and spill)
+            int tid_stage = tid;
+            asm volatile("" : "+v"(tid_stage));
             stage_slice<T, 4>(lds_rel, reinterpret_cast<const T *>(p.rel.ptr) + outer * p.rel.stride_outer, p.rel.stride_row,
-                              p.num_rel, inner, p.row_len, tid, ORDER_THREADS);
+                              p.num_rel, inner, p.row_len, tid_stage, ORDER_THREADS);
             __syncthreads();
         }
 
         // ================= chain rows of this workgroup =================
         // Chunk i of the workgroup's chunk list is produced into ring half (i & 1) before barrier i and consumed after
-        // it; the consumer reaches barrier i + 1 only after it has drained chunk i, so a ring half is never overwritten
-        // early.  Producers and the consumer run separate loops with the same number of barriers.
+        // it; the consumer reaches barrier i + 1 only after its reads of chunk i have returned (the barrier's
+        // lgkmcnt(0)), so a ring half is never overwritten early.  Producers and the consumer run separate loops with
+        // the same number of barriers: one per chunk.
         const int c0 = p.has_chain ? p.chunk_ptr[part] : 0, c1 = p.has_chain ? p.chunk_ptr[part + 1] : 0;
+        constexpr int RING_HALF = CHAIN_QUADS * 64;   // in quads-of-lane units (V)
         if (c1 > c0) {
+            const LaneGeom cg = lane_geom();
+            const int grp = cg.grp, l16 = cg.l16;
+            const uint32_t lane_bytes = cg.lane_bytes;
+            const T *lds_rel_lane = cg.lds_rel_lane;
+            (void)l16;
             if (wave == 0) {
-                T cacc = nary_zero<T, SUM>();
-                const auto finish_row = [&](const int row) {
-                    const int d = inner * SPAN + lane;
+#if ULTRA_CHAIN_PRIO
+                __builtin_amdgcn_s_setprio(3);   // the chain is the launch's critical path: win VALU / LDS issue arbitration
+#endif
+                const int d = inner * SPAN + chain_element(lane);
+                const auto finish_row = [&](const int row, T v) {
                     if (d < p.row_len) {
-                        T v = cacc;
                         if (p.has_bnd && (bnd_row < 0 || bnd_row == row))
                             v = nary<T, SUM>(v, reinterpret_cast<const T *>(p.bnd.ptr)[outer * p.bnd.stride_outer +
                                                                                       (long long)row * p.bnd.stride_row + d]);
                         reinterpret_cast<T *>(p.out)[outer * p.out_stride_outer + (long long)row * p.out_stride_row + d] = v;
                     }
                 };
-                // chunk descriptors are requested four chunks before their barrier (a load issued right before the
-                // barrier and used right behind it would put an L2 round trip into every link of the chain)
-                v4i dq[4];
                 const v4i *chunks = reinterpret_cast<const v4i *>(p.chunks);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dq[j] = load_uniform(chunks + min(c0 + j, c1 - 1));
-                T va[CHAIN_HALF], vb[CHAIN_HALF];
-                bool pend = false;            // vb holds the second half of the previous chunk, not yet added
-                int pend_row = -1;            // ... and that chunk closes this row (-1: it does not)
-                const auto consume = [&](auto jtag, const int it) {
-                    constexpr int J = decltype(jtag)::value;
-                    const v4i ch = dq[J];
-                    const int row = ch[0], count = ch[2], flags = ch[3];
-                    const T *ring_lane = ring + (size_t)((it - c0) & 1) * CHAIN_SLOTS * SPAN + lane;
-                    __syncthreads();
-                    // (scalar loads count on lgkmcnt, which the barrier drains: requested right behind it, consumed
-                    // four barriers later)
-                    dq[J] = load_uniform(chunks + min(it + 4, c1 - 1));
-                    if (count == CHAIN_SLOTS) {
-                        if (pend) {
-                            cacc = chain_add_and_read<T, SUM>(cacc, vb, va, ring_lane);
-                            if (pend_row >= 0) finish_row(pend_row);
-                        } else {
-                            ring_read(va, ring_lane);
-                        }
-                        if (flags & CHUNK_FIRST) cacc = nary_zero<T, SUM>();
-                        cacc = chain_add_and_read<T, SUM>(cacc, va, vb, ring_lane + CHAIN_HALF * SPAN);
-                        pend = true;
-                        pend_row = (flags & CHUNK_LAST) ? row : -1;
-                    } else {
-                        if (pend) {
+                const V *ring_lane = reinterpret_cast<const V *>(ring) + lane;
+                // The consumer walks ROWS: the first chunk's descriptor carries the row's length (flags >> 2), every
+                // later chunk of the row follows from it -- no descriptor load (and no scalar-memory wait) inside a
+                // row.  The next row's descriptor is requested before the row's first barrier, whose lgkmcnt(0)
+                // collects it.
+                v4i desc = load_uniform(chunks + c0);
+                int par = 0;
+#if ULTRA_DBG_CHAIN == 3   /* measurement build: cycles the consumer spends in its barriers -> trace[3 b + 2] of the LAST span */
+                long long bar_cycles = 0;
+#define ULTRA_CHAIN_BARRIER()                     \
+    do {                                          \
+        const long long t_ = clock64();           \
+        __syncthreads();                          \
+        bar_cycles += clock64() - t_;             \
+    } while (0)
+#else
+#define ULTRA_CHAIN_BARRIER() __syncthreads()
+#endif
+                for (int it = c0; it < c1;) {
+                    const int row = desc[0], len = desc[3] >> 2;
+                    const int nfull = len / CHAIN_SLOTS, rem = len - nfull * CHAIN_SLOTS;
+                    const int nch = nfull + (rem > 0 ? 1 : 0);
+                    desc = load_uniform(chunks + min(it + nch, c1 - 1));
+                    T cacc = nary_zero<T, SUM>();
+                    V va[CHAIN_QA], vb[CHAIN_QB];
+#if ULTRA_DBG_CHAIN == 1   /* measurement build: the consumer only keeps the barrier count (results are wrong) */
+                    for (int k = 0; k < nch; ++k) ULTRA_CHAIN_BARRIER();
+                    if (false)
+#endif
+                    if (nfull > 0) {
+                        // first full chunk: nothing pending yet
+                        ULTRA_CHAIN_BARRIER();
+                        ring_read(va, ring_lane + par * RING_HALF);
+                        ring_read(vb, ring_lane + par * RING_HALF + CHAIN_QA * 64);
+                        __builtin_amdgcn_sched_barrier(0);
+                        cacc = chain_add<T, SUM>(cacc, va);
+                        par ^= 1;
+                        // steady state, one chunk per barrier: the first half is requested right behind the barrier and
+                        // lands while the previous chunk's second half (in registers since the barrier) is added; the
+                        // second half is requested before the first half's adds and collected by the next barrier.
+                        for (int k = 1; k < nfull; ++k) {
+                            ULTRA_CHAIN_BARRIER();
+                            ring_read(va, ring_lane + par * RING_HALF);
+                            __builtin_amdgcn_sched_barrier(0);
                             cacc = chain_add<T, SUM>(cacc, vb);
-                            if (pend_row >= 0) finish_row(pend_row);
-                            pend = false;
+                            __builtin_amdgcn_sched_barrier(0);
+                            ring_read(vb, ring_lane + par * RING_HALF + CHAIN_QA * 64);
+                            __builtin_amdgcn_sched_barrier(0);
+                            cacc = chain_add<T, SUM>(cacc, va);
+                            par ^= 1;
                         }
-                        if (flags & CHUNK_FIRST) cacc = nary_zero<T, SUM>();
-                        cacc = consume_partial<T, SUM>(cacc, ring_lane, count);
-                        if (flags & CHUNK_LAST) finish_row(row);
+                        if (rem == 0) cacc = chain_add<T, SUM>(cacc, vb);
                     }
-                };
-                for (int it = c0;; it += 4) {
-                    consume(StepTag<0>{}, it);
-                    if (it + 1 >= c1) break;
-                    consume(StepTag<1>{}, it + 1);
-                    if (it + 2 >= c1) break;
-                    consume(StepTag<2>{}, it + 2);
-                    if (it + 3 >= c1) break;
-                    consume(StepTag<3>{}, it + 3);
-                    if (it + 4 >= c1) break;
+#if ULTRA_DBG_CHAIN == 1
+                    if (false)
+#endif
+                    if (rem > 0) {
+                        // last, partial chunk (slots past `rem` hold messages nobody asked for): same shape as a
+                        // steady-state step
+                        ULTRA_CHAIN_BARRIER();
+                        ring_read(va, ring_lane + par * RING_HALF);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (nfull > 0) cacc = chain_add<T, SUM>(cacc, vb);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ring_read(vb, ring_lane + par * RING_HALF + CHAIN_QA * 64);
+                        __builtin_amdgcn_sched_barrier(0);
+                        cacc = chain_add_partial<T, SUM>(cacc, va, 0, rem);
+                        cacc = chain_add_partial<T, SUM>(cacc, vb, CHAIN_QA, rem);
+                        par ^= 1;
+                    }
+                    finish_row(row, cacc);
+                    it += nch;
                 }
-                if (pend) {
-                    cacc = chain_add<T, SUM>(cacc, vb);
-                    if (pend_row >= 0) finish_row(pend_row);
-                }
+#if ULTRA_DBG_CHAIN == 3
+                if (p.trace && lane == 0) p.trace[3 * gridDim.x + blockIdx.x] = bar_cycles;
+#endif
+#if ULTRA_CHAIN_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             } else {
                 // Producer group `slot` computes message `slot` of every chunk.  Software pipeline per lane: source rows
                 // of the next 4 chunks in flight (xq), records of the 4 chunks after those requested (rq) -- all loads
                 // unconditional (a slot past its chunk's count reads a neighbouring record; nobody consumes its message).
                 const int slot = (wave - 1) * 4 + grp;
-                const int2 *recs = reinterpret_cast<const int2 *>(p.rec) + slot;
-                const int32_t *perm = p.perm + slot;
                 const auto chunk_begin = [&](const int ci) {
                     return load_uniform(reinterpret_cast<const int32_t *>(p.chunks + min(ci, c1 - 1)) + 1);
                 };
-                struct Rec {
-                    int c, t;
-                    T w;
-                };
-                const auto load_rec = [&](const int b) {   // b: first edge of the chunk
-                    const int2 ct = recs[b];
-                    Rec r;
-                    r.c = ct.x, r.t = ct.y, r.w = T(1);
-                    if (WEIGHTED) r.w = wt[perm[b]];
-                    return r;
-                };
-                const auto gather = [&](const Rec &r) {
-                    P v;
-                    if (MUL != BIN_LHS)
-                        v = *reinterpret_cast<const P *>(xbase + (__umul24((uint32_t)r.c, p.x_row_bytes) + lane_bytes));
-                    return v;
-                };
-                // depth of the pipeline in chunks (8 measured slower than 4: the compiler's in-order vmcnt bookkeeping
-                // collapses at the loop back-edge and drains the deeper queue once per round)
-                constexpr int D = 4;
-                Rec rx[D], rq[D];   // rx[j]: record whose source row is in xq[j]; rq[j]: record of the chunk D further on
-                P xq[D];
-                int sb[D];          // first edge of the chunk 2 D further on (scalar loads, requested D chunks before use)
-#pragma unroll
-                for (int j = 0; j < D; ++j) rx[j] = load_rec(chunk_begin(c0 + j));
-#pragma unroll
-                for (int j = 0; j < D; ++j) rq[j] = load_rec(chunk_begin(c0 + D + j));
-#pragma unroll
-                for (int j = 0; j < D; ++j) sb[j] = chunk_begin(c0 + 2 * D + j);
-#pragma unroll
-                for (int j = 0; j < D; ++j) xq[j] = gather(rx[j]);
-                const auto produce = [&](auto jtag, const int it) {
-                    constexpr int J = decltype(jtag)::value;
-                    const int b_next = sb[J];
-                    sb[J] = chunk_begin(it + 3 * D);   // scalar load: issued right behind the previous barrier (see the consumer)
-                    P rv;
-                    if (MUL != BIN_RHS) {
-                        if (REL_LDS)
-                            rv = *reinterpret_cast<const P *>(lds_rel_lane + rx[J].t * SPAN);
-                        else
-                            rv = *reinterpret_cast<const P *>(relbase + (__umul24((uint32_t)rx[J].t, p.rel_row_bytes) + lane_bytes));
+#if ULTRA_DBG_CHAIN == 2   /* measurement build: the producers only keep the barrier count */
+                if constexpr (true) {
+                    for (int k = c0; k < c1; ++k) __syncthreads();
+                } else
+#endif
+                if constexpr (OrderAsm<T, MUL, REL_LDS, WEIGHTED>::value && ULTRA_ASM_PRODUCE) {
+                    order_produce_asm<MUL>(c1 - c0, p.chunks + c0, (uint32_t)slot * 8u, lane_bytes, lds_addr(lds_rel_lane),
+                                           lds_addr(ring) + (uint32_t)((wave - 1) * 64 + lane) * 16u, xbase,
+                                           reinterpret_cast<const char *>(p.rec), p.x_row_bytes);
+                } else {
+                    const int2 *recs = reinterpret_cast<const int2 *>(p.rec) + slot;
+                    const int32_t *perm = p.perm + slot;
+                    struct Rec {
+                        int c, t;
+                        T w;
+                    };
+                    const auto load_rec = [&](const int b) {   // b: first edge of the chunk
+                        const int2 ct = recs[b];
+                        Rec r;
+                        r.c = ct.x, r.t = ct.y, r.w = T(1);
+                        if (WEIGHTED) r.w = wt[perm[b]];
+                        return r;
+                    };
+                    const auto gather = [&](const Rec &r) {
+                        P v;
+                        if (MUL != BIN_LHS)
+                            v = *reinterpret_cast<const P *>(xbase + (__umul24((uint32_t)r.c, p.x_row_bytes) + lane_bytes));
+                        return v;
+                    };
+                    // depth of the pipeline in chunks (8 measured slower than 4: the compiler's in-order vmcnt bookkeeping
+                    // collapses at the loop back-edge and drains the deeper queue once per round)
+                    constexpr int D = 4;
+                    Rec rx[D], rq[D];   // rx[j]: record whose source row is in xq[j]; rq[j]: record of the chunk D further on
+                    P xq[D];
+                    int sb[D];          // first edge of the chunk 2 D further on (scalar loads, requested D chunks before use)
+    #pragma unroll
+                    for (int j = 0; j < D; ++j) rx[j] = load_rec(chunk_begin(c0 + j));
+    #pragma unroll
+                    for (int j = 0; j < D; ++j) rq[j] = load_rec(chunk_begin(c0 + D + j));
+    #pragma unroll
+                    for (int j = 0; j < D; ++j) sb[j] = chunk_begin(c0 + 2 * D + j);
+    #pragma unroll
+                    for (int j = 0; j < D; ++j) xq[j] = gather(rx[j]);
+                    const auto produce = [&](auto jtag, const int it) {
+                        constexpr int J = decltype(jtag)::value;
+                        const int b_next = sb[J];
+                        sb[J] = chunk_begin(it + 3 * D);   // scalar load: issued right behind the previous barrier (see the consumer)
+                        P rv;
+                        if (MUL != BIN_RHS) {
+                            if (REL_LDS)
+                                rv = *reinterpret_cast<const P *>(lds_rel_lane + rx[J].t * SPAN);
+                            else
+                                rv = *reinterpret_cast<const P *>(relbase + (__umul24((uint32_t)rx[J].t, p.rel_row_bytes) + lane_bytes));
+                        }
+                        const V rr = (MUL != BIN_RHS) ? to_vec<T, 4>(rv) : V(T(0));
+                        const V xx = (MUL != BIN_LHS) ? to_vec<T, 4>(xq[J]) : V(T(0));
+                        V y = binary_vec<V, MUL>(rr, xx);
+                        if (WEIGHTED) y = weigh<T, SUM>(y, rx[J].w, p.keep_mode);
+                        // park it: 4 x 4 transpose across the wave's lane rows, then [quad = wave - 1][lane] (see CHAIN_QUADS)
+                        transpose_lane_rows<T>(y);
+                        reinterpret_cast<V *>(ring)[(((it - c0) & 1) * CHAIN_QUADS + (wave - 1)) * 64 + lane] = y;
+                        // refill this pipeline stage: source row of chunk it + D, record of chunk it + 2 D
+                        rx[J] = rq[J];
+                        xq[J] = gather(rx[J]);
+                        rq[J] = load_rec(b_next);
+                        __syncthreads();
+                    };
+                    for (int it = c0;; it += D) {
+                        produce(StepTag<0>{}, it);
+                        if (it + 1 >= c1) break;
+                        produce(StepTag<1>{}, it + 1);
+                        if (it + 2 >= c1) break;
+                        produce(StepTag<2>{}, it + 2);
+                        if (it + 3 >= c1) break;
+                        produce(StepTag<3>{}, it + 3);
+                        if (it + 4 >= c1) break;
                     }
-                    const V rr = (MUL != BIN_RHS) ? to_vec<T, 4>(rv) : V(T(0));
-                    const V xx = (MUL != BIN_LHS) ? to_vec<T, 4>(xq[J]) : V(T(0));
-                    V y = binary_vec<V, MUL>(rr, xx);
-                    if (WEIGHTED) y = weigh<T, SUM>(y, rx[J].w, p.keep_mode);
-                    *reinterpret_cast<P *>(ring + ((size_t)((it - c0) & 1) * CHAIN_SLOTS + slot) * SPAN + l16 * 4) = to_pack<T, 4>(y);
-                    // refill this pipeline stage: source row of chunk it + D, record of chunk it + 2 D
-                    rx[J] = rq[J];
-                    xq[J] = gather(rx[J]);
-                    rq[J] = load_rec(b_next);
-                    __syncthreads();
-                };
-                for (int it = c0;; it += D) {
-                    produce(StepTag<0>{}, it);
-                    if (it + 1 >= c1) break;
-                    produce(StepTag<1>{}, it + 1);
-                    if (it + 2 >= c1) break;
-                    produce(StepTag<2>{}, it + 2);
-                    if (it + 3 >= c1) break;
-                    produce(StepTag<3>{}, it + 3);
-                    if (it + 4 >= c1) break;
                 }
             }
         }
@@ -442,6 +576,11 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
         // ================= group units of this workgroup =================
         // (the next unit's item is requested before the current one is walked: two dependent loads off the critical path;
         // the unit list is read with a clamped index so that the request is unconditional)
+        const LaneGeom ug = lane_geom();
+        const int grp = ug.grp, l16 = ug.l16, d0 = ug.d0;
+        const bool dvalid = ug.dvalid;
+        const uint32_t lane_bytes = ug.lane_bytes;
+        const T *lds_rel_lane = ug.lds_rel_lane;
         const int u1 = p.unit_ptr[part + 1];
         const auto load_item = [&](const int ui) {
             const int u = load_uniform(p.units + min(ui, u1 - 1));
@@ -470,8 +609,17 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
             const int n23 = min(__shfl(cnt, 32), __shfl(cnt, 48));
             const int nfull = rfl(min(n01, n23));
 
-            P acc = walk_row_in_order<T, SUM, MUL, REL_LDS, WEIGHTED>(p, begin, cnt, nsteps, nfull, l16, xbase, relbase, lane_bytes,
-                                                                      lds_rel_lane);
+            P acc;
+            if constexpr (OrderAsm<T, MUL, REL_LDS, WEIGHTED>::value && ULTRA_ASM_WALK) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc.v[e] = nary_zero<T, SUM>();
+                if (nsteps > 0)
+                    order_walk_asm<SUM, MUL>(acc.v, cnt, (uint32_t)(begin + (l16 & 7)) * 8u, l16 & 7, lane_bytes, lds_addr(lds_rel_lane),
+                                             nsteps, nfull, xbase, reinterpret_cast<const char *>(p.rec), p.x_row_bytes);
+            } else {
+                acc = walk_row_in_order<T, SUM, MUL, REL_LDS, WEIGHTED>(p, begin, cnt, nsteps, nfull, l16, xbase, relbase, lane_bytes,
+                                                                        lds_rel_lane);
+            }
             if (row >= 0 && dvalid) {
                 if (p.has_bnd && (bnd_row < 0 || bnd_row == row)) {
                     const P b = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.bnd.ptr) + outer * p.bnd.stride_outer +
