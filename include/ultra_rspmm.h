@@ -274,7 +274,10 @@ typedef struct {
 int32_t ultra_plan_schedule_info(ultra_plan *plan, int32_t nparts, ultra_schedule_info *info);
 /* The schedule's arrays (tests, tooling): which = 0 chunk_ptr [nparts + 1], 1 unit_ptr [nparts + 1], 2 unit ids (a unit =
  * group items n_chain_row + 4 u .. + 3 of ULTRA_ARR_ITEM), 3 chunks as {row, begin, count, flags} quadruples (flags: bit 0 first,
- * bit 1 last chunk of its row; a first chunk also holds the row's edge count in flags >> 2).  Workgroup q of a span walks chunks [chunk_ptr[q], chunk_ptr[q + 1]) then its units. */
+ * bit 1 last chunk of its row; a first chunk also holds the row's edge count in flags >> 2), 4 group-stream descriptors {first record, steps} of the
+ * nparts * 64 16-lane groups, 5 stream records as (col, type) pairs: the rows of a stream back to back, each row's edges in
+ * sorted order followed by a marker (row, num_relation).  Workgroup q of a span walks chunks [chunk_ptr[q], chunk_ptr[q + 1]),
+ * then its units (C++ walk) or its 64 streams (assembly walk of the fp32 inference configuration). */
 int32_t ultra_plan_schedule_export(ultra_plan *plan, int32_t nparts, int32_t which, int32_t *dst_host, int64_t capacity_elems,
                                    int64_t *count);
 
@@ -289,7 +292,8 @@ typedef struct {
     int32_t rel_lds;      /* -1 auto, 0 never stage the relation slice in LDS, 1 force when it fits */
     int32_t x_lds;        /* -1 auto, 0 never stage the input slice in LDS, 1 force when it fits */
     int32_t unroll;       /* edges in flight per lane group (0 -> default) */
-    int32_t reserved[3];  /* [0] != 0: ULTRA_PLAN_EXACT_ORDER plans run on the general walk kernel instead of the order kernels */
+    int32_t reserved[3];  /* [0] != 0: ULTRA_PLAN_EXACT_ORDER plans run on the general walk kernel instead of the order kernels;
+                             [1] != 0: the order kernels walk units of four rows (C++ loop) instead of group streams (assembly) */
 } ultra_tuning;
 int32_t ultra_set_tuning(const ultra_tuning *t);   /* NULL restores defaults */
 int32_t ultra_get_tuning(ultra_tuning *t);

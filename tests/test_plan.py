@@ -221,3 +221,45 @@ def test_dense_twin_is_automatic_only_for_filled_graphs():
     with pytest.raises(RuntimeError):                                 # beyond ULTRA_DENSE_MAX_IN_ROW
         big = torch.zeros(2, 1, dtype=torch.long)
         Plan(big, torch.zeros(1, dtype=torch.long), 2000, 1, dense="only")
+
+
+def test_group_streams_cover_every_group_row_once_in_sorted_edge_order():
+    """Schedule of the assembly walk (plan.cpp build_schedule): every non-chain row sits in exactly one stream, its
+    records are the row's sorted edges followed by a marker (row, num_relation), descriptors tile the record array."""
+    from ultra_amd.rspmm import Plan
+    from ultra_amd import _lib
+    ei, et = helpers.random_graph(num_node=300, num_edge=2000, num_relation=9, seed=8, hub=(11, 700))
+    N, R = 300, 9
+    plan = Plan(ei, et, N, R, exact_order=True)
+    nparts = 4
+    sdesc, srec = plan.streams(nparts)
+    assert sdesc.shape == (nparts * 64, 2)
+    row_ptr = plan.export(_lib.ARR_ROW_PTR)
+    col, typ = plan.export(_lib.ARR_COL), plan.export(_lib.ARR_TYPE)
+    n_chain = plan.info()["n_chain_row"]
+    items = plan.export(_lib.ARR_ITEM).view(-1, 4)
+    chain_rows = set(items[:n_chain, 0].tolist())
+    seen = set()
+    pos = 0
+    for g in range(nparts * 64):
+        begin, steps = sdesc[g].tolist()
+        assert begin == pos
+        k = begin
+        while k < begin + steps:
+            # next marker
+            m = k
+            while srec[m, 1] != R:
+                m += 1
+            row = int(srec[m, 0])
+            assert row not in seen and row not in chain_rows
+            seen.add(row)
+            b, e = int(row_ptr[row]), int(row_ptr[row + 1])
+            assert m - k == e - b
+            assert torch.equal(srec[k:m, 0], col[b:e]) and torch.equal(srec[k:m, 1], typ[b:e])
+            k = m + 1
+        assert k == begin + steps
+        pos = begin + steps
+    assert pos == srec.shape[0]
+    assert seen == set(range(N)) - chain_rows
+    loads = sdesc[:, 1].view(nparts, 64)
+    assert int(loads.max() - loads.min()) <= int((row_ptr[1:] - row_ptr[:-1]).clamp(max=256).max()) + 64

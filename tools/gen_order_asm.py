@@ -26,7 +26,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.environ.get("ULTRA_GEN_OUT") or os.path.join(os.path.dirname(HERE), "ultra_amd", "csrc", "rspmm_order_asm.hpp")
 
 BINOPS = {0: "v_pk_mul_f32", 1: "v_pk_add_f32"}            # BIN_MUL, BIN_ADD (operator.cuh:15,29)
-IDENT = {0: "0", 1: "0x7f7fffff", 2: "0xff7fffff"}          # add: 0, min: +FLT_MAX, max: -FLT_MAX (operator.cuh:43-80)
+IDENT = {0: "0", 1: "0x7f7fffff", 2: "0xff7fffff"}
+# cache policy of the record streams: default.  " nt" (streaming) was measured slower: loads return in order, so the
+# longer latency of an nt request stands in front of the gathers queued behind it.
+REC_POLICY = os.environ.get("ULTRA_GEN_REC_POLICY", "")          # add: 0, min: +FLT_MAX, max: -FLT_MAX (operator.cuh:43-80)
 
 
 def vr(lo, n=1):
@@ -63,116 +66,146 @@ def nary(a, sum_code, acc, x):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# group walk: one 16-lane group per row, four rows per wave; two 4-step chunks of source rows + one round of records
-# in flight.  Register map (clobbers):
-#   v64..v79   chunk A source rows (4 x 16 B)    v96..v99    LDS addresses of chunk A's relation rows
+# group streams: every 16-lane group of a workgroup walks ONE stream -- the rows the schedule gave it, laid out back
+# to back in the stream's own record array: a row's edges in sorted order as (col, type) records, closed by a marker
+# record (row, num_rel).  A marker step flushes: (+ boundary), store, accumulator back to the identity.  So the walk is
+# one continuous software pipeline over the whole stream -- no per-row restart (two dependent memory round trips per
+# four rows in the unit walk), no steps masked because the four rows of a unit differ in length, no per-unit item
+# loads.  Two 4-step chunks of source rows + one round (8 steps) of records are in flight per lane.
+# Register map (clobbers):
+#   v64..v79   chunk A source rows (4 x 16 B)    v96..v99    LDS addresses of chunk A's relation rows (marker: row num_rel)
 #   v80..v95   chunk B source rows               v100..v103  ... of chunk B's
-#   v126:127   records of the round after the current one (in flight)
-#   v108/v109  current round's col / type (lane l holds step l % 8)
-#   v110..v113 broadcast cols / gather offsets while a chunk is requested; third relation row while one is summed
-#   v114..v121 first / second relation row       v104..v107  fourth relation row (v104:105: round 0's records in the prologue)
-#   v122..v125 the accumulator
-WALK_CLOBBER_LO, WALK_CLOBBER_HI = 64, 127
-RV = (114, 118, 110, 104)
+#   v104..v107 / v108..v111  byte offsets node * row_bytes + lane_bytes of chunk A / B: the gather offset of an edge, the
+#                            store offset of a marker (source and output matrix have the same row stride)
+#   v112:113   records of the round after the current one (in flight)      v120:121  round 0's records (prologue)
+#   v114/v115  current round's col / type (lane l holds step l % 8)
+#   v56..v63, v48..v55  the chunk's four relation rows          v116..v119 the accumulator       v122 scratch
+STREAM_CLOBBER_LO, STREAM_CLOBBER_HI = 48, 122
+RV = (56, 60, 48, 52)
+ACC = 116
 
 
-def walk_fetch(a, xb, tb, J):
+def stream_fetch(a, xb, tb, ob, J):
     for q in range(4):
-        a("ds_swizzle_b32 v%d, v108 offset:swizzle(BROADCAST,16,%d)" % (110 + q, J + q))
+        a("ds_swizzle_b32 v%d, v114 offset:swizzle(BROADCAST,16,%d)" % (ob + q, J + q))
     for q in range(4):
-        a("ds_swizzle_b32 v%d, v109 offset:swizzle(BROADCAST,16,%d)" % (tb + q, J + q))
+        a("ds_swizzle_b32 v%d, v115 offset:swizzle(BROADCAST,16,%d)" % (tb + q, J + q))
     for q in range(4):
         a("s_waitcnt lgkmcnt(%d)" % (7 - q))
-        a("v_mad_u32_u24 v%d, v%d, %%[xrb], %%[lb]" % (110 + q, 110 + q))
-        a("global_load_dwordx4 %s, v%d, %%[xb]" % (vr(xb + 4 * q, 4), 110 + q))
+        a("v_mad_u32_u24 v%d, v%d, %%[xrb], %%[lb]" % (ob + q, ob + q))
+        a("global_load_dwordx4 %s, v%d, %%[xb]" % (vr(xb + 4 * q, 4), ob + q))
     a("s_waitcnt lgkmcnt(0)")
     for q in range(4):
         a("v_lshl_add_u32 v%d, v%d, 8, %%[lds]" % (tb + q, tb + q))
 
 
-def walk_rel_reads(a, tb):
+def stream_rel_reads(a, tb):
     """the chunk's four relation rows: requested BEFORE the wait for its source rows, so that they land under it"""
     for q in range(4):
         a("ds_read_b128 %s, v%d" % (vr(RV[q], 4), tb + q))
 
 
-def walk_compute(a, xb, consts, binop, sum_code, first_step, tag):
-    """acc (+)= rel[t] (x) x for the chunk's four steps, in step order.  Step q of the chunk is step first_step + q of the
-    round; when every row of the unit still has the whole chunk (uniform test against nfull) the sums run unmasked,
-    otherwise step q is live in the lanes with consts[q] < rem (exec mask)."""
+def stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag):
+    """The chunk's four steps in order.  Fast form: every stream of the wave still has the whole chunk (uniform test
+    against nf) and none of the 16 (group, step) slots is a marker (the marker's LDS address is the largest there is).
+    General form, per step: live = consts[q] < rem; marker = live and relation address == mark; edges accumulate in the
+    lanes live & ~marker, markers flush."""
     a("s_add_i32 %%[t1], %%[kb], %d" % (first_step + 4))
     a("s_cmp_le_i32 %[t1], %[nf]")
-    a("s_cbranch_scc0 .Lwalk_masked_%s_%%=" % tag)
+    a("s_cbranch_scc0 .Lstream_general_%s_%%=" % tag)
+    a("v_max3_u32 v122, v%d, v%d, v%d" % (tb, tb + 1, tb + 2))
+    a("v_max_u32_e32 v122, v122, v%d" % (tb + 3))
+    a("v_cmp_eq_u32_e32 vcc, v122, %[mark]")
+    a("s_cbranch_vccnz .Lstream_general_%s_%%=" % tag)
     for q in range(4):
         a("s_waitcnt lgkmcnt(%d)" % (3 - q))
         x = xb + 4 * q
         a("%s %s, %s, %s" % (binop, vr(x, 2), vr(RV[q], 2), vr(x, 2)))
         a("%s %s, %s, %s" % (binop, vr(x + 2, 2), vr(RV[q] + 2, 2), vr(x + 2, 2)))
-        nary(a, sum_code, 122, x)
-    a("s_branch .Lwalk_summed_%s_%%=" % tag)
-    a.label(".Lwalk_masked_%s_%%=" % tag)
+        nary(a, sum_code, ACC, x)
+    a("s_branch .Lstream_summed_%s_%%=" % tag)
+    a.label(".Lstream_general_%s_%%=" % tag)
     for q in range(4):
         a("s_waitcnt lgkmcnt(%d)" % (3 - q))
         x = xb + 4 * q
         a("%s %s, %s, %s" % (binop, vr(x, 2), vr(RV[q], 2), vr(x, 2)))
         a("%s %s, %s, %s" % (binop, vr(x + 2, 2), vr(RV[q] + 2, 2), vr(x + 2, 2)))
-        a("v_cmpx_lt_i32_e32 vcc, %d, %%[rem]" % consts[q])
-        nary(a, sum_code, 122, x)
+        a("v_cmp_lt_i32_e32 vcc, %d, %%[rem]" % consts[q], "live")
+        a("v_cmp_eq_u32_e64 %%[mk], v%d, %%[mark]" % (tb + q))
+        a("s_and_b64 %[mk], %[mk], vcc", "marker")
+        a("s_andn2_b64 exec, vcc, %[mk]", "edges")
+        nary(a, sum_code, ACC, x)
+        a("s_mov_b64 exec, %[mk]")
+        a("s_cbranch_execz .Lstream_noflush_%s%d_%%=" % (tag, q))
+        # flush: out[row] = acc (+) boundary[row]   (rspmm.cpp:70-72), then a fresh accumulator
+        a("v_cmp_eq_u32_e32 vcc, v%d, %%[bndoff]" % (ob + q))
+        a("s_and_b64 exec, exec, vcc", "lanes of the boundary row")
+        op = {0: "v_add_f32_e32", 1: "v_min_f32_e32", 2: "v_max_f32_e32"}[sum_code]
+        for e in range(4):
+            a("%s v%d, v%d, %%[b%d]" % (op, ACC + e, ACC + e, e))
+        a("s_mov_b64 exec, %[mk]")
+        a("global_store_dwordx4 v%d, %s, %%[ob]" % (ob + q, vr(ACC, 4)))
+        a("s_nop 2", "gfx940+: a VALU write of the data registers of a > 8-byte store needs 2 wait states behind the store "
+                     "(with one, v_mov v116 reached the last lanes' data first)")
+        for e in range(4):
+            a("v_mov_b32_e32 v%d, %s" % (ACC + e, IDENT[sum_code]))
+        a.label(".Lstream_noflush_%s%d_%%=" % (tag, q))
         a("s_mov_b64 exec, %[ex]")
-    a.label(".Lwalk_summed_%s_%%=" % tag)
+    a.label(".Lstream_summed_%s_%%=" % tag)
 
 
-def gen_walk(sum_code, mul_code, rec_policy):
+def gen_stream(sum_code, mul_code, rec_policy):
     a = Asm()
     binop = BINOPS[mul_code]
-    A, B, TA, TB = 64, 80, 96, 100
+    A, B, TA, TB, OA, OB = 64, 80, 96, 100, 104, 108
+
+    def promote(rec):
+        a("v_cmp_lt_i32_e32 vcc, %[l8], %[rem]")
+        a("v_cndmask_b32_e32 v114, 0, v%d, vcc" % rec, "steps past the stream's end gather node 0 ...")
+        a("v_cndmask_b32_e32 v115, 0, v%d, vcc" % (rec + 1), "... multiply by relation 0, are no marker, and are masked out of the sum")
+
     a("s_mov_b64 %[ex], exec")
     a("s_mov_b32 %[kb], 0")
     for e in range(4):
-        a("v_mov_b32_e32 v%d, %s" % (122 + e, IDENT[sum_code]))
-    a("global_load_dwordx2 v[104:105], %%[roff], %%[rb]%s" % rec_policy, "records of round 0")
-    a("global_load_dwordx2 v[126:127], %%[roff], %%[rb] offset:64%s" % rec_policy, "records of round 1")
+        a("v_mov_b32_e32 v%d, %s" % (ACC + e, IDENT[sum_code]))
+    a("global_load_dwordx2 v[120:121], %%[roff], %%[rb]%s" % rec_policy, "records of round 0")
+    a("global_load_dwordx2 v[112:113], %%[roff], %%[rb] offset:64%s" % rec_policy, "records of round 1")
     a("v_add_u32_e32 %[roff], 0x80, %[roff]")
     a("s_waitcnt vmcnt(1)", "in flight: [r0, r1] -> r0")
-    a("v_cmp_lt_i32_e32 vcc, %[l8], %[rem]")
-    a("v_cndmask_b32_e32 v108, 0, v104, vcc", "steps past the row's end gather node 0 (and are masked out of the sum)")
-    a("v_mov_b32_e32 v109, v105")
-    walk_fetch(a, A, TA, 0)                                        # in flight: [r1, A x 4]
-    a.label(".Lwalk_loop_%=")
+    promote(120)
+    stream_fetch(a, A, TA, OA, 0)                                  # in flight: [r1, A x 4]
+    a.label(".Lstream_loop_%=")
     a("s_add_i32 %[t0], %[kb], 4")
     a("s_cmp_lt_i32 %[t0], %[ns]")
-    a("s_cbranch_scc0 .Lwalk_last_a_%=")
-    walk_fetch(a, B, TB, 4)                                        # [r', A x 4, B x 4]
-    walk_rel_reads(a, TA)
-    a("s_waitcnt vmcnt(4)", "[r', A x 4, B x 4] -> r', A")
-    walk_compute(a, A, (0, 1, 2, 3), binop, sum_code, 0, "a")
+    a("s_cbranch_scc0 .Lstream_last_a_%=")
+    stream_fetch(a, B, TB, OB, 4)                                  # [r', A x 4, B x 4]
+    stream_rel_reads(a, TA)
+    a("s_waitcnt vmcnt(4)", "[r', A x 4, B x 4] (+ flush stores, which only make the count stricter) -> r', A")
+    stream_compute(a, A, TA, OA, (0, 1, 2, 3), binop, sum_code, 0, "a")
     a("s_add_i32 %[t0], %[kb], 8")
     a("s_cmp_lt_i32 %[t0], %[ns]")
-    a("s_cbranch_scc0 .Lwalk_last_b_%=")
-    a("v_add_u32_e32 %[rem], -8, %[rem]", "rem = cnt - (kb + 8)")
-    a("v_cmp_lt_i32_e32 vcc, %[l8], %[rem]")
-    a("v_cndmask_b32_e32 v108, 0, v126, vcc")
-    a("v_mov_b32_e32 v109, v127")
-    a("global_load_dwordx2 v[126:127], %%[roff], %%[rb]%s" % rec_policy, "records of round kb / 8 + 2: a whole round before their first use")
+    a("s_cbranch_scc0 .Lstream_last_b_%=")
+    a("v_add_u32_e32 %[rem], -8, %[rem]", "rem = len - (kb + 8)")
+    promote(112)
+    a("global_load_dwordx2 v[112:113], %%[roff], %%[rb]%s" % rec_policy, "records of round kb / 8 + 2: a whole round before their first use")
     a("v_add_u32_e32 %[roff], 64, %[roff]")
-    walk_fetch(a, A, TA, 0)                                        # [B x 4, r'', A x 4]
-    walk_rel_reads(a, TB)
+    stream_fetch(a, A, TA, OA, 0)                                  # [B x 4, r'', A x 4]
+    stream_rel_reads(a, TB)
     a("s_waitcnt vmcnt(5)", "[B x 4, r'', A x 4] -> B")
-    walk_compute(a, B, (-4, -3, -2, -1), binop, sum_code, 4, "b")  # (rem already moved on by 8)
+    stream_compute(a, B, TB, OB, (-4, -3, -2, -1), binop, sum_code, 4, "b")   # (rem already moved on by 8)
     a("s_mov_b32 %[kb], %[t0]")
-    a("s_branch .Lwalk_loop_%=")
-    a.label(".Lwalk_last_a_%=")
-    walk_rel_reads(a, TA)
+    a("s_branch .Lstream_loop_%=")
+    a.label(".Lstream_last_a_%=")
+    stream_rel_reads(a, TA)
     a("s_waitcnt vmcnt(0)")
-    walk_compute(a, A, (0, 1, 2, 3), binop, sum_code, 0, "la")
-    a("s_branch .Lwalk_done_%=")
-    a.label(".Lwalk_last_b_%=")
-    walk_rel_reads(a, TB)
+    stream_compute(a, A, TA, OA, (0, 1, 2, 3), binop, sum_code, 0, "la")
+    a("s_branch .Lstream_done_%=")
+    a.label(".Lstream_last_b_%=")
+    stream_rel_reads(a, TB)
     a("s_waitcnt vmcnt(0)")
-    walk_compute(a, B, (4, 5, 6, 7), binop, sum_code, 4, "lb")
-    a.label(".Lwalk_done_%=")
-    for e in range(4):
-        a("v_mov_b32_e32 %%[o%d], v%d" % (e, 122 + e))
+    stream_compute(a, B, TB, OB, (4, 5, 6, 7), binop, sum_code, 4, "lb")
+    a.label(".Lstream_done_%=")
+    a("s_waitcnt vmcnt(0)", "flush stores")
     return a
 
 
@@ -305,37 +338,38 @@ HEADER = '''// GENERATED by tools/gen_order_asm.py -- do not edit; edit the gene
 
 namespace ultra {
 
-#ifndef ULTRA_REC_NT
-#define ULTRA_REC_NT 0   // 1: nt (streaming) policy on the record stream -- measured slower: in-order return puts its longer latency in front of the gathers
-#endif
 
 '''
 
 
 def main():
     parts = [HEADER]
-    parts.append("// group walk: returns the four sums of this lane; rem = the row's edge count, roff = byte offset of the lane's\n"
-                 "// first record ((begin + lane % 8) * 8), l8 = lane % 8, lb = lane's byte offset inside a source row, lds = LDS byte\n"
-                 "// address of the lane's part of relation row 0, ns / nf = steps of the unit's longest / shortest row (ns > 0, wave-uniform)\n"
+    parts.append("// group stream of this lane's 16-lane group: rem = the stream's length in steps (edges + one marker per row), roff =\n"
+                 "// byte offset of the lane's first record ((begin + lane % 8) * 8), l8 = lane % 8, lb = lane's byte offset inside a row,\n"
+                 "// lds = LDS byte address of the lane's part of relation row 0, mark = lds + 256 * num_rel, bndoff = byte offset of the\n"
+                 "// boundary row's part of this lane (0xffffffff: none), b = its boundary values, ns / nf = steps of the wave's longest /\n"
+                 "// shortest stream (ns > 0, wave-uniform), xb / rb / ob = source slice, stream records, output slice\n"
                  "template <int SUM, int MUL>\n"
-                 "__device__ __forceinline__ void order_walk_asm(float (&o)[4], int rem, uint32_t roff, const int l8, const uint32_t lb,\n"
-                 "                                               const uint32_t lds, const int ns, const int nf, const char *xb,\n"
-                 "                                               const char *rb, const uint32_t xrb) {\n"
-                 "    int kb, t0, t1;\n    unsigned long long ex;\n")
+                 "__device__ __forceinline__ void order_stream_asm(int rem, uint32_t roff, const int l8, const uint32_t lb, const uint32_t lds,\n"
+                 "                                                 const uint32_t mark, const uint32_t bndoff, const float (&b)[4], const int ns,\n"
+                 "                                                 const int nf, const char *xb, const char *rb, const char *ob,\n"
+                 "                                                 const uint32_t xrb) {\n"
+                 "    int kb, t0, t1;\n    unsigned long long ex, mk;\n")
     first = True
     for sum_code in (0, 1, 2):
         for mul_code in (0, 1):
-            for nt in (1, 0):
-                a = gen_walk(sum_code, mul_code, " nt" if nt else "")
-                cond = "SUM == %d && MUL == %d && ULTRA_REC_NT == %d" % (sum_code, mul_code, nt)
+            if True:
+                a = gen_stream(sum_code, mul_code, REC_POLICY)
+                cond = "SUM == %d && MUL == %d" % (sum_code, mul_code)
                 parts.append("    %sif constexpr (%s) {\n" % ("" if first else "else ", cond))
                 first = False
                 parts.append("        asm volatile(\n" + a.render("            ") + "\n")
-                parts.append('            : [o0] "=v"(o[0]), [o1] "=v"(o[1]), [o2] "=v"(o[2]), [o3] "=v"(o[3]), [rem] "+v"(rem), [roff] "+v"(roff),\n'
-                             '              [kb] "=&s"(kb), [t0] "=&s"(t0), [t1] "=&s"(t1), [ex] "=&s"(ex)\n'
-                             '            : [l8] "v"(l8), [lb] "v"(lb), [lds] "v"(lds), [ns] "s"(ns), [nf] "s"(nf), [xb] "s"(xb), [rb] "s"(rb),\n'
-                             '              [xrb] "s"(xrb)\n'
-                             '            : "memory", "vcc", "scc", %s);\n' % clobbers(WALK_CLOBBER_LO, WALK_CLOBBER_HI))
+                parts.append('            : [rem] "+v"(rem), [roff] "+v"(roff), [kb] "=&s"(kb), [t0] "=&s"(t0), [t1] "=&s"(t1), [ex] "=&s"(ex),\n'
+                             '              [mk] "=&s"(mk)\n'
+                             '            : [l8] "v"(l8), [lb] "v"(lb), [lds] "v"(lds), [mark] "v"(mark), [bndoff] "v"(bndoff), [b0] "v"(b[0]),\n'
+                             '              [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [ns] "s"(ns), [nf] "s"(nf), [xb] "s"(xb), [rb] "s"(rb),\n'
+                             '              [ob] "s"(ob), [xrb] "s"(xrb)\n'
+                             '            : "memory", "vcc", "scc", %s);\n' % clobbers(STREAM_CLOBBER_LO, STREAM_CLOBBER_HI))
                 parts.append("    }\n")
     parts.append("}\n\n")
 
@@ -348,9 +382,9 @@ def main():
                  "    int i, half;\n")
     first = True
     for mul_code in (0, 1):
-        for nt in (1, 0):
-            a = gen_producer(mul_code, " nt" if nt else "")
-            cond = "MUL == %d && ULTRA_REC_NT == %d" % (mul_code, nt)
+        if True:
+            a = gen_producer(mul_code, REC_POLICY)
+            cond = "MUL == %d" % mul_code
             parts.append("    %sif constexpr (%s) {\n" % ("" if first else "else ", cond))
             first = False
             parts.append("        asm volatile(\n" + a.render("            ") + "\n")

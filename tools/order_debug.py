@@ -22,6 +22,9 @@ def main():
     N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
     rel, x, w = helpers.features(N, R, 64, E, dtype=torch.float32, seed=case["seed"])
     plan = Plan(ei, et, N, R, exact_order=True)
+    if os.environ.get("UNIT_WALK"):
+        from ultra_amd import rspmm
+        rspmm.set_tuning(unit_walk=1)
     ones = torch.ones(E)
     want = rspmm_oracle.generalized_rspmm(ei, et, ones, rel, x, sum=sum_, mul=mul)
     deg = torch.bincount(ei[0], minlength=N)
@@ -32,6 +35,9 @@ def main():
             torch.save(dict(got=got, want=want, bad=bad), "gpurun_out/order_debug_case%d_rep%d.pt" % (ci, rep))
         print("lib", os.environ.get("ULTRA_AMD_LIB", "default"), "case", ci, "rep", rep, "bad rows", len(bad), "of", N,
               [(int(r), int(deg[r]), int((got[r] != want[r]).sum()), float((got[r] - want[r]).abs().max())) for r in bad[:8]])
+        if len(bad):
+            r = int(bad[0])
+            print("   row", r, "got", got[r][:6].tolist(), "want", want[r][:6].tolist())
 
 
 if __name__ == "__main__":

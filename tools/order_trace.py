@@ -29,6 +29,8 @@ def main():
     print(shape, "bs", bs, plan.info()["n_chain_row"], "chain rows;", plan.schedule_info(nparts))
     chunk_ptr, unit_ptr, units, chunks = plan.schedule(nparts)
     items = plan.export(_lib.ARR_ITEM).view(-1, 4)
+    sdesc, _ = plan.streams(nparts)
+    stream_steps = sdesc[:, 1].view(nparts, 64).sum(dim=1)
     n_chain = plan.info()["n_chain_row"]
     ms, _ = plan.forward_timed(rel, x, point=point, warmup=3, iters=20)
     print("time per call %.4f ms" % ms)
@@ -48,9 +50,9 @@ def main():
         ch_rows = int((chunks[chunk_ptr[part]:chunk_ptr[part + 1], 3] & 1).sum())
         us = units[unit_ptr[part]:unit_ptr[part + 1]].long()
         steps = int(items[n_chain + 4 * us, 2].sum()) if len(us) else 0
-        rows.append((b, part, int(t[b, 0] - t0), int(t[b, 1] - t[b, 0]), int(t[b, 2] - t[b, 1]), nch, ch_edges, ch_rows, len(us), steps, int(extra[b])))
+        rows.append((b, part, int(t[b, 0] - t0), int(t[b, 1] - t[b, 0]), int(t[b, 2] - t[b, 1]), nch, ch_edges, ch_rows, len(us), steps, int(stream_steps[part])))
     rows.sort(key=lambda r: -(r[3] + r[4]))
-    print("block part start chain_cyc unit_cyc | chunks chain_edges chain_rows units unit_steps extra")
+    print("block part start chain_cyc unit_cyc | chunks chain_edges chain_rows units unit_steps stream_steps")
     for r in rows[:12] + rows[-6:]:
         print("%5d %4d %6d %9d %8d | %6d %11d %10d %5d %10d %8d" % r)
     tot = torch.tensor([[r[3], r[4], r[5], r[6], r[7], r[8], r[9]] for r in rows], dtype=torch.float64)
@@ -61,6 +63,13 @@ def main():
     B = torch.stack([tot[:, 6], tot[:, 5], torch.ones(len(rows), dtype=torch.float64)], dim=1)
     sol2 = torch.linalg.lstsq(B, tot[:, 1:2]).solution.flatten()
     print("unit fit: %.2f cyc/step + %.1f cyc/unit + %.0f const   (clock = s_memtime ticks)" % tuple(sol2.tolist()))
+    S = torch.stack([tot[:, 7], torch.ones(len(rows), dtype=torch.float64)], dim=1) if False else None
+    st = torch.tensor([[r[10], 1.0] for r in rows], dtype=torch.float64)
+    sol3 = torch.linalg.lstsq(st, tot[:, 1:2]).solution.flatten()
+    print("stream fit (second phase vs group-stream steps): %.3f cyc/step + %.0f const" % tuple(sol3.tolist()))
+    C = torch.tensor([[r[5], r[7], 1.0] for r in rows], dtype=torch.float64)
+    sol4 = torch.linalg.lstsq(C, tot[:, 0:1]).solution.flatten()
+    print("chain fit with constant: %.1f cyc/chunk + %.0f cyc/row + %.0f const" % tuple(sol4.tolist()))
     print("span of kernel: %d ticks; mean busy %d" % (int((t[:, 2] - t0).max()), int((t[:, 2] - t[:, 0]).double().mean())))
 
 

@@ -245,14 +245,18 @@ ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *ty
 // issue slots) one walk step per edge of its longest row.
 static double COST_CHAIN_EDGE = 9.0, COST_CHAIN_CHUNK = 250.0, COST_CHAIN_ROW = 2000.0;
 static double COST_UNIT_STEP = 28.0, COST_UNIT = 100.0;
+// the stream walk (assembly paths; order_trace on MI355X): workgroup cycles per chain chunk / chain row, and per step of
+// one group stream when all sixteen waves walk (21.5 cycles per wave step / 4 groups)
+static double COST_S_CHUNK = 675.0, COST_S_ROW = 1380.0, COST_S_STEP = 6.0;
 
-static void read_cost_override() {   // calibration runs only: ULTRA_SCHED_COSTS="edge,chunk,row,step,unit"
+static void read_cost_override() {   // calibration runs only: ULTRA_SCHED_COSTS="edge,chunk,row,step,unit", ULTRA_STREAM_COSTS="chunk,row,step"
     const char *env = std::getenv("ULTRA_SCHED_COSTS");
-    if (!env) return;
     double v[5];
-    if (std::sscanf(env, "%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5) {
+    if (env && std::sscanf(env, "%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5) {
         COST_CHAIN_EDGE = v[0], COST_CHAIN_CHUNK = v[1], COST_CHAIN_ROW = v[2], COST_UNIT_STEP = v[3], COST_UNIT = v[4];
     }
+    env = std::getenv("ULTRA_STREAM_COSTS");
+    if (env && std::sscanf(env, "%lf,%lf,%lf", &v[0], &v[1], &v[2]) == 3) COST_S_CHUNK = v[0], COST_S_ROW = v[1], COST_S_STEP = v[2];
 }
 
 Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
@@ -309,6 +313,60 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
         s->unit_ptr[(size_t)q + 1] = (int32_t)s->units.size();
         s->max_cost = std::max(s->max_cost, load[(size_t)q]);
         s->mean_cost += load[(size_t)q] / nparts;
+    }
+    // ---- group streams ----
+    // Workgroup q may spend T - (its chain work) on its streams, T = the mean total; its 64 streams share that budget
+    // equally.  Rows go longest first onto the stream that stays relatively emptiest ((load + len) / budget).
+    {
+        std::vector<double> chain_cost((size_t)nparts, 0.0);
+        double total = 0.0;
+        for (int32_t q = 0; q < nparts; ++q) {
+            for (int32_t c : part_chain[(size_t)q]) {
+                const int32_t len = p->items[(size_t)c].len;
+                chain_cost[(size_t)q] += COST_S_ROW + COST_S_CHUNK * ((len + CHAIN_SLOTS - 1) / CHAIN_SLOTS);
+            }
+            total += chain_cost[(size_t)q];
+        }
+        double steps = 0.0;
+        for (int64_t g = n_chain; g < n_item; ++g) steps += p->items[(size_t)g].len + 1;
+        total += COST_S_STEP * steps;
+        const double T = total / nparts;
+        const int64_t nstream = (int64_t)nparts * ORDER_GROUPS;
+        std::vector<double> weight((size_t)nstream);
+        for (int32_t q = 0; q < nparts; ++q) {
+            const double budget = std::max(T - chain_cost[(size_t)q], 0.02 * T);   // (never zero: every row needs a home)
+            for (int g = 0; g < ORDER_GROUPS; ++g) weight[(size_t)q * ORDER_GROUPS + g] = budget;
+        }
+        typedef std::pair<double, int64_t> Slot;   // ((load + 1) / weight, stream): the heap's top is the relatively emptiest
+        std::priority_queue<Slot, std::vector<Slot>, std::greater<Slot>> sheap;
+        std::vector<int64_t> sload((size_t)nstream, 0);
+        std::vector<std::vector<int32_t>> srows((size_t)nstream);
+        for (int64_t g = 0; g < nstream; ++g) sheap.push(Slot(1.0 / weight[(size_t)g], g));
+        for (int64_t g = n_chain; g < n_item; ++g) {   // group items are sorted by descending length
+            const Slot sl = sheap.top();
+            sheap.pop();
+            srows[(size_t)sl.second].push_back((int32_t)g);
+            sload[(size_t)sl.second] += p->items[(size_t)g].len + 1;
+            sheap.push(Slot((double)(sload[(size_t)sl.second] + 1) / weight[(size_t)sl.second], sl.second));
+        }
+        s->sdesc.assign((size_t)nstream * 2, 0);
+        s->srec.reserve((size_t)(2 * (int64_t)steps) + 2 * ORDER_PAD);
+        for (int64_t g = 0; g < nstream; ++g) {
+            s->sdesc[(size_t)2 * g] = (int32_t)(s->srec.size() / 2);
+            s->sdesc[(size_t)2 * g + 1] = (int32_t)sload[(size_t)g];
+            std::sort(srows[(size_t)g].begin(), srows[(size_t)g].end(),
+                      [&](int32_t a, int32_t b) { return p->items[(size_t)a].row < p->items[(size_t)b].row; });
+            for (int32_t it : srows[(size_t)g]) {
+                const Item &row = p->items[(size_t)it];
+                for (int32_t e = row.begin; e < row.begin + row.len; ++e) {
+                    s->srec.push_back(p->col[(size_t)e]);
+                    s->srec.push_back(p->type[(size_t)e]);
+                }
+                s->srec.push_back(row.row);                  // marker: flush the accumulator to this row
+                s->srec.push_back((int32_t)p->num_rel);
+            }
+        }
+        s->srec.resize(s->srec.size() + 2 * ORDER_PAD, 0);   // (records are requested two rounds ahead without a bounds test)
     }
     // the chain producers request descriptors a fixed number of chunks ahead without a bounds test: readable, harmless
     // entries (edge 0) behind the last chunk

@@ -37,6 +37,7 @@ struct Chunk {
 };
 enum { CHUNK_FIRST = 1, CHUNK_LAST = 2, CHUNK_LEN_SHIFT = 2 };
 constexpr int CHAIN_SLOTS = 60;          // producer groups of a 1024-thread workgroup (15 waves x 4)
+constexpr int ORDER_GROUPS = 64;        // 16-lane groups of a 1024-thread workgroup
 constexpr int CHUNK_PAD = 32;           // descriptors readable behind a schedule's last chunk (>= 3 x the producers' depth)
 constexpr int ORDER_PAD = 128;           // the device record / perm streams are readable this many entries past the last edge
 
@@ -46,7 +47,11 @@ struct Schedule {
     int32_t nparts = 0;
     std::vector<int32_t> chunk_ptr, unit_ptr, units;   // [nparts + 1], [nparts + 1], unit ids in launch order
     std::vector<Chunk> chunks;
-    int32_t *d_chunk_ptr = nullptr, *d_unit_ptr = nullptr, *d_units = nullptr;
+    // Group STREAMS (the assembly walk of the inference configuration): each of the ORDER_GROUPS 16-lane groups of a
+    // workgroup gets a sequence of whole rows; `srec` holds, stream after stream, the rows' (col, type) records in sorted
+    // edge order, each row closed by a marker record (row, num_rel); sdesc[part * ORDER_GROUPS + group] = {first record, steps}.
+    std::vector<int32_t> srec, sdesc;
+    int32_t *d_chunk_ptr = nullptr, *d_unit_ptr = nullptr, *d_units = nullptr, *d_srec = nullptr, *d_sdesc = nullptr;
     Chunk *d_chunks = nullptr;
     double max_cost = 0.0, mean_cost = 0.0;             // cost model's load of the fullest / average workgroup
 };

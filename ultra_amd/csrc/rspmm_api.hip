@@ -136,6 +136,8 @@ static void free_schedules(ultra_plan *p) {
         if (s->d_unit_ptr) (void)hipFree(s->d_unit_ptr);
         if (s->d_units) (void)hipFree(s->d_units);
         if (s->d_chunks) (void)hipFree(s->d_chunks);
+        if (s->d_srec) (void)hipFree(s->d_srec);
+        if (s->d_sdesc) (void)hipFree(s->d_sdesc);
         delete s;
     }
     p->schedules.clear();
@@ -153,7 +155,8 @@ static int get_schedule(ultra_plan *p, int32_t nparts, Schedule **out) {
     Schedule *s = build_schedule(p, nparts);
     int rc;
     if ((rc = upload_array(&s->d_chunk_ptr, s->chunk_ptr)) || (rc = upload_array(&s->d_unit_ptr, s->unit_ptr)) ||
-        (rc = upload_array(&s->d_units, s->units)) || (rc = upload_array(&s->d_chunks, s->chunks))) {
+        (rc = upload_array(&s->d_units, s->units)) || (rc = upload_array(&s->d_chunks, s->chunks)) ||
+        (rc = upload_array(&s->d_srec, s->srec)) || (rc = upload_array(&s->d_sdesc, s->sdesc))) {
         delete s;
         return rc;
     }
@@ -326,7 +329,8 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
     if ((p->flags & ULTRA_PLAN_EXACT_ORDER) && VEC == 4 && g_tuning.reserved[0] == 0 && p->num_in < (1 << 24) &&
         p->num_rel < (1 << 24) && (mul == BIN_LHS || x->stride_row * (int64_t)esz < (1 << 24)) &&
         (mul == BIN_RHS || rel->stride_row * (int64_t)esz < (1 << 24))) {
-        const size_t rel_bytes = (mul != BIN_RHS) ? (size_t)p->num_rel * 64 * esz : 0;
+        // (+ one row: the stream walk's row markers carry relation index num_rel)
+        const size_t rel_bytes = (mul != BIN_RHS) ? (size_t)(p->num_rel + 1) * 64 * esz : 0;
         const size_t ring_bytes = p->n_chain > 0 ? (size_t)2 * CHAIN_SLOTS * 64 * esz : 0;
         if (ring_bytes <= di.lds_optin) {
             const bool rel_lds = g_tuning.rel_lds != 0 && rel_bytes > 0 && rel_bytes + ring_bytes <= di.lds_optin;
@@ -359,6 +363,16 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
             op.keep_mode = fp.keep_mode;
             op.x_row_bytes = fp.x_row_bytes, op.rel_row_bytes = fp.rel_row_bytes;
             op.trace = g_order_trace;
+            // The group streams (assembly walk) serve the inference configuration: fp32, unit weights, relation slice in
+            // LDS, mul / add messages, whole 64-element spans, no boundary or a point boundary, source and output rows of
+            // one stride (a marker's gather offset is its store offset), every output row also a source row.
+            op.srec = sched->d_srec;
+            op.sdesc = reinterpret_cast<const int2 *>(sched->d_sdesc);
+            op.use_streams = (g_tuning.reserved[1] == 0 && dtype == ULTRA_F32 && rel_lds && !w && (mul == BIN_MUL || mul == BIN_ADD) &&
+                              row_len % 64 == 0 && (!bnd || bnd_rows) && out->stride_row == x->stride_row &&
+                              p->num_out <= p->num_in && (uint64_t)p->num_out * (uint64_t)out->stride_row * esz < (1ull << 32))
+                                 ? 1
+                                 : 0;
             const size_t lds = (rel_lds ? rel_bytes : 0) + ring_bytes;
             hipError_t e = hipErrorInvalidValue;
             if (g_ev_before) HIP_TRY(hipEventRecord(g_ev_before, stream));
@@ -908,6 +922,8 @@ int32_t ultra_plan_schedule_export(ultra_plan *plan, int32_t nparts, int32_t whi
         case 1: src = s->unit_ptr.data(), n = (int64_t)s->unit_ptr.size(); break;
         case 2: src = s->units.data(), n = (int64_t)s->units.size(); break;
         case 3: src = reinterpret_cast<const int32_t *>(s->chunks.data()), n = (int64_t)s->chunk_ptr.back() * 4; break;
+        case 4: src = s->sdesc.data(), n = (int64_t)s->sdesc.size(); break;
+        case 5: src = s->srec.data(), n = (int64_t)s->srec.size() - 2 * ORDER_PAD; break;
         default: delete s; return invalid("ultra_plan_schedule_export: unknown array id");
     }
     *count = n;

@@ -43,6 +43,9 @@ struct OrderParams {
     const int4 *items;        // {row, begin, len, -}; chain rows first, group items from n_chain on
     const int32_t *unit_ptr, *units, *chunk_ptr;
     const int4 *chunks;       // {row, begin, count, flags}
+    const int32_t *srec;      // group streams (plan.hpp Schedule): records and {first record, steps} per (workgroup, 16-lane group)
+    const int2 *sdesc;
+    int32_t use_streams;
     int32_t n_chain, n_item;
     MatArg rel, x, bnd;
     const long long *bnd_rows;   // point boundary: bnd holds ONE row per outer slice, added at row bnd_rows[outer] only
@@ -220,9 +223,6 @@ __device__ __forceinline__ Pack<T, 4> walk_row_in_order(const OrderParams &p, co
 #ifndef ULTRA_DBG_CHAIN
 #define ULTRA_DBG_CHAIN 0
 #endif
-#ifndef ULTRA_ASM_WALK
-#define ULTRA_ASM_WALK 1
-#endif
 #ifndef ULTRA_ASM_PRODUCE
 #define ULTRA_ASM_PRODUCE 1
 #endif
@@ -320,14 +320,17 @@ __device__ __forceinline__ T chain_add_partial(T acc, const V (&v)[N], const int
     return acc;
 }
 
-template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED>
+// STREAMS: the group rows are walked as streams by the assembly loop (its own instantiation: the C++ unit walk
+// and the assembly walk in one kernel cost each other registers around the asm statements).
+template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED, bool STREAMS>
 __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderParams p) {
+    static_assert(!STREAMS || OrderAsm<T, MUL, REL_LDS, WEIGHTED>::value, "group streams exist for the assembly configurations only");
     constexpr int SPAN = 64;
     using P = Pack<T, 4>;
     using V = typename VecOf<T, 4>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *lds_rel = reinterpret_cast<T *>(smem);
-    T *ring = lds_rel + ((REL_LDS && MUL != BIN_RHS) ? (size_t)p.num_rel * SPAN : 0);   // [2][CHAIN_SLOTS][SPAN]
+    T *ring = lds_rel + ((REL_LDS && MUL != BIN_RHS) ? (size_t)(p.num_rel + 1) * SPAN : 0);   // [2][CHAIN_QUADS][64][4]; (+ 1: marker row)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -429,6 +432,12 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                     desc = load_uniform(chunks + min(it + nch, c1 - 1));
                     T cacc = nary_zero<T, SUM>();
                     V va[CHAIN_QA], vb[CHAIN_QB];
+                    // (defined on every path: left undefined, the register allocator carries the two arrays as live
+                    // values around the whole span loop and spills them at the assembly statements)
+#pragma unroll
+                    for (int q = 0; q < CHAIN_QA; ++q) va[q] = V(T(0));
+#pragma unroll
+                    for (int q = 0; q < CHAIN_QB; ++q) vb[q] = V(T(0));
 #if ULTRA_DBG_CHAIN == 1   /* measurement build: the consumer only keeps the barrier count (results are wrong) */
                     for (int k = 0; k < nch; ++k) ULTRA_CHAIN_BARRIER();
                     if (false)
@@ -496,7 +505,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                     for (int k = c0; k < c1; ++k) __syncthreads();
                 } else
 #endif
-                if constexpr (OrderAsm<T, MUL, REL_LDS, WEIGHTED>::value && ULTRA_ASM_PRODUCE) {
+                if constexpr (STREAMS && ULTRA_ASM_PRODUCE) {   // (the unit-walk kernels keep the C++ producers: see STREAMS)
                     order_produce_asm<MUL>(c1 - c0, p.chunks + c0, (uint32_t)slot * 8u, lane_bytes, lds_addr(lds_rel_lane),
                                            lds_addr(ring) + (uint32_t)((wave - 1) * 64 + lane) * 16u, xbase,
                                            reinterpret_cast<const char *>(p.rec), p.x_row_bytes);
@@ -581,6 +590,30 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
         const bool dvalid = ug.dvalid;
         const uint32_t lane_bytes = ug.lane_bytes;
         const T *lds_rel_lane = ug.lds_rel_lane;
+        if constexpr (STREAMS) {
+            {
+                // ---- group streams: one continuous walk per 16-lane group (rspmm_order_asm.hpp) ----
+                const int2 sd = p.sdesc[(part * nwave + wave) * 4 + grp];
+                const int len = sd.y;
+                const int m01 = max(__shfl(len, 0), __shfl(len, 16)), m23 = max(__shfl(len, 32), __shfl(len, 48));
+                const int n01 = min(__shfl(len, 0), __shfl(len, 16)), n23 = min(__shfl(len, 32), __shfl(len, 48));
+                const int ns = rfl(max(m01, m23)), nf = rfl(min(n01, n23));
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                uint32_t bndoff = 0xffffffffu;
+                if (p.has_bnd) {   // (a point boundary: one row per outer slice, stride_row 0)
+                    const P b = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.bnd.ptr) + outer * p.bnd.stride_outer + d0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[e] = b.v[e];
+                    bndoff = (uint32_t)bnd_row * p.x_row_bytes + lane_bytes;
+                }
+                if (ns > 0)
+                    order_stream_asm<SUM, MUL>(len, (uint32_t)(sd.x + (l16 & 7)) * 8u, l16 & 7, lane_bytes, lds_addr(lds_rel_lane),
+                                               lds_addr(lds_rel_lane) + (uint32_t)p.num_rel * 256u, bndoff, bv, ns, nf, xbase,
+                                               reinterpret_cast<const char *>(p.srec),
+                                               reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.out) + outer * p.out_stride_outer),
+                                               p.x_row_bytes);
+            }
+        } else {
         const int u1 = p.unit_ptr[part + 1];
         const auto load_item = [&](const int ui) {
             const int u = load_uniform(p.units + min(ui, u1 - 1));
@@ -609,17 +642,8 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
             const int n23 = min(__shfl(cnt, 32), __shfl(cnt, 48));
             const int nfull = rfl(min(n01, n23));
 
-            P acc;
-            if constexpr (OrderAsm<T, MUL, REL_LDS, WEIGHTED>::value && ULTRA_ASM_WALK) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc.v[e] = nary_zero<T, SUM>();
-                if (nsteps > 0)
-                    order_walk_asm<SUM, MUL>(acc.v, cnt, (uint32_t)(begin + (l16 & 7)) * 8u, l16 & 7, lane_bytes, lds_addr(lds_rel_lane),
-                                             nsteps, nfull, xbase, reinterpret_cast<const char *>(p.rec), p.x_row_bytes);
-            } else {
-                acc = walk_row_in_order<T, SUM, MUL, REL_LDS, WEIGHTED>(p, begin, cnt, nsteps, nfull, l16, xbase, relbase, lane_bytes,
-                                                                        lds_rel_lane);
-            }
+            P acc = walk_row_in_order<T, SUM, MUL, REL_LDS, WEIGHTED>(p, begin, cnt, nsteps, nfull, l16, xbase, relbase, lane_bytes,
+                                                                      lds_rel_lane);
             if (row >= 0 && dvalid) {
                 if (p.has_bnd && (bnd_row < 0 || bnd_row == row)) {
                     const P b = *reinterpret_cast<const P *>(reinterpret_cast<const T *>(p.bnd.ptr) + outer * p.bnd.stride_outer +
@@ -631,6 +655,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                 *reinterpret_cast<P *>(dst) = acc;
             }
         }
+        }   // (unit walk)
     }
     if (p.trace) {
         __syncthreads();
@@ -639,9 +664,9 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
 }
 
 // ---- per-variant launchers (explicitly instantiated in rspmm_order_*.hip) ----
-template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED>
-inline hipError_t launch_order_one(const OrderParams &p, int grid, size_t lds, hipStream_t s) {
-    auto kern = rspmm_order_kernel<T, SUM, MUL, REL_LDS, WEIGHTED>;
+template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED, bool STREAMS>
+inline hipError_t launch_order_inst(const OrderParams &p, int grid, size_t lds, hipStream_t s) {
+    auto kern = rspmm_order_kernel<T, SUM, MUL, REL_LDS, WEIGHTED, STREAMS>;
     static size_t lds_opted_in = 0;   // (see launch_one in rspmm_kernels.hpp)
     if (lds > 48 * 1024 && lds > lds_opted_in) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -650,6 +675,13 @@ inline hipError_t launch_order_one(const OrderParams &p, int grid, size_t lds, h
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(ORDER_THREADS), lds, s, p);
     return hipGetLastError();
+}
+template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED>
+inline hipError_t launch_order_one(const OrderParams &p, int grid, size_t lds, hipStream_t s) {
+    if constexpr (OrderAsm<T, MUL, REL_LDS, WEIGHTED>::value) {
+        if (p.use_streams) return launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true>(p, grid, lds, s);
+    }
+    return launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, false>(p, grid, lds, s);
 }
 
 template <typename T, bool REL_LDS, bool WEIGHTED>

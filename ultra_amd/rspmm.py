@@ -166,6 +166,17 @@ class Plan(object):
             out.append(t.view(-1, 4) if which == 3 else t)
         return tuple(out)
 
+    def streams(self, nparts):
+        """(sdesc[nparts * 64, 2] = {first record, steps}, srec[n, 2] = (col, type) records, markers (row, num_relation))"""
+        out = []
+        for which in (4, 5):
+            n = ctypes.c_int64()
+            check(lib.ultra_plan_schedule_export(self._h, int(nparts), which, None, 0, ctypes.byref(n)))
+            t = torch.empty(n.value, dtype=torch.int32)
+            check(lib.ultra_plan_schedule_export(self._h, int(nparts), which, t.data_ptr(), n.value, ctypes.byref(n)))
+            out.append(t.view(-1, 2))
+        return tuple(out)
+
     def export(self, which):
         n = ctypes.c_int64()
         check(lib.ultra_plan_export(self._h, which, None, 0, ctypes.byref(n)))
@@ -570,7 +581,10 @@ class _ReferenceExports(object):
 rspmm = _ReferenceExports()
 
 
-def set_tuning(threads=0, grid=0, rel_lds=-1, x_lds=-1, unroll=0):
-    """Kernel-launch tuning knobs (measurement / tests).  set_tuning() restores the defaults."""
-    t = _lib.Tuning(int(threads), int(grid), int(rel_lds), int(x_lds), int(unroll), (ctypes.c_int32 * 3)(0, 0, 0))
+def set_tuning(threads=0, grid=0, rel_lds=-1, x_lds=-1, unroll=0, general_walk=0, unit_walk=0):
+    """Kernel-launch tuning knobs (measurement / tests).  set_tuning() restores the defaults.
+    general_walk: reference-order plans on the general walk kernel; unit_walk: the reference-order kernels walk units of
+    four rows (C++ loops) instead of group streams (assembly loops)."""
+    t = _lib.Tuning(int(threads), int(grid), int(rel_lds), int(x_lds), int(unroll),
+                    (ctypes.c_int32 * 3)(int(general_walk), int(unit_walk), 0))
     check(lib.ultra_set_tuning(ctypes.byref(t)))
