@@ -302,6 +302,9 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes of the roofline block")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fine-tuning steps of the `secondary` block")
+    ap.add_argument("--data-root", default=None,
+                    help="directory with train.txt / valid.txt / test.txt (kg-datasets/FB15k-237 layout): score the real test "
+                         "triples instead of the synthetic graph of --shape (data: \"real\")")
     ap.add_argument("--pmc-target", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -312,10 +315,30 @@ def main():
         return
 
     import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as a plain `python bench.py --gpus N`: launch the N ranks ourselves, the way the driver does (one process per
+        # GPU over RCCL), or refuse -- never report one GPU's number as N GPUs'
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py: --gpus %d but only %d GPU(s) are visible; refusing to benchmark fewer GPUs than asked for"
+                     % (args.gpus, have))
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("[bench] launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d does not match the launcher's world size %d" % (args.gpus, world))
+    if local_rank >= torch.cuda.device_count():
+        sys.exit("bench.py: rank %d has no GPU (local rank %d, %d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # started by torch.distributed.run
@@ -327,7 +350,6 @@ def main():
             dist.init_process_group("nccl", device_id=dev)               # "nccl" is RCCL on ROCm
             dist.barrier()                                                # (communicator creation happens here)
             torch.cuda.synchronize()
-    assert world == args.gpus or world == 1, "--gpus must match the launcher's world size"
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -337,8 +359,14 @@ def main():
     from ultra_amd import distributed as udist
     from ultra_amd import host_order, models, rspmm, synthetic, tasks
 
-    shape = synthetic.SHAPES[args.shape]
-    data_cpu = synthetic.make_kg(**shape, seed=1234)
+    data_kind, data_name = "synthetic", "%s-shaped synthetic KG" % args.shape
+    if args.data_root:
+        # real triples when the files are provided
+        from ultra_amd.data import load_triples_dir
+        data_cpu = load_triples_dir(args.data_root)
+        data_kind, data_name = "real", "%s (raw triples, test split)" % os.path.basename(os.path.normpath(args.data_root))
+    else:
+        data_cpu = synthetic.make_kg(**synthetic.SHAPES[args.shape], seed=1234)
     data = data_cpu.to(dev)
     cfg = synthetic.default_model_cfg()
     torch.manual_seed(0)
@@ -422,13 +450,14 @@ def main():
         "metric": "triples scored/sec (all-tail ranking) on FB15k237",
         "value": triples_per_s, "unit": "triples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "ultra_3g architecture zero-shot all-tail ranking, %s-shaped synthetic KG "
+        "vs_baseline": None, "dtype": "f32", "data": data_kind,
+        "config": {"workload": "ultra_3g architecture zero-shot all-tail ranking, %s "
                                "(N=%d, E=%d, R=%d), distmult+sum rspmm, batch %d queries/GPU, query-sharded"
-                               % (args.shape, N, data.num_edges, data.num_relations, bs),
+                               % (data_name, N, data.num_edges, data.num_relations, bs),
                    "batch_per_gpu": bs, "triples_per_step_per_gpu": bs * N, "weights": weights,
                    "summation_order": "reference (rspmm.cpp:61-72 sequential per row; nn.Linear / nn.LayerNorm in torch's CPU order; "
-                                      "readout GEMV: %s)" % host_order.readout_stages(128)[1],
+                                      "readout GEMV %s)" % host_order.describe(128),
+                   "readout_order_id": host_order.order_id(host_order.readout_stages(128)[0]),
                    "launch": "eager" if args.no_graph else "hipGraph replay of the captured forward",
                    "rccl_world_size": dist.get_world_size() if (world > 1 or launched) else 1,
                    "per_rank": per_rank,
@@ -520,11 +549,32 @@ def main():
                              "rank_mismatches_reference_fp32_vs_fp64": int((r_cpu != r_true).sum()),
                              "scores_bit_equal": int((got == ref_score).sum()), "scores": got.numel(),
                              "metrics_gpu": ranking_metrics(r_gpu), "metrics_reference": ranking_metrics(r_cpu),
-                             "readout_order": host_order.readout_stages(128)[1],
+                             "readout_order": host_order.describe(128),
                              "note": "every operation of the forward follows the reference's order (rspmm.cpp row sums, torch's "
                                      "nn.Linear / nn.LayerNorm arithmetic, the host BLAS's association for the readout's last "
                                      "product, probed by ultra_amd/host_order.py); the host BLAS may sum a few trailing rows of "
                                      "each thread's share with a remainder kernel"}
+            # ---- Hits@k where it is not vacuous: 16 fact-graph edges whose reference ranks are 1 .. 30 (tests/golden) ----
+            topk_file = os.path.join(ROOT, "tests", "golden", "topk_queries_fb15k237.json")
+            if args.shape == "fb15k237" and not args.data_root and os.path.exists(topk_file):
+                rec = json.load(open(topk_file))
+                fact = torch.stack([data_cpu.edge_index[0], data_cpu.edge_index[1], data_cpu.edge_type], dim=-1)
+                queries = fact[torch.tensor(rec["indices"])]
+                rg, rr = [], []
+                for b0 in range(0, len(queries), bs):
+                    qb = queries[b0:b0 + bs]
+                    cand, _ = tasks.all_negative(data_cpu, qb)
+                    qmask, _ = tasks.strict_negative_mask(data_cpu, qb)
+                    want_q = ultra_oracle_model.ultra_forward(state, cfg, data_cpu, cand, rspmm_fn=fn)
+                    with torch.no_grad():
+                        got_q = model(data, cand.to(dev)).cpu()
+                    rg.append(tasks.compute_ranking(got_q, qb[:, 1], qmask))
+                    rr.append(tasks.compute_ranking(want_q, qb[:, 1], qmask))
+                rg, rr = torch.cat(rg), torch.cat(rr)
+                out["parity"]["top_ranked_queries"] = {
+                    "queries": len(queries), "source": "fact-graph edges with reference ranks 1 .. 30 (tests/golden/topk_queries_fb15k237.json)",
+                    "metrics_gpu": ranking_metrics(rg), "metrics_reference": ranking_metrics(rr),
+                    "rank_mismatches": int((rg != rr).sum()), "metrics_identical": ranking_metrics(rg) == ranking_metrics(rr)}
             # ---- the re-associating plans (round 1's timed path), same command: throughput and parity beside the timed mode ----
             rspmm.set_plan_defaults(exact_order=False)
             try:
@@ -551,7 +601,12 @@ def main():
         rspmm.clear_plan_cache()
         torch.cuda.empty_cache()
         out["secondary"] = {
-            "fine_tune": [secondary_bench.train_case("fb15k237"), secondary_bench.train_case("yago310")],
+            # BASELINE.json configs 3 and 1 (config/transductive/inference.yaml:13-14,21-22; ultra/layers.py:206-207)
+            "forward": [secondary_bench.forward_parity_case("codex_l", "max", "ultra_50g", bs=8),
+                        secondary_bench.forward_parity_case("codex_l", "sum", "ultra_50g", bs=8),
+                        secondary_bench.forward_parity_case("wn18rr", "sum", "ultra_3g", bs=4)],
+            "fine_tune": [secondary_bench.train_case("fb15k237"), secondary_bench.train_case("yago310"),
+                          secondary_bench.train_case("fb15k237", aggr="max")],
             "sparse_relation_graph": secondary_bench.sparse_relation_case("fb15k237", fill=0.12),
             "note": "one optimisation step of script/run.py:40-90 (strict negatives, train()-mode forward with the batch's own "
                     "edges dropped, self-adversarial BCE, backward, AdamW) on synthetic graphs of the named shapes; batch 8 x "

@@ -98,6 +98,26 @@ def test_readout_matches_torch(dev, bs, n, cand):
     assert err <= 2e-5, "max |fused - torch| = %g" % err
 
 
+def test_readout_flags_candidate_ids_outside_the_graph(dev):
+    """An id outside [0, num_node) must not read out of bounds: its score is NaN, every other score is unchanged (the
+    reference's gather raises an IndexError there, models.py:204-205)."""
+    from ultra_amd import dense, models, synthetic
+    torch.manual_seed(0)
+    net = models.EntityNBFNet(**{k: v for k, v in synthetic.default_model_cfg()["entity_model_cfg"].items() if k != "class"}).to(dev)
+    g = torch.Generator().manual_seed(1)
+    hidden, query = torch.randn(3, 50, 64, generator=g).to(dev), torch.randn(3, 64, generator=g).to(dev)
+    t_index = torch.randint(0, 50, (3, 40), generator=g).to(dev)
+    bad = t_index.clone()
+    bad[0, 3], bad[2, 39], bad[1, 0] = 50, -1, 1 << 40
+    with torch.no_grad():
+        good = dense.readout(net, hidden, query, t_index)
+        got = dense.readout(net, hidden, query, bad)
+    torch.cuda.synchronize()
+    flagged = torch.zeros_like(got, dtype=torch.bool)
+    flagged[0, 3] = flagged[2, 39] = flagged[1, 0] = True
+    assert torch.isnan(got[flagged]).all() and torch.equal(got[~flagged], good[~flagged])
+
+
 @pytest.mark.parametrize("bs,rows", [(1, 1), (3, 31), (8, 474), (2, 129)])
 def test_relation_projection_matches_the_per_layer_modules(dev, bs, rows):
     """ultra_relation_projection == relation_projection (layers.py:80) of every entity layer, in one launch."""

@@ -50,7 +50,10 @@ def _worker(rank, world, port, out_dir):
     score = torch.full((3, 5), float(rank))
     gathered = udist.all_gather_scores(score)
     var = udist.all_gather_variable(torch.arange(rank + 2) + 10 * rank)
-    torch.save(dict(res=res, gathered=gathered, var=var, shard=udist.shard_range(37)), os.path.join(out_dir, "r%d.pt" % rank))
+    lo, hi = udist.shard_range(7)
+    shards = udist.all_gather_shards(torch.arange(lo, hi).repeat_interleave(2).view(-1, 1) * torch.tensor([[1, 10]]), 7, rows_per_item=2)
+    torch.save(dict(res=res, gathered=gathered, var=var, shards=shards, shard=udist.shard_range(37)),
+               os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,6 +77,8 @@ def test_query_sharded_evaluation_matches_single_process(tmp_path):
         assert o["gathered"].shape == (6, 5)
         assert o["gathered"][:3].eq(0).all() and o["gathered"][3:].eq(1).all()   # rank-major
         assert o["var"].tolist() == [0, 1, 10, 11, 12]
+        # one fixed-size collective for shard_range shares (4 + 3 items, two rows each): item order, no padding left
+        assert o["shards"][:, 0].tolist() == [i for i in range(7) for _ in range(2)] and o["shards"][:, 1].tolist() == [10 * i for i in range(7) for _ in range(2)]
     assert outs[0]["shard"] == (0, 19) and outs[1]["shard"] == (19, 37)
 
 

@@ -111,3 +111,45 @@ def test_sequential_order_on_request(monkeypatch):
     stages, source = ho.readout_stages(128)
     assert stages == ho.sequential_stages(128) and source == "sequential"
     ho._CACHE.clear()
+
+
+def test_order_file_round_trip_cache_and_id(monkeypatch, tmp_path):
+    """The order in use is named (order_id), cached on disk per host, and can be carried to another host as a file."""
+    monkeypatch.setenv("ULTRA_ORDER_CACHE_DIR", str(tmp_path / "cache"))
+    monkeypatch.delenv("ULTRA_READOUT_ORDER", raising=False)
+    ho._CACHE.clear()
+    threads = torch.get_num_threads()
+    stages, source = ho.readout_stages(128)          # probed in a helper process: this process's thread count is untouched
+    assert torch.get_num_threads() == threads
+    files = list((tmp_path / "cache").glob("readout_order_*.json")) if source.startswith("host BLAS") else []
+    if source.startswith("host BLAS"):
+        assert len(files) == 1
+        ho._CACHE.clear()
+        again, source2 = ho.readout_stages(128)       # second process start: read from the cache, no probe
+        assert again == stages and source2.endswith("[cached]")
+    oid = ho.order_id(stages)
+    assert oid.startswith("order-") and len(oid) == 14 and ho.describe(128).startswith(oid)
+    path = tmp_path / "order.json"
+    ho.save_stages(str(path), stages, source)
+    monkeypatch.setenv("ULTRA_READOUT_ORDER", str(path))
+    ho._CACHE.clear()
+    loaded, source3 = ho.readout_stages(128)
+    assert loaded == stages and ho.order_id(loaded) == oid and source3.startswith("file order.json")
+    assert ho.order_id(ho.sequential_stages(128)) != oid or stages == ho.sequential_stages(128)
+    ho._CACHE.clear()
+
+
+def test_unusable_orders_fall_back_to_the_sequential_chain(monkeypatch, tmp_path):
+    """A missing / malformed order file, or a legal tree whose program exceeds the kernel's 640 words, must not break
+    the forward: sequential chain + warning."""
+    monkeypatch.setenv("ULTRA_READOUT_ORDER", str(tmp_path / "nope.json"))
+    ho._CACHE.clear()
+    with pytest.warns(UserWarning):
+        stages, source = ho.readout_stages(128)
+    assert stages == ho.sequential_stages(128) and source.startswith("sequential")
+    # eight stages of sixteen lanes: legal, but 1 + 8 (2 + 32) + 128 lanes padded to groups of eight = far beyond 640 words
+    big = [(16, s > 0, [[16 * s + p] for p in range(16)]) for s in range(8)]
+    assert len(ho.stages_to_program(big)) > ho.PROGRAM_MAX_WORDS
+    with pytest.raises(ValueError):
+        ho._check_stages(big, 128)
+    ho._CACHE.clear()

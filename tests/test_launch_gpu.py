@@ -1,0 +1,103 @@
+"""How the multi-rank paths are STARTED (reference: README.md:247-254 torch.distributed.launch, ultra/util.py:121-122 NCCL
+init, script/run.py:44-45 DDP, run.py:127 sharding) -- exercised at world size 1 on the one GPU of the test box:
+
+  * `bench.py` under torch.distributed.run: RCCL communicator + hipGraph replay + the per-step all-gather, and the
+    per-rank probe; `bench.py --gpus N` with fewer than N GPUs visible must refuse, not report one GPU as N;
+  * one DistributedDataParallel step over RCCL gives the gradients of the plain step.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_under_torchrun_world_size_one():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+           "--no-cpu-baseline", "--no-roofline", "--no-secondary"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-500:]          # exactly one JSON line on stdout (RCCL's banner goes to stderr)
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 5 and out["value"] > 0
+    cfg = out["config"]
+    assert cfg["rccl_world_size"] == 1 and cfg["launch"].startswith("hipGraph")
+    assert cfg["per_rank"]["probe_scores_identical"] is True and len(cfg["per_rank"]["ms_per_step"]) == 1
+    assert cfg["readout_order_id"].startswith("order-")
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "refusing" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    # a launcher whose world size contradicts --gpus is refused as well
+    env = dict(_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "does not match" in r.stderr
+
+
+DDP_STEP = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from ultra_amd import models, synthetic, tasks
+rank, local = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
+dev = torch.device("cuda", local)
+dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm (ultra/util.py:121-122)
+data = synthetic.make_kg(num_node=800, num_triple=8000, num_relation_base=6, num_test=16, seed=5).to(dev)
+triples = torch.stack([data.edge_index[0], data.edge_index[1], data.edge_type], dim=-1)
+torch.manual_seed(3)
+neg = tasks.negative_sampling(data, triples[rank * 4:(rank + 1) * 4], 16, strict=True)
+
+def grads(wrap):
+    torch.manual_seed(0)
+    model = models.Ultra(**synthetic.default_model_cfg()).to(dev).train()
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if wrap else model   # script/run.py:44-45
+    pred = net(data, neg)
+    target = torch.zeros_like(pred)
+    target[:, 0] = 1
+    torch.nn.functional.binary_cross_entropy_with_logits(pred, target).backward()
+    return torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
+
+plain, ddp = grads(False), grads(True)
+assert torch.isfinite(ddp).all() and ddp.numel() > 1000
+ref = ddp.clone()
+dist.broadcast(ref, 0)
+assert torch.equal(ref, ddp), "gradients differ across ranks after the all-reduce"
+# world size 1: the all-reduce averages one contribution, so the DDP step IS the plain step
+assert dist.get_world_size() > 1 or torch.equal(plain, ddp), (plain - ddp).abs().max().item()
+print("DDP_OK world %%d grads %%d" %% (dist.get_world_size(), ddp.numel()))
+dist.destroy_process_group()
+"""
+
+
+def test_ddp_step_over_rccl_equals_the_plain_step(tmp_path):
+    script = tmp_path / "ddp_step.py"
+    script.write_text(DDP_STEP % ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DDP_OK world 1" in r.stdout, (r.stdout + r.stderr)[-2000:]

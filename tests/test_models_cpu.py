@@ -82,3 +82,23 @@ def test_relation_projection_has_the_reference_interface():
     assert list(inspect.signature(RelationProjection.__init__).parameters) == ["self", "model", "threshold"]
     assert list(inspect.signature(proj.forward).parameters) == ["graph", "h_prob", "r_index"]
     assert {k for k in proj.state_dict()} == {"model." + k for k in model.state_dict()}
+
+
+def test_raw_triples_reader_builds_the_reference_fact_graph(tmp_path):
+    """ultra_amd.data.load_triples_dir: training triples + inverses as the fact graph, test triples as targets
+    (ultra/datasets.py:186-197), with and without vocabulary files."""
+    from ultra_amd.data import load_triples_dir
+    (tmp_path / "train.txt").write_text("a\tlikes\tb\nb\tlikes\tc\nc\tknows\ta\n")
+    (tmp_path / "valid.txt").write_text("a\tknows\tc\n")
+    (tmp_path / "test.txt").write_text("b\tknows\ta\nc\tlikes\tb\n")
+    d = load_triples_dir(str(tmp_path), relation_graph=False)
+    assert d.num_nodes == 3 and d.num_relations == 4 and d.num_edges == 6
+    assert d.edge_index.tolist() == [[0, 1, 2, 1, 2, 0], [1, 2, 0, 0, 1, 2]]
+    assert d.edge_type.tolist() == [0, 0, 1, 2, 2, 3]
+    assert d.target_triples.tolist() == [[1, 0, 1], [2, 1, 0]]
+    (tmp_path / "entities.dict").write_text("0\tc\n1\tb\n2\ta\n")
+    (tmp_path / "relations.dict").write_text("0\tknows\n1\tlikes\n")
+    d2 = load_triples_dir(str(tmp_path), relation_graph=False)
+    assert d2.edge_index[:, :3].tolist() == [[2, 1, 0], [1, 0, 2]] and d2.edge_type[:3].tolist() == [1, 1, 0]
+    d3 = load_triples_dir(str(tmp_path))          # with the relation graph (tasks.build_relation_graph)
+    assert d3.relation_graph.num_nodes == 4

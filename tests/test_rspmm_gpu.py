@@ -492,3 +492,20 @@ def test_fused_dense_layer_matches_rspmm_plus_update(dev, case, bnd, layer_norm,
     assert Plan(ei5, et5, 33, 9, dense=True).fused_layer(torch.zeros(1, 9, 64, device=dev), torch.zeros(1, 33, 64, device=dev),
                                                          layer.linear) is None
     assert Plan(ei, et, N, R, dense=False).fused_layer(rel, x, layer.linear) is None
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: operands on cuda:1 while cuda:0 is current")
+def test_operands_on_a_device_that_is_not_the_current_one():
+    """The reference's launch convention (rspmm.cu:243, 304: cudaSetDevice(input.get_device())): tensors on cuda:1, the
+    thread's current device still 0, torch's default stream (handle 0 on every device).  The entry must run -- and upload
+    its plan -- on the operands' device (csrc/device_scope.hpp reads it off a device pointer)."""
+    from ultra_amd.rspmm import Plan
+    assert torch.cuda.current_device() == 0
+    dev1 = torch.device("cuda:1")
+    ei, et = helpers.random_graph(num_node=64, num_edge=400, num_relation=5, seed=3)
+    rel, x, w = helpers.features(64, 5, 64, 400, dtype=torch.float32, seed=3)
+    want = rspmm_oracle.generalized_rspmm(ei, et, torch.ones(400), rel, x, sum="add", mul="mul")
+    plan = Plan(ei, et, 64, 5, exact_order=True)
+    got = plan.forward(rel.to(dev1), x.to(dev1), sum="add", mul="mul")
+    assert got.device == dev1 and torch.equal(got.cpu(), want)
+    assert torch.cuda.current_device() == 0

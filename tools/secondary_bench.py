@@ -47,6 +47,44 @@ def forward_case(shape, aggr, ckpt, bs=8):
             "ms_per_forward": 1e3 * dt, "triples_per_s": bs * data.num_nodes / dt, "launch": "eager"}
 
 
+def forward_parity_case(shape, aggr, ckpt, bs=8, n_batch=1, data=None):
+    """BASELINE.json configs 1 / 3 beside the headline: the all-tail forward of `ckpt` on a `shape`-shaped graph as a
+    hipGraph replay (ms per forward, triples/s), and its scores / filtered rankings against oracle/ultra_oracle_model.py
+    with the reference's rspmm translation unit on the host -- the comparison of tests/test_baseline_parity_gpu.py."""
+    from oracle import ultra_oracle_model
+    from ultra_amd import graph as ugraph
+    from ultra_amd import host_order
+    cpu = synthetic.make_kg(**synthetic.SHAPES[shape], seed=1234) if data is None else data
+    gdata = cpu.to(dev)
+    model = load_model(aggr, ckpt).eval()
+    cfg = synthetic.default_model_cfg(aggregate_func=aggr)
+    state = torch.load(os.path.join(ROOT, "tests", "golden", ckpt + "_model.pt"))
+    t_batch, _ = tasks.all_negative(gdata, gdata.target_triples[:bs])
+    fwd = ugraph.GraphedForward(model, gdata, t_batch)
+    dt = timeit(lambda: fwd(t_batch), 3, 20)
+    fn = ultra_oracle_model.reference_rspmm_fn()
+    equal = count = mism = queries = 0
+    worst = 0.0
+    for b in range(n_batch):
+        batch = cpu.target_triples[b * bs:(b + 1) * bs]
+        cand, _ = tasks.all_negative(cpu, batch)
+        mask, _ = tasks.strict_negative_mask(cpu, batch)
+        want = ultra_oracle_model.ultra_forward(state, cfg, cpu, cand, rspmm_fn=fn)
+        with torch.no_grad():
+            got = fwd(cand.to(dev)).cpu()
+        worst = max(worst, (got - want).abs().max().item())
+        equal += int((got == want).sum())
+        count += got.numel()
+        mism += int((tasks.compute_ranking(got, batch[:, 1], mask) != tasks.compute_ranking(want, batch[:, 1], mask)).sum())
+        queries += bs
+    return {"case": "forward all-tail", "shape": shape, "N": cpu.num_nodes, "E": cpu.num_edges, "aggregate": aggr, "weights": ckpt,
+            "batch": bs, "ms_per_forward": 1e3 * dt, "triples_per_s": bs * cpu.num_nodes / dt, "launch": "hipGraph replay",
+            "parity": {"oracle": "oracle/ultra_oracle_model.py" + (" + reference rspmm.cpp TU" if fn is not None else " + C oracle rspmm"),
+                       "batches": n_batch, "scores": count, "scores_bit_equal": equal, "bit_equal": equal == count,
+                       "max_abs_score_diff": worst, "rank_mismatches": mism, "queries": queries,
+                       "readout_order": host_order.describe(128)}}
+
+
 def sparse_relation_case(shape="fb15k237", fill=0.12, bs=8):
     """The headline forward with the relation graph thinned to `fill` of its (row, type, col) cells (uniform sample of its
     edges): below plan.DENSE_MIN_FILL the relation model leaves the byte-adjacency kernels and runs on the edge-list

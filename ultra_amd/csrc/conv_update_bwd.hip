@@ -397,7 +397,7 @@ int32_t ultra_conv_update_backward(const void *x, const void *agg, const void *g
                                    void *grad_bias, void *grad_ln_weight, void *grad_ln_bias, void *workspace,
                                    int64_t workspace_bytes, int64_t rows, int32_t input_dim, int32_t output_dim, float eps,
                                    int32_t flags, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, x);
     if (input_dim != 64 || output_dim != 64) {
         set_error("ultra_conv_update_backward: only input_dim = output_dim = 64 is built (the ULTRA checkpoints' shape)");
         return ULTRA_ERR_UNSUPPORTED;

@@ -241,6 +241,16 @@ constexpr int READOUT_HID_STRIDE = 132;   // floats per row of the hidden tile i
 //   element list (lane 0 of a later stage continues from the previous stage's value; an element flagged + 256 is added
 //   as a rounded product instead of fused), lanes folded v[p] += v[p + L/2],
 //   v[p] += v[p + L/4], ...; bias last.  The hidden tile passes through LDS so that one lane walks one row's program.
+// node id of candidate `row` (= sample b, column c), or -1 when the batch names a node outside [0, num_node)
+__device__ __forceinline__ long long readout_node(const ReadoutParams &p, const long long row, const long long b, const long long c) {
+    long long node = c;
+    if (p.triples)
+        node = p.triples[row * 3 + (p.side[b] ? 1 : 0)];
+    else if (p.t_index)
+        node = p.t_index[row];
+    return (node >= 0 && node < p.num_node) ? node : -1;
+}
+
 __global__ void __launch_bounds__(512) readout_kernel(const ReadoutParams p) {
     // [tile m (4)][i (16)][lane] float4 : W1[32 m + (lane & 31)][2 s + (lane >> 5)], s = 4 i + {0, 2, 1, 3}[q] (see swap32)
     __shared__ __attribute__((aligned(16))) float lds_w[4 * 16 * 64 * 4];
@@ -282,11 +292,9 @@ __global__ void __launch_bounds__(512) readout_kernel(const ReadoutParams p) {
         const long long rowc = row < total ? row : total - 1;
         const long long b = rowc / p.n_cand;
         const long long c = rowc - b * p.n_cand;
-        long long node = c;
-        if (p.triples)
-            node = p.triples[rowc * 3 + (p.side[b] ? 1 : 0)];
-        else if (p.t_index)
-            node = p.t_index[rowc];
+        // (an id outside [0, num_node) reads row 0 and its score becomes NaN below: the reference's gather raises there,
+        // models.py:204-205; here the batch is on the device and a host check would cost a sync)
+        const long long node = readout_node(p, rowc, b, c) < 0 ? 0 : readout_node(p, rowc, b, c);
         const float4 *hr = reinterpret_cast<const float4 *>(p.hidden + (b * p.num_node + node) * 64);
 #pragma unroll
         for (int i = 0; i < 8; ++i) bh[i] = hr[2 * i + h];
@@ -398,7 +406,10 @@ __global__ void __launch_bounds__(512) readout_kernel(const ReadoutParams p) {
                 hdr += 2 + 2 * L;
             }
             const long long prow = tile * 32 + 16 * pass + pr;
-            if (sub == 0 && prow < total) p.score[prow] = s + p.b2[0];
+            if (sub == 0 && prow < total) {
+                const long long pb = prow / p.n_cand;
+                p.score[prow] = readout_node(p, prow, pb, prow - pb * p.n_cand) < 0 ? __builtin_nanf("") : s + p.b2[0];
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();      // the next pass / tile overwrites the hidden rows
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -522,7 +533,7 @@ extern "C" {
 int32_t ultra_conv_update(const void *x, const void *agg, const void *weight, const void *bias, const void *ln_weight,
                           const void *ln_bias, void *out, int64_t rows, int32_t input_dim, int32_t output_dim, float eps,
                           int32_t flags, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, x);
     if (input_dim != 64 || output_dim != 64) {
         set_error("ultra_conv_update: only input_dim = output_dim = 64 is built (the ULTRA checkpoints' shape)");
         return ULTRA_ERR_UNSUPPORTED;
@@ -601,7 +612,7 @@ static int launch_readout(ReadoutParams &p, const void *hidden, const void *w1, 
 int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1, const void *query, const void *b1,
                       const void *w2, const void *b2, const int32_t *order_dev, int64_t order_len, void *score, int64_t batch,
                       int64_t num_node, int64_t n_cand, int32_t hidden_dim, int32_t feature_dim, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, hidden);
     ReadoutParams p;
     p.t_index = t_index;
     p.triples = nullptr;
@@ -614,7 +625,7 @@ int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const in
                             const void *b1, const void *w2, const void *b2, const int32_t *order_dev, int64_t order_len,
                             void *score, int64_t batch, int64_t num_node, int64_t n_cand, int32_t hidden_dim,
                             int32_t feature_dim, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, hidden);
     if (!triples || !side) {
         set_error("ultra_readout_batch: NULL operand");
         return ULTRA_ERR_INVALID;
@@ -629,7 +640,7 @@ int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const in
 
 int32_t ultra_relation_projection(const void *x, const void *w0, const void *b0, const void *w2, const void *b2, void *out,
                                   int64_t rows, int32_t n_layer, int32_t dim, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, x);
     if (dim != 64) {
         set_error("ultra_relation_projection: only dim = 64 is built (the ULTRA checkpoints' shape)");
         return ULTRA_ERR_UNSUPPORTED;

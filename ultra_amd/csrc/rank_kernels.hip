@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) batch_prologue_kernel(const int64_t *__re
 extern "C" int32_t ultra_batch_prologue(const int64_t *batch, int64_t batch_size, int64_t n_cand, int64_t num_direct_rel,
                                         int64_t *h0, int64_t *r0, int32_t *side, int32_t *valid, int32_t *scratch,
                                         void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, batch);
     if (!batch || !h0 || !r0 || !side || !valid || !scratch || batch_size < 0 || n_cand <= 0) {
         ultra::set_error("ultra_batch_prologue: NULL operand or empty candidate set");
         return ULTRA_ERR_INVALID;
@@ -130,7 +130,7 @@ extern "C" int32_t ultra_batch_prologue(const int64_t *batch, int64_t batch_size
 extern "C" int32_t ultra_filtered_rank(const void *score, const int64_t *pos_index, const int64_t *known_ptr,
                                        const int64_t *known_index, int64_t batch, int64_t n_cand, int64_t *rank_out,
                                        int64_t *num_negative_out, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, score);
     if (!score || !pos_index || !known_ptr || !rank_out || !num_negative_out || batch < 0 || n_cand <= 0) {
         ultra::set_error("ultra_filtered_rank: NULL operand or empty candidate set");
         return ULTRA_ERR_INVALID;

@@ -141,7 +141,7 @@ extern "C" {
 int32_t ultra_relation_graph_bits(const int64_t *edge_index_dev, const int64_t *edge_type_dev, int64_t num_edge, int64_t num_node,
                                   int64_t num_relation, void *hbits_dev, void *tbits_dev, void *adj_dev, int64_t *row_counts_dev,
                                   void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, edge_index_dev);
     if (num_edge < 0 || num_node < 0 || num_relation <= 0 || (num_edge > 0 && (!edge_index_dev || !edge_type_dev)) || !hbits_dev ||
         !tbits_dev || !adj_dev || !row_counts_dev) {
         set_error("ultra_relation_graph_bits: bad argument");
@@ -173,7 +173,7 @@ int32_t ultra_relation_graph_bits(const int64_t *edge_index_dev, const int64_t *
 
 int32_t ultra_relation_graph_emit(const void *adj_dev, const int64_t *row_offsets_dev, int64_t num_relation, int64_t total_edges,
                                   int64_t *edge_index_out_dev, int64_t *edge_type_out_dev, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, adj_dev);
     if (!adj_dev || !row_offsets_dev || num_relation <= 0 || total_edges < 0 || (total_edges > 0 && (!edge_index_out_dev || !edge_type_out_dev))) {
         set_error("ultra_relation_graph_emit: bad argument");
         return ULTRA_ERR_INVALID;
@@ -193,7 +193,7 @@ int32_t ultra_relation_graph_emit(const void *adj_dev, const int64_t *row_offset
 }
 
 int32_t ultra_relation_graph_dense_adjacency(const void *adj_dev, int64_t num_relation, void *a_ex_out_dev, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, adj_dev);
     if (!adj_dev || !a_ex_out_dev || num_relation <= 0) {
         set_error("ultra_relation_graph_dense_adjacency: bad argument");
         return ULTRA_ERR_INVALID;

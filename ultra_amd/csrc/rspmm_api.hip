@@ -740,9 +740,11 @@ int32_t ultra_plan_upload(ultra_plan *plan) {
 
 int32_t ultra_plan_pin(ultra_plan *plan, int32_t delta) {
     if (!plan) return invalid("plan is NULL");
-    plan->pinned += delta;
-    if (plan->tplan) plan->tplan->pinned += delta;
-    if (plan->rplan) plan->rplan->pinned += delta;
+    // (clamped at 0: a backward plan derived after the pin sees the matching -1 without ever having seen the +1)
+    const auto bump = [&](ultra_plan *q) { q->pinned = std::max<int32_t>(0, q->pinned + delta); };
+    bump(plan);
+    if (plan->tplan) bump(plan->tplan);
+    if (plan->rplan) bump(plan->rplan);
     return ULTRA_OK;
 }
 
@@ -758,7 +760,7 @@ int32_t ultra_plan_destroy(ultra_plan *plan) {
 int32_t ultra_rspmm_forward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype, const void *edge_weight_dev,
                             const ultra_mat *relation, const ultra_mat *input, const ultra_mat *boundary,
                             const ultra_mat *output, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, output ? output->ptr : nullptr);
     if (mul < 0 || mul > 1) return invalid("unknown mul code");
     return forward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, boundary, output,
                         reinterpret_cast<hipStream_t>(stream));
@@ -767,7 +769,7 @@ int32_t ultra_rspmm_forward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t 
 int32_t ultra_rspmm_forward_masked(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype, const void *edge_keep_dev,
                                    const ultra_mat *relation, const ultra_mat *input, const ultra_mat *boundary,
                                    const ultra_mat *output, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, output ? output->ptr : nullptr);
     if (mul < 0 || mul > 1) return invalid("unknown mul code");
     if (!edge_keep_dev) return invalid("ultra_rspmm_forward_masked: edge_keep is NULL");
     g_keep_mode = 1;
@@ -780,7 +782,7 @@ int32_t ultra_rspmm_forward_masked(ultra_plan *plan, int32_t sum, int32_t mul, i
 int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t mul, int32_t dtype, const void *edge_weight_dev,
                                   const ultra_mat *relation, const ultra_mat *input, const int64_t *point_rows_dev,
                                   const ultra_mat *point_values, const ultra_mat *output, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, output ? output->ptr : nullptr);
     if (mul < 0 || mul > 1) return invalid("unknown mul code");
     if (!point_rows_dev || !point_values) return invalid("ultra_rspmm_forward_point: NULL point boundary");
     return forward_impl(plan, ULTRA_SUM_ADD, mul, dtype, edge_weight_dev, relation, input, point_values, output,
@@ -790,7 +792,7 @@ int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t mul, int32_t dtype, 
 int32_t ultra_rspmm_forward_onehot(ultra_plan *plan, int32_t dtype, const void *edge_weight_dev,
                                    const ultra_mat *relation, const ultra_mat *input, const int64_t *src_rows_dev,
                                    const ultra_mat *boundary, const ultra_mat *output, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, output ? output->ptr : nullptr);
     return forward_onehot_impl(plan, dtype, edge_weight_dev, relation, input, src_rows_dev, boundary, output,
                                reinterpret_cast<hipStream_t>(stream));
 }
@@ -798,7 +800,7 @@ int32_t ultra_rspmm_forward_onehot(ultra_plan *plan, int32_t dtype, const void *
 int32_t ultra_nbf_layer0(ultra_plan *plan, const void *edge_weight_dev, const ultra_mat *relation, const int64_t *src_rows_dev,
                          const void *src_values_dev, const void *weight, const void *bias, const void *ln_weight,
                          const void *ln_bias, float eps, int32_t flags, const ultra_mat *output, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, output ? output->ptr : nullptr);
     return layer0_impl(plan, edge_weight_dev, relation, src_rows_dev, src_values_dev, weight, bias, ln_weight, ln_bias, eps,
                        flags, output, reinterpret_cast<hipStream_t>(stream));
 }
@@ -806,7 +808,7 @@ int32_t ultra_nbf_layer0(ultra_plan *plan, const void *edge_weight_dev, const ul
 int32_t ultra_nbf_dense_layer(ultra_plan *plan, const ultra_mat *relation, const ultra_mat *input, const ultra_mat *boundary,
                               const int64_t *point_rows_dev, const void *weight, const void *bias, const void *ln_weight,
                               const void *ln_bias, float eps, int32_t flags, const ultra_mat *output, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, output ? output->ptr : nullptr);
     if (!plan) return invalid("plan is NULL");
     (void)hipGetLastError();
     if (!output || !output->ptr || !weight) return invalid("ultra_nbf_dense_layer: NULL operand");
@@ -831,7 +833,7 @@ int32_t ultra_rspmm_backward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t
                              const ultra_mat *relation, const ultra_mat *input, const ultra_mat *output,
                              const ultra_mat *output_grad, void *weight_grad_dev, const ultra_mat *relation_grad,
                              const ultra_mat *input_grad, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, output ? output->ptr : nullptr);
     return backward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, output, output_grad, weight_grad_dev,
                          relation_grad, input_grad, reinterpret_cast<hipStream_t>(stream));
 }
@@ -840,7 +842,7 @@ int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, in
                                   const void *edge_weight_dev, const ultra_mat *relation, const ultra_mat *input,
                                   const ultra_mat *boundary, const int64_t *point_rows_dev, const ultra_mat *output,
                                   void *stream, int32_t warmup, int32_t iters, float *ms_per_call, float *ms_main_kernel) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, output ? output->ptr : nullptr);
     if (mul < 0 || mul > 1) return invalid("unknown mul code");
     const auto once = [&]() {
         return forward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, boundary, output,
@@ -957,7 +959,7 @@ int32_t ultra_get_tuning(ultra_tuning *t) {
         const int64_t *edge_index_dev, const int64_t *edge_type_dev, const void *edge_weight_dev,                    \
         const void *relation_dev, const void *input_dev, void *output_dev, int64_t num_edge, int64_t num_node,       \
         int64_t num_relation, int64_t dim, int32_t dtype, void *stream) {                                            \
-        ULTRA_DEVICE_SCOPE(stream);                                                                                  \
+        ULTRA_DEVICE_SCOPE(stream, edge_index_dev);                                                                                  \
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);                                                       \
         ultra_plan *plan = nullptr;                                                                                  \
         int rc = stateless_plan(&plan, edge_index_dev, edge_type_dev, num_edge, num_node, num_relation, s);         \
@@ -974,7 +976,7 @@ int32_t ultra_get_tuning(ultra_tuning *t) {
         const void *relation_dev, const void *input_dev, const void *output_dev, const void *output_grad_dev,        \
         void *weight_grad_dev, void *relation_grad_dev, void *input_grad_dev, int64_t num_edge, int64_t num_node,    \
         int64_t num_relation, int64_t dim, int32_t dtype, void *stream) {                                            \
-        ULTRA_DEVICE_SCOPE(stream);                                                                                  \
+        ULTRA_DEVICE_SCOPE(stream, edge_index_dev);                                                                                  \
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);                                                       \
         ultra_plan *plan = nullptr;                                                                                  \
         int rc = stateless_plan(&plan, edge_index_dev, edge_type_dev, num_edge, num_node, num_relation, s);         \

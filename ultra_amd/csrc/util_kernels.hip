@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) edge_keep_mask_kernel(const long long *he
 
 extern "C" int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void *values, int64_t batch, int64_t num_node,
                                      int64_t dim, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, out);
     if (!out || !rows || batch < 0 || num_node < 0 || dim <= 0 || (dim & 3)) {
         ultra::set_error("ultra_onehot_rows: NULL operand or dim not a multiple of 4");
         return ULTRA_ERR_INVALID;
@@ -169,7 +169,7 @@ extern "C" int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void 
 extern "C" int32_t ultra_query_boundary(void *out, void *query_out, const int64_t *rows, const void *table,
                                         const int64_t *pick, int64_t batch, int64_t num_node, int64_t table_rows, int64_t dim,
                                         const void *w1, const void *b1, void *qbias_out, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, out);
     if (!query_out || !rows || !table || !pick || batch < 0 || num_node <= 0 || table_rows <= 0 || dim <= 0 || (dim & 3)) {
         ultra::set_error("ultra_query_boundary: NULL operand, empty graph or dim not a multiple of 4");
         return ULTRA_ERR_INVALID;
@@ -192,7 +192,7 @@ extern "C" int32_t ultra_query_boundary(void *out, void *query_out, const int64_
 }
 
 extern "C" int32_t ultra_stream_copy(void *dst, const void *src, int64_t bytes, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, dst);
     if (!dst || !src || bytes < 0 || (bytes & 15)) {
         ultra::set_error("ultra_stream_copy: NULL pointer or size not a multiple of 16");
         return ULTRA_ERR_INVALID;
@@ -213,7 +213,7 @@ extern "C" int32_t ultra_stream_copy(void *dst, const void *src, int64_t bytes, 
 extern "C" int32_t ultra_edge_keep_mask(const int64_t *head, const int64_t *tail, const int64_t *type, int64_t num_edge,
                                         const int64_t *easy_key_sorted, int64_t n_easy, int64_t num_node, int64_t num_rel,
                                         void *keep, void *stream) {
-    ULTRA_DEVICE_SCOPE(stream);
+    ULTRA_DEVICE_SCOPE(stream, keep);
     if (!head || !tail || !keep || num_edge < 0 || n_easy < 0 || (n_easy > 0 && !easy_key_sorted) || num_node <= 0 ||
         (type && num_rel <= 0)) {
         ultra::set_error("ultra_edge_keep_mask: NULL operand or empty key space");

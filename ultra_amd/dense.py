@@ -146,15 +146,20 @@ def readout(model, hidden, query, t_index, order=None):
 
 
 _PROLOGUE_SCRATCH = {}
+_PROLOGUE_SCRATCH_RETIRED = []   # outgrown buffers: never freed (a captured hipGraph may still point at one)
 
 
 def _prologue_scratch(device, bs):
     """The meeting point of the prologue's workgroups: zero on entry, left zero on exit.  One per device, allocated by the
     first (eager) call so that a later hipGraph capture finds it in place; prologues of one device are expected on one
-    stream at a time (the C entry takes the buffer as an argument for callers that need more)."""
+    stream at a time (the C entry takes the buffer as an argument for callers that need more).  A buffer that was handed
+    out once stays allocated for the life of the process: a GraphedForward captured earlier keeps its raw pointer, and the
+    kernel increments and re-zeroes words of it on every replay."""
     key = str(device)
     buf = _PROLOGUE_SCRATCH.get(key)
     if buf is None or buf.numel() < 4 * bs:
+        if buf is not None:
+            _PROLOGUE_SCRATCH_RETIRED.append(buf)
         buf = torch.zeros(4 * max(bs, 256), dtype=torch.int32, device=device)
         _PROLOGUE_SCRATCH[key] = buf
     return buf

@@ -39,6 +39,25 @@ def all_gather_scores(score):
     return out
 
 
+def all_gather_shards(local, num_items, rows_per_item=1):
+    """Rows of a quantity sharded by shard_range(num_items): rank r holds rows_per_item * (its share) rows of `local`
+    (shape (rows, ...)); returns all rows in item order on every rank.  The shard sizes follow from num_items, so this is
+    ONE collective: every rank pads to the largest share, all_gather_into_tensor, the padding is cut away."""
+    world = world_size()
+    if world == 1:
+        return local
+    shares = [shard_range(num_items, r, world) for r in range(world)]
+    rows = [rows_per_item * (hi - lo) for lo, hi in shares]
+    if local.shape[0] != rows[rank()]:
+        raise ValueError("rank %d holds %d rows, its share of %d items is %d" % (rank(), local.shape[0], num_items, rows[rank()]))
+    cap = max(rows)
+    pad = local.new_zeros((cap,) + tuple(local.shape[1:]))
+    pad[:local.shape[0]] = local
+    out = local.new_empty((world * cap,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, pad.contiguous())
+    return torch.cat([out[r * cap:r * cap + rows[r]] for r in range(world)])
+
+
 def all_gather_variable(t):
     """Concatenate 1-D tensors of different lengths from every rank (rank order).  Two collectives:
     lengths, then padded payloads."""

@@ -95,7 +95,7 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
         local = torch.cat(rows).long()
     else:
         local = torch.zeros(0, 3, dtype=torch.long, device=triples.device)
-    flat = udist.all_gather_variable(local.reshape(-1)).view(-1, 3)     # the single gather of the evaluation
+    flat = udist.all_gather_shards(local, len(triples), rows_per_item=2)     # the single collective of the evaluation
     model.train(was_training)
 
     ranking, num_neg, is_tail = flat[:, 0], flat[:, 1], flat[:, 2].bool()

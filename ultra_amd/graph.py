@@ -8,8 +8,9 @@ torch's current stream, which is the capturing stream during capture; plans, sch
 LDS opt-in are created by the eager warm-up runs, so nothing allocates inside the captured region.
 
 What the captured graph points at stays alive and in place for as long as the GraphedForward does:
-  * the aggregation plans its launches used are held (and pinned: ultra_plan_pin) -- the plan cache is an LRU and
-    would otherwise free device arrays the graph still reads once enough other graphs have been seen;
+  * the aggregation plans its warm-up runs asked for (rspmm.record_plans) are held and pinned (ultra_plan_pin) -- the
+    plan cache is an LRU and would otherwise free device arrays the graph still reads once enough other graphs have
+    been seen; plans the capture never used stay free to grow their scratch buffers;
   * the model's parameters are watched: the forward caches stacked copies of some weights (relation projections), so a
     parameter update (optimizer step, load_state_dict) makes the next call re-capture instead of replaying stale values.
 """
@@ -45,12 +46,12 @@ class GraphedForward(object):
         with torch.cuda.device(self.static_batch.device):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.no_grad(), torch.cuda.stream(side):
+            with torch.no_grad(), torch.cuda.stream(side), rspmm.record_plans() as used:
                 for _ in range(self.warmup):
                     model(data, self.static_batch)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            self._pinned = rspmm.cached_plans()       # every plan the warm-up touched is in the cache right now
+            self._pinned = used.plans                 # exactly the plans the warm-up runs asked for
             for plan in self._pinned:
                 plan.pin(+1)
             self.graph = torch.cuda.CUDAGraph()

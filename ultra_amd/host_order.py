@@ -264,29 +264,149 @@ def emulate(stages, x, w):
 
 
 _CACHE = {}
+PROGRAM_MAX_WORDS = 640    # READOUT_ORDER_MAX of the readout kernel (csrc/dense_kernels.hip)
+
+
+def order_id(stages):
+    """Short name of a summation order: 'order-' + 8 hex digits of the SHA-1 of its kernel program.  Two runs with the same
+    id add the readout's 128 products in the same association (printed in bench.py's config and parity block)."""
+    import hashlib
+    words = np.asarray(stages_to_program(stages), dtype=np.int32)
+    return "order-" + hashlib.sha1(words.tobytes()).hexdigest()[:8]
+
+
+def _host_key(K):
+    """What the association depends on: the CPU model, the torch build and its BLAS."""
+    import hashlib
+    import platform
+    cpu = platform.processor() or platform.machine()
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    cpu = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    blas = ""
+    try:
+        blas = torch.__config__.show()
+        blas = " ".join(l.strip() for l in blas.splitlines() if "MKL" in l or "BLAS" in l or "LAPACK" in l)
+    except Exception:
+        pass
+    text = "%s|torch %s|%s|K=%d" % (cpu, torch.__version__, blas, K)
+    return hashlib.sha1(text.encode()).hexdigest()[:16], text
+
+
+def _cache_dir():
+    d = os.environ.get("ULTRA_ORDER_CACHE_DIR")
+    if not d:
+        d = os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "ultra_amd")
+    return d
+
+
+def save_stages(path, stages, source, K=128, host=""):
+    import json
+    tmp = "%s.%d.tmp" % (path, os.getpid())
+    with open(tmp, "w") as f:
+        json.dump({"format": 1, "K": K, "id": order_id(stages), "source": source, "host": host,
+                   "stages": [[L, bool(carry), [list(map(int, lane)) for lane in lists]] for L, carry, lists in stages]}, f)
+    os.replace(tmp, path)      # atomic: ranks of one node may write the same file
+
+
+def load_stages(path, K=128):
+    """(stages, source) of an order file written by save_stages / `python -m ultra_amd.host_order --save FILE`: run host B
+    with host A's association (ULTRA_READOUT_ORDER=FILE) to reproduce A's score bits."""
+    import json
+    with open(path) as f:
+        rec = json.load(f)
+    if rec.get("format") != 1 or rec.get("K") != K:
+        raise ValueError("%s is not a readout order file for K = %d" % (path, K))
+    stages = [(int(L), bool(carry), [list(map(int, lane)) for lane in lists]) for L, carry, lists in rec["stages"]]
+    _check_stages(stages, K)
+    return stages, rec.get("source", "file")
+
+
+def _check_stages(stages, K):
+    covered = sorted(e & 255 for _, _, lists in stages for lane in lists for e in lane)
+    if covered != list(range(K)):
+        raise ValueError("stages do not cover every product exactly once")
+    if len(stages_to_program(stages)) > PROGRAM_MAX_WORDS:
+        raise ValueError("summation program of %d words exceeds the readout kernel's %d"
+                         % (len(stages_to_program(stages)), PROGRAM_MAX_WORDS))
+
+
+def probe_host(K=128):
+    """(stages, source) probed from this process's BLAS and validated against torch on random rows; raises ValueError
+    when the tree is outside the family, the program too long, or the emulation misses torch.  Toggles the process-wide
+    torch thread count while it runs (readout_stages runs it in a helper process for that reason)."""
+    cand = tree_to_stages(annotate(probe_tree(K), K))
+    _check_stages(cand, K)
+    g = torch.Generator().manual_seed(0)
+    x, w = torch.randn(4096, K, generator=g), torch.randn(1, K, generator=g)
+    with _single_thread():          # one share: at most a handful of remainder rows among the 4096
+        want = torch.nn.functional.linear(x, w)[:, 0].numpy()
+    match = float((emulate(cand, x.numpy(), w[0].numpy()) == want).mean())
+    if match < 0.99:                # (the BLAS sums a few trailing rows of each thread's share with another kernel)
+        raise ValueError("probed GEMV order reproduces only %.1f %% of rows" % (100 * match))
+    return cand, "host BLAS (probed; %.2f %% of 4096 random rows bit-equal)" % (100 * match)
+
+
+def _probe_in_subprocess(K, path):
+    """The probe in a helper process: O(K^2) single-threaded GEMV calls and torch.set_num_threads(1) stay out of the
+    caller's process (data-loader or OpenMP threads there keep their thread count).  The helper links the same torch, i.e.
+    the same BLAS.  Returns (stages, source) read back from `path`."""
+    import subprocess
+    import sys
+    env = dict(os.environ, ULTRA_READOUT_ORDER="host")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-m", "ultra_amd.host_order", "--probe-to", path, "--K", str(K)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise ValueError((r.stderr or r.stdout).strip().splitlines()[-1] if (r.stderr or r.stdout).strip() else "probe failed")
+    return load_stages(path, K)
 
 
 def readout_stages(K=128):
-    """The stages of this host's F.linear(x, (1, K)) (validated against torch on random rows), or the sequential chain."""
+    """(stages, source) of the readout's last product.  ULTRA_READOUT_ORDER selects:
+        host (default)   this host's F.linear(x, (1, K)) association: read from the on-disk cache (keyed by CPU model, torch
+                         build and BLAS; ULTRA_ORDER_CACHE_DIR, default ~/.cache/ultra_amd) or probed in a helper
+                         process (ULTRA_ORDER_PROBE=inprocess: in this one) and cached;
+        sequential       one k-ascending fma chain;
+        <path>           an order file (save_stages): another host's association, for bit-reproducible scores across hosts.
+    Anything that fails falls back to the sequential chain with a warning; the choice is logged once per process."""
     if K in _CACHE:
         return _CACHE[K]
     mode = os.environ.get("ULTRA_READOUT_ORDER", "host")
     stages, source = sequential_stages(K), "sequential"
-    if mode == "host":
-        try:
-            cand = tree_to_stages(annotate(probe_tree(K), K))
-            g = torch.Generator().manual_seed(0)
-            x, w = torch.randn(4096, K, generator=g), torch.randn(1, K, generator=g)
-            with _single_thread():          # one share: at most a handful of remainder rows among the 4096
-                want = torch.nn.functional.linear(x, w)[:, 0].numpy()
-            match = float((emulate(cand, x.numpy(), w[0].numpy()) == want).mean())
-            if match >= 0.99:            # (the BLAS sums a few trailing rows of each thread's share with another kernel)
-                stages, source = cand, "host BLAS (probed; %.2f %% of 4096 random rows bit-equal)" % (100 * match)
+    try:
+        if mode == "host":
+            key, text = _host_key(K)
+            path = os.path.join(_cache_dir(), "readout_order_%s.json" % key)
+            if os.path.exists(path):
+                stages, source = load_stages(path, K)
+                source += " [cached]"
             else:
-                warnings.warn("ultra_amd: probed GEMV order reproduces only %.1f %% of rows; using the sequential chain"
-                              % (100 * match))
-        except ValueError as exc:
-            warnings.warn("ultra_amd: host GEMV order not recognised (%s); using the sequential chain" % exc)
+                try:
+                    os.makedirs(_cache_dir(), exist_ok=True)
+                except OSError:
+                    path = None
+                if path and os.environ.get("ULTRA_ORDER_PROBE", "subprocess") == "subprocess":
+                    stages, source = _probe_in_subprocess(K, path)
+                else:
+                    stages, source = probe_host(K)
+                    if path:
+                        save_stages(path, stages, source, K, text)
+        elif mode != "sequential":
+            stages, source = load_stages(mode, K)
+            source = "file %s (%s)" % (os.path.basename(mode), source)
+    except Exception as exc:        # noqa: BLE001 -- whatever went wrong, the sequential chain always works
+        warnings.warn("ultra_amd: readout summation order '%s' unavailable (%s: %s); using the sequential chain"
+                      % (mode, type(exc).__name__, exc))
+        stages, source = sequential_stages(K), "sequential (fallback)"
+    import logging
+    logging.getLogger("ultra_amd").info("readout summation order %s: %s", order_id(stages), source)
     _CACHE[K] = (stages, source)
     return _CACHE[K]
 
@@ -294,3 +414,30 @@ def readout_stages(K=128):
 def readout_program(K=128):
     stages, source = readout_stages(K)
     return stages_to_program(stages), source
+
+
+def describe(K=128):
+    """'order-xxxxxxxx: source' of the order in use (bench.py's config.summation_order)."""
+    stages, source = readout_stages(K)
+    return "%s: %s" % (order_id(stages), source)
+
+
+def _main():
+    import argparse
+    ap = argparse.ArgumentParser(description="Probe / save the host BLAS summation order of nn.Linear(K, 1)")
+    ap.add_argument("--K", type=int, default=128)
+    ap.add_argument("--probe-to", help="probe this host and write the order file (used by readout_stages' helper process)")
+    ap.add_argument("--save", help="write the order this host would use (cache or probe) to FILE, for ULTRA_READOUT_ORDER=FILE elsewhere")
+    args = ap.parse_args()
+    if args.probe_to:
+        stages, source = probe_host(args.K)
+        save_stages(args.probe_to, stages, source, args.K, _host_key(args.K)[1])
+        return
+    stages, source = readout_stages(args.K)
+    if args.save:
+        save_stages(args.save, stages, source, args.K, _host_key(args.K)[1])
+    print(describe(args.K))
+
+
+if __name__ == "__main__":
+    _main()

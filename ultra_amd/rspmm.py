@@ -416,8 +416,12 @@ def get_plan(edge_index, edge_type, num_node, num_relation, exact_order=None):
     if hit is not None:
         plan, ei_ref, et_ref = hit
         _PLAN_CACHE.move_to_end(key)
+        if _PLAN_RECORDER is not None:
+            _PLAN_RECORDER.append(plan)
         return plan
     plan = Plan(edge_index, edge_type, num_node, num_relation, **defaults)
+    if _PLAN_RECORDER is not None:
+        _PLAN_RECORDER.append(plan)
     # the tensors are kept alive with the plan so a recycled data_ptr can never alias a stale entry
     _PLAN_CACHE[key] = (plan, edge_index, edge_type)
     while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
@@ -430,8 +434,36 @@ def clear_plan_cache():
 
 
 def cached_plans():
-    """The Plan objects currently held by the cache (a hipGraph capture pins the ones its launches used)."""
+    """The Plan objects currently held by the cache."""
     return [entry[0] for entry in _PLAN_CACHE.values()]
+
+
+_PLAN_RECORDER = None
+
+
+class record_plans(object):
+    """with record_plans() as used: ...   -- `used` collects the plans get_plan() hands out inside the block (each once).
+    A hipGraph capture pins exactly the plans its warm-up runs asked for (graph.py), not whatever else sits in the cache."""
+
+    def __enter__(self):
+        global _PLAN_RECORDER
+        self._outer = _PLAN_RECORDER
+        self._raw = []
+        _PLAN_RECORDER = self._raw
+        self.plans = []
+        return self
+
+    def __exit__(self, *exc):
+        global _PLAN_RECORDER
+        _PLAN_RECORDER = self._outer
+        seen = set()
+        for plan in self._raw:
+            if id(plan) not in seen:
+                seen.add(id(plan))
+                self.plans.append(plan)
+        if self._outer is not None:
+            self._outer.extend(self.plans)
+        return False
 
 
 class _PlanRSPMM(autograd.Function):
