@@ -8,7 +8,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 part="${1:-A}"
-R="${2:-r2}"
+R="${2:-r3}"
 OUT=gpurun_out/$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp

@@ -35,5 +35,7 @@ def run(flags, iters=50):
 print("rows", rows)
 print("full (LN+relu+residual)      %.1f us" % run(7))
 print("no LN                        %.1f us" % run(6))
+print("no matrix chain (measurement)  %.1f us" % run(7 | 256))
+print("no matrix chain, no LN          %.1f us" % run(6 | 256))
 flops = rows * 128 * 64 * 2
 print("matrix floor @157 TF         %.1f us;  bytes floor @5 TB/s %.1f us" % (flops / 157e12 * 1e6, rows * 64 * 4 * 3 / 5e12 * 1e6))
