@@ -557,7 +557,58 @@ static int backward_impl(ultra_plan *p, int sum, int mul, int dtype, const void 
         }
         return ULTRA_OK;
     }
-    // min / max: gradient flows to every edge whose message equals the output (operator.cuh:62-64,75-77)
+    // min / max: gradient flows to every edge whose message equals the output (operator.cuh:62-64,75-77).  With whole
+    // 16-byte chunks the destinations GATHER over the transposed / relation-major plans (no atomics, deterministic); the
+    // reference's scatter with atomics (restated in rspmm_edge_bwd_kernel) remains for unaligned / odd-length rows.
+    if (vec4 && row_len % 4 == 0 && p->num_edge > 0) {
+        if ((rc = ensure_backward_plans(p))) return rc;
+        for (int which = 0; which < 2; ++which) {
+            ultra_plan *q = which == 0 ? p->tplan : p->rplan;
+            const ultra_mat *dst = which == 0 ? xgrad : rgrad;
+            if ((rc = upload_plan(q))) return rc;
+            if (q->n_slot > 0 &&
+                (rc = ensure_scratch(&q->d.partial, &q->d.partial_bytes, (size_t)q->n_slot * n_outer * row_len * esz, q)))
+                return rc;
+            GatherBwdParams gp;
+            std::memset(&gp, 0, sizeof(gp));
+            gp.items = q->d.items;
+            gp.n_item = (int32_t)q->items.size();
+            gp.col = q->d.col, gp.type = q->d.type, gp.perm = q->d.perm;
+            gp.w = w;
+            gp.rel = ep.rel, gp.x = ep.x, gp.out = ep.out, gp.og = ep.og;
+            gp.grad = dst->ptr, gp.grad_so = dst->stride_outer, gp.grad_sr = dst->stride_row;
+            gp.partial = q->d.partial;
+            gp.n_outer = (int32_t)n_outer, gp.row_len = (int32_t)row_len;
+            gp.spans_per_outer = (int32_t)((row_len + 63) / 64);
+            gp.n_span = gp.spans_per_outer * gp.n_outer;
+            const int grid = 2048;
+            gp.smod = std::min<int32_t>(gp.n_span, grid);
+            gp.nparts = grid / gp.smod;
+            const hipError_t e = dtype == ULTRA_F32 ? launch_gather_bwd_t<float>(sum, mul, which == 1, gp, grid, stream)
+                                                    : launch_gather_bwd_t<double>(sum, mul, which == 1, gp, grid, stream);
+            if (e != hipSuccess) return hip_fail(e, "rspmm_minmax_bwd_gather_kernel launch");
+            if (!q->split_row.empty()) {
+                FixupParams xp;
+                std::memset(&xp, 0, sizeof(xp));
+                xp.split_row = q->d.split_row, xp.split_ptr = q->d.split_ptr;
+                xp.n_split = (int32_t)q->split_row.size();
+                xp.partial = q->d.partial;
+                xp.out = dst->ptr, xp.out_stride_outer = dst->stride_outer, xp.out_stride_row = dst->stride_row;
+                xp.n_outer = gp.n_outer, xp.row_len = gp.row_len;
+                const long long total = (long long)xp.n_split * n_outer * (row_len / 4);
+                const int blocks = (int)std::min<long long>((total + 15) / 16, 16384);
+                if (dtype == ULTRA_F32)
+                    hipLaunchKernelGGL((rspmm_fixup_kernel<float, 4, 0>), dim3(blocks), dim3(256), 0, stream, xp);
+                else
+                    hipLaunchKernelGGL((rspmm_fixup_kernel<double, 4, 0>), dim3(blocks), dim3(256), 0, stream, xp);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        if (wgrad) {
+            if ((rc = launch_edge_kernel(dtype, 4, sum, mul, /*want_ri=*/false, ep, stream))) return rc;
+        }
+        return ULTRA_OK;
+    }
     if ((rc = launch_fill_zero(dtype, rgrad, p->num_rel, stream))) return rc;
     if ((rc = launch_fill_zero(dtype, xgrad, p->num_in, stream))) return rc;
     if (p->num_edge > 0) {

@@ -207,6 +207,112 @@ inline int launch_fill_zero(int dtype, const ultra_mat *m, int64_t rows, hipStre
     return ULTRA_OK;
 }
 
+// ---- min / max backward as a GATHER (no atomics, run-to-run deterministic) ----
+// The reference scatters with atomicAdd (rspmm.cu:153-214): every edge whose message equals the forward output
+// (operator.cuh:62-64, 75-77 -- every tying edge gets the full gradient) adds into input_grad[col] and
+// relation_grad[type].  Here each destination row gathers instead, over the plan whose rows are that destination:
+//   input_grad    : the transposed plan (rows = col).     self = x[col];    per edge: i = row, t = type
+//   relation_grad : the relation-major plan (rows = type). self = rel[type]; per edge: j = col, i = row
+//   contribution  = og[i] * [out[i] == w * (rel (x) x)] * w * d(rel (x) x)/d(destination)     -- the reference's factor order
+// One 16-lane group walks one item (a run of at most seg_len sorted edges of one destination row) per 64-element span,
+// four edges' operands in flight; rows cut into several items leave partial sums that rspmm_fixup_kernel adds in slot
+// order, exactly like the forward of a re-associating plan.
+struct GatherBwdParams {
+    const Item *items;
+    int32_t n_item;
+    const int32_t *col, *type, *perm;   // of the destination-major plan: (a, b) per sorted edge, see above
+    const void *w;                      // original edge order, may be NULL (= ones)
+    MatArg rel, x, out, og;
+    void *grad;                         // destination matrix
+    long long grad_so, grad_sr;
+    void *partial;
+    int32_t n_outer, row_len, spans_per_outer, n_span, smod, nparts;
+};
+
+template <typename T, int SUM, int MUL, bool REL_GRAD>
+__global__ void __launch_bounds__(256) rspmm_minmax_bwd_gather_kernel(const GatherBwdParams p) {
+    constexpr int SPAN = 64;
+    using P = Pack<T, 4>;
+    const int l16 = threadIdx.x & 15;
+    const int part = blockIdx.x / p.smod;
+    if (part >= p.nparts) return;
+    const int groups_per_block = blockDim.x >> 4;
+    const T *wt = reinterpret_cast<const T *>(p.w);
+    for (int span = blockIdx.x % p.smod; span < p.n_span; span += p.smod) {
+        const int outer = span / p.spans_per_outer, inner = span - outer * p.spans_per_outer;
+        const int d0 = inner * SPAN + l16 * 4;
+        if (d0 >= p.row_len) continue;
+        const T *relp = reinterpret_cast<const T *>(p.rel.ptr) + outer * p.rel.stride_outer + d0;
+        const T *xp = reinterpret_cast<const T *>(p.x.ptr) + outer * p.x.stride_outer + d0;
+        const T *outp = reinterpret_cast<const T *>(p.out.ptr) + outer * p.out.stride_outer + d0;
+        const T *ogp = reinterpret_cast<const T *>(p.og.ptr) + outer * p.og.stride_outer + d0;
+        for (int q = part * groups_per_block + (threadIdx.x >> 4); q < p.n_item; q += p.nparts * groups_per_block) {
+            const Item it = p.items[q];
+            const P self = REL_GRAD ? *reinterpret_cast<const P *>(relp + (long long)it.row * p.rel.stride_row)
+                                    : *reinterpret_cast<const P *>(xp + (long long)it.row * p.x.stride_row);
+            T acc[4] = {T(0), T(0), T(0), T(0)};
+            const int end = it.begin + it.len;
+            for (int k = it.begin; k < end; k += 4) {
+                int a[4], b[4];
+                T wv[4];
+                P other[4], o[4], g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = k + u < end ? k + u : end - 1;
+                    a[u] = p.col[kk], b[u] = p.type[kk];
+                    wv[u] = wt ? wt[p.perm[kk]] : T(1);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = REL_GRAD ? b[u] : a[u];     // the aggregation row of the edge
+                    other[u] = REL_GRAD ? *reinterpret_cast<const P *>(xp + (long long)a[u] * p.x.stride_row)
+                                        : *reinterpret_cast<const P *>(relp + (long long)b[u] * p.rel.stride_row);
+                    o[u] = *reinterpret_cast<const P *>(outp + (long long)i * p.out.stride_row);
+                    g[u] = *reinterpret_cast<const P *>(ogp + (long long)i * p.og.stride_row);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (k + u < end) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const T r = REL_GRAD ? self.v[e] : other[u].v[e];
+                            const T xi = REL_GRAD ? other[u].v[e] : self.v[e];
+                            const T xb = binary<T, MUL>(r, xi);
+                            const T y = wv[u] * xb;
+                            const T t = g[u].v[e] * (o[u].v[e] == y ? T(1) : T(0));     // operator.cuh:62-64, 75-77
+                            const T tw = t * wv[u];
+                            const T d = (MUL == BIN_MUL) ? (REL_GRAD ? xi : r) : T(1);
+                            acc[e] += tw * d;
+                        }
+                    }
+                }
+            }
+            P res;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) res.v[e] = acc[e];
+            if (it.slot >= 0)
+                *reinterpret_cast<P *>(reinterpret_cast<T *>(p.partial) + ((long long)it.slot * p.n_outer + outer) * p.row_len + d0) = res;
+            else
+                *reinterpret_cast<P *>(reinterpret_cast<T *>(p.grad) + outer * p.grad_so + (long long)it.row * p.grad_sr + d0) = res;
+        }
+    }
+}
+
+template <typename T>
+inline hipError_t launch_gather_bwd_t(int sum, int mul, bool rel_grad, const GatherBwdParams &p, int grid, hipStream_t s) {
+#define ULTRA_GB(S, M)                                                                                                     \
+    if (sum == S && mul == M) {                                                                                            \
+        if (rel_grad)                                                                                                      \
+            hipLaunchKernelGGL((rspmm_minmax_bwd_gather_kernel<T, S, M, true>), dim3(grid), dim3(256), 0, s, p);           \
+        else                                                                                                               \
+            hipLaunchKernelGGL((rspmm_minmax_bwd_gather_kernel<T, S, M, false>), dim3(grid), dim3(256), 0, s, p);          \
+        return hipGetLastError();                                                                                          \
+    }
+    ULTRA_GB(1, 0) ULTRA_GB(1, 1) ULTRA_GB(2, 0) ULTRA_GB(2, 1)
+#undef ULTRA_GB
+    return hipErrorInvalidValue;
+}
+
 template <typename T, int VEC>
 inline hipError_t launch_edge_t(int sum, int mul, bool want_ri, const EdgeParams &p, hipStream_t s) {
     const long long groups = p.num_edge;
