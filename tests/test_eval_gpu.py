@@ -169,3 +169,23 @@ def test_relation_graph_builder_at_dataset_shape_and_plan_format(dev, shape):
         want = dense.export(_lib.ARR_DENSE_ORDER)
         got = tasks.relation_graph_dense_adjacency(rg.adjacency_bits).cpu()
         assert torch.equal(got, want)
+
+
+def test_captured_evaluation_step_equals_the_eager_protocol(dev):
+    """evaluate() replays one hipGraph per full batch (graph.GraphedEvalStep: candidates, tail and head forward, both rank
+    kernels; known answers listed once per shard) and runs the ragged last batch eagerly: same rankings, same metrics as
+    the all-eager run, and the same again when evaluated a second time (fresh capture, plans re-pinned)."""
+    from tests.test_oracle_model import load_golden
+    from ultra_amd import eval as ueval
+    from ultra_amd import models, synthetic
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    data = synthetic.make_kg(num_node=500, num_triple=4000, num_relation_base=5, num_test=45, seed=11).to(dev)
+    model = models.Ultra(**cfg)
+    model.load_state_dict(state)
+    model = model.to(dev).eval()
+    names = ("mr", "mrr", "hits@1", "hits@3", "hits@10", "hits@10_50", "mrr-tail")
+    eager = ueval.evaluate(model, data, batch_size=8, metrics=names, use_graph=False)
+    graphed = ueval.evaluate(model, data, batch_size=8, metrics=names)          # 5 replays + 1 eager batch of 5
+    again = ueval.evaluate(model, data, batch_size=8, metrics=names)
+    assert eager["_num_rankings"] == 90
+    assert graphed == eager and again == eager

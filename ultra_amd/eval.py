@@ -61,28 +61,32 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
     was_training = model.training
     model.eval()
     rows = []
-    graphed = None
-    for start in range(0, len(mine), batch_size):
+    n_full = (len(mine) // batch_size) * batch_size
+    start = 0
+    if use_graph and mine.is_cuda and n_full >= 4 * batch_size:
+        # Full batches: the known true answers of the whole shard are listed ONCE (one sort / unique instead of one per batch
+        # and direction), then every batch is one replay of the captured step (graph.GraphedEvalStep: candidates, both
+        # forwards, both rank kernels) -- the host only feeds (bs, 3) triples and two offset vectors.
+        from .graph import GraphedEvalStep
+        try:
+            t_ptr, t_index = tasks.known_answers(filt, mine[:n_full], "tail")
+            h_ptr, h_index = tasks.known_answers(filt, mine[:n_full], "head")
+            step = GraphedEvalStep(model, test_data, batch_size, t_index, h_index)
+            out = torch.empty(n_full // batch_size, 2 * batch_size, 3, dtype=torch.long, device=mine.device)
+            for b in range(n_full // batch_size):
+                lo = b * batch_size
+                out[b].copy_(step(mine[lo:lo + batch_size], t_ptr[lo:lo + batch_size + 1], h_ptr[lo:lo + batch_size + 1]),
+                             non_blocking=True)
+            rows.append(out.view(-1, 3))
+            start = n_full
+            del step
+        except models.NotOnFusedPath:       # model outside the fused inference path: everything runs eagerly below
+            torch.cuda.synchronize()
+    for start in range(start, len(mine), batch_size):
         batch = mine[start:start + batch_size]
         t_batch, h_batch = tasks.all_negative(test_data, batch)
-        if use_graph and t_batch.is_cuda and len(batch) == batch_size and len(mine) >= 4 * batch_size:
-            # full batches replay the captured hipGraph of the forward (ultra_amd/graph.py); the ragged last one runs eagerly
-            if graphed is None:
-                from .graph import GraphedForward
-                try:
-                    graphed = GraphedForward(model, test_data, t_batch)
-                except models.NotOnFusedPath:       # model outside the fused inference path: stay eager
-                    torch.cuda.synchronize()
-                    use_graph = False
-            if graphed is not None:
-                t_pred = graphed(t_batch).clone()
-                h_pred = graphed(h_batch).clone()
-            else:
-                t_pred = model(test_data, t_batch)
-                h_pred = model(test_data, h_batch)
-        else:
-            t_pred = model(test_data, t_batch)
-            h_pred = model(test_data, h_batch)
+        t_pred = model(test_data, t_batch)
+        h_pred = model(test_data, h_batch)
         # filtered rank of the positives and their number of negatives (tasks.py:94-141): one fused kernel per direction
         # on the GPU (no (bs, N) masks); the mask-based formulation of the reference with the same interface elsewhere
         rank_fn = tasks.filtered_ranking if t_pred.is_cuda else tasks.filtered_ranking_masks

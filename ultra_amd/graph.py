@@ -92,3 +92,70 @@ class GraphedForward(object):
         if check and self.valid is not None:
             assert bool(self.valid.all()), "every row of `batch` must share its head (or tail) and its relation (models.py:196-197)"
         return self.static_out
+
+
+class GraphedEvalStep(object):
+    """One batch of the filtered-ranking protocol (script/run.py:131-160) as ONE hipGraph replay: candidate construction
+    (tasks.all_negative), the tail and the head forward, and the two fused rank kernels.  Per batch the host copies three
+    small tensors into the graph's inputs -- the (bs, 3) triples and the two (bs + 1) offset vectors into the known-answer
+    lists, which evaluate() builds once for its whole shard -- and replays; the (2 bs, 3) rows [rank, #negatives, is_tail]
+    come back in a static buffer.  No (bs, N, 3) candidate copy, no score clone, no per-batch sort / unique."""
+
+    def __init__(self, model, data, batch_size, known_tail, known_head, warmup=2):
+        import ctypes
+        from . import tasks
+        from ._lib import check, lib
+        dev = data.edge_index.device
+        self.model, self.data, self.bs = model, data, batch_size
+        self.t_index, self.h_index = known_tail.contiguous(), known_head.contiguous()
+        self.batch = torch.zeros(batch_size, 3, dtype=torch.long, device=dev)
+        self.t_ptr = torch.zeros(batch_size + 1, dtype=torch.long, device=dev)
+        self.h_ptr = torch.zeros(batch_size + 1, dtype=torch.long, device=dev)
+        self.rows = torch.zeros(2 * batch_size, 3, dtype=torch.long, device=dev)
+        self.rows[:batch_size, 2] = 1
+        self._pinned = []
+        n = data.num_nodes
+
+        def step():
+            t_batch, h_batch = tasks.all_negative(data, self.batch)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            for cand, pos_col, ptr, index, lo in ((t_batch, 1, self.t_ptr, self.t_index, 0),
+                                                   (h_batch, 0, self.h_ptr, self.h_index, batch_size)):
+                pred = model(data, cand).float().contiguous()
+                pos = self.batch[:, pos_col].contiguous()
+                rank = torch.empty(batch_size, dtype=torch.long, device=dev)
+                neg = torch.empty_like(rank)
+                check(lib.ultra_filtered_rank(pred.data_ptr(), pos.data_ptr(), ptr.data_ptr(), index.data_ptr(), batch_size, n,
+                                              rank.data_ptr(), neg.data_ptr(), stream))
+                self.rows[lo:lo + batch_size, 0] = rank
+                self.rows[lo:lo + batch_size, 1] = neg
+
+        with torch.cuda.device(dev):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.no_grad(), torch.cuda.stream(side), rspmm.record_plans() as used:
+                for _ in range(warmup):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._pinned = used.plans
+            for plan in self._pinned:
+                plan.pin(+1)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                step()
+
+    def __call__(self, batch, t_ptr, h_ptr):
+        """rows (2 bs, 3) of this batch -- a view of the static buffer: copy before the next call."""
+        self.batch.copy_(batch, non_blocking=True)
+        self.t_ptr.copy_(t_ptr, non_blocking=True)
+        self.h_ptr.copy_(h_ptr, non_blocking=True)
+        self.graph.replay()
+        return self.rows
+
+    def __del__(self):
+        try:
+            for plan in self._pinned:
+                plan.pin(-1)
+        except Exception:
+            pass
