@@ -29,7 +29,11 @@ BINOPS = {0: "v_pk_mul_f32", 1: "v_pk_add_f32"}            # BIN_MUL, BIN_ADD (o
 IDENT = {0: "0", 1: "0x7f7fffff", 2: "0xff7fffff"}
 # cache policy of the record streams: default.  " nt" (streaming) was measured slower: loads return in order, so the
 # longer latency of an nt request stands in front of the gathers queued behind it.
-REC_POLICY = os.environ.get("ULTRA_GEN_REC_POLICY", "")          # add: 0, min: +FLT_MAX, max: -FLT_MAX (operator.cuh:43-80)
+REC_POLICY = os.environ.get("ULTRA_GEN_REC_POLICY", "")
+# cache policy of the flush stores of the stream walk: nt (written once, read by the NEXT kernel).  Measured (r3, rocprofv3
+# FETCH_SIZE + WRITE_SIZE): FB15k237 bs 8 180 -> 155 MB and 78.3 -> 77.5 us, CoDEx-L bs 8 1.91 -> 1.88 GB and 266 -> 257 us;
+# " sc1" the same within noise; "" = default policy.
+OUT_POLICY = os.environ.get("ULTRA_GEN_OUT_POLICY", " nt")          # add: 0, min: +FLT_MAX, max: -FLT_MAX (operator.cuh:43-80)
 
 
 def vr(lo, n=1):
@@ -144,7 +148,7 @@ def stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag):
         for e in range(4):
             a("%s v%d, v%d, %%[b%d]" % (op, ACC + e, ACC + e, e))
         a("s_mov_b64 exec, %[mk]")
-        a("global_store_dwordx4 v%d, %s, %%[ob]" % (ob + q, vr(ACC, 4)))
+        a("global_store_dwordx4 v%d, %s, %%[ob]%s" % (ob + q, vr(ACC, 4), OUT_POLICY))
         a("s_nop 2", "gfx940+: a VALU write of the data registers of a > 8-byte store needs 2 wait states behind the store "
                      "(with one, v_mov v116 reached the last lanes' data first)")
         for e in range(4):
