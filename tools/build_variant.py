@@ -3,7 +3,7 @@
     python tools/build_variant.py NAME -DULTRA_ASM_WALK=0 [...]      ->  ultra_amd/lib/variants/libultra_amd_NAME.so
     ULTRA_AMD_LIB=ultra_amd/lib/variants/libultra_amd_NAME.so python tools/...
 
-Only the translation units that see the flags (the reference-order kernels) are recompiled; the other objects of the
+Only the translation units that see such flags (the reference-order kernels, the dense epilogues) are recompiled; the other objects of the
 default build are linked as they are."""
 import glob
 import os
@@ -24,7 +24,7 @@ def main():
     procs = []
     for src in B._sources():
         base = os.path.basename(src)
-        if base.startswith("rspmm_order_") or base in ("rspmm_api.hip", "plan.cpp"):
+        if base.startswith("rspmm_order_") or base in ("rspmm_api.hip", "plan.cpp", "dense_kernels.hip"):
             obj = os.path.join(odir, base + ".o")
             cmd = [B.HIPCC] + B.CFLAGS + flags + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
             procs.append((subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), src))

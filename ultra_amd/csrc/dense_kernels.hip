@@ -83,7 +83,8 @@ __device__ __forceinline__ void row_moments_pair(const float (&v)[2][16], const 
 // (CONV_DBG_NO_MATRIX: loads, operand swaps, epilogue, stores only) against a 14 us matrix floor and an 18 us byte floor
 // -- the memory side bounds the kernel.  Measured and dropped: coalesced 1-KB row loads turned into the operand layout
 // through LDS (56 us: the staging round trip costs more than the 32-B-per-row requests it replaces); three waves per
-// SIMD without the register prefetch of the next tile (33.6 us); one wave per SIMD with 3.5 tiles each (33.7 us).
+// SIMD without the register prefetch of the next tile (33.6 us); one wave per SIMD with 3.5 tiles each (33.7 us);
+// nt loads of the aggregate / nt stores of the output (35.9 / 36.7 / 39.5 us for loads / stores / both).
 __global__ void __launch_bounds__(512, 2) conv_update_kernel(const ConvParams p) {
     // [tile m][i][lane][q] : W[32 m + (lane & 31)][2 s + (lane >> 5)], s = 4 i + {0, 2, 1, 3}[q] -- the k pair that
     // register q of the swapped data chunk i holds (see swap32)
