@@ -474,6 +474,7 @@ def main():
             from oracle import ultra_oracle_model
             fn = ultra_oracle_model.reference_rspmm_fn()
             ncores = available_cores()
+            host_threads = torch.get_num_threads()
             torch.set_num_threads(ncores)
             batch = data_cpu.target_triples[:bs]
             t_batch_cpu, _ = tasks.all_negative(data_cpu, batch)
@@ -575,6 +576,7 @@ def main():
                     "queries": len(queries), "source": "fact-graph edges with reference ranks 1 .. 30 (tests/golden/topk_queries_fb15k237.json)",
                     "metrics_gpu": ranking_metrics(rg), "metrics_reference": ranking_metrics(rr),
                     "rank_mismatches": int((rg != rr).sum()), "metrics_identical": ranking_metrics(rg) == ranking_metrics(rr)}
+            torch.set_num_threads(host_threads)      # (the CPU baseline's thread count must not leak into the host-side work below)
             # ---- the re-associating plans (round 1's timed path), same command: throughput and parity beside the timed mode ----
             rspmm.set_plan_defaults(exact_order=False)
             try:
