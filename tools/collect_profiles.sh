@@ -2,7 +2,7 @@
 # Collect the round's measurement artefacts on a GPU box into gpurun_out/<round>/ (copied to profiles/ afterwards).
 #   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh A r2'   smoke, the bench line (+ raw PMC passes), kernel stats of the
 #                                                                    judged command, 1-process torchrun line
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh B r2'   secondary cases, fine-tune kernel stats, kernel probes,
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh B r2'   secondary cases, fine-tune and config-3 kernel stats, kernel probes,
 #                                                                    evaluation protocol speed
 #   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh C r2'   SQ / TCC counter passes over tools/pmc_target.py
 set -u
@@ -36,6 +36,9 @@ else
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -o run -- \
         python "$OLDPWD/tools/train_probe.py" > /dev/null 2>&1)
     find /tmp/prof_train -name "*kernel_stats.csv" -exec cp {} "$OUT/${R}_finetune_kernel_stats.csv" \;
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c3 -o run -- \
+        python "$OLDPWD/tools/config3_probe.py" max > /dev/null 2>&1)
+    find /tmp/prof_c3 -name "*kernel_stats.csv" -exec cp {} "$OUT/${R}_config3_kernel_stats.csv" \;
     { timeout 120 python tools/conv_probe.py; timeout 120 python tools/readout_probe.py; } > "$OUT/${R}_kernel_probes.txt" 2>&1
     timeout 600 python tools/eval_speed.py 512 > "$OUT/${R}_eval_speed.txt" 2>&1
 fi
