@@ -263,3 +263,25 @@ def test_group_streams_cover_every_group_row_once_in_sorted_edge_order():
     assert seen == set(range(N)) - chain_rows
     loads = sdesc[:, 1].view(nparts, 64)
     assert int(loads.max() - loads.min()) <= int((row_ptr[1:] - row_ptr[:-1]).clamp(max=256).max()) + 64
+
+
+def test_generated_assembly_header_is_in_sync_with_its_generator(tmp_path, monkeypatch):
+    """csrc/rspmm_order_asm.hpp is generated (tools/gen_order_asm.py) and committed: the committed text must be what the
+    generator writes with its default switches, so that the two can not drift apart."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for k in ("ULTRA_GEN_REC_POLICY", "ULTRA_GEN_OUT_POLICY", "ULTRA_GEN_PROD_NOWAIT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("ULTRA_GEN_OUT", str(tmp_path / "asm.hpp"))
+    spec = importlib.util.spec_from_file_location("gen_order_asm", os.path.join(root, "tools", "gen_order_asm.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gen.main()
+    fresh = (tmp_path / "asm.hpp").read_text()
+    committed = open(os.path.join(root, "ultra_amd", "csrc", "rspmm_order_asm.hpp")).read()
+    assert fresh == committed
+    # every path out of a statement drains the vector-memory queue, and the statements declare what they clobber
+    assert fresh.count("asm volatile(") == 14 and fresh.count('"memory"') == 14
+    for block in fresh.split("asm volatile(")[1:]:
+        assert "s_waitcnt vmcnt(0)" in block.split(");")[0]
