@@ -85,6 +85,12 @@ __device__ __forceinline__ void row_moments_pair(const float (&v)[2][16], const 
 // through LDS (56 us: the staging round trip costs more than the 32-B-per-row requests it replaces); three waves per
 // SIMD without the register prefetch of the next tile (33.6 us); one wave per SIMD with 3.5 tiles each (33.7 us);
 // nt loads of the aggregate / nt stores of the output (35.9 / 36.7 / 39.5 us for loads / stores / both).
+// Round 3, second pass (tools/conv_sweep.py, same box A/B; 116 k rows | 624 k rows = CoDEx-L bs 8, HBM bound): this kernel 30.9 | 158 us
+// (memory side alone 23 | 110 us = 4.3 TB/s with 32 MB of requests in flight: the memory system is saturated for this
+// pattern, not starved -- more waves do not help).  First tile requested before the weight staging: 33.2 | 155.  Operands
+// swapped in place + aggregate chunks of the next tile requested inside the second half of the chain + one 16-byte weight
+// read per four MFMAs: 184 registers, 33.0 | 154 at two waves per SIMD; capped at 168 registers for three waves per SIMD
+// (23 spilled): 37.3 | 179 (256 x 768 launch: 42.0 | 176).  256-thread or 128-thread workgroups, 1-8 per CU: no better.
 __global__ void __launch_bounds__(512, 2) conv_update_kernel(const ConvParams p) {
     // [tile m][i][lane][q] : W[32 m + (lane & 31)][2 s + (lane >> 5)], s = 4 i + {0, 2, 1, 3}[q] -- the k pair that
     // register q of the swapped data chunk i holds (see swap32)
