@@ -595,6 +595,21 @@ def main():
                                              "re-associated, nn.Linear / nn.LayerNorm still in torch's order"}}
             finally:
                 rspmm.set_plan_defaults()
+            # ---- layers as ONE launch each (ultra_rspmm_forward_update: the update applied in the tail of the rspmm kernel) ----
+            from ultra_amd import layers as _layers
+            was = _layers.FUSED_SPARSE_LAYER
+            _layers.FUSED_SPARSE_LAYER = True
+            try:
+                el3 = timed_run(make_forward(), False)
+                with torch.no_grad():
+                    got3 = model(data, t_batch_cpu.to(dev)).cpu()
+                out.setdefault("modes", {})["one_launch_layers"] = {
+                    "timed": False, "triples_per_s": bs * N * args.steps / el3, "ms_per_step": 1e3 * el3 / args.steps,
+                    "scores_bit_equal_with_the_timed_mode": bool(torch.equal(got3, got)),
+                    "note": "layers.FUSED_SPARSE_LAYER (ULTRA_FUSED_SPARSE_LAYER=1): aggregate + update of entity layers 1-5 in one "
+                            "launch; same bits; not the timed mode (DESIGN.md 3.8: the tail is a chip-wide burst, the gain is ~1 %)"}
+            finally:
+                _layers.FUSED_SPARSE_LAYER = was
     if rank == 0 and world == 1 and not launched and not args.no_secondary:
         # ---- BASELINE.json config 5 (fine-tuning): fwd + bwd + AdamW per step, beside the headline ----
         sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -182,6 +182,25 @@ int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t mul, int32_t dtype, 
                                   const ultra_mat *point_values, const ultra_mat *output, void *stream);
 
 /*
+ * Aggregate + layer update in ONE launch (fp32 inference path of GeneralizedRelationalConv.forward,
+ * /root/reference/ultra/layers.py:84-131, 190-240, with the residual of /root/reference/ultra/models.py:158-160):
+ *
+ *   aggregate = rspmm(sum, mul)(relation, input) [+ point boundary]        -- as ultra_rspmm_forward_point / _forward
+ *   output    = [input +] relu( LayerNorm( W . [input ; aggregate] + b ) ) -- as ultra_conv_update (ultra_nbfnet.h), same `flags` / `eps`
+ *
+ * Every workgroup of the reference-order kernel applies the update to the rows it has just aggregated (they are still in
+ * its L2), so the aggregate is not read back by a second launch.  Results are bit-equal with the two separate calls.
+ * `aggregate` receives the aggregate as before (scratch for the caller); `output` must not alias it or `input`.
+ * point_rows_dev / point_values: both NULL = no boundary.  Served where the stream walk serves ultra_rspmm_forward_point
+ * (ULTRA_PLAN_EXACT_ORDER plan in the sparse format, 64-element rows, every stride equal): ULTRA_ERR_UNSUPPORTED
+ * otherwise, nothing launched -- the caller then makes the two calls.
+ */
+int32_t ultra_rspmm_forward_update(ultra_plan *plan, int32_t mul, const ultra_mat *relation, const ultra_mat *input,
+                                   const int64_t *point_rows_dev, const ultra_mat *point_values, const ultra_mat *aggregate,
+                                   const void *weight, const void *bias, const void *ln_weight, const void *ln_bias, float eps,
+                                   int32_t flags, const ultra_mat *output, void *stream);
+
+/*
  * Layer 0 of an NBFNet applied to its own boundary condition (/root/reference/ultra/models.py:72-80, 150-163 with
  * /root/reference/ultra/layers.py:183-207, 233-240; sum aggregate, DistMult message, hidden dim 64, fp32):
  *     x0[b, n] = src_values[b] (or ones if NULL) at n == src_rows[b], else 0
@@ -276,7 +295,8 @@ int32_t ultra_plan_schedule_info(ultra_plan *plan, int32_t nparts, ultra_schedul
  * group items n_chain_row + 4 u .. + 3 of ULTRA_ARR_ITEM), 3 chunks as {row, begin, count, flags} quadruples (flags: bit 0 first,
  * bit 1 last chunk of its row; a first chunk also holds the row's edge count in flags >> 2), 4 group-stream descriptors {first record, steps} of the
  * nparts * 64 16-lane groups, 5 stream records as (col, type) pairs: the rows of a stream back to back, each row's edges in
- * sorted order followed by a marker (row, num_relation).  Workgroup q of a span walks chunks [chunk_ptr[q], chunk_ptr[q + 1]),
+ * sorted order followed by a marker (row, num_relation), 6 the rows each workgroup aggregates (ascending, -1 padded to whole 32-row
+ * tiles), 7 their bounds [nparts + 1].  Workgroup q of a span walks chunks [chunk_ptr[q], chunk_ptr[q + 1]),
  * then its units (C++ walk) or its 64 streams (assembly walk of the fp32 inference configuration). */
 int32_t ultra_plan_schedule_export(ultra_plan *plan, int32_t nparts, int32_t which, int32_t *dst_host, int64_t capacity_elems,
                                    int64_t *count);

@@ -1,0 +1,125 @@
+"""ultra_rspmm_forward_update: aggregate + layer update in one launch (the update runs in the tail of the reference-order
+rspmm kernel, on the rows each workgroup has just summed) must equal the two launches it replaces -- ultra_rspmm_forward_point
+then ultra_conv_update -- BIT FOR BIT, and with them the oracle chain (rspmm_oracle + the torch fp32 update)."""
+import itertools
+
+import pytest
+import torch
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    dict(num_node=50, num_edge=400, num_relation=5, seed=0),
+    dict(num_node=64, num_edge=300, num_relation=3, seed=1, hub=(7, 700)),          # a chain row
+    dict(num_node=40, num_edge=100, num_relation=4, seed=2, empty_rows=10),         # rows without edges are updated too
+    dict(num_node=1, num_edge=17, num_relation=2, seed=5),
+    dict(num_node=300, num_edge=2000, num_relation=9, seed=8, hub=(11, 4321)),
+    dict(num_node=3000, num_edge=40000, num_relation=40, seed=9, hub=(5, 3000)),    # several tiles per workgroup
+]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _reset():
+    from ultra_amd import rspmm
+    rspmm.set_tuning()
+    rspmm.set_plan_defaults()
+    yield
+    rspmm.set_tuning()
+    rspmm.set_plan_defaults()
+
+
+def _operands(case, batch, dev, seed):
+    N, R = case["num_node"], case["num_relation"]
+    g = torch.Generator().manual_seed(seed)
+    rel = torch.randn(batch, R, 64, generator=g).to(dev)
+    x = torch.randn(batch, N, 64, generator=g).to(dev)
+    rows = torch.randint(0, N, (batch,), generator=g).to(dev)
+    vals = torch.randn(batch, 64, generator=g).to(dev)
+    weight = (torch.randn(64, 128, generator=g) / 11).to(dev)
+    bias = torch.randn(64, generator=g).to(dev)
+    ln_w, ln_b = torch.randn(64, generator=g).to(dev), torch.randn(64, generator=g).to(dev)
+    return rel, x, rows, vals, weight, bias, ln_w, ln_b
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("mul", ["mul", "add"])
+@pytest.mark.parametrize("batch,flags,point", [(8, 7, True), (3, 7, False), (1, 3, True), (2, 4, True), (5, 0, True), (16, 6, True)])
+def test_one_launch_equals_the_two_launches(dev, case, mul, batch, flags, point):
+    from ultra_amd import dense
+    from ultra_amd.rspmm import Plan
+    ei, et = helpers.random_graph(**case)
+    plan = Plan(ei, et, case["num_node"], case["num_relation"], exact_order=True)
+    rel, x, rows, vals, weight, bias, ln_w, ln_b = _operands(case, batch, dev, case["seed"] + 100)
+    pt = (rows, vals) if point else None
+    agg = plan.forward(rel, x, sum="add", mul=mul, point=pt)
+    want = dense._conv_update_forward(x, agg, weight, bias, ln_w if flags & 1 else None, ln_b if flags & 1 else None, 1e-5, flags)
+    got = plan.forward_update(rel, x, weight, bias, ln_w if flags & 1 else None, ln_b if flags & 1 else None, 1e-5, flags,
+                              mul=mul, point=pt)
+    assert got is not None, "the stream walk serves this call"
+    assert torch.equal(got, want), "max |d| = %g at %d elements" % ((got - want).abs().max().item(), int((got != want).sum()))
+    again = plan.forward_update(rel, x, weight, bias, ln_w if flags & 1 else None, ln_b if flags & 1 else None, 1e-5, flags,
+                                mul=mul, point=pt)
+    assert torch.equal(again, want)
+
+
+@pytest.mark.parametrize("grid", [8, 64, 256])
+def test_any_number_of_workgroups_per_span(dev, grid):
+    from ultra_amd import dense, rspmm
+    from ultra_amd.rspmm import Plan
+    case = CASES[4]
+    ei, et = helpers.random_graph(**case)
+    plan = Plan(ei, et, case["num_node"], case["num_relation"], exact_order=True)
+    rel, x, rows, vals, weight, bias, ln_w, ln_b = _operands(case, 8, dev, 3)
+    rspmm.set_tuning(grid=grid)
+    agg = plan.forward(rel, x, sum="add", mul="mul", point=(rows, vals))
+    want = dense._conv_update_forward(x, agg, weight, bias, ln_w, ln_b, 1e-5, 7)
+    got = plan.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7, point=(rows, vals))
+    assert got is not None and torch.equal(got, want)
+
+
+def test_calls_the_launch_does_not_serve_are_declined_not_approximated(dev):
+    from ultra_amd.rspmm import Plan
+    case = CASES[0]
+    ei, et = helpers.random_graph(**case)
+    rel, x, rows, vals, weight, bias, ln_w, ln_b = _operands(case, 2, dev, 4)
+    loose = Plan(ei, et, case["num_node"], case["num_relation"], exact_order=False)
+    assert loose.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7, point=(rows, vals)) is None
+    exact = Plan(ei, et, case["num_node"], case["num_relation"], exact_order=True)
+    wide = torch.randn(2, case["num_node"], 128, device=dev)
+    assert exact.forward_update(torch.randn(2, case["num_relation"], 128, device=dev), wide, weight, bias, ln_w, ln_b, 1e-5, 7) is None
+    strided = torch.randn(2, case["num_node"], 128, device=dev)[:, :, :64]          # row stride 128: not the aggregate's stride
+    assert exact.forward_update(rel, strided, weight, bias, ln_w, ln_b, 1e-5, 7, point=(rows, vals)) is None
+
+
+@pytest.mark.parametrize("message_func", ["distmult", "transe"])
+def test_layer_takes_the_one_launch_path_and_keeps_its_bits(dev, message_func):
+    """GeneralizedRelationalConv (layers.py:84-131) on a point boundary, inference: FUSED_SPARSE_LAYER on / off."""
+    from ultra_amd import layers
+    case = CASES[4]
+    ei, et = helpers.random_graph(**case)
+    ei, et = ei.to(dev), et.to(dev)
+    N, R = case["num_node"], case["num_relation"]
+    torch.manual_seed(0)
+    conv = layers.GeneralizedRelationalConv(64, 64, R, 64, message_func=message_func, aggregate_func="sum", layer_norm=True,
+                                            activation="relu", dependent=False, project_relations=False).to(dev)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, N, 64, generator=g).to(dev)
+    query = torch.randn(4, 64, generator=g).to(dev)
+    boundary = layers.PointBoundary(torch.tensor([3, 0, 77, 299], device=dev), torch.randn(4, 64, generator=g).to(dev), N)
+    outs = []
+    with torch.no_grad():
+        for on in (True, False):
+            layers.FUSED_SPARSE_LAYER = on
+            try:
+                outs.append(conv._forward_impl(x, query, boundary, ei, et, (N, N), residual=True))
+            finally:
+                layers.FUSED_SPARSE_LAYER = True
+    assert torch.equal(outs[0], outs[1])

@@ -265,6 +265,40 @@ def test_group_streams_cover_every_group_row_once_in_sorted_edge_order():
     assert int(loads.max() - loads.min()) <= int((row_ptr[1:] - row_ptr[:-1]).clamp(max=256).max()) + 64
 
 
+def test_workgroup_row_lists_partition_the_rows_along_the_streams():
+    """Work list of the update tail (plan.cpp build_schedule): workgroup q's list = its chain rows + the rows of its 64
+    streams, ascending, padded with -1 to whole 32-row tiles; the lists partition the rows."""
+    from ultra_amd.rspmm import Plan
+    from ultra_amd import _lib
+    ei, et = helpers.random_graph(num_node=300, num_edge=2000, num_relation=9, seed=8, hub=(11, 700))
+    N, R = 300, 9
+    plan = Plan(ei, et, N, R, exact_order=True)
+    for nparts in (1, 4):
+        sdesc, srec = plan.streams(nparts)
+        prow, prow_ptr = plan.part_rows(nparts)
+        assert prow_ptr.shape == (nparts + 1,) and int(prow_ptr[0]) == 0 and int(prow_ptr[-1]) == prow.numel()
+        n_chain = plan.info()["n_chain_row"]
+        chain_rows = set(plan.export(_lib.ARR_ITEM).view(-1, 4)[:n_chain, 0].tolist())
+        assert len(chain_rows) >= 1
+        seen = []
+        for q in range(nparts):
+            b, e = int(prow_ptr[q]), int(prow_ptr[q + 1])
+            assert (e - b) % 32 == 0
+            mine = prow[b:e]
+            real = mine[mine >= 0]
+            assert torch.equal(mine[:real.numel()], real) and real.numel() > e - b - 32     # padding at the end, under one tile
+            assert torch.equal(real, real.sort()[0])
+            stream_rows = set()
+            for g in range(q * 64, (q + 1) * 64):
+                first, steps = sdesc[g].tolist()
+                seg = srec[first:first + steps]
+                stream_rows |= set(seg[seg[:, 1] == R, 0].tolist())
+            assert stream_rows <= set(real.tolist())
+            assert set(real.tolist()) - stream_rows <= chain_rows
+            seen += real.tolist()
+        assert sorted(seen) == list(range(N))
+
+
 def test_generated_assembly_header_is_in_sync_with_its_generator(tmp_path, monkeypatch):
     """csrc/rspmm_order_asm.hpp is generated (tools/gen_order_asm.py) and committed: the committed text must be what the
     generator writes with its default switches, so that the two can not drift apart."""

@@ -22,10 +22,9 @@
 #include "plan.hpp"
 #include "device_scope.hpp"
 #include "torch_math.hpp"
+#include "update_tile.hpp"
 
 namespace ultra {
-
-using f32x16 = float __attribute__((ext_vector_type(16)));
 
 struct ConvParams {
     const float *x;
@@ -37,47 +36,6 @@ struct ConvParams {
     float eps;
     int flags;
 };
-
-enum { CONV_LN = 1, CONV_RELU = 2, CONV_RESIDUAL = 4, CONV_DBG_NO_MATRIX = 256 /* measurement: skip the matrix chain */ };
-
-// feature owned by accumulator register r of feature tile m in lane half h (32x32 C/D layout)
-__device__ __forceinline__ int feat_of(int m, int r, int h) { return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// v_permlane32_swap: lanes 32..63 of `lo_pair` trade places with lanes 0..31 of `hi_pair`.  A lane half h holds the
-// 16-byte chunk k = 8 i + 4 h .. + 3 of its row; after swapping (.x, .y) and (.z, .w) the four registers hold, in lane
-// half h, element 2 s + h of the k pairs s = 4 i, 4 i + 2 and 4 i + 1, 4 i + 3: each v_mfma_f32_32x32x2_f32 then consumes
-// two CONSECUTIVE k, and the accumulator chain runs over k = 0, 1, 2, ... exactly like the reference's nn.Linear
-// (torch_math.hpp).
-__device__ __forceinline__ void swap32(float &lo_pair, float &hi_pair) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_pair), __float_as_uint(hi_pair), false, false);
-    lo_pair = __uint_as_float(r[0]);
-    hi_pair = __uint_as_float(r[1]);
-}
-
-// LayerNorm statistics of a row held by the lane pair (lane, lane ^ 32) in the accumulator layout of the transposed
-// product: lane half h owns features 32 m + (r & 3) + 8 (r >> 2) + 4 h, i.e. ALL eight members 8 j + i of the Welford
-// accumulators i = (r & 3) + 4 h (torch_math.hpp) -- four accumulators per lane, the other four come over one swap.
-__device__ __forceinline__ void row_moments_pair(const float (&v)[2][16], const int h, const float eps, float &mean, float &rstd) {
-    Moments own[4], other[4];
-#pragma unroll
-    for (int il = 0; il < 4; ++il) {
-        float x[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = v[j >> 2][4 * (j & 3) + il];
-        own[il] = welford8(x);
-        other[il].m1 = __shfl_xor(own[il].m1, 32);
-        other[il].m2 = __shfl_xor(own[il].m2, 32);
-    }
-    Moments all[8];
-#pragma unroll
-    for (int il = 0; il < 4; ++il) {
-        all[il].m1 = h ? other[il].m1 : own[il].m1;
-        all[il].m2 = h ? other[il].m2 : own[il].m2;
-        all[4 + il].m1 = h ? own[il].m1 : other[il].m1;
-        all[4 + il].m2 = h ? own[il].m2 : other[il].m2;
-    }
-    merge8(all, eps, mean, rstd);
-}
 
 // Where the time goes at 116 k rows (tools/conv_probe.py; r3): 31-33 us with the matrix chain, 22-23 us without it
 // (CONV_DBG_NO_MATRIX: loads, operand swaps, epilogue, stores only) against a 14 us matrix floor and an 18 us byte floor

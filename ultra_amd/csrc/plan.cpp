@@ -367,6 +367,18 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
             }
         }
         s->srec.resize(s->srec.size() + 2 * ORDER_PAD, 0);   // (records are requested two rounds ahead without a bounds test)
+        // rows per workgroup: chain rows + stream rows, ascending, whole 32-row tiles
+        s->prow_ptr.assign((size_t)nparts + 1, 0);
+        for (int32_t q = 0; q < nparts; ++q) {
+            std::vector<int32_t> mine;
+            for (int32_t c : part_chain[(size_t)q]) mine.push_back(p->items[(size_t)c].row);
+            for (int g = 0; g < ORDER_GROUPS; ++g)
+                for (int32_t it : srows[(size_t)q * ORDER_GROUPS + g]) mine.push_back(p->items[(size_t)it].row);
+            std::sort(mine.begin(), mine.end());
+            s->prow.insert(s->prow.end(), mine.begin(), mine.end());
+            while (s->prow.size() % 32) s->prow.push_back(-1);
+            s->prow_ptr[(size_t)q + 1] = (int32_t)s->prow.size();
+        }
     }
     // the chain producers request descriptors a fixed number of chunks ahead without a bounds test: readable, harmless
     // entries (edge 0) behind the last chunk

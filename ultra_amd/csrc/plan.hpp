@@ -51,7 +51,12 @@ struct Schedule {
     // workgroup gets a sequence of whole rows; `srec` holds, stream after stream, the rows' (col, type) records in sorted
     // edge order, each row closed by a marker record (row, num_rel); sdesc[part * ORDER_GROUPS + group] = {first record, steps}.
     std::vector<int32_t> srec, sdesc;
+    // Rows each workgroup aggregates (its chain rows and the rows of its streams), ascending, padded with -1 to whole
+    // 32-row tiles: prow[prow_ptr[part] .. prow_ptr[part + 1]) -- the work list of the update the workgroup applies to its
+    // own rows after the walk (rspmm_order_kernels.hpp, UPDATE).
+    std::vector<int32_t> prow, prow_ptr;
     int32_t *d_chunk_ptr = nullptr, *d_unit_ptr = nullptr, *d_units = nullptr, *d_srec = nullptr, *d_sdesc = nullptr;
+    int32_t *d_prow = nullptr, *d_prow_ptr = nullptr;
     Chunk *d_chunks = nullptr;
     double max_cost = 0.0, mean_cost = 0.0;             // cost model's load of the fullest / average workgroup
 };

@@ -138,6 +138,8 @@ static void free_schedules(ultra_plan *p) {
         if (s->d_chunks) (void)hipFree(s->d_chunks);
         if (s->d_srec) (void)hipFree(s->d_srec);
         if (s->d_sdesc) (void)hipFree(s->d_sdesc);
+        if (s->d_prow) (void)hipFree(s->d_prow);
+        if (s->d_prow_ptr) (void)hipFree(s->d_prow_ptr);
         delete s;
     }
     p->schedules.clear();
@@ -156,7 +158,8 @@ static int get_schedule(ultra_plan *p, int32_t nparts, Schedule **out) {
     int rc;
     if ((rc = upload_array(&s->d_chunk_ptr, s->chunk_ptr)) || (rc = upload_array(&s->d_unit_ptr, s->unit_ptr)) ||
         (rc = upload_array(&s->d_units, s->units)) || (rc = upload_array(&s->d_chunks, s->chunks)) ||
-        (rc = upload_array(&s->d_srec, s->srec)) || (rc = upload_array(&s->d_sdesc, s->sdesc))) {
+        (rc = upload_array(&s->d_srec, s->srec)) || (rc = upload_array(&s->d_sdesc, s->sdesc)) ||
+        (rc = upload_array(&s->d_prow, s->prow)) || (rc = upload_array(&s->d_prow_ptr, s->prow_ptr))) {
         delete s;
         return rc;
     }
@@ -244,9 +247,11 @@ static bool mat_vec_ok(const ultra_mat *m, int64_t step) {
 // Generic forward on a plan (internal: accepts the BIN_LHS / BIN_RHS variants used by backward).
 // bnd_rows != NULL: `bnd` is a POINT boundary -- one row per outer slice (n_row == 1), added to output row
 // bnd_rows[outer] only (the NBFNet boundary condition is zero everywhere else, models.py:135-141); sum aggregate only.
+// upd != NULL: the layer update of every output row is applied by the same launch (ultra_rspmm_forward_update); served by
+// the stream walk only -- ULTRA_ERR_UNSUPPORTED otherwise, with nothing launched.
 static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *w, const ultra_mat *rel,
                         const ultra_mat *x, const ultra_mat *bnd, const ultra_mat *out, hipStream_t stream,
-                        const int64_t *bnd_rows = nullptr) {
+                        const int64_t *bnd_rows = nullptr, const OrderParams::Update *upd = nullptr) {
     if (!p) return invalid("plan is NULL");
     (void)hipGetLastError();   // drop any stale error left by other users of the HIP runtime
     if (sum < 0 || sum > 2 || mul < 0 || mul > 3) return invalid("unknown sum/mul code");
@@ -263,6 +268,10 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
     if (bnd && (rc = check_mat(bnd, "boundary", bnd_rows ? 1 : p->num_out, n_outer, row_len))) return rc;
     if (p->num_out == 0) return ULTRA_OK;
     if ((rc = upload_plan(p))) return rc;
+    if (upd && ((p->flags & ULTRA_PLAN_DENSE) || !(p->flags & ULTRA_PLAN_EXACT_ORDER))) {
+        set_error("ultra_rspmm_forward_update: served by reference-order plans in the sparse format only");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
     if (p->flags & ULTRA_PLAN_DENSE) {
         if (g_ev_before) HIP_TRY(hipEventRecord(g_ev_before, stream));
         if ((rc = launch_dense_forward(p, sum, mul, dtype, w, rel, x, bnd, bnd_rows, out, stream))) return rc;
@@ -373,7 +382,18 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
                               p->num_out <= p->num_in && (uint64_t)p->num_out * (uint64_t)out->stride_row * esz < (1ull << 32))
                                  ? 1
                                  : 0;
-            const size_t lds = (rel_lds ? rel_bytes : 0) + ring_bytes;
+            size_t lds = (rel_lds ? rel_bytes : 0) + ring_bytes;
+            if (upd) {
+                if (!op.use_streams || row_len != 64 || sum != ULTRA_SUM_ADD) {
+                    set_error("ultra_rspmm_forward_update: this call is not served by the stream walk (fp32, 64-element rows, sum aggregate, "
+                              "unit weights, relation slice in LDS, point boundary or none)");
+                    return ULTRA_ERR_UNSUPPORTED;
+                }
+                op.upd = *upd;
+                op.upd.prow = sched->d_prow;
+                op.upd.prow_ptr = sched->d_prow_ptr;
+                lds = std::max(lds, (size_t)UPDATE_LDS_FLOATS * sizeof(float));   // (the weight image takes the dead relation slice's place)
+            }
             hipError_t e = hipErrorInvalidValue;
             if (g_ev_before) HIP_TRY(hipEventRecord(g_ev_before, stream));
 #define ULTRA_ORDER_LAUNCH(T_)                                                                          \
@@ -389,6 +409,10 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
         }
     }
 
+    if (upd) {
+        set_error("ultra_rspmm_forward_update: this call is not served by the reference-order kernels");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
     // per-call edge weights -> sorted order
     if (w && p->num_edge > 0) {
         if ((rc = ensure_scratch(&p->d.w_sorted, &p->d.w_sorted_bytes, (size_t)p->num_edge * esz, p))) return rc;
@@ -840,6 +864,32 @@ int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t mul, int32_t dtype, 
                         reinterpret_cast<hipStream_t>(stream), point_rows_dev);
 }
 
+int32_t ultra_rspmm_forward_update(ultra_plan *plan, int32_t mul, const ultra_mat *relation, const ultra_mat *input,
+                                   const int64_t *point_rows_dev, const ultra_mat *point_values, const ultra_mat *aggregate,
+                                   const void *weight, const void *bias, const void *ln_weight, const void *ln_bias, float eps,
+                                   int32_t flags, const ultra_mat *output, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream, output ? output->ptr : nullptr);
+    if (mul < 0 || mul > 1) return invalid("unknown mul code");
+    if ((point_rows_dev == nullptr) != (point_values == nullptr)) return invalid("ultra_rspmm_forward_update: half a point boundary");
+    if (!weight || !output || !output->ptr || !aggregate || !aggregate->ptr || ((flags & CONV_LN) && (!ln_weight || !ln_bias)))
+        return invalid("ultra_rspmm_forward_update: NULL operand");
+    if (flags & ~(CONV_LN | CONV_RELU | CONV_RESIDUAL | CONV_DBG_NO_MATRIX)) return invalid("ultra_rspmm_forward_update: unknown flag");
+    if (!plan) return invalid("plan is NULL");
+    if (output->row_len != 64 || output->n_outer != aggregate->n_outer || output->n_row != aggregate->n_row ||
+        output->stride_row < 64 || (output->stride_row % 4) != 0 || (output->stride_outer % 4) != 0 ||
+        (reinterpret_cast<uintptr_t>(output->ptr) & 15) || output->ptr == aggregate->ptr || (input && output->ptr == input->ptr))
+        return invalid("ultra_rspmm_forward_update: output must be a 16-byte aligned (n_outer, num_node, 64) tensor of its own");
+    OrderParams::Update u;
+    std::memset(&u, 0, sizeof(u));
+    u.weight = (const float *)weight, u.bias = (const float *)bias;
+    u.ln_w = (const float *)ln_weight, u.ln_b = (const float *)ln_bias;
+    u.out = (float *)output->ptr;
+    u.out_stride_outer = output->stride_outer, u.out_stride_row = output->stride_row;
+    u.eps = eps, u.flags = flags;
+    return forward_impl(plan, ULTRA_SUM_ADD, mul, ULTRA_F32, nullptr, relation, input, point_values, aggregate,
+                        reinterpret_cast<hipStream_t>(stream), point_rows_dev, &u);
+}
+
 int32_t ultra_rspmm_forward_onehot(ultra_plan *plan, int32_t dtype, const void *edge_weight_dev,
                                    const ultra_mat *relation, const ultra_mat *input, const int64_t *src_rows_dev,
                                    const ultra_mat *boundary, const ultra_mat *output, void *stream) {
@@ -977,6 +1027,8 @@ int32_t ultra_plan_schedule_export(ultra_plan *plan, int32_t nparts, int32_t whi
         case 3: src = reinterpret_cast<const int32_t *>(s->chunks.data()), n = (int64_t)s->chunk_ptr.back() * 4; break;
         case 4: src = s->sdesc.data(), n = (int64_t)s->sdesc.size(); break;
         case 5: src = s->srec.data(), n = (int64_t)s->srec.size() - 2 * ORDER_PAD; break;
+        case 6: src = s->prow.data(), n = (int64_t)s->prow.size(); break;
+        case 7: src = s->prow_ptr.data(), n = (int64_t)s->prow_ptr.size(); break;
         default: delete s; return invalid("ultra_plan_schedule_export: unknown array id");
     }
     *count = n;

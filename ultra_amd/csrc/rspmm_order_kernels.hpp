@@ -25,6 +25,7 @@
 
 #include "rspmm_kernels.hpp"
 #include "rspmm_order_asm.hpp"
+#include "update_tile.hpp"
 
 #pragma clang fp contract(off)
 
@@ -57,6 +58,15 @@ struct OrderParams {
     int32_t smod, nparts;
     uint32_t x_row_bytes, rel_row_bytes;
     long long *trace;         // measurement hook (NULL in production): per workgroup {start, chains done, end} shader clocks
+    // UPDATE instances: the layer update (update_tile.hpp) of the rows this workgroup aggregated, applied after its walk
+    struct Update {
+        const float *weight, *bias, *ln_w, *ln_b;   // Linear(128 -> 64) [+ LayerNorm(64)]
+        float *out;                                  // (n_outer, num_node, 64) with the strides below, in floats
+        long long out_stride_outer, out_stride_row;
+        const int32_t *prow, *prow_ptr;              // plan.hpp Schedule
+        float eps;
+        int32_t flags;                               // CONV_LN | CONV_RELU | CONV_RESIDUAL
+    } upd;
 };
 
 // value of lane K of each 16-lane row, in every lane of that row (ds_swizzle bit mode: lane' = (lane & 0x10) | K within
@@ -322,9 +332,10 @@ __device__ __forceinline__ T chain_add_partial(T acc, const V (&v)[N], const int
 
 // STREAMS: the group rows are walked as streams by the assembly loop (its own instantiation: the C++ unit walk
 // and the assembly walk in one kernel cost each other registers around the asm statements).
-template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED, bool STREAMS>
+template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED, bool STREAMS, bool UPDATE = false>
 __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderParams p) {
     static_assert(!STREAMS || OrderAsm<T, MUL, REL_LDS, WEIGHTED>::value, "group streams exist for the assembly configurations only");
+    static_assert(!UPDATE || (STREAMS && SUM == 0 && sizeof(T) == 4), "the update tail follows the fp32 sum stream walk");
     constexpr int SPAN = 64;
     using P = Pack<T, 4>;
     using V = typename VecOf<T, 4>::type;
@@ -613,6 +624,53 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                                                reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.out) + outer * p.out_stride_outer),
                                                p.x_row_bytes);
             }
+            if constexpr (UPDATE) {
+                // ---- layer update of this workgroup's own rows (whole spans only: row_len == 64) ----
+                // Every flush above has completed (each walk ends on vmcnt(0); the chain consumer's stores are collected
+                // by the barrier's wait), and a workgroup's waves share their CU's vector L1: after the barrier the
+                // aggregate rows are readable.  The relation slice is dead: its LDS takes the weight image.
+                // (Measured and dropped -- the tail is a burst of 60 MB of x and aggregate rows across the chip, then 12 us of
+                // matrix work, and every workgroup reaches it at the same time: the weight image staged into the ring's
+                // place right after the chain phase + the x rows requested before the barrier, 100.7 us per layer instead
+                // of 95.1; two shifts -- waves 0..7 request and multiply while waves 8..15 stage the image and request
+                // behind them -- 97.8 us: half the burst takes as long as the whole one.)
+                __syncthreads();
+                // (measurement hook: tail timestamps at trace[3 * grid + 4 * workgroup + {0: walks done, 1: weights staged,
+                // 2: wave 0's operands landed, 3: wave 0's tile done}])
+                long long *utrace = p.trace ? p.trace + 3 * gridDim.x + 4 * blockIdx.x : nullptr;
+                if (utrace && tid == 0) utrace[0] = clock64();
+                float *lds_w = reinterpret_cast<float *>(smem);
+                int tid_u = tid;
+                asm volatile("" : "+v"(tid_u));
+                update_stage_weights(lds_w, p.upd.weight, p.upd.bias, p.upd.ln_w, p.upd.ln_b, p.upd.flags, tid_u, ORDER_THREADS);
+                __syncthreads();
+                if (utrace && tid == 0) utrace[1] = clock64();
+                const int lane_u = tid_u & 63, ju = lane_u & 31, hu = lane_u >> 5;
+                const int r1 = p.upd.prow_ptr[part + 1];
+                const char *aggbase = reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.out) + outer * p.out_stride_outer);
+                float *ubase = p.upd.out + outer * p.upd.out_stride_outer;
+                for (int base = p.upd.prow_ptr[part] + 32 * wave; base < r1; base += 32 * nwave) {
+                    const int row = p.upd.prow[base + ju];
+                    const bool valid = row >= 0;
+                    const uint32_t roff = (uint32_t)(valid ? row : 0) * p.x_row_bytes + (uint32_t)hu * 16u;
+                    const float4 *xr = reinterpret_cast<const float4 *>(xbase + roff);
+                    const float4 *ar = reinterpret_cast<const float4 *>(aggbase + roff);
+                    float4 b[16];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) b[i] = xr[2 * i];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) b[8 + i] = ar[2 * i];
+                    if (utrace && tid == 0) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        utrace[2] = clock64();
+                    }
+                    update_tile(b, lds_w, lane_u, p.upd.flags, p.upd.eps, ubase + (long long)(valid ? row : 0) * p.upd.out_stride_row, valid);
+                    if (utrace && tid == 0) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        utrace[3] = clock64();
+                    }
+                }
+            }
         } else {
         const int u1 = p.unit_ptr[part + 1];
         const auto load_item = [&](const int ui) {
@@ -664,9 +722,9 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
 }
 
 // ---- per-variant launchers (explicitly instantiated in rspmm_order_*.hip) ----
-template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED, bool STREAMS>
+template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED, bool STREAMS, bool UPDATE = false>
 inline hipError_t launch_order_inst(const OrderParams &p, int grid, size_t lds, hipStream_t s) {
-    auto kern = rspmm_order_kernel<T, SUM, MUL, REL_LDS, WEIGHTED, STREAMS>;
+    auto kern = rspmm_order_kernel<T, SUM, MUL, REL_LDS, WEIGHTED, STREAMS, UPDATE>;
     static size_t lds_opted_in = 0;   // (see launch_one in rspmm_kernels.hpp)
     if (lds > 48 * 1024 && lds > lds_opted_in) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -679,8 +737,12 @@ inline hipError_t launch_order_inst(const OrderParams &p, int grid, size_t lds, 
 template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED>
 inline hipError_t launch_order_one(const OrderParams &p, int grid, size_t lds, hipStream_t s) {
     if constexpr (OrderAsm<T, MUL, REL_LDS, WEIGHTED>::value) {
+        if constexpr (SUM == 0 && sizeof(T) == 4) {
+            if (p.use_streams && p.upd.weight) return launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true, true>(p, grid, lds, s);
+        }
         if (p.use_streams) return launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true>(p, grid, lds, s);
     }
+    if (p.upd.weight) return hipErrorInvalidValue;   // (the caller checks use_streams first)
     return launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, false>(p, grid, lds, s);
 }
 

@@ -1,0 +1,170 @@
+// The NBFNet layer update on one 32-row tile (layers.py:233-240 + models.py:158-160):
+//
+//   out = [x +] relu( LayerNorm( W . [x ; agg] + b ) )        W: (64, 128) row-major, x / agg / out rows of 64 floats
+//
+// as the TRANSPOSED product D[feature][row] on v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains over k = 0, 1, 2, ...: the
+// reference's nn.Linear order, torch_math.hpp), so that a data row's 64 features land in the lane pair (lane, lane ^ 32)
+// and LayerNorm needs one cross-lane exchange.  Shared by conv_update_kernel (dense_kernels.hip: the stand-alone launch)
+// and by the tail of the reference-order rspmm kernel (rspmm_order_kernels.hpp: the update applied by the workgroup that
+// aggregated the rows).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "torch_math.hpp"
+
+namespace ultra {
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+
+enum { CONV_LN = 1, CONV_RELU = 2, CONV_RESIDUAL = 4, CONV_DBG_NO_MATRIX = 256 /* measurement: skip the matrix chain */ };
+
+// feature owned by accumulator register r of feature tile m in lane half h (32x32 C/D layout)
+__device__ __forceinline__ int feat_of(int m, int r, int h) { return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// v_permlane32_swap: lanes 32..63 of `lo_pair` trade places with lanes 0..31 of `hi_pair`.  A lane half h holds the
+// 16-byte chunk k = 8 i + 4 h .. + 3 of its row; after swapping (.x, .y) and (.z, .w) the four registers hold, in lane
+// half h, element 2 s + h of the k pairs s = 4 i, 4 i + 2 and 4 i + 1, 4 i + 3: each v_mfma_f32_32x32x2_f32 then consumes
+// two CONSECUTIVE k, and the accumulator chain runs over k = 0, 1, 2, ... exactly like the reference's nn.Linear
+// (torch_math.hpp).
+__device__ __forceinline__ void swap32(float &lo_pair, float &hi_pair) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_pair), __float_as_uint(hi_pair), false, false);
+    lo_pair = __uint_as_float(r[0]);
+    hi_pair = __uint_as_float(r[1]);
+}
+
+// LayerNorm statistics of a row held by the lane pair (lane, lane ^ 32) in the accumulator layout of the transposed
+// product: lane half h owns features 32 m + (r & 3) + 8 (r >> 2) + 4 h, i.e. ALL eight members 8 j + i of the Welford
+// accumulators i = (r & 3) + 4 h (torch_math.hpp) -- four accumulators per lane, the other four come over one swap.
+__device__ __forceinline__ void row_moments_pair(const float (&v)[2][16], const int h, const float eps, float &mean, float &rstd) {
+    Moments own[4], other[4];
+#pragma unroll
+    for (int il = 0; il < 4; ++il) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = v[j >> 2][4 * (j & 3) + il];
+        own[il] = welford8(x);
+        other[il].m1 = __shfl_xor(own[il].m1, 32);
+        other[il].m2 = __shfl_xor(own[il].m2, 32);
+    }
+    Moments all[8];
+#pragma unroll
+    for (int il = 0; il < 4; ++il) {
+        all[il].m1 = h ? other[il].m1 : own[il].m1;
+        all[il].m2 = h ? other[il].m2 : own[il].m2;
+        all[4 + il].m1 = h ? own[il].m1 : other[il].m1;
+        all[4 + il].m2 = h ? own[il].m2 : other[il].m2;
+    }
+    merge8(all, eps, mean, rstd);
+}
+
+// ---- the tile as a unit (the rspmm tail; 8 weight registers instead of 16: it runs under a 128-register cap) ----
+constexpr int UPDATE_LDS_FLOATS = 32 * 64 * 4 + 3 * 64;   // weight image + {bias, LayerNorm weight, LayerNorm bias}
+
+// Weight image [hs (32)][lane (64)] float4: one 16-byte read per lane feeds the four matrix instructions of half-step hs
+// (k = 4 hs .. 4 hs + 3): {tile 0, pair s = 2 hs; tile 1, same pair; tile 0, pair s + 1; tile 1, pair s + 1}, element
+// 2 s + (lane >> 5) of the pair, feature 32 m + (lane & 31).
+__device__ __forceinline__ void update_stage_weights(float *lds_w, const float *weight, const float *bias, const float *ln_w,
+                                                     const float *ln_b, const int flags, const int tid, const int nthreads) {
+    for (int idx4 = tid; idx4 < 32 * 64; idx4 += nthreads) {
+        const int l = idx4 & 63, hs = idx4 >> 6;
+        const float *wr = weight + (l & 31) * 128 + 4 * hs;
+        const float4 m0 = *reinterpret_cast<const float4 *>(wr), m1 = *reinterpret_cast<const float4 *>(wr + 32 * 128);
+        const bool odd = (l >> 5) != 0;
+        reinterpret_cast<float4 *>(lds_w)[idx4] =
+            make_float4(odd ? m0.y : m0.x, odd ? m1.y : m1.x, odd ? m0.w : m0.z, odd ? m1.w : m1.z);
+    }
+    float *lds_vec = lds_w + 32 * 64 * 4;
+    if (tid < 64) {
+        lds_vec[tid] = bias ? bias[tid] : 0.f;
+        lds_vec[64 + tid] = (flags & CONV_LN) ? ln_w[tid] : 1.f;
+        lds_vec[128 + tid] = (flags & CONV_LN) ? ln_b[tid] : 0.f;
+    }
+}
+
+// b[0..7]: the eight 16-byte chunks 2 i + h of the lane's x row, b[8..15]: of its aggregate row (lane = (row j, half h)).
+// Writes the 32 output features this lane ends up owning to out_row[32 m + 8 g + 4 h ..] when `valid`.
+__device__ __forceinline__ void update_tile(float4 (&b)[16], const float *lds_w, const int lane, const int flags, const float eps,
+                                            float *out_row, const bool valid) {
+    const int h = lane >> 5;
+    const float4 *w4 = reinterpret_cast<const float4 *>(lds_w);
+    const float *lds_vec = lds_w + 32 * 64 * 4;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc0[r] = 0.f;
+        acc1[r] = 0.f;
+    }
+    float4 wc = w4[lane];
+    // all operand swaps BEFORE the chain (an instruction between two dependent matrix instructions delays the second one
+    // far beyond its own issue time); in place -- the x chunks are swapped back afterwards for the residual
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        swap32(b[i].x, b[i].y);   // .x: k pair s = 4 i,     .y: s = 4 i + 2
+        swap32(b[i].z, b[i].w);   // .z: k pair s = 4 i + 1, .w: s = 4 i + 3
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(flags & CONV_DBG_NO_MATRIX))
+#pragma unroll
+    for (int hs = 0; hs < 32; ++hs) {
+        // k ascending: half 0 of chunk i holds s = 4 i (.x), 4 i + 1 (.z); half 1 holds s = 4 i + 2 (.y), 4 i + 3 (.w)
+        const float b0 = (hs & 1) ? b[hs >> 1].y : b[hs >> 1].x;
+        const float b1 = (hs & 1) ? b[hs >> 1].w : b[hs >> 1].z;
+        float4 wn = wc;
+        if (hs + 1 < 32) wn = w4[(hs + 1) * 64 + lane];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.x, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.y, b0, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.z, b1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.w, b1, acc1, 0, 0, 0);
+        wc = wn;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (flags & CONV_RESIDUAL) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            swap32(b[i].x, b[i].y);
+            swap32(b[i].z, b[i].w);
+        }
+    }
+    // ---- epilogue: bias (added after the chain, like addmm), LayerNorm in the reference's operation order
+    // (torch_math.hpp), ReLU, residual ----
+    float v[2][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        v[0][r] = acc0[r] + lds_vec[feat_of(0, r, h)];
+        v[1][r] = acc1[r] + lds_vec[feat_of(1, r, h)];
+    }
+    if (flags & CONV_LN) {
+        float mean, rstd;
+        row_moments_pair(v, h, eps, mean, rstd);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = feat_of(m, r, h);
+                v[m][r] = ln_apply(v[m][r], mean, rstd, lds_vec[64 + f], lds_vec[128 + f]);
+            }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 y = make_float4(v[m][4 * g + 0], v[m][4 * g + 1], v[m][4 * g + 2], v[m][4 * g + 3]);
+            if (flags & CONV_RELU) {
+                y.x = fmaxf(y.x, 0.f);
+                y.y = fmaxf(y.y, 0.f);
+                y.z = fmaxf(y.z, 0.f);
+                y.w = fmaxf(y.w, 0.f);
+            }
+            if (flags & CONV_RESIDUAL) {
+                const float4 xi = b[4 * m + g];  // x[row][32 m + 8 g + 4 h ..]: the chunk this lane holds
+                y.x += xi.x;
+                y.y += xi.y;
+                y.z += xi.z;
+                y.w += xi.w;
+            }
+            if (valid) *reinterpret_cast<float4 *>(out_row + 32 * m + 8 * g + 4 * h) = y;
+        }
+}
+
+}  // namespace ultra

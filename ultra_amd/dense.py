@@ -4,6 +4,7 @@ and `cat -> gather -> Linear -> ReLU -> Linear` (models.py:166-170, 202-209) on 
 import ctypes
 
 import torch
+from torch.autograd.function import once_differentiable
 from torch.nn import functional as F
 
 from ._lib import check, lib
@@ -50,6 +51,7 @@ class ConvUpdateFunction(torch.autograd.Function):
         return _conv_update_forward(x, agg, weight, bias, ln_w, ln_b, eps, flags)
 
     @staticmethod
+    @once_differentiable      # (the backward kernels are not themselves differentiable)
     def backward(ctx, grad_out):
         x, agg, weight, bias, ln_w, ln_b = ctx.saved_tensors
         grad_out = grad_out.contiguous()

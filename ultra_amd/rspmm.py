@@ -32,6 +32,10 @@ def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
 def _require_gpu(*tensors):
     for t in tensors:
         if t is not None and t.device.type != "cuda":
@@ -177,6 +181,18 @@ class Plan(object):
             out.append(t.view(-1, 2))
         return tuple(out)
 
+    def part_rows(self, nparts):
+        """(prow, prow_ptr): the rows each workgroup aggregates -- ascending, -1 padded to whole 32-row tiles -- and their
+        bounds per workgroup (schedule arrays 6 and 7: the work list of the update tail)."""
+        out = []
+        for which in (6, 7):
+            n = ctypes.c_int64()
+            check(lib.ultra_plan_schedule_export(self._h, int(nparts), which, None, 0, ctypes.byref(n)))
+            t = torch.empty(n.value, dtype=torch.int32)
+            check(lib.ultra_plan_schedule_export(self._h, int(nparts), which, t.data_ptr(), n.value, ctypes.byref(n)))
+            out.append(t)
+        return tuple(out)
+
     def export(self, which):
         n = ctypes.c_int64()
         check(lib.ultra_plan_export(self._h, which, None, 0, ctypes.byref(n)))
@@ -237,6 +253,39 @@ class Plan(object):
         entry = lib.ultra_rspmm_forward_masked if (keep and w is not None and sum != "add") else lib.ultra_rspmm_forward
         check(entry(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
                     ctypes.byref(mx), mb, ctypes.byref(mout), _stream(input)))
+        return out
+
+    def forward_update(self, relation, input, weight, bias, ln_weight, ln_bias, eps, flags, mul="mul", point=None):
+        """Aggregate (sum, `mul`, optional point boundary) AND the layer update
+        `[input +] relu(layer_norm(linear(cat[input, aggregate])))` in one launch (ultra_rspmm_forward_update: the workgroup
+        that aggregated a row also updates it).  Bit-equal with forward(point=...) followed by dense.conv_update.
+        Returns the layer output, or None where the launch does not serve the call (the caller makes the two calls)."""
+        if not self.exact or input.dtype != torch.float32 or input.dim() != 3 or input.shape[-1] != 64 or not input.is_cuda:
+            return None
+        _require_gpu(relation, input, weight)
+        relation, mrel = as_mat(relation)
+        input, mx = as_mat(input)
+        agg = torch.empty((input.shape[0], self.num_node, 64), dtype=torch.float32, device=input.device)
+        out = torch.empty_like(agg)
+        agg, magg = as_mat(agg)
+        out, mout = as_mat(out)
+        rows_ptr, mv = None, None
+        if point is not None:
+            rows, vals = point
+            rows = rows.to(torch.int64).contiguous()
+            if rows.numel() != input.shape[0]:
+                raise RuntimeError("Expected one boundary row per outer slice (%d), got %d" % (input.shape[0], rows.numel()))
+            vals = vals.reshape(input.shape[0], 1, vals.shape[-1])
+            _require_gpu(rows, vals)
+            vals, mvv = as_mat(vals)
+            rows_ptr, mv = rows.data_ptr(), ctypes.byref(mvv)
+        weight = weight.contiguous()
+        rc = lib.ultra_rspmm_forward_update(self._h, _lib.MUL_CODES[mul], ctypes.byref(mrel), ctypes.byref(mx), rows_ptr, mv,
+                                            ctypes.byref(magg), weight.data_ptr(), _ptr(bias), _ptr(ln_weight), _ptr(ln_bias),
+                                            float(eps), int(flags), ctypes.byref(mout), _stream(input))
+        if rc == _lib.ULTRA_ERR_UNSUPPORTED:
+            return None
+        check(rc)
         return out
 
     def forward_onehot(self, relation, input, src_rows, edge_weight=None, boundary=None):
