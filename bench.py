@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 L2_PEAK_GBS = 34500.0      # MI355X_MICROARCH.md: aggregate L2 bandwidth
 COPY_BYTES = 1 << 30
 ROOFLINE_POINTS = [("fb15k237", 8), ("codex_l", 8)]
-ORDER_KERNEL = "rspmm_order_kernel<float, 0, 0, true, false, true>"
+ORDER_KERNEL = "rspmm_order_kernel<float, 0, 0, true, false, true, false>"   # (..., STREAMS, UPDATE)
 
 
 def available_cores():

@@ -112,3 +112,19 @@ def test_torch_binding_has_the_reference_extension_surface():
         mod.rspmm_add_mul_forward_cpu(torch.zeros(2, 0, dtype=torch.long), torch.zeros(0, dtype=torch.long), torch.zeros(0), x, x)
     with pytest.raises(RuntimeError, match="same GPU"):      # reference: checkAllSameGPU (rspmm.cu:225)
         mod.rspmm_add_mul_forward_cuda(torch.zeros(2, 0, dtype=torch.long), torch.zeros(0, dtype=torch.long), torch.zeros(0), x, x)
+
+
+def test_bench_names_the_timed_kernel_with_all_its_template_arguments():
+    """bench.py matches rocprofv3 dispatches against ORDER_KERNEL by name: a template parameter added to the kernel without
+    the constant following it silently drops the counter passes (the roofline then falls back to the byte model)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "ultra_amd", "csrc", "rspmm_order_kernels.hpp")).read()
+    m = re.search(r"template <([^>]*)>\s*__global__ void __launch_bounds__\(ORDER_THREADS\) rspmm_order_kernel", src)
+    assert m, "kernel declaration not found"
+    n_params = len(m.group(1).split(","))
+    bench = open(os.path.join(root, "bench.py")).read()
+    name = re.search(r'^ORDER_KERNEL = "([^"]*)"', bench, re.M).group(1)
+    assert name.startswith("rspmm_order_kernel<") and name.endswith(">")
+    assert len(name[len("rspmm_order_kernel<"):-1].split(",")) == n_params
