@@ -302,7 +302,9 @@ int32_t ultra_plan_schedule_export(ultra_plan *plan, int32_t nparts, int32_t whi
                                    int64_t *count);
 
 /* Measurement hook: while non-NULL (calling thread), the reference-order kernel stores three shader-clock samples per
- * workgroup -- start, chain rows done, end -- at trace_dev[3 * workgroup + {0, 1, 2}] (int64, device memory). */
+ * workgroup -- start, chain rows done, end -- at trace_dev[3 * workgroup + {0, 1, 2}] (int64, device memory); further words
+ * up to 32 * workgroups hold the update tail's stamps (3 * grid + 4 * workgroup + k) and each wave's end of walk
+ * (8 * grid + 16 * workgroup + wave): the buffer must hold 32 * workgroups words. */
 int32_t ultra_order_trace(void *trace_dev);
 
 /* Tuning / measurement hooks. */

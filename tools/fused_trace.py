@@ -24,7 +24,7 @@ grid = 256
 for _ in range(3):
     plan.forward_update(rel, x, w, b, lw, lb, 1e-5, 7, point=point)
 torch.cuda.synchronize()
-trace = torch.zeros(grid * 8, dtype=torch.int64, device=dev)
+trace = torch.zeros(grid * 32, dtype=torch.int64, device=dev)
 _lib.check(_lib.lib.ultra_order_trace(trace.data_ptr()))
 plan.forward_update(rel, x, w, b, lw, lb, 1e-5, 7, point=point)
 torch.cuda.synchronize()

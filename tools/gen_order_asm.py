@@ -329,6 +329,134 @@ def gen_producer(mul_code, rec_policy):
     return a
 
 
+# ---- chain producers, OVERLAP form: eight producer waves, two messages per chunk each, no workgroup barrier ----
+# The other seven waves of the workgroup walk their streams while the chain runs, so s_barrier (which counts every wave) is
+# out: the hand-off goes through three LDS words behind the ring -- ready[0], ready[1] (messages parked for chunks of even /
+# odd index: every producer wave adds 1 per half-chunk, 16 per chunk) and done (chunks the consumer has read completely).
+# The producers see the chunk list as HALF-chunks (plan.cpp vchunks: slots 0..31, then 32..59 of each chunk): step v parks
+# quad (wave - 1) + 8 (v & 1) of ring half (v >> 1) & 1 (a half holds 16 quads here; quad 15 is wave 8's idle second step).
+# A producer may park chunk j only when done >= j - 1 (chunk j - 2, the previous tenant of that ring half, has been read).
+OV_RING_HALF_BYTES = 16 * 64 * 16
+OV_CLOBBER_LO = 40
+
+
+def gen_producer_overlap(mul_code, rec_policy):
+    a = Asm()
+    D = PROD_D
+    binop = BINOPS[mul_code]
+    SETS = (120, 52, 48, 44)   # four 4-register sets: relation row (requested two steps ahead) -> message -> transposed -> parked
+
+    def xq(j):
+        return 64 + 4 * (j % D)
+
+    def rq(j):
+        return 96 + 2 * (j % D)
+
+    def tq(j):
+        return 112 + (j % D)
+
+    def bq(j):
+        return 56 + (j % D)
+
+    def begin_request_imm(j, k):
+        a("global_load_dword v%d, v127, %%[chunks] offset:%d" % (bq(j), 16 * k + 4), "B_%d: Chunk::begin" % k)
+
+    def rec_request(j):
+        a("v_lshl_add_u32 v125, v%d, 3, %%[slot8]" % bq(j))
+        a("global_load_dwordx2 %s, v125, %%[rb]%s" % (vr(rq(j), 2), rec_policy))
+
+    def row_request(j):
+        a("v_lshl_add_u32 v%d, v%d, 8, %%[lds]" % (tq(j), rq(j) + 1))
+        a("v_mad_u32_u24 v124, v%d, %%[xrb], %%[lb]" % rq(j))
+        a("global_load_dwordx4 %s, v124, %%[xb]" % vr(xq(j), 4))
+
+    def prepare(k, lgkm):
+        """message of half-chunk k (stage k % D, set k % 4; its relation row was requested two steps ago) -> transposed, in
+        registers; the stage is refilled and the relation row of half-chunk k + 2 requested.  lgkm: LDS operations this wave
+        has issued since that relation row's read (they may stay outstanding), or None when everything has been drained."""
+        m = SETS[k % 4]
+        a("s_waitcnt vmcnt(%d)" % (3 * (D - 1)))
+        if lgkm is not None:
+            a("s_waitcnt lgkmcnt(%d)" % lgkm)
+        x = xq(k)
+        a("%s %s, %s, %s" % (binop, vr(m, 2), vr(m, 2), vr(x, 2)))
+        a("%s %s, %s, %s" % (binop, vr(m + 2, 2), vr(m + 2, 2), vr(x + 2, 2)))
+        a("s_nop 1", "VALU write -> v_permlane*_swap read: 2 wait states")
+        a("v_permlane32_swap_b32_e32 v%d, v%d" % (m, m + 2))
+        a("v_permlane32_swap_b32_e32 v%d, v%d" % (m + 1, m + 3))
+        a("s_nop 1")
+        a("v_permlane16_swap_b32_e32 v%d, v%d" % (m, m + 1))
+        a("v_permlane16_swap_b32_e32 v%d, v%d" % (m + 2, m + 3))
+        row_request(k)
+        rec_request(k)
+        a("v_add_u32_e32 v127, 16, v127")
+        a("global_load_dword v%d, v127, %%[chunks]" % bq(k), "B_k+3D")
+        a("ds_read_b128 %s, v%d" % (vr(SETS[(k + 2) % 4], 4), tq(k + 2)), "relation row of half-chunk k + 2")
+
+    a("s_mov_b32 %[i], 0")
+    a("s_mov_b32 %[half], 0")
+    a("s_mov_b32 %[par], 0")
+    a("v_mov_b32_e32 v127, 0")
+    a("v_mov_b32_e32 v40, %[flags]")
+    a("v_mov_b32_e32 v41, 1")
+    for j in range(D):
+        begin_request_imm(j, j)
+    a("s_waitcnt vmcnt(0)")
+    for j in range(D):
+        rec_request(j)
+        begin_request_imm(j, D + j)
+    a("s_waitcnt vmcnt(0)")
+    for j in range(D):
+        row_request(j)
+        rec_request(j)
+        begin_request_imm(j, 2 * D + j)
+    a("v_mov_b32_e32 v127, 0x%x" % (16 * (3 * D - 1) + 4), "descriptor offset of half-chunk 3 D - 1")
+    a("ds_read_b128 %s, v%d" % (vr(SETS[0], 4), tq(0)), "relation rows of half-chunks 0 and 1")
+    a("ds_read_b128 %s, v%d" % (vr(SETS[1], 4), tq(1)))
+    a("s_waitcnt lgkmcnt(0)")
+    prepare(0, None)
+    a("ds_read_b32 v42, v40 offset:8", "done (for the first gate)")
+    a.label(".Lov_loop_%=")
+    for J in range(D):
+        if J % 2 == 0:
+            # first half of chunk j = i / 2: its ring half is free once done >= j - 1.  `done` was requested at the end of
+            # the previous step; the wait also collects the relation row requested one step ago.
+            a("s_lshr_b32 %[t], %[i], 1")
+            a.label(".Lov_gate%d_%%=" % J)
+            a("s_waitcnt lgkmcnt(0)")
+            a("v_readfirstlane_b32 %[d], v42")
+            a("s_add_i32 %[d], %[d], 1")
+            a("s_cmp_ge_i32 %[d], %[t]")
+            a("s_cbranch_scc1 .Lov_go%d_%%=" % J)
+            a("s_sleep 1")
+            a("ds_read_b32 v42, v40 offset:8", "done")
+            a("s_branch .Lov_gate%d_%%=" % J)
+            a.label(".Lov_go%d_%%=" % J)
+        a("v_add_u32_e32 v126, %[half], %[ring]")
+        a("ds_write_b128 v126, %s%s" % (vr(SETS[J % 4], 4), " offset:8192" if J % 2 else ""))
+        a("v_add_u32_e32 v43, %[par], v40", "ready[chunk parity]")
+        a("s_mov_b64 %[ex], exec")
+        a("s_mov_b64 exec, 1")
+        a("ds_add_u32 v43, v41", "(behind the write: a wave's LDS operations execute in order)")
+        a("s_mov_b64 exec, %[ex]")
+        if J % 2:
+            a("s_xor_b32 %%[half], %%[half], %d" % OV_RING_HALF_BYTES)
+            a("s_xor_b32 %[par], %[par], 4")
+        # LDS operations issued since the read of relation row J + 1 (at the end of step J - 1's preparation): even step --
+        # everything was drained at the gate, then write + add; odd step -- [row J + 1 ... ] then write + add: 2 may stay out.
+        # (odd steps: the previous (even) step issued, behind row J + 1's read: nothing else; so 2 = this step's write + add.)
+        prepare(J + 1, None if J % 2 == 0 else 2)
+        if J % 2:
+            a("ds_read_b32 v42, v40 offset:8", "done (for the next step's gate)")
+        a("s_add_i32 %[i], %[i], 1")
+        a("s_cmp_ge_i32 %[i], %[n]")
+        a("s_cbranch_scc1 .Lov_done_%=")
+    a("s_branch .Lov_loop_%=")
+    a.label(".Lov_done_%=")
+    a("s_waitcnt vmcnt(0) lgkmcnt(0)", "requests past the last half-chunk: nobody consumes them")
+    return a
+
+
 def clobbers(lo, hi):
     return ", ".join('"v%d"' % r for r in range(lo, hi + 1))
 
@@ -400,6 +528,25 @@ def main():
                          '              [xb] "s"(xb), [rb] "s"(rb), [xrb] "s"(xrb)\n'
                          '            : "memory", "scc", %s);\n' % clobbers(PROD_CLOBBER_LO, PROD_CLOBBER_HI))
             parts.append("    }\n")
+    parts.append("}\n\n")
+    parts.append("// chain producers, overlap form (no barrier; see the generator): `n` HALF-chunks from descriptor `chunks` on, flags = LDS byte\n"
+                 "// address of {ready[0], ready[1], done}; ring = LDS byte address of this lane's 16 B in quad (wave - 1) of ring half 0\n"
+                 "template <int MUL>\n"
+                 "__device__ __forceinline__ void order_produce_overlap_asm(const int n, const void *chunks, const uint32_t slot8, const uint32_t lb,\n"
+                 "                                                          const uint32_t lds, const uint32_t ring, const uint32_t flags,\n"
+                 "                                                          const char *xb, const char *rb, const uint32_t xrb) {\n"
+                 "    int i, half, par, t, d;\n    unsigned long long ex;\n")
+    first = True
+    for mul_code in (0, 1):
+        a = gen_producer_overlap(mul_code, REC_POLICY)
+        parts.append("    %sif constexpr (MUL == %d) {\n" % ("" if first else "else ", mul_code))
+        first = False
+        parts.append("        asm volatile(\n" + a.render("            ") + "\n")
+        parts.append('            : [i] "=&s"(i), [half] "=&s"(half), [par] "=&s"(par), [t] "=&s"(t), [d] "=&s"(d), [ex] "=&s"(ex)\n'
+                     '            : [n] "s"(n), [chunks] "s"(chunks), [slot8] "v"(slot8), [lb] "v"(lb), [lds] "v"(lds), [ring] "v"(ring),\n'
+                     '              [flags] "s"(flags), [xb] "s"(xb), [rb] "s"(rb), [xrb] "s"(xrb)\n'
+                     '            : "memory", "scc", %s);\n' % clobbers(OV_CLOBBER_LO, PROD_CLOBBER_HI))
+        parts.append("    }\n")
     parts.append("}\n\n}  // namespace ultra\n")
     with open(OUT, "w") as f:
         f.write("".join(parts))

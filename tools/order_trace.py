@@ -34,7 +34,7 @@ def main():
     n_chain = plan.info()["n_chain_row"]
     ms, _ = plan.forward_timed(rel, x, point=point, warmup=3, iters=20)
     print("time per call %.4f ms" % ms)
-    trace = torch.zeros(grid * 4, dtype=torch.int64, device=dev)   # (+ grid spare words for measurement builds)
+    trace = torch.zeros(grid * 32, dtype=torch.int64, device=dev)   # (see ultra_order_trace: 32 words per workgroup)
     _lib.check(_lib.lib.ultra_order_trace(trace.data_ptr()))
     plan.forward(rel, x, point=point)
     torch.cuda.synchronize()

@@ -248,6 +248,9 @@ static double COST_UNIT_STEP = 28.0, COST_UNIT = 100.0;
 // the stream walk (assembly paths; order_trace on MI355X): workgroup cycles per chain chunk / chain row, and per step of
 // one group stream when all sixteen waves walk (21.5 cycles per wave step / 4 groups)
 static double COST_S_CHUNK = 675.0, COST_S_ROW = 1380.0, COST_S_STEP = 6.0;
+// ULTRA_CHAIN_OVERLAP: cycles one walking stream needs per step while the chain crew is still busy (fewer streams share the
+// vector L1 then: a stream steps faster than the 64 x COST_S_STEP of the all-streams phase)
+static double COST_S_STEP_SIDE = 252.0, SIDE_TAPER = 1.0;
 
 static void read_cost_override() {   // calibration runs only: ULTRA_SCHED_COSTS="edge,chunk,row,step,unit", ULTRA_STREAM_COSTS="chunk,row,step"
     const char *env = std::getenv("ULTRA_SCHED_COSTS");
@@ -256,7 +259,12 @@ static void read_cost_override() {   // calibration runs only: ULTRA_SCHED_COSTS
         COST_CHAIN_EDGE = v[0], COST_CHAIN_CHUNK = v[1], COST_CHAIN_ROW = v[2], COST_UNIT_STEP = v[3], COST_UNIT = v[4];
     }
     env = std::getenv("ULTRA_STREAM_COSTS");
-    if (env && std::sscanf(env, "%lf,%lf,%lf", &v[0], &v[1], &v[2]) == 3) COST_S_CHUNK = v[0], COST_S_ROW = v[1], COST_S_STEP = v[2];
+    if (env) {
+        const int n = std::sscanf(env, "%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4]);
+        if (n >= 3) COST_S_CHUNK = v[0], COST_S_ROW = v[1], COST_S_STEP = v[2];
+        if (n >= 4) COST_S_STEP_SIDE = v[3];
+        if (n >= 5) SIDE_TAPER = v[4];
+    }
 }
 
 Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
@@ -329,14 +337,32 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
         }
         double steps = 0.0;
         for (int64_t g = n_chain; g < n_item; ++g) steps += p->items[(size_t)g].len + 1;
-        total += COST_S_STEP * steps;
-        const double T = total / nparts;
         const int64_t nstream = (int64_t)nparts * ORDER_GROUPS;
         std::vector<double> weight((size_t)nstream);
+#if ULTRA_CHAIN_OVERLAP
+        // Side by side: while workgroup q's chain runs (C_q cycles), its ORDER_GROUPS - ORDER_OV_CREW_GROUPS walking streams
+        // step every COST_S_STEP_SIDE cycles; afterwards all 64 streams step every 64 COST_S_STEP cycles.  Equal finishing
+        // times T for all workgroups: steps_q = (T - C_q) / COST_S_STEP + n_side C_q / COST_S_STEP_SIDE.
+        const double n_side = ORDER_GROUPS - ORDER_OV_CREW_GROUPS;
+        const double side_gain = 1.0 - COST_S_STEP * n_side / COST_S_STEP_SIDE;   // share of C_q that is NOT recovered by the walkers
+        const double T = (COST_S_STEP * steps + side_gain * total) / nparts;
+        for (int32_t q = 0; q < nparts; ++q) {
+            const double after = std::max(T - chain_cost[(size_t)q], 0.02 * T) / (COST_S_STEP * ORDER_GROUPS);   // steps per stream, all walking
+            // (tapered: walkers slow the chain they run beside -- they share its LDS and its vector L1 -- so a workgroup whose
+            // chain is the launch's critical path, C_q near T, gets fewer side steps)
+            const double taper = SIDE_TAPER > 0.0 ? std::max(0.0, 1.0 - SIDE_TAPER * chain_cost[(size_t)q] / T) : 1.0;
+            const double side = taper * chain_cost[(size_t)q] / COST_S_STEP_SIDE;                                // steps per walking stream, chain busy
+            for (int g = 0; g < ORDER_GROUPS; ++g)
+                weight[(size_t)q * ORDER_GROUPS + g] = after + (g >= ORDER_OV_CREW_GROUPS ? side : 0.0);
+        }
+#else
+        total += COST_S_STEP * steps;
+        const double T = total / nparts;
         for (int32_t q = 0; q < nparts; ++q) {
             const double budget = std::max(T - chain_cost[(size_t)q], 0.02 * T);   // (never zero: every row needs a home)
             for (int g = 0; g < ORDER_GROUPS; ++g) weight[(size_t)q * ORDER_GROUPS + g] = budget;
         }
+#endif
         typedef std::pair<double, int64_t> Slot;   // ((load + 1) / weight, stream): the heap's top is the relatively emptiest
         std::priority_queue<Slot, std::vector<Slot>, std::greater<Slot>> sheap;
         std::vector<int64_t> sload((size_t)nstream, 0);
@@ -382,7 +408,13 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
     }
     // the chain producers request descriptors a fixed number of chunks ahead without a bounds test: readable, harmless
     // entries (edge 0) behind the last chunk
+    s->vchunks.reserve(2 * s->chunks.size() + CHUNK_PAD);
+    for (const Chunk &c : s->chunks) {
+        s->vchunks.push_back(Chunk{c.row, c.begin, std::min<int32_t>(c.count, 32), 0});
+        s->vchunks.push_back(Chunk{c.row, c.begin + 32, std::max<int32_t>(c.count - 32, 0), 0});
+    }
     for (int k = 0; k < CHUNK_PAD; ++k) s->chunks.push_back(Chunk{0, 0, 0, 0});
+    for (int k = 0; k < CHUNK_PAD; ++k) s->vchunks.push_back(Chunk{0, 0, 0, 0});
     return s;
 }
 

@@ -38,6 +38,18 @@ struct Chunk {
 enum { CHUNK_FIRST = 1, CHUNK_LAST = 2, CHUNK_LEN_SHIFT = 2 };
 constexpr int CHAIN_SLOTS = 60;          // producer groups of a 1024-thread workgroup (15 waves x 4)
 constexpr int ORDER_GROUPS = 64;        // 16-lane groups of a 1024-thread workgroup
+// Chain and stream phases side by side (the fp32 stream kernels): wave 0 consumes, waves 1..ORDER_OV_PRODUCERS produce two
+// messages per chunk each (half-chunks: slots 0..31, then 32..59), the remaining waves walk their streams from the start.
+// MEASUREMENT BUILD (-DULTRA_CHAIN_OVERLAP=1), not the default: bit-exact (tests/test_order_gpu.py), the average workgroup
+// finishes 8 % earlier (129 k instead of 140 k cycles at FB15k237 bs 8), but the chain itself slows from 675 to 800 cycles
+// per chunk -- eight producer waves prefetch four chunks ahead instead of eight, less than a gather's latency while 255 other
+// CUs are walking -- and the workgroup with the 9,067-edge row becomes the launch: 77.3 vs 79 us stand-alone, - 1.4 % on the
+// benchmark step.
+#ifndef ULTRA_CHAIN_OVERLAP
+#define ULTRA_CHAIN_OVERLAP 0
+#endif
+constexpr int ORDER_OV_PRODUCERS = 8;
+constexpr int ORDER_OV_CREW_GROUPS = 4 * (1 + ORDER_OV_PRODUCERS);   // streams (16-lane groups) of the consumer and producer waves
 constexpr int CHUNK_PAD = 32;           // descriptors readable behind a schedule's last chunk (>= 3 x the producers' depth)
 constexpr int ORDER_PAD = 128;           // the device record / perm streams are readable this many entries past the last edge
 
@@ -55,6 +67,10 @@ struct Schedule {
     // 32-row tiles: prow[prow_ptr[part] .. prow_ptr[part + 1]) -- the work list of the update the workgroup applies to its
     // own rows after the walk (rspmm_order_kernels.hpp, UPDATE).
     std::vector<int32_t> prow, prow_ptr;
+    // ULTRA_CHAIN_OVERLAP: the chunk list as half-chunks {row, begin (+ 32), count in this half, 0}, two per chunk, in chunk
+    // order (workgroup q: [2 chunk_ptr[q], 2 chunk_ptr[q + 1])), CHUNK_PAD readable entries behind the last one
+    std::vector<Chunk> vchunks;
+    Chunk *d_vchunks = nullptr;
     int32_t *d_chunk_ptr = nullptr, *d_unit_ptr = nullptr, *d_units = nullptr, *d_srec = nullptr, *d_sdesc = nullptr;
     int32_t *d_prow = nullptr, *d_prow_ptr = nullptr;
     Chunk *d_chunks = nullptr;

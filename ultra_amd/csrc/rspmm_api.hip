@@ -138,6 +138,7 @@ static void free_schedules(ultra_plan *p) {
         if (s->d_chunks) (void)hipFree(s->d_chunks);
         if (s->d_srec) (void)hipFree(s->d_srec);
         if (s->d_sdesc) (void)hipFree(s->d_sdesc);
+        if (s->d_vchunks) (void)hipFree(s->d_vchunks);
         if (s->d_prow) (void)hipFree(s->d_prow);
         if (s->d_prow_ptr) (void)hipFree(s->d_prow_ptr);
         delete s;
@@ -159,7 +160,8 @@ static int get_schedule(ultra_plan *p, int32_t nparts, Schedule **out) {
     if ((rc = upload_array(&s->d_chunk_ptr, s->chunk_ptr)) || (rc = upload_array(&s->d_unit_ptr, s->unit_ptr)) ||
         (rc = upload_array(&s->d_units, s->units)) || (rc = upload_array(&s->d_chunks, s->chunks)) ||
         (rc = upload_array(&s->d_srec, s->srec)) || (rc = upload_array(&s->d_sdesc, s->sdesc)) ||
-        (rc = upload_array(&s->d_prow, s->prow)) || (rc = upload_array(&s->d_prow_ptr, s->prow_ptr))) {
+        (rc = upload_array(&s->d_prow, s->prow)) || (rc = upload_array(&s->d_prow_ptr, s->prow_ptr)) ||
+        (rc = upload_array(&s->d_vchunks, s->vchunks))) {
         delete s;
         return rc;
     }
@@ -340,7 +342,11 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
         (mul == BIN_RHS || rel->stride_row * (int64_t)esz < (1 << 24))) {
         // (+ one row: the stream walk's row markers carry relation index num_rel)
         const size_t rel_bytes = (mul != BIN_RHS) ? (size_t)(p->num_rel + 1) * 64 * esz : 0;
-        const size_t ring_bytes = p->n_chain > 0 ? (size_t)2 * CHAIN_SLOTS * 64 * esz : 0;
+        // ring: [2 halves][15 quads][64 lanes][4 messages]; the side-by-side chain of the fp32 stream kernels keeps 16 quads per
+        // half (the eighth producer wave's idle second step) and three hand-off words behind them
+        const size_t ring_bytes = p->n_chain > 0 ? ((ULTRA_CHAIN_OVERLAP && dtype == ULTRA_F32) ? (size_t)2 * 16 * 64 * 16 + 64
+                                                                                                  : (size_t)2 * CHAIN_SLOTS * 64 * esz)
+                                                 : 0;
         if (ring_bytes <= di.lds_optin) {
             const bool rel_lds = g_tuning.rel_lds != 0 && rel_bytes > 0 && rel_bytes + ring_bytes <= di.lds_optin;
             int grid = g_tuning.grid > 0 ? g_tuning.grid : di.cu;
@@ -359,6 +365,7 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
             op.units = sched->d_units;
             op.chunk_ptr = sched->d_chunk_ptr;
             op.chunks = reinterpret_cast<const int4 *>(sched->d_chunks);
+            op.vchunks = reinterpret_cast<const int4 *>(sched->d_vchunks);
             op.n_chain = (int32_t)p->n_chain;
             op.n_item = (int32_t)p->items.size();
             op.rel = fp.rel, op.x = fp.x, op.bnd = fp.bnd;

@@ -35,6 +35,12 @@ constexpr int ORDER_THREADS = 1024;
 #ifndef ULTRA_CHAIN_PRIO
 #define ULTRA_CHAIN_PRIO 1
 #endif
+#ifndef ULTRA_OV_SPIN
+#define ULTRA_OV_SPIN 0
+#endif
+#ifndef ULTRA_OV_PROD_PRIO
+#define ULTRA_OV_PROD_PRIO 0
+#endif
 static_assert(CHAIN_SLOTS == 4 * (ORDER_THREADS / 64 - 1), "one ring slot per producer group");
 
 struct OrderParams {
@@ -44,6 +50,7 @@ struct OrderParams {
     const int4 *items;        // {row, begin, len, -}; chain rows first, group items from n_chain on
     const int32_t *unit_ptr, *units, *chunk_ptr;
     const int4 *chunks;       // {row, begin, count, flags}
+    const int4 *vchunks;      // the same list as half-chunks, two per chunk (ULTRA_CHAIN_OVERLAP; plan.hpp Schedule)
     const int32_t *srec;      // group streams (plan.hpp Schedule): records and {first record, steps} per (workgroup, 16-lane group)
     const int2 *sdesc;
     int32_t use_streams;
@@ -342,6 +349,10 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *lds_rel = reinterpret_cast<T *>(smem);
     T *ring = lds_rel + ((REL_LDS && MUL != BIN_RHS) ? (size_t)(p.num_rel + 1) * SPAN : 0);   // [2][CHAIN_QUADS][64][4]; (+ 1: marker row)
+    // Chain and stream phases side by side (plan.hpp ULTRA_CHAIN_OVERLAP): the stream kernels' chain runs on nine waves and
+    // hands chunks over through LDS words instead of workgroup barriers; the other seven waves are already walking.
+    constexpr bool OVERLAP = STREAMS && ULTRA_CHAIN_OVERLAP && ULTRA_ASM_PRODUCE;
+    constexpr int OV_RING_HALF = 16 * 64;   // quads-of-lane units per ring half in that form (16 quads: see the generator)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -382,6 +393,9 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
 
         if (REL_LDS && MUL != BIN_RHS) {
             __syncthreads();  // readers of the previous span are done with the LDS image
+            if constexpr (OVERLAP) {   // hand-off words {ready[0], ready[1], done} behind the ring (see the chain phase)
+                if (tid < 3) reinterpret_cast<volatile int *>(reinterpret_cast<char *>(ring) + 2 * OV_RING_HALF * 16)[tid] = 0;
+            }
             // (the staging addresses are recomputed per span: hoisted out of the span loop they would stay live through
             // the walks below and spill)
             int tid_stage = tid;
@@ -397,8 +411,8 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
         // lgkmcnt(0)), so a ring half is never overwritten early.  Producers and the consumer run separate loops with
         // the same number of barriers: one per chunk.
         const int c0 = p.has_chain ? p.chunk_ptr[part] : 0, c1 = p.has_chain ? p.chunk_ptr[part + 1] : 0;
-        constexpr int RING_HALF = CHAIN_QUADS * 64;   // in quads-of-lane units (V)
-        if (c1 > c0) {
+        constexpr int RING_HALF = OVERLAP ? OV_RING_HALF : CHAIN_QUADS * 64;   // in quads-of-lane units (V)
+        if (c1 > c0 && (!OVERLAP || wave <= ORDER_OV_PRODUCERS)) {
             const LaneGeom cg = lane_geom();
             const int grp = cg.grp, l16 = cg.l16;
             const uint32_t lane_bytes = cg.lane_bytes;
@@ -436,6 +450,34 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
 #else
 #define ULTRA_CHAIN_BARRIER() __syncthreads()
 #endif
+                // side-by-side form: "chunk kc is parked" = ready[kc & 1] has reached 16 per chunk of that parity (eight
+                // producer waves x two half-chunks); the consumer publishes done = kc + 1 right behind its last read of chunk
+                // kc (a wave's LDS operations execute in order), which frees that ring half for chunk kc + 2
+                volatile int *ov_flags = reinterpret_cast<volatile int *>(reinterpret_cast<char *>(ring) + 2 * OV_RING_HALF * 16);
+                int kc = 0, ready_seen = 0;   // ready_seen: ready[kc & 1] as read right behind the previous chunk's ring reads
+                const auto chunk_wait = [&]() {
+                    if constexpr (OVERLAP) {
+                        const int target = 16 * ((kc >> 1) + 1);
+                        if (ready_seen < target) {
+#if ULTRA_OV_SPIN
+                            while (ov_flags[kc & 1] < target) {}
+#else
+                            while (ov_flags[kc & 1] < target) __builtin_amdgcn_s_sleep(1);
+#endif
+                        }
+                        asm volatile("" ::: "memory");
+                    } else {
+                        ULTRA_CHAIN_BARRIER();
+                    }
+                };
+                const auto chunk_read = [&]() {
+                    if constexpr (OVERLAP) {
+                        asm volatile("" ::: "memory");
+                        ov_flags[2] = ++kc;
+                        ready_seen = ov_flags[kc & 1];   // (returns behind the ring reads: off the critical path when the producers are ahead)
+                        asm volatile("" ::: "memory");
+                    }
+                };
                 for (int it = c0; it < c1;) {
                     const int row = desc[0], len = desc[3] >> 2;
                     const int nfull = len / CHAIN_SLOTS, rem = len - nfull * CHAIN_SLOTS;
@@ -455,9 +497,10 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
 #endif
                     if (nfull > 0) {
                         // first full chunk: nothing pending yet
-                        ULTRA_CHAIN_BARRIER();
+                        chunk_wait();
                         ring_read(va, ring_lane + par * RING_HALF);
                         ring_read(vb, ring_lane + par * RING_HALF + CHAIN_QA * 64);
+                        chunk_read();
                         __builtin_amdgcn_sched_barrier(0);
                         cacc = chain_add<T, SUM>(cacc, va);
                         par ^= 1;
@@ -465,12 +508,13 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                         // lands while the previous chunk's second half (in registers since the barrier) is added; the
                         // second half is requested before the first half's adds and collected by the next barrier.
                         for (int k = 1; k < nfull; ++k) {
-                            ULTRA_CHAIN_BARRIER();
+                            chunk_wait();
                             ring_read(va, ring_lane + par * RING_HALF);
                             __builtin_amdgcn_sched_barrier(0);
                             cacc = chain_add<T, SUM>(cacc, vb);
                             __builtin_amdgcn_sched_barrier(0);
                             ring_read(vb, ring_lane + par * RING_HALF + CHAIN_QA * 64);
+                            chunk_read();
                             __builtin_amdgcn_sched_barrier(0);
                             cacc = chain_add<T, SUM>(cacc, va);
                             par ^= 1;
@@ -483,12 +527,13 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                     if (rem > 0) {
                         // last, partial chunk (slots past `rem` hold messages nobody asked for): same shape as a
                         // steady-state step
-                        ULTRA_CHAIN_BARRIER();
+                        chunk_wait();
                         ring_read(va, ring_lane + par * RING_HALF);
                         __builtin_amdgcn_sched_barrier(0);
                         if (nfull > 0) cacc = chain_add<T, SUM>(cacc, vb);
                         __builtin_amdgcn_sched_barrier(0);
                         ring_read(vb, ring_lane + par * RING_HALF + CHAIN_QA * 64);
+                        chunk_read();
                         __builtin_amdgcn_sched_barrier(0);
                         cacc = chain_add_partial<T, SUM>(cacc, va, 0, rem);
                         cacc = chain_add_partial<T, SUM>(cacc, vb, CHAIN_QA, rem);
@@ -516,7 +561,16 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                     for (int k = c0; k < c1; ++k) __syncthreads();
                 } else
 #endif
-                if constexpr (STREAMS && ULTRA_ASM_PRODUCE) {   // (the unit-walk kernels keep the C++ producers: see STREAMS)
+                if constexpr (OVERLAP) {
+#if ULTRA_OV_PROD_PRIO
+                    __builtin_amdgcn_s_setprio(ULTRA_OV_PROD_PRIO);
+#endif
+                    // half-chunks: this group's slot is 4 (wave - 1) + grp of 0..31 in each; see the generator
+                    order_produce_overlap_asm<MUL>(2 * (c1 - c0), p.vchunks + 2 * c0, (uint32_t)slot * 8u, lane_bytes, lds_addr(lds_rel_lane),
+                                                   lds_addr(ring) + (uint32_t)((wave - 1) * 64 + lane) * 16u,
+                                                   lds_addr(ring) + 2u * OV_RING_HALF * 16u, xbase, reinterpret_cast<const char *>(p.rec),
+                                                   p.x_row_bytes);
+                } else if constexpr (STREAMS && ULTRA_ASM_PRODUCE) {   // (the unit-walk kernels keep the C++ producers: see STREAMS)
                     order_produce_asm<MUL>(c1 - c0, p.chunks + c0, (uint32_t)slot * 8u, lane_bytes, lds_addr(lds_rel_lane),
                                            lds_addr(ring) + (uint32_t)((wave - 1) * 64 + lane) * 16u, xbase,
                                            reinterpret_cast<const char *>(p.rec), p.x_row_bytes);
@@ -624,6 +678,8 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                                                reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.out) + outer * p.out_stride_outer),
                                                p.x_row_bytes);
             }
+            // (measurement hook: when each wave's walk ended, trace[8 * grid + 16 * workgroup + wave]; the buffer holds 32 * grid words)
+            if (p.trace && lane == 0) p.trace[8 * gridDim.x + 16 * blockIdx.x + wave] = clock64();
             if constexpr (UPDATE) {
                 // ---- layer update of this workgroup's own rows (whole spans only: row_len == 64) ----
                 // Every flush above has completed (each walk ends on vmcnt(0); the chain consumer's stores are collected
