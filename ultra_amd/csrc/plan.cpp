@@ -250,7 +250,7 @@ static double COST_UNIT_STEP = 28.0, COST_UNIT = 100.0;
 static double COST_S_CHUNK = 675.0, COST_S_ROW = 1380.0, COST_S_STEP = 6.0;
 // ULTRA_CHAIN_OVERLAP: cycles one walking stream needs per step while the chain crew is still busy (fewer streams share the
 // vector L1 then: a stream steps faster than the 64 x COST_S_STEP of the all-streams phase)
-static double COST_S_STEP_SIDE = 252.0, SIDE_TAPER = 1.0;
+static double COST_S_STEP_SIDE = 252.0, SIDE_TAPER = 0.6;   // (SIDE_TAPER: share of T above which a chain stays classic)
 
 static void read_cost_override() {   // calibration runs only: ULTRA_SCHED_COSTS="edge,chunk,row,step,unit", ULTRA_STREAM_COSTS="chunk,row,step"
     const char *env = std::getenv("ULTRA_SCHED_COSTS");
@@ -342,16 +342,22 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
 #if ULTRA_CHAIN_OVERLAP
         // Side by side: while workgroup q's chain runs (C_q cycles), its ORDER_GROUPS - ORDER_OV_CREW_GROUPS walking streams
         // step every COST_S_STEP_SIDE cycles; afterwards all 64 streams step every 64 COST_S_STEP cycles.  Equal finishing
-        // times T for all workgroups: steps_q = (T - C_q) / COST_S_STEP + n_side C_q / COST_S_STEP_SIDE.
+        // times T for all workgroups: steps_q = (T - C_q) / COST_S_STEP + n_side C_q / COST_S_STEP_SIDE.  Walkers slow the
+        // chain they run beside (they share its LDS and its vector L1, and eight producer waves prefetch half as far ahead as
+        // fifteen), so a workgroup whose chain is most of the launch -- C_q > SIDE_TAPER x T -- keeps the classic form.
         const double n_side = ORDER_GROUPS - ORDER_OV_CREW_GROUPS;
-        const double side_gain = 1.0 - COST_S_STEP * n_side / COST_S_STEP_SIDE;   // share of C_q that is NOT recovered by the walkers
-        const double T = (COST_S_STEP * steps + side_gain * total) / nparts;
+        s->part_mode.assign((size_t)nparts, 1);
+        double T = 0.0;
+        for (int iter = 0; iter < 4; ++iter) {
+            double recovered = 0.0;
+            for (int32_t q = 0; q < nparts; ++q)
+                if (s->part_mode[(size_t)q]) recovered += COST_S_STEP * n_side * chain_cost[(size_t)q] / COST_S_STEP_SIDE;
+            T = (COST_S_STEP * steps + total - recovered) / nparts;
+            for (int32_t q = 0; q < nparts; ++q) s->part_mode[(size_t)q] = chain_cost[(size_t)q] <= SIDE_TAPER * T ? 1 : 0;
+        }
         for (int32_t q = 0; q < nparts; ++q) {
             const double after = std::max(T - chain_cost[(size_t)q], 0.02 * T) / (COST_S_STEP * ORDER_GROUPS);   // steps per stream, all walking
-            // (tapered: walkers slow the chain they run beside -- they share its LDS and its vector L1 -- so a workgroup whose
-            // chain is the launch's critical path, C_q near T, gets fewer side steps)
-            const double taper = SIDE_TAPER > 0.0 ? std::max(0.0, 1.0 - SIDE_TAPER * chain_cost[(size_t)q] / T) : 1.0;
-            const double side = taper * chain_cost[(size_t)q] / COST_S_STEP_SIDE;                                // steps per walking stream, chain busy
+            const double side = s->part_mode[(size_t)q] ? chain_cost[(size_t)q] / COST_S_STEP_SIDE : 0.0;        // steps per walking stream, chain busy
             for (int g = 0; g < ORDER_GROUPS; ++g)
                 weight[(size_t)q * ORDER_GROUPS + g] = after + (g >= ORDER_OV_CREW_GROUPS ? side : 0.0);
         }
@@ -408,6 +414,7 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
     }
     // the chain producers request descriptors a fixed number of chunks ahead without a bounds test: readable, harmless
     // entries (edge 0) behind the last chunk
+    if (s->part_mode.empty()) s->part_mode.assign((size_t)nparts, 0);
     s->vchunks.reserve(2 * s->chunks.size() + CHUNK_PAD);
     for (const Chunk &c : s->chunks) {
         s->vchunks.push_back(Chunk{c.row, c.begin, std::min<int32_t>(c.count, 32), 0});

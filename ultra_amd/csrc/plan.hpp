@@ -44,7 +44,10 @@ constexpr int ORDER_GROUPS = 64;        // 16-lane groups of a 1024-thread workg
 // finishes 8 % earlier (129 k instead of 140 k cycles at FB15k237 bs 8), but the chain itself slows from 675 to 800 cycles
 // per chunk -- eight producer waves prefetch four chunks ahead instead of eight, less than a gather's latency while 255 other
 // CUs are walking -- and the workgroup with the 9,067-edge row becomes the launch: 77.3 vs 79 us stand-alone, - 1.4 % on the
-// benchmark step.
+// benchmark step.  Keeping the classic form for workgroups whose chain is most of the launch (part_mode, C_q >
+// 0.6 T) does not rescue it: the classic chain also slows (152 chunks in 147 k cycles instead of 130 k) once the other
+// workgroups walk from the start -- in the default kernel every CU is in its chain phase at the same time, i.e. the chains
+// run against a quiet memory system -- 82-85 us.
 #ifndef ULTRA_CHAIN_OVERLAP
 #define ULTRA_CHAIN_OVERLAP 0
 #endif
@@ -71,6 +74,10 @@ struct Schedule {
     // order (workgroup q: [2 chunk_ptr[q], 2 chunk_ptr[q + 1])), CHUNK_PAD readable entries behind the last one
     std::vector<Chunk> vchunks;
     Chunk *d_vchunks = nullptr;
+    // ... and per workgroup: 1 = its chain runs side by side with its walkers, 0 = classic (fifteen producers, one barrier per
+    // chunk, then the walk) -- the form kept for workgroups whose chain is the launch's critical path
+    std::vector<int32_t> part_mode;
+    int32_t *d_part_mode = nullptr;
     int32_t *d_chunk_ptr = nullptr, *d_unit_ptr = nullptr, *d_units = nullptr, *d_srec = nullptr, *d_sdesc = nullptr;
     int32_t *d_prow = nullptr, *d_prow_ptr = nullptr;
     Chunk *d_chunks = nullptr;

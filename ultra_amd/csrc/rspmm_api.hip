@@ -139,6 +139,7 @@ static void free_schedules(ultra_plan *p) {
         if (s->d_srec) (void)hipFree(s->d_srec);
         if (s->d_sdesc) (void)hipFree(s->d_sdesc);
         if (s->d_vchunks) (void)hipFree(s->d_vchunks);
+        if (s->d_part_mode) (void)hipFree(s->d_part_mode);
         if (s->d_prow) (void)hipFree(s->d_prow);
         if (s->d_prow_ptr) (void)hipFree(s->d_prow_ptr);
         delete s;
@@ -161,7 +162,7 @@ static int get_schedule(ultra_plan *p, int32_t nparts, Schedule **out) {
         (rc = upload_array(&s->d_units, s->units)) || (rc = upload_array(&s->d_chunks, s->chunks)) ||
         (rc = upload_array(&s->d_srec, s->srec)) || (rc = upload_array(&s->d_sdesc, s->sdesc)) ||
         (rc = upload_array(&s->d_prow, s->prow)) || (rc = upload_array(&s->d_prow_ptr, s->prow_ptr)) ||
-        (rc = upload_array(&s->d_vchunks, s->vchunks))) {
+        (rc = upload_array(&s->d_vchunks, s->vchunks)) || (rc = upload_array(&s->d_part_mode, s->part_mode))) {
         delete s;
         return rc;
     }
@@ -366,6 +367,7 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
             op.chunk_ptr = sched->d_chunk_ptr;
             op.chunks = reinterpret_cast<const int4 *>(sched->d_chunks);
             op.vchunks = reinterpret_cast<const int4 *>(sched->d_vchunks);
+            op.part_mode = sched->d_part_mode;
             op.n_chain = (int32_t)p->n_chain;
             op.n_item = (int32_t)p->items.size();
             op.rel = fp.rel, op.x = fp.x, op.bnd = fp.bnd;
@@ -1036,6 +1038,7 @@ int32_t ultra_plan_schedule_export(ultra_plan *plan, int32_t nparts, int32_t whi
         case 5: src = s->srec.data(), n = (int64_t)s->srec.size() - 2 * ORDER_PAD; break;
         case 6: src = s->prow.data(), n = (int64_t)s->prow.size(); break;
         case 7: src = s->prow_ptr.data(), n = (int64_t)s->prow_ptr.size(); break;
+        case 8: src = s->part_mode.data(), n = (int64_t)s->part_mode.size(); break;
         default: delete s; return invalid("ultra_plan_schedule_export: unknown array id");
     }
     *count = n;

@@ -51,6 +51,7 @@ struct OrderParams {
     const int32_t *unit_ptr, *units, *chunk_ptr;
     const int4 *chunks;       // {row, begin, count, flags}
     const int4 *vchunks;      // the same list as half-chunks, two per chunk (ULTRA_CHAIN_OVERLAP; plan.hpp Schedule)
+    const int32_t *part_mode; // ... and per workgroup: chain side by side with the walkers (1) or classic (0)
     const int32_t *srec;      // group streams (plan.hpp Schedule): records and {first record, steps} per (workgroup, 16-lane group)
     const int2 *sdesc;
     int32_t use_streams;
@@ -411,8 +412,10 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
         // lgkmcnt(0)), so a ring half is never overwritten early.  Producers and the consumer run separate loops with
         // the same number of barriers: one per chunk.
         const int c0 = p.has_chain ? p.chunk_ptr[part] : 0, c1 = p.has_chain ? p.chunk_ptr[part + 1] : 0;
-        constexpr int RING_HALF = OVERLAP ? OV_RING_HALF : CHAIN_QUADS * 64;   // in quads-of-lane units (V)
-        if (c1 > c0 && (!OVERLAP || wave <= ORDER_OV_PRODUCERS)) {
+        bool ov = false;   // this workgroup's chain runs side by side with its walkers (workgroup-uniform)
+        if constexpr (OVERLAP) ov = load_uniform(p.part_mode + part) != 0;
+        const int RING_HALF = ov ? OV_RING_HALF : CHAIN_QUADS * 64;   // in quads-of-lane units (V)
+        if (c1 > c0 && (!ov || wave <= ORDER_OV_PRODUCERS)) {
             const LaneGeom cg = lane_geom();
             const int grp = cg.grp, l16 = cg.l16;
             const uint32_t lane_bytes = cg.lane_bytes;
@@ -456,7 +459,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                 volatile int *ov_flags = reinterpret_cast<volatile int *>(reinterpret_cast<char *>(ring) + 2 * OV_RING_HALF * 16);
                 int kc = 0, ready_seen = 0;   // ready_seen: ready[kc & 1] as read right behind the previous chunk's ring reads
                 const auto chunk_wait = [&]() {
-                    if constexpr (OVERLAP) {
+                    if (OVERLAP && ov) {
                         const int target = 16 * ((kc >> 1) + 1);
                         if (ready_seen < target) {
 #if ULTRA_OV_SPIN
@@ -471,7 +474,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                     }
                 };
                 const auto chunk_read = [&]() {
-                    if constexpr (OVERLAP) {
+                    if (OVERLAP && ov) {
                         asm volatile("" ::: "memory");
                         ov_flags[2] = ++kc;
                         ready_seen = ov_flags[kc & 1];   // (returns behind the ring reads: off the critical path when the producers are ahead)
@@ -561,7 +564,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                     for (int k = c0; k < c1; ++k) __syncthreads();
                 } else
 #endif
-                if constexpr (OVERLAP) {
+                if (OVERLAP && ov) {
 #if ULTRA_OV_PROD_PRIO
                     __builtin_amdgcn_s_setprio(ULTRA_OV_PROD_PRIO);
 #endif
