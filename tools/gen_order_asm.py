@@ -340,7 +340,10 @@ OV_RING_HALF_BYTES = 16 * 64 * 16
 OV_CLOBBER_LO = 40
 
 
-def gen_producer_overlap(mul_code, rec_policy):
+def gen_producer_overlap(mul_code, rec_policy, halves=True):
+    """halves=True: eight producer waves, two half-chunk steps per chunk (the side-by-side form).  halves=False: fifteen producer
+    waves, one step per chunk, classic ring (15 quads per half) -- the classic chain with the LDS-word hand-off in place of its
+    barrier."""
     a = Asm()
     D = PROD_D
     binop = BINOPS[mul_code]
@@ -418,10 +421,15 @@ def gen_producer_overlap(mul_code, rec_policy):
     a("ds_read_b32 v42, v40 offset:8", "done (for the first gate)")
     a.label(".Lov_loop_%=")
     for J in range(D):
-        if J % 2 == 0:
-            # first half of chunk j = i / 2: its ring half is free once done >= j - 1.  `done` was requested at the end of
-            # the previous step; the wait also collects the relation row requested one step ago.
-            a("s_lshr_b32 %[t], %[i], 1")
+        first = (J % 2 == 0) or not halves     # first (or only) step of a chunk: gated
+        last = (J % 2 == 1) or not halves      # last (or only) step of a chunk: ring half and parity flip behind it
+        if first:
+            # chunk j = i / 2 (i with one step per chunk): its ring half is free once done >= j - 1.  `done` was requested at
+            # the end of the previous step; the wait also collects the relation row requested one step ago.
+            if halves:
+                a("s_lshr_b32 %[t], %[i], 1")
+            else:
+                a("s_mov_b32 %[t], %[i]")
             a.label(".Lov_gate%d_%%=" % J)
             a("s_waitcnt lgkmcnt(0)")
             a("v_readfirstlane_b32 %[d], v42")
@@ -433,20 +441,19 @@ def gen_producer_overlap(mul_code, rec_policy):
             a("s_branch .Lov_gate%d_%%=" % J)
             a.label(".Lov_go%d_%%=" % J)
         a("v_add_u32_e32 v126, %[half], %[ring]")
-        a("ds_write_b128 v126, %s%s" % (vr(SETS[J % 4], 4), " offset:8192" if J % 2 else ""))
+        a("ds_write_b128 v126, %s%s" % (vr(SETS[J % 4], 4), " offset:8192" if (halves and J % 2) else ""))
         a("v_add_u32_e32 v43, %[par], v40", "ready[chunk parity]")
         a("s_mov_b64 %[ex], exec")
         a("s_mov_b64 exec, 1")
         a("ds_add_u32 v43, v41", "(behind the write: a wave's LDS operations execute in order)")
         a("s_mov_b64 exec, %[ex]")
-        if J % 2:
-            a("s_xor_b32 %%[half], %%[half], %d" % OV_RING_HALF_BYTES)
+        if last:
+            a("s_xor_b32 %%[half], %%[half], %d" % (OV_RING_HALF_BYTES if halves else RING_HALF_BYTES))
             a("s_xor_b32 %[par], %[par], 4")
-        # LDS operations issued since the read of relation row J + 1 (at the end of step J - 1's preparation): even step --
-        # everything was drained at the gate, then write + add; odd step -- [row J + 1 ... ] then write + add: 2 may stay out.
-        # (odd steps: the previous (even) step issued, behind row J + 1's read: nothing else; so 2 = this step's write + add.)
-        prepare(J + 1, None if J % 2 == 0 else 2)
-        if J % 2:
+        # LDS operations this wave has issued since the read of relation row J + 1 (two steps ago): a gated step drained
+        # everything at its gate; an ungated (second-half) step has only its own write + add outstanding behind it.
+        prepare(J + 1, None if first else 2)
+        if last:
             a("ds_read_b32 v42, v40 offset:8", "done (for the next step's gate)")
         a("s_add_i32 %[i], %[i], 1")
         a("s_cmp_ge_i32 %[i], %[n]")
@@ -539,6 +546,24 @@ def main():
     first = True
     for mul_code in (0, 1):
         a = gen_producer_overlap(mul_code, REC_POLICY)
+        parts.append("    %sif constexpr (MUL == %d) {\n" % ("" if first else "else ", mul_code))
+        first = False
+        parts.append("        asm volatile(\n" + a.render("            ") + "\n")
+        parts.append('            : [i] "=&s"(i), [half] "=&s"(half), [par] "=&s"(par), [t] "=&s"(t), [d] "=&s"(d), [ex] "=&s"(ex)\n'
+                     '            : [n] "s"(n), [chunks] "s"(chunks), [slot8] "v"(slot8), [lb] "v"(lb), [lds] "v"(lds), [ring] "v"(ring),\n'
+                     '              [flags] "s"(flags), [xb] "s"(xb), [rb] "s"(rb), [xrb] "s"(xrb)\n'
+                     '            : "memory", "scc", %s);\n' % clobbers(OV_CLOBBER_LO, PROD_CLOBBER_HI))
+        parts.append("    }\n")
+    parts.append("}\n\n")
+    parts.append("// chain producers, classic layout with the LDS-word hand-off instead of the barrier: `n` chunks, fifteen producer waves\n"
+                 "template <int MUL>\n"
+                 "__device__ __forceinline__ void order_produce_polled_asm(const int n, const void *chunks, const uint32_t slot8, const uint32_t lb,\n"
+                 "                                                         const uint32_t lds, const uint32_t ring, const uint32_t flags,\n"
+                 "                                                         const char *xb, const char *rb, const uint32_t xrb) {\n"
+                 "    int i, half, par, t, d;\n    unsigned long long ex;\n")
+    first = True
+    for mul_code in (0, 1):
+        a = gen_producer_overlap(mul_code, REC_POLICY, halves=False)
         parts.append("    %sif constexpr (MUL == %d) {\n" % ("" if first else "else ", mul_code))
         first = False
         parts.append("        asm volatile(\n" + a.render("            ") + "\n")

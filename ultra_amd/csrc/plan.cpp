@@ -346,9 +346,13 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
         // chain they run beside (they share its LDS and its vector L1, and eight producer waves prefetch half as far ahead as
         // fifteen), so a workgroup whose chain is most of the launch -- C_q > SIDE_TAPER x T -- keeps the classic form.
         const double n_side = ORDER_GROUPS - ORDER_OV_CREW_GROUPS;
-        s->part_mode.assign((size_t)nparts, 1);
+        s->part_mode.assign((size_t)nparts, SIDE_TAPER < 0.0 ? 2 : 1);   // (< 0: every chain classic, with the LDS-word hand-off)
         double T = 0.0;
         for (int iter = 0; iter < 4; ++iter) {
+            if (SIDE_TAPER < 0.0) {
+                T = (COST_S_STEP * steps + total) / nparts;
+                break;
+            }
             double recovered = 0.0;
             for (int32_t q = 0; q < nparts; ++q)
                 if (s->part_mode[(size_t)q]) recovered += COST_S_STEP * n_side * chain_cost[(size_t)q] / COST_S_STEP_SIDE;
@@ -357,7 +361,7 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
         }
         for (int32_t q = 0; q < nparts; ++q) {
             const double after = std::max(T - chain_cost[(size_t)q], 0.02 * T) / (COST_S_STEP * ORDER_GROUPS);   // steps per stream, all walking
-            const double side = s->part_mode[(size_t)q] ? chain_cost[(size_t)q] / COST_S_STEP_SIDE : 0.0;        // steps per walking stream, chain busy
+            const double side = s->part_mode[(size_t)q] == 1 ? chain_cost[(size_t)q] / COST_S_STEP_SIDE : 0.0;   // steps per walking stream, chain busy
             for (int g = 0; g < ORDER_GROUPS; ++g)
                 weight[(size_t)q * ORDER_GROUPS + g] = after + (g >= ORDER_OV_CREW_GROUPS ? side : 0.0);
         }

@@ -47,7 +47,10 @@ constexpr int ORDER_GROUPS = 64;        // 16-lane groups of a 1024-thread workg
 // benchmark step.  Keeping the classic form for workgroups whose chain is most of the launch (part_mode, C_q >
 // 0.6 T) does not rescue it: the classic chain also slows (152 chunks in 147 k cycles instead of 130 k) once the other
 // workgroups walk from the start -- in the default kernel every CU is in its chain phase at the same time, i.e. the chains
-// run against a quiet memory system -- 82-85 us.
+// run against a quiet memory system -- 82-85 us.  And the hand-off itself is the slower primitive: the classic chain (fifteen
+// producers, nobody walking) with the LDS words in place of its barrier (part_mode 2, ULTRA_STREAM_COSTS=...,-1) runs at 813
+// cycles per chunk against 641 with s_barrier on the same box -- with two ring halves the producer -> consumer -> producer
+// signalling round trip (two LDS polls) sits on every chunk, and a deeper ring does not fit beside the relation slice.
 #ifndef ULTRA_CHAIN_OVERLAP
 #define ULTRA_CHAIN_OVERLAP 0
 #endif

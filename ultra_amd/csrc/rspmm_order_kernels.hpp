@@ -412,10 +412,12 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
         // lgkmcnt(0)), so a ring half is never overwritten early.  Producers and the consumer run separate loops with
         // the same number of barriers: one per chunk.
         const int c0 = p.has_chain ? p.chunk_ptr[part] : 0, c1 = p.has_chain ? p.chunk_ptr[part + 1] : 0;
-        bool ov = false;   // this workgroup's chain runs side by side with its walkers (workgroup-uniform)
-        if constexpr (OVERLAP) ov = load_uniform(p.part_mode + part) != 0;
-        const int RING_HALF = ov ? OV_RING_HALF : CHAIN_QUADS * 64;   // in quads-of-lane units (V)
-        if (c1 > c0 && (!ov || wave <= ORDER_OV_PRODUCERS)) {
+        // this workgroup's chain (workgroup-uniform): 0 classic (one barrier per chunk), 1 side by side with its walkers (nine-wave
+        // crew, LDS-word hand-off), 2 classic with the LDS-word hand-off
+        int ov = 0;
+        if constexpr (OVERLAP) ov = load_uniform(p.part_mode + part);
+        const int RING_HALF = ov == 1 ? OV_RING_HALF : CHAIN_QUADS * 64;   // in quads-of-lane units (V)
+        if (c1 > c0 && (ov != 1 || wave <= ORDER_OV_PRODUCERS)) {
             const LaneGeom cg = lane_geom();
             const int grp = cg.grp, l16 = cg.l16;
             const uint32_t lane_bytes = cg.lane_bytes;
@@ -460,7 +462,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                 int kc = 0, ready_seen = 0;   // ready_seen: ready[kc & 1] as read right behind the previous chunk's ring reads
                 const auto chunk_wait = [&]() {
                     if (OVERLAP && ov) {
-                        const int target = 16 * ((kc >> 1) + 1);
+                        const int target = (ov == 1 ? 16 : 15) * ((kc >> 1) + 1);
                         if (ready_seen < target) {
 #if ULTRA_OV_SPIN
                             while (ov_flags[kc & 1] < target) {}
@@ -564,7 +566,12 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                     for (int k = c0; k < c1; ++k) __syncthreads();
                 } else
 #endif
-                if (OVERLAP && ov) {
+                if (OVERLAP && ov == 2) {
+                    order_produce_polled_asm<MUL>(c1 - c0, p.chunks + c0, (uint32_t)slot * 8u, lane_bytes, lds_addr(lds_rel_lane),
+                                                  lds_addr(ring) + (uint32_t)((wave - 1) * 64 + lane) * 16u,
+                                                  lds_addr(ring) + 2u * OV_RING_HALF * 16u, xbase, reinterpret_cast<const char *>(p.rec),
+                                                  p.x_row_bytes);
+                } else if (OVERLAP && ov == 1) {
 #if ULTRA_OV_PROD_PRIO
                     __builtin_amdgcn_s_setprio(ULTRA_OV_PROD_PRIO);
 #endif
