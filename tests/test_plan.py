@@ -265,6 +265,22 @@ def test_group_streams_cover_every_group_row_once_in_sorted_edge_order():
     assert int(loads.max() - loads.min()) <= int((row_ptr[1:] - row_ptr[:-1]).clamp(max=256).max()) + 64
 
 
+def test_stream_work_follows_the_wave_age_shares():
+    """plan.cpp WAVE_SHARE: a CU issues oldest wave first, so the schedule gives the four wave quartets of a workgroup
+    1.7 / 1.3 / 0.7 / 0.3 of an even share of its stream steps (they then finish their walks together)."""
+    from ultra_amd.rspmm import Plan
+    ei, et = helpers.random_graph(num_node=6000, num_edge=90000, num_relation=12, seed=3)
+    plan = Plan(ei, et, 6000, 12, exact_order=True)
+    nparts = 2
+    sdesc, _ = plan.streams(nparts)
+    quartet = sdesc[:, 1].view(nparts, 4, 16).sum(dim=2).double()          # steps per (workgroup, wave quartet)
+    share = quartet / quartet.mean(dim=1, keepdim=True)
+    want = torch.tensor([1.7, 1.3, 0.7, 0.3], dtype=torch.double)
+    assert torch.allclose(share, want.expand_as(share), atol=0.05), share
+    per_stream = sdesc[:, 1].view(nparts, 4, 16).double()
+    assert float((per_stream.max(dim=2)[0] - per_stream.min(dim=2)[0]).max()) <= 40      # streams of one quartet: balanced among themselves
+
+
 def test_workgroup_row_lists_partition_the_rows_along_the_streams():
     """Work list of the update tail (plan.cpp build_schedule): workgroup q's list = its chain rows + the rows of its 64
     streams, ascending, padded with -1 to whole 32-row tiles; the lists partition the rows."""

@@ -43,6 +43,9 @@ for q in range(nparts):
                                                      we[:, 9:].mean(), we[:, 9:].max(dim=1)[0].mean()))
 print("all: chain %.0f, crew end %.0f, walkers end %.0f, workgroup end mean %.0f max %.0f" %
       (chain.mean(), wave_end[:, :9].mean(), wave_end[:, 9:].mean(), wave_end.max(dim=1)[0].mean(), wave_end.max()))
+rel = wave_end - chain.unsqueeze(1)
+print("end of walk per wave, cycles since the workgroup's chains were done (mean over workgroups):")
+print(" ".join("%6.0f" % v for v in rel.mean(dim=0).tolist()))
 sel = nchunk[part] > 4
 if sel.any():
     A = torch.stack([nchunk[part][sel], torch.ones(int(sel.sum()), dtype=torch.double)], dim=1)

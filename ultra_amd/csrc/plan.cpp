@@ -248,6 +248,14 @@ static double COST_UNIT_STEP = 28.0, COST_UNIT = 100.0;
 // the stream walk (assembly paths; order_trace on MI355X): workgroup cycles per chain chunk / chain row, and per step of
 // one group stream when all sixteen waves walk (21.5 cycles per wave step / 4 groups)
 static double COST_S_CHUNK = 675.0, COST_S_ROW = 1380.0, COST_S_STEP = 6.0;
+// Share of a workgroup's stream work per wave quartet (waves 0-3, 4-7, 8-11, 12-15; mean 1).  The CU issues oldest wave
+// first: with equal shares the four quartets finish their walks at 48 k / 59 k / 76 k / 89 k cycles (tools/overlap_trace.py,
+// FB15k237 bs 8) and the last one walks alone at a quarter of the CU's gather rate.  Rates by age rank solved from those
+// four times come out as 1 : 0.77 : 0.47 : 0.35, but the young waves are nearly starved while older ones run, so the shares were
+// swept instead (tools/share_sweep.sh): 1.7 / 1.3 / 0.7 / 0.3 lets the quartets finish at 84 k / 80 k / 82 k / 85 k -- the
+// launch's last workgroup at 142.5 k cycles instead of 147.7 k, 69.5 us instead of 71.8 stand-alone.  (s_setprio against
+// the age order only reverses who finishes first: 50 k / 60 k / 76 k / 89 k from the youngest quartet up.)
+static double WAVE_SHARE[4] = {1.7, 1.3, 0.7, 0.3};
 // ULTRA_CHAIN_OVERLAP: cycles one walking stream needs per step while the chain crew is still busy (fewer streams share the
 // vector L1 then: a stream steps faster than the 64 x COST_S_STEP of the all-streams phase)
 static double COST_S_STEP_SIDE = 252.0, SIDE_TAPER = 0.6;   // (SIDE_TAPER: share of T above which a chain stays classic)
@@ -257,6 +265,11 @@ static void read_cost_override() {   // calibration runs only: ULTRA_SCHED_COSTS
     double v[5];
     if (env && std::sscanf(env, "%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5) {
         COST_CHAIN_EDGE = v[0], COST_CHAIN_CHUNK = v[1], COST_CHAIN_ROW = v[2], COST_UNIT_STEP = v[3], COST_UNIT = v[4];
+    }
+    env = std::getenv("ULTRA_STREAM_SHARES");   // calibration runs: "q0,q1,q2,q3"
+    if (env && std::sscanf(env, "%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3]) == 4) {
+        const double mean = (v[0] + v[1] + v[2] + v[3]) / 4.0;
+        for (int k = 0; k < 4; ++k) WAVE_SHARE[k] = mean > 0 ? v[k] / mean : 1.0;
     }
     env = std::getenv("ULTRA_STREAM_COSTS");
     if (env) {
@@ -370,7 +383,7 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
         const double T = total / nparts;
         for (int32_t q = 0; q < nparts; ++q) {
             const double budget = std::max(T - chain_cost[(size_t)q], 0.02 * T);   // (never zero: every row needs a home)
-            for (int g = 0; g < ORDER_GROUPS; ++g) weight[(size_t)q * ORDER_GROUPS + g] = budget;
+            for (int g = 0; g < ORDER_GROUPS; ++g) weight[(size_t)q * ORDER_GROUPS + g] = budget * WAVE_SHARE[g / 16];
         }
 #endif
         typedef std::pair<double, int64_t> Slot;   // ((load + 1) / weight, stream): the heap's top is the relatively emptiest
