@@ -11,7 +11,8 @@ shard over ranks (each rank scores its own 8 queries, graph + weights replicated
 with one RCCL all-gather of the per-rank score rows.  Weak scaling: per-GPU work is fixed.  Rank 0 prints ONE JSON line.
 
 Extra blocks of the JSON line (rank 0, N = 1):
-  roofline     -- the dominant kernel (entity-graph rspmm, reference-order kernel) at the benchmark point AND at the
+  roofline     -- the dominant kernel (one entity layer: reference-order rspmm + the layer update in its tail,
+                  ultra_rspmm_forward_update) at the benchmark point AND at the
                   HBM-bound point (CoDEx-L shape, batch 8: x + out = 319 MB > the 256 MB Infinity Cache): kernel time
                   from HIP events on the launch stream, HBM-side and L2 bytes from rocprofv3 --pmc passes run by this
                   script (FETCH_SIZE / WRITE_SIZE / TCC_REQ in separate passes, calibrated on a 1 GiB stream copy in the
@@ -42,7 +43,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 L2_PEAK_GBS = 34500.0      # MI355X_MICROARCH.md: aggregate L2 bandwidth
 COPY_BYTES = 1 << 30
 ROOFLINE_POINTS = [("fb15k237", 8), ("codex_l", 8)]
-ORDER_KERNEL = "rspmm_order_kernel<float, 0, 0, true, false, true, false>"   # (..., STREAMS, UPDATE)
+ORDER_KERNEL = "rspmm_order_kernel<float, 0, 0, true, false, true, true>"   # (..., STREAMS, UPDATE): aggregate + layer update
 
 
 def available_cores():
@@ -70,6 +71,21 @@ def b_gather(E, N, R, D):
 def b_min(E, N, R, D):
     # compulsory model: x read once, out written once, relation table once, records once
     return 4 * D * (2 * N + R) + 8 * E + 16 * N
+
+
+UPDATE_WEIGHT_BYTES = 4 * (64 * 128 + 3 * 64)      # Linear(128 -> 64) + bias + LayerNorm weight / bias
+
+
+def b_gather_layer(E, N, R, D):
+    # the one-launch layer (ultra_rspmm_forward_update): the rspmm above (its "output" is the aggregate), then the update reads x
+    # and the aggregate back and writes the layer output
+    return b_gather(E, N, R, D) + 3 * 4 * D * N + 4 * N + UPDATE_WEIGHT_BYTES
+
+
+def b_min_layer(E, N, R, D):
+    # compulsory for the layer: x read once, LAYER OUTPUT written once (the aggregate is an intermediate: every byte of its
+    # round trip counts as avoidable traffic), relation table, records, row lists, weights once
+    return b_min(E, N, R, D) + 4 * N + UPDATE_WEIGHT_BYTES
 
 
 @contextlib.contextmanager
@@ -102,7 +118,9 @@ def _point_operands(shape, bs, dev):
     # the boundary condition as the forward passes it: one row per sample (ultra_rspmm_forward_point)
     point = (data.target_triples[:bs, 0].contiguous().to(dev), torch.randn(bs, 64, generator=g).to(dev))
     plan = rspmm.Plan(data.edge_index, data.edge_type, N, R, exact_order=True)
-    return data, plan, rel, x, point
+    # the layer update's parameters (Linear(128 -> 64), LayerNorm(64)); flags 7 = LayerNorm | ReLU | residual
+    upd = ((torch.randn(64, 128, generator=g) / 11).to(dev),) + tuple(torch.randn(64, generator=g).to(dev) for _ in range(3))
+    return data, plan, rel, x, point, upd
 
 
 def _stream_copy(dst, src):
@@ -112,8 +130,8 @@ def _stream_copy(dst, src):
 
 
 def pmc_target():
-    """Child process of the --pmc passes: 1 GiB stream copy x 4, then per roofline point the entity rspmm x 4 (first of
-    each = warm-up).  Nothing else runs on the GPU between them, in this fixed order."""
+    """Child process of the --pmc passes: 1 GiB stream copy x 4, then per roofline point the entity layer (rspmm + update in
+    one launch) x 4 (first of each = warm-up).  Nothing else runs on the GPU between them, in this fixed order."""
     dev = torch.device("cuda:0")
     src = torch.empty(COPY_BYTES // 4, device=dev).normal_()
     dst = torch.empty_like(src)
@@ -122,9 +140,10 @@ def pmc_target():
     torch.cuda.synchronize()
     del src, dst
     for shape, bs in ROOFLINE_POINTS:
-        _, plan, rel, x, point = _point_operands(shape, bs, dev)
+        _, plan, rel, x, point, upd = _point_operands(shape, bs, dev)
         for _ in range(4):
-            plan.forward(rel, x, point=point)
+            if plan.forward_update(rel, x, upd[0], upd[1], upd[2], upd[3], 1e-5, 7, point=point) is None:
+                raise RuntimeError("the one-launch layer does not serve this point")
         torch.cuda.synchronize()
         del plan, rel, x
 
@@ -175,7 +194,8 @@ def _run_pmc_pass(counters, timeout=240):
 def measure_roofline(dev, use_pmc=True):
     from ultra_amd import _lib
     out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "kernel": "ultra::" + ORDER_KERNEL + " (entity graph, add_mul, point boundary, relation slice in LDS)"}
+           "kernel": "ultra::" + ORDER_KERNEL + " (entity layer in one launch: rspmm add_mul with point boundary, relation slice "
+                     "in LDS, then Linear(128->64) + LayerNorm + ReLU + residual on the rows each workgroup aggregated)"}
     # ---- stream-copy ceiling ----
     src = torch.empty(COPY_BYTES // 4, device=dev).normal_()
     dst = torch.empty_like(src)
@@ -194,14 +214,18 @@ def measure_roofline(dev, use_pmc=True):
     # ---- kernel times (HIP events right around the kernel launch, on the launch stream) ----
     points = []
     for shape, bs in ROOFLINE_POINTS:
-        data, plan, rel, x, point = _point_operands(shape, bs, dev)
+        data, plan, rel, x, point, upd = _point_operands(shape, bs, dev)
         E, N, R, D = data.num_edges, data.num_nodes, data.num_relations, bs * 64
-        plan.forward_timed(rel, x, point=point, warmup=5, iters=30)
-        ms = plan.last_main_kernel_ms
+        timed = plan.forward_update(rel, x, upd[0], upd[1], upd[2], upd[3], 1e-5, 7, point=point, timed=(5, 30))
+        if timed is None:
+            raise RuntimeError("the one-launch layer does not serve the roofline point %s" % shape)
+        ms = timed[1]
+        plan.forward_timed(rel, x, point=point, warmup=5, iters=30)      # (the aggregate alone, for the record)
         info = plan.info()
         points.append({"shape": shape, "batch": bs, "N": N, "E": E, "R": R, "D": D, "ms_per_launch": ms,
+                       "ms_per_launch_aggregate_only": plan.last_main_kernel_ms,
                        "x_plus_out_MB": 2 * 4 * D * N / 1e6, "chain_rows": info["n_chain_row"],
-                       "gather_model_bytes": b_gather(E, N, R, D), "compulsory_bytes": b_min(E, N, R, D)})
+                       "gather_model_bytes": b_gather_layer(E, N, R, D), "compulsory_bytes": b_min_layer(E, N, R, D)})
         del plan, rel, x
     # ---- HBM-side and L2 traffic: rocprofv3 counter passes over the same launches (separate passes, no trace domains
     # besides --kernel-trace), calibrated on the 1 GiB copy of the same pass ----
@@ -257,7 +281,10 @@ def measure_roofline(dev, use_pmc=True):
         "points": points,
     })
     out["frac"] = out["achieved"] / HBM_PEAK_GBS
-    out["note"] = ("gather-model GB/s exceeds the HBM peak where x is cache resident (every edge re-reads a 256-B source row "
+    out["note"] = ("the kernel is the whole entity layer: aggregate, then the update of the same rows in the kernel's tail "
+                   "(compulsory bytes: x in, layer output out, relation table, records, weights -- the aggregate's round trip "
+                   "is counted as avoidable traffic).  "
+                   "gather-model GB/s exceeds the HBM peak where x is cache resident (every edge re-reads a 256-B source row "
                    "from L2 / Infinity Cache, not from HBM); `frac` is the measured HBM-side fraction.  FETCH_SIZE counts "
                    "L2 misses, Infinity-Cache hits included (MI355X_MICROARCH.md).")
     if pmc_note:
@@ -595,19 +622,19 @@ def main():
                                              "re-associated, nn.Linear / nn.LayerNorm still in torch's order"}}
             finally:
                 rspmm.set_plan_defaults()
-            # ---- layers as ONE launch each (ultra_rspmm_forward_update: the update applied in the tail of the rspmm kernel) ----
+            # ---- entity layers as TWO launches each (rspmm, then conv_update): the timed mode runs them as one ----
             from ultra_amd import layers as _layers
             was = _layers.FUSED_SPARSE_LAYER
-            _layers.FUSED_SPARSE_LAYER = True
+            _layers.FUSED_SPARSE_LAYER = False
             try:
                 el3 = timed_run(make_forward(), False)
                 with torch.no_grad():
                     got3 = model(data, t_batch_cpu.to(dev)).cpu()
-                out.setdefault("modes", {})["one_launch_layers"] = {
+                out.setdefault("modes", {})["two_launch_layers"] = {
                     "timed": False, "triples_per_s": bs * N * args.steps / el3, "ms_per_step": 1e3 * el3 / args.steps,
                     "scores_bit_equal_with_the_timed_mode": bool(torch.equal(got3, got)),
-                    "note": "layers.FUSED_SPARSE_LAYER (ULTRA_FUSED_SPARSE_LAYER=1): aggregate + update of entity layers 1-5 in one "
-                            "launch; same bits; not the timed mode (DESIGN.md 3.8: the tail is a chip-wide burst, the gain is ~1 %)"}
+                    "note": "ULTRA_FUSED_SPARSE_LAYER=0: ultra_rspmm_forward_point + ultra_conv_update per entity layer instead of "
+                            "ultra_rspmm_forward_update; same bits (DESIGN.md 3.8)"}
             finally:
                 _layers.FUSED_SPARSE_LAYER = was
     if rank == 0 and world == 1 and not launched and not args.no_secondary:

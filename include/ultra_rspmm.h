@@ -334,6 +334,13 @@ int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, in
                                   const ultra_mat *boundary, const int64_t *point_rows_dev, const ultra_mat *output,
                                   void *stream, int32_t warmup, int32_t iters, float *ms_per_call, float *ms_main_kernel);
 
+/* ultra_rspmm_forward_timed for the one-launch layer (ultra_rspmm_forward_update): same two figures. */
+int32_t ultra_rspmm_forward_update_timed(ultra_plan *plan, int32_t mul, const ultra_mat *relation, const ultra_mat *input,
+                                         const int64_t *point_rows_dev, const ultra_mat *point_values, const ultra_mat *aggregate,
+                                         const void *weight, const void *bias, const void *ln_weight, const void *ln_bias, float eps,
+                                         int32_t flags, const ultra_mat *output, void *stream, int32_t warmup, int32_t iters,
+                                         float *ms_per_call, float *ms_main_kernel);
+
 /* Measurement helper: streaming 16-B/lane copy of `bytes` (multiple of 16) device bytes.  Used for the
  * achievable-HBM-copy ceiling and to calibrate the FETCH_SIZE / WRITE_SIZE counters on a known byte count. */
 int32_t ultra_stream_copy(void *dst_dev, const void *src_dev, int64_t bytes, void *stream);

@@ -88,6 +88,8 @@ def _load():
     lib.ultra_rspmm_forward_onehot.argtypes = [vp, i32, vp, matp, matp, vp, matp, matp, vp]
     lib.ultra_rspmm_forward_point.argtypes = [vp, i32, i32, vp, matp, matp, vp, matp, matp, vp]
     lib.ultra_rspmm_forward_update.argtypes = [vp, i32, matp, matp, vp, matp, matp, vp, vp, vp, vp, ctypes.c_float, i32, matp, vp]
+    lib.ultra_rspmm_forward_update_timed.argtypes = [vp, i32, matp, matp, vp, matp, matp, vp, vp, vp, vp, ctypes.c_float, i32, matp, vp,
+                                                     i32, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     lib.ultra_nbf_dense_layer.argtypes = [vp, matp, matp, matp, vp, vp, vp, vp, vp, ctypes.c_float, i32, matp, vp]
     lib.ultra_nbf_layer0.argtypes = [vp, vp, matp, vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, matp, vp]
     lib.ultra_rspmm_backward.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp, matp, matp, vp]

@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -948,18 +949,11 @@ int32_t ultra_rspmm_backward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t
                          relation_grad, input_grad, reinterpret_cast<hipStream_t>(stream));
 }
 
-int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype,
-                                  const void *edge_weight_dev, const ultra_mat *relation, const ultra_mat *input,
-                                  const ultra_mat *boundary, const int64_t *point_rows_dev, const ultra_mat *output,
-                                  void *stream, int32_t warmup, int32_t iters, float *ms_per_call, float *ms_main_kernel) {
-    ULTRA_DEVICE_SCOPE(stream, output ? output->ptr : nullptr);
-    if (mul < 0 || mul > 1) return invalid("unknown mul code");
-    const auto once = [&]() {
-        return forward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, boundary, output,
-                            reinterpret_cast<hipStream_t>(stream), point_rows_dev);
-    };
-    if (!ms_per_call || iters <= 0) return invalid("ultra_rspmm_forward_timed: bad iters / ms_per_call");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+// Times `once` (a launch sequence on stream s) with HIP events: the mean of `iters` back-to-back calls, and -- the figure
+// comparable with rocprofv3's per-kernel average -- the main kernel alone, events recorded right around its launch.
+static int time_launches(const std::function<int()> &once, hipStream_t s, int32_t warmup, int32_t iters, float *ms_per_call, float *ms_main_kernel,
+                         const char *who) {
+    if (!ms_per_call || iters <= 0) return invalid(std::string(who) + ": bad iters / ms_per_call");
     int rc;
     for (int i = 0; i < warmup; ++i)
         if ((rc = once()))
@@ -996,6 +990,33 @@ int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, in
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return ULTRA_OK;
+}
+
+int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype,
+                                  const void *edge_weight_dev, const ultra_mat *relation, const ultra_mat *input,
+                                  const ultra_mat *boundary, const int64_t *point_rows_dev, const ultra_mat *output,
+                                  void *stream, int32_t warmup, int32_t iters, float *ms_per_call, float *ms_main_kernel) {
+    ULTRA_DEVICE_SCOPE(stream, output ? output->ptr : nullptr);
+    if (mul < 0 || mul > 1) return invalid("unknown mul code");
+    const auto once = [&]() {
+        return forward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, boundary, output,
+                            reinterpret_cast<hipStream_t>(stream), point_rows_dev);
+    };
+    return time_launches(once, reinterpret_cast<hipStream_t>(stream), warmup, iters, ms_per_call, ms_main_kernel,
+                         "ultra_rspmm_forward_timed");
+}
+
+int32_t ultra_rspmm_forward_update_timed(ultra_plan *plan, int32_t mul, const ultra_mat *relation, const ultra_mat *input,
+                                         const int64_t *point_rows_dev, const ultra_mat *point_values, const ultra_mat *aggregate,
+                                         const void *weight, const void *bias, const void *ln_weight, const void *ln_bias, float eps,
+                                         int32_t flags, const ultra_mat *output, void *stream, int32_t warmup, int32_t iters,
+                                         float *ms_per_call, float *ms_main_kernel) {
+    const auto once = [&]() {
+        return ultra_rspmm_forward_update(plan, mul, relation, input, point_rows_dev, point_values, aggregate, weight, bias, ln_weight,
+                                          ln_bias, eps, flags, output, stream);
+    };
+    return time_launches(once, reinterpret_cast<hipStream_t>(stream), warmup, iters, ms_per_call, ms_main_kernel,
+                         "ultra_rspmm_forward_update_timed");
 }
 
 int32_t ultra_order_trace(void *trace_dev) {

@@ -26,9 +26,9 @@ POINT_BOUNDARY_FAST_PATH = True
 # aggregate + update of a layer in one launch on dense-format plans (A/B switch for tests)
 FUSED_DENSE_LAYER = True
 # aggregate + update of a layer in one launch on the reference-order plan of a sparse graph: the update runs in the tail of
-# the rspmm kernel, on the rows each workgroup has just summed.  Same bits; measured +1 % on the benchmark step (DESIGN.md
-# 3.8), so the two-launch path stays the default and this one is opt-in.
-FUSED_SPARSE_LAYER = os.environ.get("ULTRA_FUSED_SPARSE_LAYER", "0") == "1"
+# the rspmm kernel, on the rows each workgroup has just summed.  Same bits as the two launches, 1 - 2.7 % faster on the
+# benchmark step.  ULTRA_FUSED_SPARSE_LAYER=0 (or the attribute, for A/B tests) selects the two launches.
+FUSED_SPARSE_LAYER = os.environ.get("ULTRA_FUSED_SPARSE_LAYER", "1") != "0"
 
 
 class PointBoundary(object):

@@ -255,11 +255,13 @@ class Plan(object):
                     ctypes.byref(mx), mb, ctypes.byref(mout), _stream(input)))
         return out
 
-    def forward_update(self, relation, input, weight, bias, ln_weight, ln_bias, eps, flags, mul="mul", point=None):
+    def forward_update(self, relation, input, weight, bias, ln_weight, ln_bias, eps, flags, mul="mul", point=None, timed=None):
         """Aggregate (sum, `mul`, optional point boundary) AND the layer update
         `[input +] relu(layer_norm(linear(cat[input, aggregate])))` in one launch (ultra_rspmm_forward_update: the workgroup
         that aggregated a row also updates it).  Bit-equal with forward(point=...) followed by dense.conv_update.
-        Returns the layer output, or None where the launch does not serve the call (the caller makes the two calls)."""
+        Returns the layer output, or None where the launch does not serve the call (the caller makes the two calls).
+        timed=(warmup, iters): returns (ms per call, ms of the kernel alone) between HIP events instead
+        (ultra_rspmm_forward_update_timed)."""
         if not self.exact or input.dtype != torch.float32 or input.dim() != 3 or input.shape[-1] != 64 or not input.is_cuda:
             return None
         _require_gpu(relation, input, weight)
@@ -280,9 +282,16 @@ class Plan(object):
             vals, mvv = as_mat(vals)
             rows_ptr, mv = rows.data_ptr(), ctypes.byref(mvv)
         weight = weight.contiguous()
-        rc = lib.ultra_rspmm_forward_update(self._h, _lib.MUL_CODES[mul], ctypes.byref(mrel), ctypes.byref(mx), rows_ptr, mv,
-                                            ctypes.byref(magg), weight.data_ptr(), _ptr(bias), _ptr(ln_weight), _ptr(ln_bias),
-                                            float(eps), int(flags), ctypes.byref(mout), _stream(input))
+        args = (self._h, _lib.MUL_CODES[mul], ctypes.byref(mrel), ctypes.byref(mx), rows_ptr, mv, ctypes.byref(magg), weight.data_ptr(),
+                _ptr(bias), _ptr(ln_weight), _ptr(ln_bias), float(eps), int(flags), ctypes.byref(mout), _stream(input))
+        if timed is not None:
+            ms, ms_kernel = ctypes.c_float(), ctypes.c_float()
+            rc = lib.ultra_rspmm_forward_update_timed(*(args + (int(timed[0]), int(timed[1]), ctypes.byref(ms), ctypes.byref(ms_kernel))))
+            if rc == _lib.ULTRA_ERR_UNSUPPORTED:
+                return None
+            check(rc)
+            return ms.value, ms_kernel.value
+        rc = lib.ultra_rspmm_forward_update(*args)
         if rc == _lib.ULTRA_ERR_UNSUPPORTED:
             return None
         check(rc)
