@@ -1,5 +1,6 @@
 """Minimal PMC target: the kernels that make up 90 % of the benchmark forward (FB15k237 shape, batch 8), in the reference's
-operation order -- entity-graph rspmm (add_mul, point boundary), the entity-graph layer update, the relation-graph layer, the readout.
+operation order -- entity-graph rspmm (add_mul, point boundary), the entity-graph layer update, the two in one launch (what the step
+runs), the relation-graph layer, the readout.
 1 warm-up + a few launches each.  Run under rocprofv3 --pmc <counters> (tools/collect_profiles.sh C)."""
 import os
 import sys
@@ -25,6 +26,11 @@ with torch.no_grad():
         agg = plan.forward(rel, x, point=point)
     for _ in range(4):
         dense.conv_update(layer, x, agg, True)
+    # ... and the two as the step runs them: one launch (ultra_rspmm_forward_update)
+    ln = layer.layer_norm
+    for _ in range(4):
+        one = plan.forward_update(rel, x, layer.linear.weight, layer.linear.bias, ln.weight, ln.bias, ln.eps, 7, point=point)
+    assert one is not None
     # relation graph: the whole layer in one launch
     rg = data.relation_graph
     xr = torch.randn(bs, rg.num_nodes, 64, generator=g).to(dev)
