@@ -326,6 +326,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-graph", action="store_true", help="launch the forward eagerly instead of replaying its hipGraph")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="captured forwards replayed round-robin on as many streams (consecutive batches are independent); 1 = one stream")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes of the roofline block")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fine-tuning steps of the `secondary` block")
@@ -413,20 +415,34 @@ def main():
         lo = ((step * world + rank) * bs) % (triples.shape[0] - bs)
         return triples[lo:lo + bs]
 
+    def eager_forward(data_, batch_, post=None):
+        score = model(data_, batch_)
+        return post(score) if post is not None else score
+
     def make_forward():
         if args.no_graph:
-            return model
+            return eager_forward
         # the ~30-launch forward is captured once into a hipGraph and replayed (ultra_amd/graph.py); every step
-        # still scores a fresh batch: its candidates are copied into the graph's input buffer first
-        from ultra_amd.graph import GraphedForward
+        # still scores a fresh batch: its candidates are copied into the graph's input buffer first.  With --in-flight 2
+        # (default) two such captures take the batches alternately on two streams: the launches of one batch that leave the
+        # chip idle -- relation model, glue -- run beside the entity layers of its neighbour (graph.PipelinedForward).
+        from ultra_amd.graph import GraphedForward, PipelinedForward
         try:
-            graphed = GraphedForward(model, data, tasks.all_negative(data, batch_for(0))[0])
-            return lambda data_, batch_: graphed(batch_)
+            example = tasks.all_negative(data, batch_for(0))[0]
+            if args.in_flight > 1 and rspmm._plan_defaults["exact_order"]:
+                piped = PipelinedForward(model, data, example, depth=args.in_flight)
+                return lambda data_, batch_, post=None: piped(batch_, post=post)
+            graphed = GraphedForward(model, data, example)
+
+            def graphed_forward(data_, batch_, post=None):
+                score = graphed(batch_)
+                return post(score) if post is not None else score
+            return graphed_forward
         except Exception as exc:      # capture refused by the runtime: the same forward, launched eagerly
             print("[bench] hipGraph capture failed (%s); running eagerly" % exc, file=sys.stderr)
             torch.cuda.synchronize()
             args.no_graph = True
-            return model
+            return eager_forward
 
     # synthetic input, resident in HBM before the timed region: one (bs, N, 3) all-tail candidate batch per step
     # (distinct queries per step; cycled beyond 256 steps)
@@ -435,10 +451,9 @@ def main():
 
     def timed_run(forward, gather):
         def one_step(step):
-            score = forward(data, inputs[step % n_inputs])                   # (bs, N)
-            if gather:
-                score = udist.all_gather_scores(score)                       # (world * bs, N): one RCCL all-gather per step
-            return score
+            # (bs, N) scores; with `gather` one RCCL all-gather per step, enqueued right behind the forward on its stream:
+            # (world * bs, N)
+            return forward(data, inputs[step % n_inputs], post=udist.all_gather_scores if gather else None)
         with torch.no_grad():
             for i in range(args.warmup):
                 one_step(i)
@@ -485,7 +500,10 @@ def main():
                    "summation_order": "reference (rspmm.cpp:61-72 sequential per row; nn.Linear / nn.LayerNorm in torch's CPU order; "
                                       "readout GEMV %s)" % host_order.describe(128),
                    "readout_order_id": host_order.order_id(host_order.readout_stages(128)[0]),
-                   "launch": "eager" if args.no_graph else "hipGraph replay of the captured forward",
+                   "launch": ("eager" if args.no_graph else
+                              "hipGraph replay of the captured forward" +
+                              (", %d batches in flight on %d streams (graph.PipelinedForward)" % (args.in_flight, args.in_flight)
+                               if args.in_flight > 1 else "")),
                    "rccl_world_size": dist.get_world_size() if (world > 1 or launched) else 1,
                    "per_rank": per_rank,
                    "parallelism": "query-shard x%d + RCCL all-gather of scores" % world if world > 1 else "single GPU"},
@@ -637,6 +655,17 @@ def main():
                             "ultra_rspmm_forward_update; same bits (DESIGN.md 3.8)"}
             finally:
                 _layers.FUSED_SPARSE_LAYER = was
+            # ---- one batch at a time: the same captured forward on one stream ----
+            if args.in_flight > 1 and not args.no_graph:
+                keep = args.in_flight
+                args.in_flight = 1
+                try:
+                    el4 = timed_run(make_forward(), False)
+                    out.setdefault("modes", {})["one_batch_in_flight"] = {
+                        "timed": False, "triples_per_s": bs * N * args.steps / el4, "ms_per_step": 1e3 * el4 / args.steps,
+                        "note": "--in-flight 1: every batch waits for its predecessor's readout (DESIGN.md 3.9)"}
+                finally:
+                    args.in_flight = keep
     if rank == 0 and world == 1 and not launched and not args.no_secondary:
         # ---- BASELINE.json config 5 (fine-tuning): fwd + bwd + AdamW per step, beside the headline ----
         sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -383,3 +383,34 @@ def test_relation_projection_matches_reference_golden(dev, threshold, key):
         got = proj(data, g["h_prob"].to(dev), g["r_index"].to(dev)).cpu()
     assert got.shape == g[key].shape
     assert (got - g[key]).abs().max().item() <= 1e-5, (got - g[key]).abs().max().item()
+
+
+def test_two_batches_in_flight_score_like_one_at_a_time(dev):
+    """graph.PipelinedForward: captured forwards replayed round-robin on two streams (own buffers and own prologue meeting
+    point each) return, batch for batch, the bits of the one-at-a-time forward."""
+    from ultra_amd import graph as ugraph, models, synthetic, tasks
+    data = synthetic.make_kg(num_node=900, num_triple=6000, num_relation_base=11, seed=5).to(dev)
+    torch.manual_seed(3)
+    model = models.Ultra(**synthetic.default_model_cfg()).to(dev).eval()
+    bs = 4
+    batches = [tasks.all_negative(data, data.target_triples[i * bs:(i + 1) * bs])[0] for i in range(6)]
+    with torch.no_grad():
+        want = [model(data, b).clone() for b in batches]
+    piped = ugraph.PipelinedForward(model, data, batches[0], depth=2)
+    for rep in range(3):
+        got = []
+        for i, b in enumerate(batches):
+            out = piped(b)
+            if i >= 1:          # the previous slot's output: still in place (the slot is reused two calls later)
+                piped.join()
+                got.append((i - 1, prev.clone()))
+            prev = out
+        piped.join()
+        got.append((len(batches) - 1, prev.clone()))
+        for i, g in got:
+            assert torch.equal(g, want[i]), "batch %d, repetition %d" % (i, rep)
+    # back to back without joining in between: only the last two are still readable
+    for b in batches:
+        out = piped(b)
+    piped.join()
+    assert torch.equal(out, want[-1])

@@ -2,6 +2,7 @@
 torch op chains `cat -> Linear -> LayerNorm -> ReLU (-> + residual)` (layers.py:233-240, models.py:158-160)
 and `cat -> gather -> Linear -> ReLU -> Linear` (models.py:166-170, 202-209) on the inference path."""
 import ctypes
+import threading
 
 import torch
 from torch.autograd.function import once_differentiable
@@ -151,12 +152,39 @@ _PROLOGUE_SCRATCH = {}
 _PROLOGUE_SCRATCH_RETIRED = []   # outgrown buffers: never freed (a captured hipGraph may still point at one)
 
 
+_PROLOGUE_SCRATCH_OWNER = threading.local()   # .buf: a caller-owned meeting buffer (graph.GraphedForward: one per captured forward)
+
+
+class own_prologue_scratch(object):
+    """with own_prologue_scratch(buf): ...   -- prologues launched by this thread inside the block meet in `buf` (int32 zeros,
+    >= 4 * batch words) instead of the device-wide buffer: forwards that may run concurrently on different streams (two captured
+    forwards in flight) must not share a meeting point."""
+
+    def __init__(self, buf):
+        self.buf = buf
+
+    def __enter__(self):
+        self.prev = getattr(_PROLOGUE_SCRATCH_OWNER, "buf", None)
+        _PROLOGUE_SCRATCH_OWNER.buf = self.buf
+        return self.buf
+
+    def __exit__(self, *exc):
+        _PROLOGUE_SCRATCH_OWNER.buf = self.prev
+        return False
+
+
 def _prologue_scratch(device, bs):
     """The meeting point of the prologue's workgroups: zero on entry, left zero on exit.  One per device, allocated by the
     first (eager) call so that a later hipGraph capture finds it in place; prologues of one device are expected on one
     stream at a time (the C entry takes the buffer as an argument for callers that need more).  A buffer that was handed
     out once stays allocated for the life of the process: a GraphedForward captured earlier keeps its raw pointer, and the
     kernel increments and re-zeroes words of it on every replay."""
+    own = getattr(_PROLOGUE_SCRATCH_OWNER, "buf", None)
+    if own is not None:
+        if own.numel() < 4 * bs or own.device != torch.device(device):
+            raise RuntimeError("own_prologue_scratch: the buffer holds %d words on %s, the batch needs %d on %s"
+                               % (own.numel(), own.device, 4 * bs, device))
+        return own
     key = str(device)
     buf = _PROLOGUE_SCRATCH.get(key)
     if buf is None or buf.numel() < 4 * bs:

@@ -16,7 +16,7 @@ What the captured graph points at stays alive and in place for as long as the Gr
 """
 import torch
 
-from . import rspmm
+from . import dense, rspmm
 
 
 class GraphedForward(object):
@@ -29,6 +29,9 @@ class GraphedForward(object):
         self.warmup = warmup
         self.static_batch = example_batch.clone()
         self._pinned = []
+        # this forward's own meeting buffer for the batch prologue's workgroups (dense.own_prologue_scratch): captured forwards
+        # may be replayed concurrently on different streams (PipelinedForward)
+        self._scratch = torch.zeros(4 * max(int(example_batch.shape[0]), 256), dtype=torch.int32, device=example_batch.device)
         self._capture()
 
     def _param_state(self):
@@ -46,7 +49,7 @@ class GraphedForward(object):
         with torch.cuda.device(self.static_batch.device):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.no_grad(), torch.cuda.stream(side), rspmm.record_plans() as used:
+            with torch.no_grad(), torch.cuda.stream(side), rspmm.record_plans() as used, dense.own_prologue_scratch(self._scratch):
                 for _ in range(self.warmup):
                     model(data, self.static_batch)
             torch.cuda.current_stream().wait_stream(side)
@@ -57,7 +60,8 @@ class GraphedForward(object):
             self.graph = torch.cuda.CUDAGraph()
             # thread-local capture mode: helper threads of the process (RCCL's watchdog polls events) must not be able to
             # invalidate the capture; everything captured here is enqueued by this thread
-            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"), \
+                    dense.own_prologue_scratch(self._scratch):
                 self.static_out = model(data, self.static_batch)
         self.valid = getattr(model.entity_model, "_pending_valid", None) if hasattr(model, "entity_model") else None
         self._params = self._param_state()
@@ -92,6 +96,48 @@ class GraphedForward(object):
         if check and self.valid is not None:
             assert bool(self.valid.all()), "every row of `batch` must share its head (or tail) and its relation (models.py:196-197)"
         return self.static_out
+
+
+class PipelinedForward(object):
+    """`depth` captured forwards (own input, activation and output buffers each) replayed round-robin on `depth` streams:
+    consecutive batches are independent, so the launches of one batch that leave the chip idle (relation model, glue) run
+    beside the entity layers of its neighbour -- 0.69 -> 0.62 ms per batch at the benchmark point with two in flight.
+
+        pf = PipelinedForward(model, data, example_batch)
+        for batch in batches:
+            score = pf(batch)        # enqueued; `score` is that slot's output buffer ...
+            ...                      # ... readable after pf.join(), and until the slot's next call (`depth` calls later)
+        pf.join()                    # the caller's stream waits for everything in flight
+
+    Reference-order plans only: the re-associating plans keep per-plan scratch that concurrent forwards would share."""
+
+    def __init__(self, model, data, example_batch, depth=2, warmup=3):
+        if not rspmm._plan_defaults["exact_order"]:
+            raise RuntimeError("PipelinedForward needs the reference-order plans (the re-associating plans own scratch buffers)")
+        self.slots = [GraphedForward(model, data, example_batch, warmup=warmup) for _ in range(int(depth))]
+        dev = example_batch.device
+        with torch.cuda.device(dev):
+            self.streams = [torch.cuda.Stream() for _ in self.slots]
+        self.device = dev
+        self.calls = 0
+
+    def __call__(self, batch, post=None):
+        """Enqueue the forward of `batch` on the next slot's stream; post(score), if given, runs on that stream right behind
+        it (e.g. the all-gather of a multi-GPU step) and its result is returned instead."""
+        k = self.calls % len(self.slots)
+        self.calls += 1
+        stream = self.streams[k]
+        stream.wait_stream(torch.cuda.current_stream(self.device))     # `batch` was produced on the caller's stream
+        with torch.cuda.stream(stream):
+            out = self.slots[k](batch)
+            if post is not None:
+                out = post(out)
+        return out
+
+    def join(self):
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            cur.wait_stream(s)
 
 
 class GraphedEvalStep(object):
