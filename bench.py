@@ -9,6 +9,9 @@ One step = one Ultra.forward(data, t_batch) per GPU with t_batch = (bs=8, N, 3) 
 bs * N triples -- with the plans that sum in the REFERENCE'S ORDER (rspmm.cpp:61-72; ultra_amd's default).  Queries
 shard over ranks (each rank scores its own 8 queries, graph + weights replicated); with N > 1 GPUs every step ends
 with one RCCL all-gather of the per-rank score rows.  Weak scaling: per-GPU work is fixed.  Rank 0 prints ONE JSON line.
+The forward is a captured hipGraph; by default TWO captures take the steps alternately on two streams (--in-flight 2,
+ultra_amd/graph.py PipelinedForward): steps are independent batches, and the launches of one that leave the chip idle run
+beside the entity layers of the next.  ms_per_step = elapsed / steps; `modes.one_batch_in_flight` has the one-stream figure.
 
 Extra blocks of the JSON line (rank 0, N = 1):
   roofline     -- the dominant kernel (one entity layer: reference-order rspmm + the layer update in its tail,
