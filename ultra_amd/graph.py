@@ -161,6 +161,8 @@ class GraphedEvalStep(object):
         self.rows[:batch_size, 2] = 1
         self._pinned = []
         n = data.num_nodes
+        # own meeting point of the batch prologues (see GraphedForward): two captured steps may be in flight on two streams
+        self._scratch = torch.zeros(4 * max(int(batch_size), 256), dtype=torch.int32, device=dev)
 
         def step():
             t_batch, h_batch = tasks.all_negative(data, self.batch)
@@ -179,7 +181,7 @@ class GraphedEvalStep(object):
         with torch.cuda.device(dev):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.no_grad(), torch.cuda.stream(side), rspmm.record_plans() as used:
+            with torch.no_grad(), torch.cuda.stream(side), rspmm.record_plans() as used, dense.own_prologue_scratch(self._scratch):
                 for _ in range(warmup):
                     step()
             torch.cuda.current_stream().wait_stream(side)
@@ -188,7 +190,8 @@ class GraphedEvalStep(object):
             for plan in self._pinned:
                 plan.pin(+1)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"), \
+                    dense.own_prologue_scratch(self._scratch):
                 step()
 
     def __call__(self, batch, t_ptr, h_ptr):
