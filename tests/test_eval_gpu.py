@@ -189,3 +189,6 @@ def test_captured_evaluation_step_equals_the_eager_protocol(dev):
     again = ueval.evaluate(model, data, batch_size=8, metrics=names)
     assert eager["_num_rankings"] == 90
     assert graphed == eager and again == eager
+    # two captured steps in flight on two streams (the default from 128 batches on): same rankings, same metrics
+    piped = ueval.evaluate(model, data, batch_size=8, metrics=names, in_flight=2)
+    assert piped == eager

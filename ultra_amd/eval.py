@@ -50,8 +50,10 @@ def metrics_from_rankings(ranking, num_negative, metric_names):
 
 @torch.no_grad()
 def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", "mrr", "hits@1", "hits@3", "hits@10"),
-             max_triples=None, use_graph=True):
-    """Returns {metric: value} on every rank (the reference only fills it on rank 0)."""
+             max_triples=None, use_graph=True, in_flight=None):
+    """Returns {metric: value} on every rank (the reference only fills it on rank 0).
+    in_flight: captured evaluation steps replayed round-robin on as many streams (1 or 2; None: 2 for shards of 128 full
+    batches or more, where the second capture pays for itself)."""
     world, rank = udist.world_size(), udist.rank()
     triples = torch.cat([test_data.target_edge_index, test_data.target_edge_type.unsqueeze(0)]).t()
     if max_triples is not None:
@@ -79,8 +81,9 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
             # re-associating plans own scratch buffers that concurrent steps would share.
             from . import rspmm
             # (a second capture costs about what it saves on a hundred batches: 130 vs 125 M scores/s on 64 batches, 170 vs 160 on 512)
-            n_slot = 2 if (rspmm._plan_defaults["exact_order"] and n_full >= 128 * batch_size
-                           and os.environ.get("ULTRA_EVAL_IN_FLIGHT", "2") != "1") else 1
+            if in_flight is None:
+                in_flight = 1 if os.environ.get("ULTRA_EVAL_IN_FLIGHT", "2") == "1" or n_full < 128 * batch_size else 2
+            n_slot = 2 if (int(in_flight) >= 2 and rspmm._plan_defaults["exact_order"] and n_full >= 2 * batch_size) else 1
             steps = [GraphedEvalStep(model, test_data, batch_size, t_index, h_index) for _ in range(n_slot)]
             cur = torch.cuda.current_stream(mine.device)
             with torch.cuda.device(mine.device):
