@@ -127,7 +127,9 @@ class PipelinedForward(object):
         k = self.calls % len(self.slots)
         self.calls += 1
         stream = self.streams[k]
-        stream.wait_stream(torch.cuda.current_stream(self.device))     # `batch` was produced on the caller's stream
+        stream.wait_stream(torch.cuda.current_stream(self.device))     # `batch` was produced on the caller's stream ...
+        if batch.is_cuda:
+            batch.record_stream(stream)                                 # ... and may be released by the caller right after this call
         with torch.cuda.stream(stream):
             out = self.slots[k](batch)
             if post is not None:
