@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_ABI_VERSION 4
+#define ULTRA_ABI_VERSION 5
 
 typedef enum {
     ULTRA_OK = 0,
@@ -175,9 +175,13 @@ int32_t ultra_rspmm_forward_masked(ultra_plan *plan, int32_t sum, int32_t mul, i
  * Forward with a POINT boundary: the NBFNet boundary condition (/root/reference/ultra/models.py:59-66, 135-141) is zero
  * except for one row per outer slice, so `update + boundary` (/root/reference/ultra/layers.py:199-200) only touches that
  * row.  point_values: (n_outer, 1, row_len) -- n_row == 1 -- is added to output row point_rows[outer]; nothing of size
- * (n_outer, num_node, row_len) is read.  Sum aggregate only (zero is not the identity of min / max).
+ * (n_outer, num_node, row_len) is read.
+ * sum = ULTRA_SUM_MIN / _MAX (layers.py:206-207: max(update, boundary)): zero is not the identity of min / max, so the
+ * boundary tensor the point stands for takes part at EVERY row -- row point_rows[outer] meets its value, every other row
+ * meets 0 (an edge-less row therefore outputs 0, like the reference).  Served by ULTRA_PLAN_EXACT_ORDER plans in the
+ * sparse format; ULTRA_ERR_UNSUPPORTED otherwise (the caller then passes the boundary as a tensor).
  */
-int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t mul, int32_t dtype, const void *edge_weight_dev,
+int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype, const void *edge_weight_dev,
                                   const ultra_mat *relation, const ultra_mat *input, const int64_t *point_rows_dev,
                                   const ultra_mat *point_values, const ultra_mat *output, void *stream);
 
@@ -188,14 +192,18 @@ int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t mul, int32_t dtype, 
  *   aggregate = rspmm(sum, mul)(relation, input) [+ point boundary]        -- as ultra_rspmm_forward_point / _forward
  *   output    = [input +] relu( LayerNorm( W . [input ; aggregate] + b ) ) -- as ultra_conv_update (ultra_nbfnet.h), same `flags` / `eps`
  *
- * Every workgroup of the reference-order kernel applies the update to the rows it has just aggregated (they are still in
- * its L2), so the aggregate is not read back by a second launch.  Results are bit-equal with the two separate calls.
+ * Every workgroup of the reference-order kernel applies the update to the rows it aggregates: twelve of its sixteen waves
+ * walk the graph, four multiply -- on the matrix cores, while the walk goes on -- the rows the walkers hand over through an
+ * LDS queue (each row is read back from the workgroup's own L2 moments after it was written).  Where that form does not fit
+ * (LDS beside the relation slice, rows per workgroup) the update runs in the kernel's tail instead.  Results are bit-equal
+ * with the two separate calls in both forms.  sum: ULTRA_SUM_ADD / _MIN / _MAX (min / max with a point boundary: see
+ * ultra_rspmm_forward_point).
  * `aggregate` receives the aggregate as before (scratch for the caller); `output` must not alias it or `input`.
  * point_rows_dev / point_values: both NULL = no boundary.  Served where the stream walk serves ultra_rspmm_forward_point
  * (ULTRA_PLAN_EXACT_ORDER plan in the sparse format, 64-element rows, every stride equal): ULTRA_ERR_UNSUPPORTED
  * otherwise, nothing launched -- the caller then makes the two calls.
  */
-int32_t ultra_rspmm_forward_update(ultra_plan *plan, int32_t mul, const ultra_mat *relation, const ultra_mat *input,
+int32_t ultra_rspmm_forward_update(ultra_plan *plan, int32_t sum, int32_t mul, const ultra_mat *relation, const ultra_mat *input,
                                    const int64_t *point_rows_dev, const ultra_mat *point_values, const ultra_mat *aggregate,
                                    const void *weight, const void *bias, const void *ln_weight, const void *ln_bias, float eps,
                                    int32_t flags, const ultra_mat *output, void *stream);
@@ -290,6 +298,9 @@ typedef struct {
     int64_t max_chunk_per_part, max_unit_per_part;
     double max_cost, mean_cost;              /* modelled workgroup-cycles of the fullest / the average workgroup */
 } ultra_schedule_info;
+/* nparts | ULTRA_SCHEDULE_12_WALKERS (both schedule calls): the schedule of the launches whose last four waves apply the layer
+ * update beside the walk (ultra_rspmm_forward_update) -- the 16 streams of those waves take no rows. */
+#define ULTRA_SCHEDULE_12_WALKERS (1 << 24)
 int32_t ultra_plan_schedule_info(ultra_plan *plan, int32_t nparts, ultra_schedule_info *info);
 /* The schedule's arrays (tests, tooling): which = 0 chunk_ptr [nparts + 1], 1 unit_ptr [nparts + 1], 2 unit ids (a unit =
  * group items n_chain_row + 4 u .. + 3 of ULTRA_ARR_ITEM), 3 chunks as {row, begin, count, flags} quadruples (flags: bit 0 first,
@@ -315,7 +326,9 @@ typedef struct {
     int32_t x_lds;        /* -1 auto, 0 never stage the input slice in LDS, 1 force when it fits */
     int32_t unroll;       /* edges in flight per lane group (0 -> default) */
     int32_t reserved[3];  /* [0] != 0: ULTRA_PLAN_EXACT_ORDER plans run on the general walk kernel instead of the order kernels;
-                             [1] != 0: the order kernels walk units of four rows (C++ loop) instead of group streams (assembly) */
+                             [1] != 0: the order kernels walk units of four rows (C++ loop) instead of group streams (assembly);
+                             [2]: ultra_rspmm_forward_update -- 0 the update beside the walk where it fits, else in the kernel's tail;
+                                  1 always in the tail; 2 beside the walk or ULTRA_ERR_UNSUPPORTED */
 } ultra_tuning;
 int32_t ultra_set_tuning(const ultra_tuning *t);   /* NULL restores defaults */
 int32_t ultra_get_tuning(ultra_tuning *t);
@@ -327,7 +340,7 @@ int32_t ultra_get_tuning(ultra_tuning *t);
  *   *ms_main_kernel : (optional) mean duration of the main rspmm_fwd_kernel alone, events recorded right
  *                     around its launch, one call at a time -- the figure bench.py's roofline block uses
  *                     and the one comparable with rocprofv3's per-kernel average.
- * point_rows_dev != NULL: `boundary` is a point boundary (see ultra_rspmm_forward_point), sum aggregate only.
+ * point_rows_dev != NULL: `boundary` is a point boundary (see ultra_rspmm_forward_point).
  */
 int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype,
                                   const void *edge_weight_dev, const ultra_mat *relation, const ultra_mat *input,
@@ -335,7 +348,7 @@ int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, in
                                   void *stream, int32_t warmup, int32_t iters, float *ms_per_call, float *ms_main_kernel);
 
 /* ultra_rspmm_forward_timed for the one-launch layer (ultra_rspmm_forward_update): same two figures. */
-int32_t ultra_rspmm_forward_update_timed(ultra_plan *plan, int32_t mul, const ultra_mat *relation, const ultra_mat *input,
+int32_t ultra_rspmm_forward_update_timed(ultra_plan *plan, int32_t sum, int32_t mul, const ultra_mat *relation, const ultra_mat *input,
                                          const int64_t *point_rows_dev, const ultra_mat *point_values, const ultra_mat *aggregate,
                                          const void *weight, const void *bias, const void *ln_weight, const void *ln_bias, float eps,
                                          int32_t flags, const ultra_mat *output, void *stream, int32_t warmup, int32_t iters,

@@ -49,11 +49,15 @@ def _operands(case, batch, dev, seed):
     return rel, x, rows, vals, weight, bias, ln_w, ln_b
 
 
+FORMS = {"tail": 1, "beside": 2}     # rspmm.set_tuning(update_form=...): the update in the kernel's tail / beside the walk
+
+
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("mul", ["mul", "add"])
+@pytest.mark.parametrize("form", ["tail", "beside"])
 @pytest.mark.parametrize("batch,flags,point", [(8, 7, True), (3, 7, False), (1, 3, True), (2, 4, True), (5, 0, True), (16, 6, True)])
-def test_one_launch_equals_the_two_launches(dev, case, mul, batch, flags, point):
-    from ultra_amd import dense
+def test_one_launch_equals_the_two_launches(dev, case, mul, batch, flags, point, form):
+    from ultra_amd import dense, rspmm
     from ultra_amd.rspmm import Plan
     ei, et = helpers.random_graph(**case)
     plan = Plan(ei, et, case["num_node"], case["num_relation"], exact_order=True)
@@ -61,6 +65,7 @@ def test_one_launch_equals_the_two_launches(dev, case, mul, batch, flags, point)
     pt = (rows, vals) if point else None
     agg = plan.forward(rel, x, sum="add", mul=mul, point=pt)
     want = dense._conv_update_forward(x, agg, weight, bias, ln_w if flags & 1 else None, ln_b if flags & 1 else None, 1e-5, flags)
+    rspmm.set_tuning(update_form=FORMS[form])
     got = plan.forward_update(rel, x, weight, bias, ln_w if flags & 1 else None, ln_b if flags & 1 else None, 1e-5, flags,
                               mul=mul, point=pt)
     assert got is not None, "the stream walk serves this call"
@@ -70,8 +75,83 @@ def test_one_launch_equals_the_two_launches(dev, case, mul, batch, flags, point)
     assert torch.equal(again, want)
 
 
+@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[4], CASES[5]])
+@pytest.mark.parametrize("form", ["tail", "beside"])
+@pytest.mark.parametrize("sum", ["max", "min"])
+def test_max_aggregate_layer_in_one_launch(dev, case, form, sum):
+    """BASELINE config 3 (max aggregate): the point boundary under max -- every other row meets 0, layers.py:206-207 -- and the
+    update of the same launch, against the two launches on the boundary TENSOR."""
+    from ultra_amd import dense, rspmm
+    from ultra_amd.rspmm import Plan
+    ei, et = helpers.random_graph(**case)
+    N = case["num_node"]
+    plan = Plan(ei, et, N, case["num_relation"], exact_order=True)
+    batch = 4
+    rel, x, rows, vals, weight, bias, ln_w, ln_b = _operands(case, batch, dev, case["seed"] + 7)
+    bnd = torch.zeros(batch, N, 64, device=dev)
+    bnd[torch.arange(batch, device=dev), rows] = vals
+    agg = plan.forward(rel, x, sum=sum, mul="mul", boundary=bnd)
+    want = dense._conv_update_forward(x, agg, weight, bias, ln_w, ln_b, 1e-5, 7)
+    rspmm.set_tuning(update_form=FORMS[form])
+    got = plan.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7, mul="mul", point=(rows, vals), sum=sum)
+    assert got is not None
+    assert torch.equal(got, want), "max |d| = %g at %d elements" % ((got - want).abs().max().item(), int((got != want).sum()))
+
+
+@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[3], CASES[5]])
+@pytest.mark.parametrize("form", ["tail", "beside"])
+@pytest.mark.parametrize("sum", ["add", "max"])
+def test_one_launch_layer_against_the_oracle_chain(dev, case, form, sum):
+    """Not through the two launches: the C oracle's rspmm (rspmm.cpp:50-75) on the host, the boundary as the reference
+    combines it (layers.py:199-207), then torch's CPU Linear / LayerNorm / ReLU / residual (layers.py:233-240,
+    models.py:158-160) -- bit for bit."""
+    import torch.nn.functional as F
+    from oracle import rspmm_oracle
+    from ultra_amd import rspmm
+    from ultra_amd.rspmm import Plan
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    batch = 3
+    rel, x, rows, vals, weight, bias, ln_w, ln_b = _operands(case, batch, dev, case["seed"] + 31)
+    bnd = torch.zeros(batch, N, 64)
+    bnd[torch.arange(batch), rows.cpu()] = vals.cpu()
+    xn, reln, bndn = (t.cpu().transpose(0, 1).flatten(1).contiguous() for t in (x, rel, bnd))
+    agg = rspmm_oracle.generalized_rspmm(ei, et, torch.ones(E), reln, xn, sum=sum, mul="mul")
+    agg = agg + bndn if sum == "add" else torch.max(agg, bndn)
+    agg = agg.view(N, batch, 64).transpose(0, 1)
+    hidden = F.linear(torch.cat([x.cpu(), agg], dim=-1), weight.cpu(), bias.cpu())
+    want = torch.relu(F.layer_norm(hidden, (64,), ln_w.cpu(), ln_b.cpu(), 1e-5)) + x.cpu()
+    plan = Plan(ei, et, N, R, exact_order=True)
+    rspmm.set_tuning(update_form=FORMS[form])
+    got = plan.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7, mul="mul", point=(rows, vals), sum=sum)
+    assert got is not None
+    same = (got.cpu() == want).float().mean().item()
+    # (torch's CPU GEMM may use a remainder kernel for the last rows of a thread's share: tests/test_torch_order_gpu.py)
+    assert same >= 0.999 and (got.cpu() - want).abs().max().item() <= 1e-5, (same, (got.cpu() - want).abs().max().item())
+
+
+def test_beside_the_walk_is_the_default_where_it_fits_and_repeats_its_bits(dev):
+    """update_form 0 takes the update beside the walk on a graph whose relation slice leaves the room; 200 launches of it give
+    the same bits (the hand-off of rows between waves is not a race)."""
+    from ultra_amd import dense, rspmm
+    from ultra_amd.rspmm import Plan
+    case = CASES[5]
+    ei, et = helpers.random_graph(**case)
+    plan = Plan(ei, et, case["num_node"], case["num_relation"], exact_order=True)
+    rel, x, rows, vals, weight, bias, ln_w, ln_b = _operands(case, 8, dev, 77)
+    agg = plan.forward(rel, x, sum="add", mul="mul", point=(rows, vals))
+    want = dense._conv_update_forward(x, agg, weight, bias, ln_w, ln_b, 1e-5, 7)
+    rspmm.set_tuning(update_form=2)
+    assert plan.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7, point=(rows, vals)) is not None
+    rspmm.set_tuning()
+    outs = [plan.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7, point=(rows, vals)) for _ in range(200)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, want) for o in outs)
+
+
 @pytest.mark.parametrize("grid", [8, 64, 256])
-def test_any_number_of_workgroups_per_span(dev, grid):
+@pytest.mark.parametrize("form", ["tail", "beside"])
+def test_any_number_of_workgroups_per_span(dev, grid, form):
     from ultra_amd import dense, rspmm
     from ultra_amd.rspmm import Plan
     case = CASES[4]
@@ -81,6 +161,7 @@ def test_any_number_of_workgroups_per_span(dev, grid):
     rspmm.set_tuning(grid=grid)
     agg = plan.forward(rel, x, sum="add", mul="mul", point=(rows, vals))
     want = dense._conv_update_forward(x, agg, weight, bias, ln_w, ln_b, 1e-5, 7)
+    rspmm.set_tuning(grid=grid, update_form=FORMS[form])
     got = plan.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7, point=(rows, vals))
     assert got is not None and torch.equal(got, want)
 

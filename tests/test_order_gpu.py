@@ -82,8 +82,6 @@ def test_chain_threshold_does_not_change_a_bit(dev, case, chain_min):
 @pytest.mark.parametrize("boundary", ["none", "tensor", "point"])
 def test_layouts_and_boundaries(dev, sum, layout, boundary):
     from ultra_amd.rspmm import Plan
-    if boundary == "point" and sum != "add":
-        pytest.skip("a point boundary serves the sum aggregate only")
     case = CASES[8]
     ei, et = helpers.random_graph(**case)
     N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
@@ -117,6 +115,41 @@ def test_layouts_and_boundaries(dev, sum, layout, boundary):
         rel_dev = rel[:1].to(dev).expand(bs, -1, -1) if layout == "shared_relation" else rel.contiguous().to(dev)
         got = plan.forward(rel_dev, x.to(dev), sum=sum, **kw).cpu().transpose(0, 1).flatten(1)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("sum", ["min", "max"])
+@pytest.mark.parametrize("walk", ["streams", "units", "weighted", "f64"])
+@pytest.mark.parametrize("case", [CASES[2], CASES[8]])
+def test_point_boundary_under_min_max_meets_zero_off_the_query_rows(dev, sum, walk, case):
+    """layers.py:206-207: max(update, boundary) against a tensor that is zero off the query rows -- the point form must give
+    every other row max(update, 0) (an edge-less row: 0, not -FLT_MAX), on the assembly walk, the C++ unit walk, the
+    weighted kernels and the fp64 kernels, chain rows included."""
+    from ultra_amd import rspmm
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    dtype = torch.float64 if walk == "f64" else torch.float32
+    bs, d = 3, 64
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(bs, N, d, generator=g, dtype=torch.float64).to(dtype)
+    rel = torch.randn(bs, R, d, generator=g, dtype=torch.float64).to(dtype)
+    w = (torch.rand(E, generator=g, dtype=torch.float64) + 0.5).to(dtype) if walk == "weighted" else torch.ones(E, dtype=dtype)
+    rows = torch.tensor([11 % N, 0, N - 1])      # (N - 1: an edge-less row in CASES[2])
+    vals = torch.randn(bs, d, generator=g, dtype=torch.float64).to(dtype)
+    bnd = torch.zeros(bs, N, d, dtype=dtype)
+    bnd[torch.arange(bs), rows] = vals
+    xn, reln, bndn = (t.transpose(0, 1).flatten(1).contiguous() for t in (x, rel, bnd))
+    want = rspmm_oracle.generalized_rspmm(ei, et, w, reln, xn, sum=sum, mul="mul")
+    want = torch.max(want, bndn) if sum == "max" else torch.min(want, bndn)
+    plan = rspmm.Plan(ei, et, N, R, exact_order=True)
+    if walk == "units":
+        rspmm.set_tuning(unit_walk=1)
+    got = plan.forward(rel.to(dev), x.to(dev), edge_weight=w.to(dev) if walk == "weighted" else None, sum=sum,
+                       point=(rows.to(dev), vals.to(dev)))
+    assert got is not None
+    assert torch.equal(got.cpu().transpose(0, 1).flatten(1), want)
+    # a plan that re-associates declines the point form under min / max (the caller passes the tensor)
+    loose = rspmm.Plan(ei, et, N, R, exact_order=False)
+    assert loose.forward(rel.to(dev), x.to(dev), sum=sum, point=(rows.to(dev), vals.to(dev))) is None
 
 
 @pytest.mark.parametrize("grid", [1, 3, 8, 77, 256, 1000])

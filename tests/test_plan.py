@@ -265,6 +265,27 @@ def test_group_streams_cover_every_group_row_once_in_sorted_edge_order():
     assert int(loads.max() - loads.min()) <= int((row_ptr[1:] - row_ptr[:-1]).clamp(max=256).max()) + 64
 
 
+def test_twelve_walker_schedule_leaves_the_update_waves_without_rows():
+    """The schedule of the launches whose last four waves apply the layer update beside the walk (rspmm_order_kernel,
+    UPDATE == 2): streams 48..63 of every workgroup are empty, every non-chain row still sits in exactly one stream."""
+    from ultra_amd.rspmm import Plan
+    from ultra_amd import _lib
+    ei, et = helpers.random_graph(num_node=3000, num_edge=40000, num_relation=9, seed=8, hub=(11, 700))
+    N, R = 3000, 9
+    plan = Plan(ei, et, N, R, exact_order=True)
+    nparts = 4
+    sdesc, srec = plan.streams(nparts, walkers=12)
+    per = sdesc[:, 1].view(nparts, 64)
+    assert int(per[:, 48:].sum()) == 0 and int(per[:, :48].min()) > 0
+    n_chain = plan.info()["n_chain_row"]
+    chain_rows = set(plan.export(_lib.ARR_ITEM).view(-1, 4)[:n_chain, 0].tolist())
+    markers = srec[srec[:, 1] == R, 0].tolist()
+    assert len(markers) == len(set(markers)) and set(markers) == set(range(N)) - chain_rows
+    # the sixteen-walker schedule of the same plan is untouched by the request
+    sdesc16, _ = plan.streams(nparts)
+    assert int(sdesc16[:, 1].view(nparts, 64)[:, 48:].min()) > 0
+
+
 def test_stream_work_follows_the_wave_age_shares():
     """plan.cpp WAVE_SHARE: a CU issues oldest wave first, so the schedule gives the four wave quartets of a workgroup
     1.7 / 1.3 / 0.7 / 0.3 of an even share of its stream steps (they then finish their walks together)."""
@@ -332,7 +353,8 @@ def test_generated_assembly_header_is_in_sync_with_its_generator(tmp_path, monke
     committed = open(os.path.join(root, "ultra_amd", "csrc", "rspmm_order_asm.hpp")).read()
     assert fresh == committed
     # every path out of a statement drains the vector-memory queue, and the statements declare what they clobber
-    # 3 sums x 2 messages (stream walk) + 2 messages (producers) + 2 x 2 messages (producers of the measurement builds: LDS-word hand-off)
-    assert fresh.count("asm volatile(") == 12 and fresh.count('"memory"') == 12
+    # 2 x 3 sums x 2 messages (stream walk, without / with the hand-off of finished rows to the update waves) + 2 messages
+    # (producers) + 2 x 2 messages (producers of the measurement builds: LDS-word hand-off)
+    assert fresh.count("asm volatile(") == 18 and fresh.count('"memory"') == 18
     for block in fresh.split("asm volatile(")[1:]:
         assert "s_waitcnt vmcnt(0)" in block.split(");")[0]

@@ -1,0 +1,111 @@
+"""The entity layer in one launch, two forms (ultra_rspmm_forward_update): the update in the kernel's TAIL (update_form 1) vs
+BESIDE the walk (update_form 2: twelve waves walk, four multiply the rows handed over through LDS).  Prints times between
+HIP events (back-to-back launches and inside a hipGraph of 20 launches), bit-equality with the two launches, and the
+per-wave end-of-work clocks of one traced launch (walkers 0..11, update waves 12..15).
+
+    python tools/beside_probe.py [shape] [batch] [sum]       env: ULTRA_STREAM_SHARES_12="q0,q1,q2" (calibration)
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ultra_amd import _lib, dense, rspmm, synthetic  # noqa: E402
+
+shape = sys.argv[1] if len(sys.argv) > 1 else "fb15k237"
+bs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+agg_sum = sys.argv[3] if len(sys.argv) > 3 else "add"
+dev = torch.device("cuda:0")
+data = synthetic.make_kg(**synthetic.SHAPES[shape], seed=1234, relation_graph=False)
+N, R = data.num_nodes, int(data.num_relations)
+g = torch.Generator().manual_seed(0)
+x = torch.randn(bs, N, 64, generator=g).to(dev)
+rel = torch.randn(bs, R, 64, generator=g).to(dev)
+point = (torch.arange(bs, device=dev) * 7 % N, torch.randn(bs, 64, generator=g).to(dev))
+w = (torch.randn(64, 128, generator=g) / 11).to(dev)
+b, lw, lb = (torch.randn(64, generator=g).to(dev) for _ in range(3))
+plan = rspmm.Plan(data.edge_index, data.edge_type, N, R, exact_order=True)
+grid = 256
+
+
+def agg_only():
+    return plan.forward(rel, x, sum=agg_sum, mul="mul", point=point)
+
+
+def two():
+    return dense._conv_update_forward(x, agg_only(), w, b, lw, lb, 1e-5, 7)
+
+
+def one(form):
+    rspmm.set_tuning(update_form=form)
+    out = plan.forward_update(rel, x, w, b, lw, lb, 1e-5, 7, point=point, sum=agg_sum)
+    rspmm.set_tuning()
+    return out
+
+
+def timed(fn, iters=50):
+    for _ in range(5):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def graphed(fn, n=20, reps=10):
+    fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            for _ in range(n):
+                fn()
+        gr.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        for _ in range(reps):
+            gr.replay()
+        e1.record(s)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (reps * n) * 1e3
+
+
+want = two()
+served = one(2) is not None
+print("%s bs %d %s: tail == two launches %s | beside == two launches %s" %
+      (shape, bs, agg_sum, torch.equal(one(1), want), torch.equal(one(2), want) if served else "not served"))
+for k in range(2):
+    print("back to back: aggregate %.1f us | two launches %.1f | tail %.1f | beside %.1f" %
+          (timed(agg_only), timed(two), timed(lambda: one(1)), timed(lambda: one(2)) if served else float("nan")))
+print("in a hipGraph of 20: aggregate %.1f us | two launches %.1f | tail %.1f | beside %.1f" %
+      (graphed(agg_only), graphed(two), graphed(lambda: one(1)), graphed(lambda: one(2)) if served else float("nan")))
+# repeatability of the hand-off: 100 launches, every output compared
+if served:
+    outs = [one(2) for _ in range(100)]
+    torch.cuda.synchronize()
+    print("beside, 100 launches all equal to the two launches: %s" % all(torch.equal(o, want) for o in outs))
+
+if served:
+    for form in (1, 2):
+        trace = torch.zeros(grid * 32, dtype=torch.int64, device=dev)
+        one(form)
+        torch.cuda.synchronize()
+        _lib.check(_lib.lib.ultra_order_trace(trace.data_ptr()))
+        one(form)
+        torch.cuda.synchronize()
+        _lib.check(_lib.lib.ultra_order_trace(None))
+        t = trace.cpu()
+        main = t[:3 * grid].view(grid, 3).double()
+        wave_end = t[8 * grid:24 * grid].view(grid, 16).double() - main[:, :1]
+        chain = main[:, 1] - main[:, 0]
+        end = main[:, 2] - main[:, 0]
+        print("form %d: cycles since the workgroup's start -- chains done %.0f, end mean %.0f max %.0f" %
+              (form, chain.mean(), end.mean(), end.max()))
+        print("  end of work per wave (mean over workgroups): " + " ".join("%6.0f" % v for v in wave_end.mean(dim=0).tolist()))
+        print("  ... max over workgroups:                     " + " ".join("%6.0f" % v for v in wave_end.max(dim=0)[0].tolist()))

@@ -33,7 +33,9 @@ REC_POLICY = os.environ.get("ULTRA_GEN_REC_POLICY", "")
 # cache policy of the flush stores of the stream walk: nt (written once, read by the NEXT kernel).  Measured (r3, rocprofv3
 # FETCH_SIZE + WRITE_SIZE): FB15k237 bs 8 180 -> 155 MB and 78.3 -> 77.5 us, CoDEx-L bs 8 1.91 -> 1.88 GB and 266 -> 257 us;
 # " sc1" the same within noise; "" = default policy.
-OUT_POLICY = os.environ.get("ULTRA_GEN_OUT_POLICY", " nt")          # add: 0, min: +FLT_MAX, max: -FLT_MAX (operator.cuh:43-80)
+OUT_POLICY = os.environ.get("ULTRA_GEN_OUT_POLICY", " nt")
+# ... and in the POST variants, whose flushed rows are read back by the update waves of the same workgroup moments later
+POST_OUT_POLICY = os.environ.get("ULTRA_GEN_POST_OUT_POLICY", " nt")
 
 
 def vr(lo, n=1):
@@ -84,9 +86,48 @@ def nary(a, sum_code, acc, x):
 #   v112:113   records of the round after the current one (in flight)      v120:121  round 0's records (prologue)
 #   v114/v115  current round's col / type (lane l holds step l % 8)
 #   v56..v63, v48..v55  the chunk's four relation rows          v116..v119 the accumulator       v122 scratch
+#   POST variants (the walk also hands its finished rows to the workgroup's update waves, see stream_post):
+#   v44..v47   byte offset of the row flushed at step q of the previous chunk (-1: none)     v123 queue slot
+#   v124 LDS address of the hand-off block     v125 the constant 1
 STREAM_CLOBBER_LO, STREAM_CLOBBER_HI = 48, 122
+POST_CLOBBER_LO, POST_CLOBBER_HI = 44, 125
 RV = (56, 60, 48, 52)
 ACC = 116
+PEND = 44
+# hand-off block in LDS (rspmm_order_kernels.hpp, UpdateCtl): word 0 queue tail, 1 walkers done, 2 weight image ready,
+# 3 chain done, then HANDOFF_TILES counters "rows of tile t posted", then the queue of row byte offsets
+HANDOFF_TILES = 256
+HANDOFF_TILE_OFF = 16
+HANDOFF_QUEUE_OFF = HANDOFF_TILE_OFF + 4 * HANDOFF_TILES
+
+
+def stream_post(a, tag):
+    """Hand the rows flushed during the PREVIOUS chunk to the update waves.  Placed right behind a vmcnt wait that leaves
+    only requests issued after those flush stores outstanding: completion is reported to a wave in issue order, so the
+    stores have reached the L2 and the rows are readable by the other waves of this CU.  One lane per 16-lane group posts:
+    slot = tail++, queue[slot] = row offset, posted[slot / 32]++ -- a wave's LDS operations execute in order, so a reader
+    that sees the tile's count complete also sees its 32 queue entries.  Ends with every LDS operation of the wave
+    collected (the chunk's relation rows included: the counted lgkm waits of the steps below then pass at once)."""
+    a("s_cmp_eq_u32 %[pf], 0")
+    a("s_cbranch_scc1 .Lstream_nopost_%s_%%=" % tag)
+    a("v_cmp_eq_u32_e64 %[mk], 0, %[lb]", "lane 0 of each group (whole-span rows: lb = 16 (lane % 16))")
+    for q in range(4):
+        a("v_cmp_ne_u32_e32 vcc, -1, v%d" % (PEND + q))
+        a("s_and_b64 exec, vcc, %[mk]")
+        a("s_cbranch_execz .Lstream_posted_%s%d_%%=" % (tag, q))
+        a("ds_add_rtn_u32 v123, v124, v125")
+        a("s_waitcnt lgkmcnt(0)")
+        a("v_lshl_add_u32 v122, v123, 2, v124")
+        a("ds_write_b32 v122, v%d offset:%d" % (PEND + q, HANDOFF_QUEUE_OFF))
+        a("v_lshrrev_b32_e32 v123, 5, v123")
+        a("v_lshl_add_u32 v122, v123, 2, v124")
+        a("ds_add_u32 v122, v125 offset:%d" % HANDOFF_TILE_OFF)
+        a.label(".Lstream_posted_%s%d_%%=" % (tag, q))
+        a("s_mov_b64 exec, %[ex]")
+        a("v_mov_b32_e32 v%d, -1" % (PEND + q))
+    a("s_mov_b32 %[pf], 0")
+    a("s_waitcnt lgkmcnt(0)")
+    a.label(".Lstream_nopost_%s_%%=" % tag)
 
 
 def stream_fetch(a, xb, tb, ob, J):
@@ -109,7 +150,7 @@ def stream_rel_reads(a, tb):
         a("ds_read_b128 %s, v%d" % (vr(RV[q], 4), tb + q))
 
 
-def stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag):
+def stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag, post=False):
     """The chunk's four steps in order.  Fast form: every stream of the wave still has the whole chunk (uniform test
     against nf) and none of the 16 (group, step) slots is a marker (the marker's LDS address is the largest there is).
     General form, per step: live = consts[q] < rem; marker = live and relation address == mark; edges accumulate in the
@@ -143,12 +184,22 @@ def stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag):
         a("s_cbranch_execz .Lstream_noflush_%s%d_%%=" % (tag, q))
         # flush: out[row] = acc (+) boundary[row]   (rspmm.cpp:70-72), then a fresh accumulator
         a("v_cmp_eq_u32_e32 vcc, v%d, %%[bndoff]" % (ob + q))
-        a("s_and_b64 exec, exec, vcc", "lanes of the boundary row")
-        op = {0: "v_add_f32_e32", 1: "v_min_f32_e32", 2: "v_max_f32_e32"}[sum_code]
-        for e in range(4):
-            a("%s v%d, v%d, %%[b%d]" % (op, ACC + e, ACC + e, e))
-        a("s_mov_b64 exec, %[mk]")
-        a("global_store_dwordx4 v%d, %s, %%[ob]%s" % (ob + q, vr(ACC, 4), OUT_POLICY))
+        if sum_code == 0:
+            a("s_and_b64 exec, exec, vcc", "lanes of the boundary row")
+            for e in range(4):
+                a("v_add_f32_e32 v%d, v%d, %%[b%d]" % (ACC + e, ACC + e, e))
+            a("s_mov_b64 exec, %[mk]")
+        else:
+            # min / max: the boundary row meets its value, every other row the fill (layers.py:206-207: the boundary
+            # tensor is zero off the query rows -> fill 0; a call without that tensor passes -+inf, which changes nothing)
+            op = {1: "v_min_f32_e32", 2: "v_max_f32_e32"}[sum_code]
+            for e in range(4):
+                a("v_cndmask_b32_e32 v122, %%[bz], %%[b%d], vcc" % e)
+                a("%s v%d, v%d, v122" % (op, ACC + e, ACC + e))
+        a("global_store_dwordx4 v%d, %s, %%[ob]%s" % (ob + q, vr(ACC, 4), POST_OUT_POLICY if post else OUT_POLICY))
+        if post:
+            a("v_mov_b32_e32 v%d, v%d" % (PEND + q, ob + q), "posted behind the next vmcnt wait (stream_post)")
+            a("s_mov_b32 %[pf], 1")
         a("s_nop 2", "gfx940+: a VALU write of the data registers of a > 8-byte store needs 2 wait states behind the store "
                      "(with one, v_mov v116 reached the last lanes' data first)")
         for e in range(4):
@@ -158,7 +209,7 @@ def stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag):
     a.label(".Lstream_summed_%s_%%=" % tag)
 
 
-def gen_stream(sum_code, mul_code, rec_policy):
+def gen_stream(sum_code, mul_code, rec_policy, post=False):
     a = Asm()
     binop = BINOPS[mul_code]
     A, B, TA, TB, OA, OB = 64, 80, 96, 100, 104, 108
@@ -168,10 +219,21 @@ def gen_stream(sum_code, mul_code, rec_policy):
         a("v_cndmask_b32_e32 v114, 0, v%d, vcc" % rec, "steps past the stream's end gather node 0 ...")
         a("v_cndmask_b32_e32 v115, 0, v%d, vcc" % (rec + 1), "... multiply by relation 0, are no marker, and are masked out of the sum")
 
+    def compute(xb, tb, ob, consts, first_step, tag):
+        if post:
+            stream_post(a, tag)
+        stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag, post)
+
     a("s_mov_b64 %[ex], exec")
     a("s_mov_b32 %[kb], 0")
     for e in range(4):
         a("v_mov_b32_e32 v%d, %s" % (ACC + e, IDENT[sum_code]))
+    if post:
+        a("s_mov_b32 %[pf], 0")
+        for q in range(4):
+            a("v_mov_b32_e32 v%d, -1" % (PEND + q))
+        a("v_mov_b32_e32 v124, %[qctl]")
+        a("v_mov_b32_e32 v125, 1")
     a("global_load_dwordx2 v[120:121], %%[roff], %%[rb]%s" % rec_policy, "records of round 0")
     a("global_load_dwordx2 v[112:113], %%[roff], %%[rb] offset:64%s" % rec_policy, "records of round 1")
     a("v_add_u32_e32 %[roff], 0x80, %[roff]")
@@ -184,8 +246,9 @@ def gen_stream(sum_code, mul_code, rec_policy):
     a("s_cbranch_scc0 .Lstream_last_a_%=")
     stream_fetch(a, B, TB, OB, 4)                                  # [r', A x 4, B x 4]
     stream_rel_reads(a, TA)
-    a("s_waitcnt vmcnt(4)", "[r', A x 4, B x 4] (+ flush stores, which only make the count stricter) -> r', A")
-    stream_compute(a, A, TA, OA, (0, 1, 2, 3), binop, sum_code, 0, "a")
+    a("s_waitcnt vmcnt(4)", "[r', A x 4, B x 4] (+ flush stores, which only make the count stricter) -> r', A; the previous "
+                            "chunk's flush stores are older than B x 4: complete")
+    compute(A, TA, OA, (0, 1, 2, 3), 0, "a")
     a("s_add_i32 %[t0], %[kb], 8")
     a("s_cmp_lt_i32 %[t0], %[ns]")
     a("s_cbranch_scc0 .Lstream_last_b_%=")
@@ -195,21 +258,23 @@ def gen_stream(sum_code, mul_code, rec_policy):
     a("v_add_u32_e32 %[roff], 64, %[roff]")
     stream_fetch(a, A, TA, OA, 0)                                  # [B x 4, r'', A x 4]
     stream_rel_reads(a, TB)
-    a("s_waitcnt vmcnt(5)", "[B x 4, r'', A x 4] -> B")
-    stream_compute(a, B, TB, OB, (-4, -3, -2, -1), binop, sum_code, 4, "b")   # (rem already moved on by 8)
+    a("s_waitcnt vmcnt(5)", "[B x 4, r'', A x 4] -> B; chunk A's flush stores are older than r'', A x 4: complete")
+    compute(B, TB, OB, (-4, -3, -2, -1), 4, "b")   # (rem already moved on by 8)
     a("s_mov_b32 %[kb], %[t0]")
     a("s_branch .Lstream_loop_%=")
     a.label(".Lstream_last_a_%=")
     stream_rel_reads(a, TA)
     a("s_waitcnt vmcnt(0)")
-    stream_compute(a, A, TA, OA, (0, 1, 2, 3), binop, sum_code, 0, "la")
+    compute(A, TA, OA, (0, 1, 2, 3), 0, "la")
     a("s_branch .Lstream_done_%=")
     a.label(".Lstream_last_b_%=")
     stream_rel_reads(a, TB)
     a("s_waitcnt vmcnt(0)")
-    stream_compute(a, B, TB, OB, (4, 5, 6, 7), binop, sum_code, 4, "lb")
+    compute(B, TB, OB, (4, 5, 6, 7), 4, "lb")
     a.label(".Lstream_done_%=")
     a("s_waitcnt vmcnt(0)", "flush stores")
+    if post:
+        stream_post(a, "end")
     return a
 
 
@@ -489,29 +554,33 @@ def main():
     parts.append("// group stream of this lane's 16-lane group: rem = the stream's length in steps (edges + one marker per row), roff =\n"
                  "// byte offset of the lane's first record ((begin + lane % 8) * 8), l8 = lane % 8, lb = lane's byte offset inside a row,\n"
                  "// lds = LDS byte address of the lane's part of relation row 0, mark = lds + 256 * num_rel, bndoff = byte offset of the\n"
-                 "// boundary row's part of this lane (0xffffffff: none), b = its boundary values, ns / nf = steps of the wave's longest /\n"
-                 "// shortest stream (ns > 0, wave-uniform), xb / rb / ob = source slice, stream records, output slice\n"
-                 "template <int SUM, int MUL>\n"
+                 "// boundary row's part of this lane (0xffffffff: none), b = its boundary values, bz = what a row other than the boundary\n"
+                 "// row meets at its flush under min / max (0: the boundary tensor's zeros; -+inf: nothing), ns / nf = steps of the wave's\n"
+                 "// longest / shortest stream (ns > 0, wave-uniform), xb / rb / ob = source slice, stream records, output slice.\n"
+                 "// POST: every flushed row is also handed to the workgroup's update waves through the LDS block at byte address qctl\n"
+                 "// (stream_post in the generator; whole-span rows only: lb = 16 (lane % 16)).\n"
+                 "template <int SUM, int MUL, bool POST>\n"
                  "__device__ __forceinline__ void order_stream_asm(int rem, uint32_t roff, const int l8, const uint32_t lb, const uint32_t lds,\n"
-                 "                                                 const uint32_t mark, const uint32_t bndoff, const float (&b)[4], const int ns,\n"
-                 "                                                 const int nf, const char *xb, const char *rb, const char *ob,\n"
-                 "                                                 const uint32_t xrb) {\n"
-                 "    int kb, t0, t1;\n    unsigned long long ex, mk;\n")
+                 "                                                 const uint32_t mark, const uint32_t bndoff, const float (&b)[4], const float bz,\n"
+                 "                                                 const int ns, const int nf, const char *xb, const char *rb, const char *ob,\n"
+                 "                                                 const uint32_t xrb, const uint32_t qctl) {\n"
+                 "    int kb, t0, t1, pf;\n    unsigned long long ex, mk;\n    (void)pf;\n")
     first = True
-    for sum_code in (0, 1, 2):
-        for mul_code in (0, 1):
-            if True:
-                a = gen_stream(sum_code, mul_code, REC_POLICY)
-                cond = "SUM == %d && MUL == %d" % (sum_code, mul_code)
+    for post in (False, True):
+        for sum_code in (0, 1, 2):
+            for mul_code in (0, 1):
+                a = gen_stream(sum_code, mul_code, REC_POLICY, post)
+                cond = "SUM == %d && MUL == %d && %sPOST" % (sum_code, mul_code, "" if post else "!")
                 parts.append("    %sif constexpr (%s) {\n" % ("" if first else "else ", cond))
                 first = False
                 parts.append("        asm volatile(\n" + a.render("            ") + "\n")
                 parts.append('            : [rem] "+v"(rem), [roff] "+v"(roff), [kb] "=&s"(kb), [t0] "=&s"(t0), [t1] "=&s"(t1), [ex] "=&s"(ex),\n'
-                             '              [mk] "=&s"(mk)\n'
-                             '            : [l8] "v"(l8), [lb] "v"(lb), [lds] "v"(lds), [mark] "v"(mark), [bndoff] "v"(bndoff), [b0] "v"(b[0]),\n'
+                             '              [mk] "=&s"(mk)%s\n' % (', [pf] "=&s"(pf)' if post else ''))
+                parts.append('            : [l8] "v"(l8), [lb] "v"(lb), [lds] "v"(lds), [mark] "v"(mark), [bndoff] "v"(bndoff), [b0] "v"(b[0]),\n'
                              '              [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [ns] "s"(ns), [nf] "s"(nf), [xb] "s"(xb), [rb] "s"(rb),\n'
-                             '              [ob] "s"(ob), [xrb] "s"(xrb)\n'
-                             '            : "memory", "vcc", "scc", %s);\n' % clobbers(STREAM_CLOBBER_LO, STREAM_CLOBBER_HI))
+                             '              [ob] "s"(ob), [xrb] "s"(xrb)%s%s\n' % (', [bz] "v"(bz)' if sum_code else '', ', [qctl] "s"(qctl)' if post else ''))
+                lo, hi = (POST_CLOBBER_LO, POST_CLOBBER_HI) if post else (STREAM_CLOBBER_LO, STREAM_CLOBBER_HI)
+                parts.append('            : "memory", "vcc", "scc", %s);\n' % clobbers(lo, hi))
                 parts.append("    }\n")
     parts.append("}\n\n")
 

@@ -86,9 +86,9 @@ def _load():
     lib.ultra_rspmm_forward.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp]
     lib.ultra_rspmm_forward_masked.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp]
     lib.ultra_rspmm_forward_onehot.argtypes = [vp, i32, vp, matp, matp, vp, matp, matp, vp]
-    lib.ultra_rspmm_forward_point.argtypes = [vp, i32, i32, vp, matp, matp, vp, matp, matp, vp]
-    lib.ultra_rspmm_forward_update.argtypes = [vp, i32, matp, matp, vp, matp, matp, vp, vp, vp, vp, ctypes.c_float, i32, matp, vp]
-    lib.ultra_rspmm_forward_update_timed.argtypes = [vp, i32, matp, matp, vp, matp, matp, vp, vp, vp, vp, ctypes.c_float, i32, matp, vp,
+    lib.ultra_rspmm_forward_point.argtypes = [vp, i32, i32, i32, vp, matp, matp, vp, matp, matp, vp]
+    lib.ultra_rspmm_forward_update.argtypes = [vp, i32, i32, matp, matp, vp, matp, matp, vp, vp, vp, vp, ctypes.c_float, i32, matp, vp]
+    lib.ultra_rspmm_forward_update_timed.argtypes = [vp, i32, i32, matp, matp, vp, matp, matp, vp, vp, vp, vp, ctypes.c_float, i32, matp, vp,
                                                      i32, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     lib.ultra_nbf_dense_layer.argtypes = [vp, matp, matp, matp, vp, vp, vp, vp, vp, ctypes.c_float, i32, matp, vp]
     lib.ultra_nbf_layer0.argtypes = [vp, vp, matp, vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, matp, vp]
@@ -126,7 +126,7 @@ def _load():
 
 
 lib = _load()
-if lib.ultra_abi_version() != 4:
+if lib.ultra_abi_version() != 5:
     raise ImportError("ultra_amd: libultra_amd.so ABI version mismatch")
 
 

@@ -256,6 +256,9 @@ static double COST_S_CHUNK = 675.0, COST_S_ROW = 1380.0, COST_S_STEP = 6.0;
 // launch's last workgroup at 142.5 k cycles instead of 147.7 k, 69.5 us instead of 71.8 stand-alone.  (s_setprio against
 // the age order only reverses who finishes first: 50 k / 60 k / 76 k / 89 k from the youngest quartet up.)
 static double WAVE_SHARE[4] = {1.7, 1.3, 0.7, 0.3};
+// ... and when the youngest quartet does not walk at all (its waves apply the layer update beside the walk:
+// rspmm_order_kernel, UPDATE == 2): the same age effect among the three walking quartets
+static double WAVE_SHARE_12[4] = {1.5, 1.2, 0.7, 0.0};
 // ULTRA_CHAIN_OVERLAP: cycles one walking stream needs per step while the chain crew is still busy (fewer streams share the
 // vector L1 then: a stream steps faster than the 64 x COST_S_STEP of the all-streams phase)
 static double COST_S_STEP_SIDE = 252.0, SIDE_TAPER = 0.6;   // (SIDE_TAPER: share of T above which a chain stays classic)
@@ -271,6 +274,11 @@ static void read_cost_override() {   // calibration runs only: ULTRA_SCHED_COSTS
         const double mean = (v[0] + v[1] + v[2] + v[3]) / 4.0;
         for (int k = 0; k < 4; ++k) WAVE_SHARE[k] = mean > 0 ? v[k] / mean : 1.0;
     }
+    env = std::getenv("ULTRA_STREAM_SHARES_12");   // calibration runs: "q0,q1,q2" (the update waves take no rows)
+    if (env && std::sscanf(env, "%lf,%lf,%lf", &v[0], &v[1], &v[2]) == 3) {
+        for (int k = 0; k < 3; ++k) WAVE_SHARE_12[k] = v[k];
+        WAVE_SHARE_12[3] = 0.0;
+    }
     env = std::getenv("ULTRA_STREAM_COSTS");
     if (env) {
         const int n = std::sscanf(env, "%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4]);
@@ -280,10 +288,11 @@ static void read_cost_override() {   // calibration runs only: ULTRA_SCHED_COSTS
     }
 }
 
-Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
+Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
     read_cost_override();
     Schedule *s = new Schedule();
     s->nparts = nparts;
+    const double *wave_share = walkers == 12 ? WAVE_SHARE_12 : WAVE_SHARE;
     const int64_t n_chain = p->n_chain, n_item = (int64_t)p->items.size();
     const int64_t n_unit = (n_item - n_chain + 3) / 4;
     struct Work {
@@ -383,14 +392,15 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
         const double T = total / nparts;
         for (int32_t q = 0; q < nparts; ++q) {
             const double budget = std::max(T - chain_cost[(size_t)q], 0.02 * T);   // (never zero: every row needs a home)
-            for (int g = 0; g < ORDER_GROUPS; ++g) weight[(size_t)q * ORDER_GROUPS + g] = budget * WAVE_SHARE[g / 16];
+            for (int g = 0; g < ORDER_GROUPS; ++g) weight[(size_t)q * ORDER_GROUPS + g] = budget * wave_share[g / 16];
         }
 #endif
         typedef std::pair<double, int64_t> Slot;   // ((load + 1) / weight, stream): the heap's top is the relatively emptiest
         std::priority_queue<Slot, std::vector<Slot>, std::greater<Slot>> sheap;
         std::vector<int64_t> sload((size_t)nstream, 0);
         std::vector<std::vector<int32_t>> srows((size_t)nstream);
-        for (int64_t g = 0; g < nstream; ++g) sheap.push(Slot(1.0 / weight[(size_t)g], g));
+        for (int64_t g = 0; g < nstream; ++g)
+            if (weight[(size_t)g] > 0.0) sheap.push(Slot(1.0 / weight[(size_t)g], g));   // (a stream without a share takes no rows)
         for (int64_t g = n_chain; g < n_item; ++g) {   // group items are sorted by descending length
             const Slot sl = sheap.top();
             sheap.pop();
@@ -427,6 +437,7 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts) {
             s->prow.insert(s->prow.end(), mine.begin(), mine.end());
             while (s->prow.size() % 32) s->prow.push_back(-1);
             s->prow_ptr[(size_t)q + 1] = (int32_t)s->prow.size();
+            s->max_rows = std::max<int32_t>(s->max_rows, (int32_t)mine.size());
         }
     }
     // the chain producers request descriptors a fixed number of chunks ahead without a bounds test: readable, harmless

@@ -85,6 +85,7 @@ struct Schedule {
     int32_t *d_prow = nullptr, *d_prow_ptr = nullptr;
     Chunk *d_chunks = nullptr;
     double max_cost = 0.0, mean_cost = 0.0;             // cost model's load of the fullest / average workgroup
+    int32_t max_rows = 0;                               // most rows any one workgroup aggregates
 };
 
 struct DevicePlan {
@@ -173,6 +174,8 @@ ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *ty
 
 // The schedule of a reference-order plan for `nparts` workgroups per span (host arrays only; cached in the plan by
 // the caller under sched_mu).
-Schedule *build_schedule(const ultra_plan *p, int32_t nparts);
+// walkers: 16 = every wave of a workgroup walks streams; 12 = the last four waves take no rows (they apply the layer update
+// beside the walk).
+Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers = 16);
 
 }  // namespace ultra

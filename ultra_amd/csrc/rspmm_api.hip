@@ -150,14 +150,15 @@ static void free_schedules(ultra_plan *p) {
 
 // The static work assignment of a reference-order plan for `nparts` workgroups per span: built and uploaded on first
 // use (warm-up calls do that before any hipGraph capture), then read-only.
-static int get_schedule(ultra_plan *p, int32_t nparts, Schedule **out) {
+static int get_schedule(ultra_plan *p, int32_t nparts, Schedule **out, int32_t walkers = 16) {
     std::lock_guard<std::mutex> lock(p->sched_mu);
-    auto it = p->schedules.find(nparts);
+    const int32_t key = nparts | (walkers == 12 ? ULTRA_SCHEDULE_12_WALKERS : 0);   // (nparts <= the workgroup count of a launch)
+    auto it = p->schedules.find(key);
     if (it != p->schedules.end()) {
         *out = it->second;
         return ULTRA_OK;
     }
-    Schedule *s = build_schedule(p, nparts);
+    Schedule *s = build_schedule(p, nparts, walkers);
     int rc;
     if ((rc = upload_array(&s->d_chunk_ptr, s->chunk_ptr)) || (rc = upload_array(&s->d_unit_ptr, s->unit_ptr)) ||
         (rc = upload_array(&s->d_units, s->units)) || (rc = upload_array(&s->d_chunks, s->chunks)) ||
@@ -167,7 +168,7 @@ static int get_schedule(ultra_plan *p, int32_t nparts, Schedule **out) {
         delete s;
         return rc;
     }
-    p->schedules[nparts] = s;
+    p->schedules[key] = s;
     *out = s;
     return ULTRA_OK;
 }
@@ -267,13 +268,19 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
     if ((rc = check_mat(out, "output", p->num_out, n_outer, row_len))) return rc;
     if (mul != BIN_RHS && (rc = check_mat(rel, "relation", p->num_rel, n_outer, row_len))) return rc;
     if (mul != BIN_LHS && (rc = check_mat(x, "input", p->num_in, n_outer, row_len))) return rc;
-    if (bnd_rows && (!bnd || sum != ULTRA_SUM_ADD))
-        return invalid("a point boundary needs its value rows and serves the sum aggregate only (zero is not the identity of min/max)");
+    if (bnd_rows && !bnd) return invalid("a point boundary needs its value rows");
+    // min / max with a point boundary: the boundary tensor it stands for is ZERO off the query rows, and zero is not the
+    // identity of min / max -- every other row meets the value 0 at its flush (layers.py:206-207)
+    const bool point_fill = bnd_rows && sum != ULTRA_SUM_ADD;
     if (bnd && (rc = check_mat(bnd, "boundary", bnd_rows ? 1 : p->num_out, n_outer, row_len))) return rc;
     if (p->num_out == 0) return ULTRA_OK;
     if ((rc = upload_plan(p))) return rc;
     if (upd && ((p->flags & ULTRA_PLAN_DENSE) || !(p->flags & ULTRA_PLAN_EXACT_ORDER))) {
         set_error("ultra_rspmm_forward_update: served by reference-order plans in the sparse format only");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    if (point_fill && ((p->flags & ULTRA_PLAN_DENSE) || !(p->flags & ULTRA_PLAN_EXACT_ORDER))) {
+        set_error("a point boundary under min / max is served by reference-order plans in the sparse format only");
         return ULTRA_ERR_UNSUPPORTED;
     }
     if (p->flags & ULTRA_PLAN_DENSE) {
@@ -373,6 +380,8 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
             op.n_item = (int32_t)p->items.size();
             op.rel = fp.rel, op.x = fp.x, op.bnd = fp.bnd;
             op.bnd_rows = fp.bnd_rows;
+            op.bnd_fill_on = point_fill ? 1 : 0;
+            op.bnd_fill = 0.f;
             op.out = fp.out;
             op.out_stride_outer = fp.out_stride_outer, op.out_stride_row = fp.out_stride_row;
             op.n_outer = fp.n_outer, op.row_len = fp.row_len, op.spans_per_outer = fp.spans_per_outer, op.n_span = fp.n_span;
@@ -394,15 +403,37 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
                                  : 0;
             size_t lds = (rel_lds ? rel_bytes : 0) + ring_bytes;
             if (upd) {
-                if (!op.use_streams || row_len != 64 || sum != ULTRA_SUM_ADD) {
-                    set_error("ultra_rspmm_forward_update: this call is not served by the stream walk (fp32, 64-element rows, sum aggregate, "
-                              "unit weights, relation slice in LDS, point boundary or none)");
+                if (!op.use_streams || row_len != 64) {
+                    set_error("ultra_rspmm_forward_update: this call is not served by the stream walk (fp32, 64-element rows, unit "
+                              "weights, relation slice in LDS, point boundary or none)");
                     return ULTRA_ERR_UNSUPPORTED;
                 }
                 op.upd = *upd;
                 op.upd.prow = sched->d_prow;
                 op.upd.prow_ptr = sched->d_prow_ptr;
+                op.upd.mode = 1;
                 lds = std::max(lds, (size_t)UPDATE_LDS_FLOATS * sizeof(float));   // (the weight image takes the dead relation slice's place)
+                // The update BESIDE the walk (rspmm_order_kernel, UPDATE == 2): twelve waves walk, four multiply the rows handed
+                // over through LDS.  Needs the weight image (in the ring's place once the chain is done) and the hand-off
+                // block beside the relation slice, and update rows of the input's stride (a queue entry is a byte offset).
+                Schedule *sched12 = nullptr;
+                if (g_tuning.reserved[2] != 1 && op.nparts * op.smod == grid &&
+                    upd->out_stride_row * (int64_t)sizeof(float) == (int64_t)op.x_row_bytes) {
+                    if ((rc = get_schedule(p, op.nparts, &sched12, ORDER_WALKERS))) return rc;
+                    const size_t image = std::max(ring_bytes, (size_t)UPDATE_LDS_FLOATS * sizeof(float));
+                    const size_t need = rel_bytes + image + UPDATE_CTL_QUEUE_OFF + (size_t)sched12->max_rows * 4 + 64;
+                    if (need <= di.lds_optin && sched12->max_rows <= 32 * (UPDATE_CTL_TILES - 1)) {
+                        op.upd.mode = 2;
+                        op.upd.ctl_off = (uint32_t)(rel_bytes + image);
+                        op.srec = sched12->d_srec;
+                        op.sdesc = reinterpret_cast<const int2 *>(sched12->d_sdesc);
+                        lds = need;
+                    }
+                }
+                if (g_tuning.reserved[2] == 2 && op.upd.mode != 2) {
+                    set_error("ultra_rspmm_forward_update: the update beside the walk does not fit this call (LDS / rows per workgroup)");
+                    return ULTRA_ERR_UNSUPPORTED;
+                }
             }
             hipError_t e = hipErrorInvalidValue;
             if (g_ev_before) HIP_TRY(hipEventRecord(g_ev_before, stream));
@@ -864,17 +895,17 @@ int32_t ultra_rspmm_forward_masked(ultra_plan *plan, int32_t sum, int32_t mul, i
     return rc;
 }
 
-int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t mul, int32_t dtype, const void *edge_weight_dev,
+int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype, const void *edge_weight_dev,
                                   const ultra_mat *relation, const ultra_mat *input, const int64_t *point_rows_dev,
                                   const ultra_mat *point_values, const ultra_mat *output, void *stream) {
     ULTRA_DEVICE_SCOPE(stream, output ? output->ptr : nullptr);
     if (mul < 0 || mul > 1) return invalid("unknown mul code");
     if (!point_rows_dev || !point_values) return invalid("ultra_rspmm_forward_point: NULL point boundary");
-    return forward_impl(plan, ULTRA_SUM_ADD, mul, dtype, edge_weight_dev, relation, input, point_values, output,
+    return forward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, point_values, output,
                         reinterpret_cast<hipStream_t>(stream), point_rows_dev);
 }
 
-int32_t ultra_rspmm_forward_update(ultra_plan *plan, int32_t mul, const ultra_mat *relation, const ultra_mat *input,
+int32_t ultra_rspmm_forward_update(ultra_plan *plan, int32_t sum, int32_t mul, const ultra_mat *relation, const ultra_mat *input,
                                    const int64_t *point_rows_dev, const ultra_mat *point_values, const ultra_mat *aggregate,
                                    const void *weight, const void *bias, const void *ln_weight, const void *ln_bias, float eps,
                                    int32_t flags, const ultra_mat *output, void *stream) {
@@ -896,7 +927,7 @@ int32_t ultra_rspmm_forward_update(ultra_plan *plan, int32_t mul, const ultra_ma
     u.out = (float *)output->ptr;
     u.out_stride_outer = output->stride_outer, u.out_stride_row = output->stride_row;
     u.eps = eps, u.flags = flags;
-    return forward_impl(plan, ULTRA_SUM_ADD, mul, ULTRA_F32, nullptr, relation, input, point_values, aggregate,
+    return forward_impl(plan, sum, mul, ULTRA_F32, nullptr, relation, input, point_values, aggregate,
                         reinterpret_cast<hipStream_t>(stream), point_rows_dev, &u);
 }
 
@@ -1006,13 +1037,14 @@ int32_t ultra_rspmm_forward_timed(ultra_plan *plan, int32_t sum, int32_t mul, in
                          "ultra_rspmm_forward_timed");
 }
 
-int32_t ultra_rspmm_forward_update_timed(ultra_plan *plan, int32_t mul, const ultra_mat *relation, const ultra_mat *input,
+int32_t ultra_rspmm_forward_update_timed(ultra_plan *plan, int32_t sum, int32_t mul, const ultra_mat *relation, const ultra_mat *input,
                                          const int64_t *point_rows_dev, const ultra_mat *point_values, const ultra_mat *aggregate,
                                          const void *weight, const void *bias, const void *ln_weight, const void *ln_bias, float eps,
                                          int32_t flags, const ultra_mat *output, void *stream, int32_t warmup, int32_t iters,
                                          float *ms_per_call, float *ms_main_kernel) {
+    ULTRA_DEVICE_SCOPE(stream, output ? output->ptr : nullptr);   // (the events are created and recorded on the operands' device)
     const auto once = [&]() {
-        return ultra_rspmm_forward_update(plan, mul, relation, input, point_rows_dev, point_values, aggregate, weight, bias, ln_weight,
+        return ultra_rspmm_forward_update(plan, sum, mul, relation, input, point_rows_dev, point_values, aggregate, weight, bias, ln_weight,
                                           ln_bias, eps, flags, output, stream);
     };
     return time_launches(once, reinterpret_cast<hipStream_t>(stream), warmup, iters, ms_per_call, ms_main_kernel,
@@ -1025,9 +1057,11 @@ int32_t ultra_order_trace(void *trace_dev) {
 }
 
 int32_t ultra_plan_schedule_info(ultra_plan *plan, int32_t nparts, ultra_schedule_info *info) {
+    const int32_t walkers = (nparts & ULTRA_SCHEDULE_12_WALKERS) ? 12 : 16;
+    nparts &= ~ULTRA_SCHEDULE_12_WALKERS;
     if (!plan || !info || nparts <= 0) return invalid("ultra_plan_schedule_info: bad argument");
     if (!(plan->flags & ULTRA_PLAN_EXACT_ORDER)) return invalid("schedules belong to ULTRA_PLAN_EXACT_ORDER plans");
-    Schedule *s = build_schedule(plan, nparts);
+    Schedule *s = build_schedule(plan, nparts, walkers);
     info->nparts = nparts;
     info->n_chunk = (int64_t)s->chunk_ptr.back();   // (the array carries CHUNK_PAD readable entries behind the last chunk)
     info->n_unit = (int64_t)s->units.size();
@@ -1045,9 +1079,11 @@ int32_t ultra_plan_schedule_info(ultra_plan *plan, int32_t nparts, ultra_schedul
 }
 
 int32_t ultra_plan_schedule_export(ultra_plan *plan, int32_t nparts, int32_t which, int32_t *dst, int64_t capacity, int64_t *count) {
+    const int32_t walkers = (nparts & ULTRA_SCHEDULE_12_WALKERS) ? 12 : 16;
+    nparts &= ~ULTRA_SCHEDULE_12_WALKERS;
     if (!plan || !count || nparts <= 0) return invalid("ultra_plan_schedule_export: bad argument");
     if (!(plan->flags & ULTRA_PLAN_EXACT_ORDER)) return invalid("schedules belong to ULTRA_PLAN_EXACT_ORDER plans");
-    Schedule *s = build_schedule(plan, nparts);
+    Schedule *s = build_schedule(plan, nparts, walkers);
     const int32_t *src = nullptr;
     int64_t n = 0;
     switch (which) {

@@ -24,7 +24,11 @@
 #pragma once
 
 #include "rspmm_kernels.hpp"
+#ifdef ULTRA_ORDER_ASM_HEADER   // measurement builds: a header generated with other switches (tools/build_variant.py)
+#include ULTRA_ORDER_ASM_HEADER
+#else
 #include "rspmm_order_asm.hpp"
+#endif
 #include "update_tile.hpp"
 
 #pragma clang fp contract(off)
@@ -32,6 +36,12 @@
 namespace ultra {
 
 constexpr int ORDER_THREADS = 1024;
+// UPDATE == 2 (the layer update runs BESIDE the walk): waves [0, ORDER_WALKERS) walk the streams, the last ORDER_UPDATERS
+// waves -- one per SIMD -- multiply the rows the walkers hand over.  Hand-off block in LDS (the generator's HANDOFF_*
+// constants are the same numbers): word 0 queue tail, 1 walkers done, 2 weight image ready, 3 chain done, then
+// UPDATE_CTL_TILES counters "rows of tile t posted", then the queue of row byte offsets in posting order.
+constexpr int ORDER_UPDATERS = 4, ORDER_WALKERS = ORDER_THREADS / 64 - ORDER_UPDATERS;
+constexpr int UPDATE_CTL_TILES = 256, UPDATE_CTL_TILE_OFF = 16, UPDATE_CTL_QUEUE_OFF = UPDATE_CTL_TILE_OFF + 4 * UPDATE_CTL_TILES;
 #ifndef ULTRA_CHAIN_PRIO
 #define ULTRA_CHAIN_PRIO 1
 #endif
@@ -58,6 +68,10 @@ struct OrderParams {
     int32_t n_chain, n_item;
     MatArg rel, x, bnd;
     const long long *bnd_rows;   // point boundary: bnd holds ONE row per outer slice, added at row bnd_rows[outer] only
+    // min / max with a point boundary: every OTHER row meets this value at its flush (layers.py:206-207 takes
+    // max(update, boundary) against a tensor that is zero off the query rows); off: rows other than the boundary row are left alone
+    int32_t bnd_fill_on;
+    float bnd_fill;
     void *out;
     long long out_stride_outer, out_stride_row;
     int32_t n_outer, row_len, spans_per_outer, n_span;
@@ -74,6 +88,8 @@ struct OrderParams {
         const int32_t *prow, *prow_ptr;              // plan.hpp Schedule
         float eps;
         int32_t flags;                               // CONV_LN | CONV_RELU | CONV_RESIDUAL
+        int32_t mode;                                // 1: in the kernel's tail, 2: beside the walk (rspmm_order_kernel, UPDATE)
+        uint32_t ctl_off;                            // mode 2: byte offset of the hand-off block in LDS
     } upd;
 };
 
@@ -338,12 +354,33 @@ __device__ __forceinline__ T chain_add_partial(T acc, const V (&v)[N], const int
     return acc;
 }
 
+// One lane hands a finished row (its stores reported complete) to the workgroup's update waves: slot = tail++,
+// queue[slot] = byte offset of the row, posted[slot / 32]++ (the generator's stream_post is the walkers' copy of this).
+__device__ __forceinline__ void post_row(const uint32_t ctl_addr, const uint32_t row_off) {
+    uint32_t slot, a;
+    asm volatile(
+        "ds_add_rtn_u32 %0, %2, %3\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_lshl_add_u32 %1, %0, 2, %2\n"
+        "ds_write_b32 %1, %4 offset:%5\n"
+        "v_lshrrev_b32_e32 %0, 5, %0\n"
+        "v_lshl_add_u32 %1, %0, 2, %2\n"
+        "ds_add_u32 %1, %3 offset:%6\n"
+        : "=&v"(slot), "=&v"(a)
+        : "v"(ctl_addr), "v"(1u), "v"(row_off), "n"(UPDATE_CTL_QUEUE_OFF), "n"(UPDATE_CTL_TILE_OFF)
+        : "memory");
+}
+
 // STREAMS: the group rows are walked as streams by the assembly loop (its own instantiation: the C++ unit walk
 // and the assembly walk in one kernel cost each other registers around the asm statements).
-template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED, bool STREAMS, bool UPDATE = false>
+// UPDATE: 0 none; 1 the layer update of the workgroup's rows in the kernel's TAIL (after every walk has ended); 2 the update
+// BESIDE the walk -- the last ORDER_UPDATERS waves do not walk: they wait for rows the walkers hand over through an LDS
+// queue and multiply them on the matrix cores while the walk goes on (what is left when the walks end is at most one
+// tile per update wave).
+template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED, bool STREAMS, int UPDATE = 0>
 __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderParams p) {
     static_assert(!STREAMS || OrderAsm<T, MUL, REL_LDS, WEIGHTED>::value, "group streams exist for the assembly configurations only");
-    static_assert(!UPDATE || (STREAMS && SUM == 0 && sizeof(T) == 4), "the update tail follows the fp32 sum stream walk");
+    static_assert(!UPDATE || (STREAMS && sizeof(T) == 4), "the layer update follows the fp32 stream walk");
     constexpr int SPAN = 64;
     using P = Pack<T, 4>;
     using V = typename VecOf<T, 4>::type;
@@ -362,6 +399,9 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
     const int part = blockIdx.x / p.smod;
     if (part >= p.nparts) return;
     const T *wt = reinterpret_cast<const T *>(p.w);
+    // UPDATE == 2: the hand-off block (see ORDER_UPDATERS); the weight image takes the ring's place once the chain is done
+    volatile uint32_t *ctl = reinterpret_cast<volatile uint32_t *>(smem + (UPDATE == 2 ? p.upd.ctl_off : 0));
+    const T fill = (SUM != 0 && p.bnd_fill_on) ? (T)p.bnd_fill : nary_zero<T, SUM>();   // (what a non-boundary row meets under min / max)
 
     if (p.trace && tid == 0) p.trace[3 * blockIdx.x + 0] = clock64();
     for (int span = blockIdx.x % p.smod; span < p.n_span; span += p.smod) {
@@ -399,6 +439,9 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
             }
             // (the staging addresses are recomputed per span: hoisted out of the span loop they would stay live through
             // the walks below and spill)
+            if constexpr (UPDATE == 2) {
+                if (tid < 4 + UPDATE_CTL_TILES) ctl[tid] = 0;
+            }
             int tid_stage = tid;
             asm volatile("" : "+v"(tid_stage));
             stage_slice<T, 4>(lds_rel, reinterpret_cast<const T *>(p.rel.ptr) + outer * p.rel.stride_outer, p.rel.stride_row,
@@ -428,13 +471,28 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                 __builtin_amdgcn_s_setprio(3);   // the chain is the launch's critical path: win VALU / LDS issue arbitration
 #endif
                 const int d = inner * SPAN + chain_element(lane);
+                long long posted_off = -1;   // UPDATE == 2: the row stored last, not yet handed to the update waves
+                const auto post_pending = [&]() {
+                    if constexpr (UPDATE == 2) {
+                        if (posted_off >= 0) {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (issued a whole row ago: no stall in practice)
+                            if (lane == 0) post_row(lds_addr(const_cast<uint32_t *>(ctl)), (uint32_t)posted_off);
+                        }
+                    }
+                };
                 const auto finish_row = [&](const int row, T v) {
+                    post_pending();
                     if (d < p.row_len) {
-                        if (p.has_bnd && (bnd_row < 0 || bnd_row == row))
-                            v = nary<T, SUM>(v, reinterpret_cast<const T *>(p.bnd.ptr)[outer * p.bnd.stride_outer +
-                                                                                      (long long)row * p.bnd.stride_row + d]);
+                        if (p.has_bnd) {
+                            if (bnd_row < 0 || bnd_row == row)
+                                v = nary<T, SUM>(v, reinterpret_cast<const T *>(p.bnd.ptr)[outer * p.bnd.stride_outer +
+                                                                                          (long long)row * p.bnd.stride_row + d]);
+                            else if (SUM != 0 && p.bnd_fill_on)
+                                v = nary<T, SUM>(v, fill);
+                        }
                         reinterpret_cast<T *>(p.out)[outer * p.out_stride_outer + (long long)row * p.out_stride_row + d] = v;
                     }
+                    posted_off = (long long)row * (long long)p.x_row_bytes;
                 };
                 const v4i *chunks = reinterpret_cast<const v4i *>(p.chunks);
                 const V *ring_lane = reinterpret_cast<const V *>(ring) + lane;
@@ -546,6 +604,12 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                     }
                     finish_row(row, cacc);
                     it += nch;
+                }
+                post_pending();
+                if constexpr (UPDATE == 2) {
+                    // (behind the last post in this wave's LDS order; the ring is free: its last reads have been added)
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) ctl[3] = 1;
                 }
 #if ULTRA_DBG_CHAIN == 3
                 if (p.trace && lane == 0) p.trace[3 * gridDim.x + blockIdx.x] = bar_cycles;
@@ -666,7 +730,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
         const uint32_t lane_bytes = ug.lane_bytes;
         const T *lds_rel_lane = ug.lds_rel_lane;
         if constexpr (STREAMS) {
-            {
+            if (UPDATE != 2 || wave < ORDER_WALKERS) {
                 // ---- group streams: one continuous walk per 16-lane group (rspmm_order_asm.hpp) ----
                 const int2 sd = p.sdesc[(part * nwave + wave) * 4 + grp];
                 const int len = sd.y;
@@ -681,16 +745,77 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                     for (int e = 0; e < 4; ++e) bv[e] = b.v[e];
                     bndoff = (uint32_t)bnd_row * p.x_row_bytes + lane_bytes;
                 }
+                // (min / max: a flushed row other than the boundary row meets `bz`: the fill, or the value that changes nothing)
+                const float bz = (SUM != 0 && p.bnd_fill_on) ? p.bnd_fill : (SUM == 1 ? __builtin_inff() : -__builtin_inff());
                 if (ns > 0)
-                    order_stream_asm<SUM, MUL>(len, (uint32_t)(sd.x + (l16 & 7)) * 8u, l16 & 7, lane_bytes, lds_addr(lds_rel_lane),
-                                               lds_addr(lds_rel_lane) + (uint32_t)p.num_rel * 256u, bndoff, bv, ns, nf, xbase,
-                                               reinterpret_cast<const char *>(p.srec),
-                                               reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.out) + outer * p.out_stride_outer),
-                                               p.x_row_bytes);
+                    order_stream_asm<SUM, MUL, UPDATE == 2>(len, (uint32_t)(sd.x + (l16 & 7)) * 8u, l16 & 7, lane_bytes, lds_addr(lds_rel_lane),
+                                                            lds_addr(lds_rel_lane) + (uint32_t)p.num_rel * 256u, bndoff, bv, bz, ns, nf, xbase,
+                                                            reinterpret_cast<const char *>(p.srec),
+                                                            reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.out) + outer * p.out_stride_outer),
+                                                            p.x_row_bytes, lds_addr(const_cast<uint32_t *>(ctl)));
+                if constexpr (UPDATE == 2) {
+                    // this wave has posted all its rows (the walk ends on vmcnt(0) + its last posts; LDS operations of a
+                    // wave execute in order)
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) __hip_atomic_fetch_add(const_cast<uint32_t *>(ctl) + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            if constexpr (UPDATE == 2) {
+                if (wave >= ORDER_WALKERS) {
+                    // ---- update waves: rows come over the LDS queue in posting order, 32 to a tile; update wave u takes tiles
+                    // u, u + ORDER_UPDATERS, ...  A tile is ready when its 32 rows are posted -- or, once every walker has
+                    // finished, with the rows there are (the workgroup's last, partial tile). ----
+                    int tid_u = tid;
+                    asm volatile("" : "+v"(tid_u));
+                    if (c1 > c0) {
+                        while (ctl[3] == 0) __builtin_amdgcn_s_sleep(4);   // the chain consumer still reads the ring
+                    }
+                    float *lds_w = reinterpret_cast<float *>(ring);
+                    update_stage_weights(lds_w, p.upd.weight, p.upd.bias, p.upd.ln_w, p.upd.ln_b, p.upd.flags, tid_u - ORDER_WALKERS * 64,
+                                         ORDER_UPDATERS * 64);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_fetch_add(const_cast<uint32_t *>(ctl) + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    while (ctl[2] < (uint32_t)ORDER_UPDATERS) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                    const int lane_u = tid_u & 63, ju = lane_u & 31, hu = lane_u >> 5;
+                    const char *aggbase = reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.out) + outer * p.out_stride_outer);
+                    float *ubase = p.upd.out + outer * p.upd.out_stride_outer;
+                    const volatile uint32_t *queue = ctl + UPDATE_CTL_QUEUE_OFF / 4;
+                    for (int t = wave - ORDER_WALKERS;; t += ORDER_UPDATERS) {
+                        int n;
+                        for (;;) {
+                            const uint32_t walked = ctl[1];   // (read FIRST: with every walker done, the reads below see the final state)
+                            asm volatile("" ::: "memory");
+                            const uint32_t have = ctl[UPDATE_CTL_TILE_OFF / 4 + t];
+                            if (have == 32u) {
+                                n = 32;
+                                break;
+                            }
+                            if (walked == (uint32_t)ORDER_WALKERS) {
+                                n = min(32, (int)ctl[0] - 32 * t);
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                        n = rfl(n);
+                        if (n <= 0) break;
+                        const bool valid = ju < n;
+                        const uint32_t roff = (valid ? queue[32 * t + ju] : 0u) + (uint32_t)hu * 16u;
+                        const float4 *xr = reinterpret_cast<const float4 *>(xbase + roff);
+                        const float4 *ar = reinterpret_cast<const float4 *>(aggbase + roff);
+                        float4 b[16];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) b[i] = xr[2 * i];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) b[8 + i] = ar[2 * i];
+                        update_tile(b, lds_w, lane_u, p.upd.flags, p.upd.eps,
+                                    reinterpret_cast<float *>(reinterpret_cast<char *>(ubase) + (roff - (uint32_t)hu * 16u)), valid);
+                    }
+                }
             }
             // (measurement hook: when each wave's walk ended, trace[8 * grid + 16 * workgroup + wave]; the buffer holds 32 * grid words)
             if (p.trace && lane == 0) p.trace[8 * gridDim.x + 16 * blockIdx.x + wave] = clock64();
-            if constexpr (UPDATE) {
+            if constexpr (UPDATE == 1) {
                 // ---- layer update of this workgroup's own rows (whole spans only: row_len == 64) ----
                 // Every flush above has completed (each walk ends on vmcnt(0); the chain consumer's stores are collected
                 // by the barrier's wait), and a workgroup's waves share their CU's vector L1: after the barrier the
@@ -775,6 +900,9 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                                                              (long long)row * p.bnd.stride_row + d0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc.v[e] = nary<T, SUM>(acc.v[e], b.v[e]);
+                } else if (SUM != 0 && p.has_bnd && p.bnd_fill_on) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc.v[e] = nary<T, SUM>(acc.v[e], fill);
                 }
                 T *dst = reinterpret_cast<T *>(p.out) + outer * p.out_stride_outer + (long long)row * p.out_stride_row + d0;
                 *reinterpret_cast<P *>(dst) = acc;
@@ -789,7 +917,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
 }
 
 // ---- per-variant launchers (explicitly instantiated in rspmm_order_*.hip) ----
-template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED, bool STREAMS, bool UPDATE = false>
+template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED, bool STREAMS, int UPDATE = 0>
 inline hipError_t launch_order_inst(const OrderParams &p, int grid, size_t lds, hipStream_t s) {
     auto kern = rspmm_order_kernel<T, SUM, MUL, REL_LDS, WEIGHTED, STREAMS, UPDATE>;
     static size_t lds_opted_in = 0;   // (see launch_one in rspmm_kernels.hpp)
@@ -804,8 +932,10 @@ inline hipError_t launch_order_inst(const OrderParams &p, int grid, size_t lds, 
 template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED>
 inline hipError_t launch_order_one(const OrderParams &p, int grid, size_t lds, hipStream_t s) {
     if constexpr (OrderAsm<T, MUL, REL_LDS, WEIGHTED>::value) {
-        if constexpr (SUM == 0 && sizeof(T) == 4) {
-            if (p.use_streams && p.upd.weight) return launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true, true>(p, grid, lds, s);
+        if constexpr (sizeof(T) == 4) {
+            if (p.use_streams && p.upd.weight)
+                return p.upd.mode == 2 ? launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true, 2>(p, grid, lds, s)
+                                       : launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true, 1>(p, grid, lds, s);
         }
         if (p.use_streams) return launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true>(p, grid, lds, s);
     }

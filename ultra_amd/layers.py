@@ -38,19 +38,27 @@ class PointBoundary(object):
     def __init__(self, rows, values, num_node):
         # (made contiguous once here: every layer hands these pointers to a kernel)
         self.rows, self.values, self.num_node = rows.to(torch.int64).contiguous(), values.contiguous(), num_node
+        self._dense = None
 
     @property
     def requires_grad(self):
         return self.values.requires_grad
 
     def dense(self):
-        """The (batch, num_node, dim) tensor the reference builds with zeros + scatter_add_."""
+        """The (batch, num_node, dim) tensor the reference builds with zeros + scatter_add_ (built once per boundary
+        where no gradient flows through it)."""
+        if self._dense is not None:
+            return self._dense
         if dense.boundary_supported(self.rows, self.values):
-            return dense.onehot_boundary(self.rows, self.values, self.num_node, self.values.shape[-1])
-        out = torch.zeros(len(self.rows), self.num_node, self.values.shape[-1], device=self.values.device,
-                          dtype=self.values.dtype)
-        index = self.rows.view(-1, 1, 1).expand(-1, 1, self.values.shape[-1])
-        return out.scatter_add_(1, index, self.values.unsqueeze(1))
+            out = dense.onehot_boundary(self.rows, self.values, self.num_node, self.values.shape[-1])
+        else:
+            out = torch.zeros(len(self.rows), self.num_node, self.values.shape[-1], device=self.values.device,
+                              dtype=self.values.dtype)
+            index = self.rows.view(-1, 1, 1).expand(-1, 1, self.values.shape[-1])
+            out = out.scatter_add_(1, index, self.values.unsqueeze(1))
+        if not (torch.is_grad_enabled() and self.values.requires_grad):
+            self._dense = out
+        return out
 
 
 def _scatter(src, index, dim_size, reduce):
@@ -172,7 +180,8 @@ class GeneralizedRelationalConv(nn.Module):
             raise RuntimeError("edge_keep masks serve the fused TransE / DistMult path")
         if isinstance(kwargs["boundary"], PointBoundary) and (
                 (edge_weight is not None and edge_weight.requires_grad) or self.message_func == "rotate"
-                or self.aggregate_func != "sum" or not kwargs["input"].is_cuda
+                or self.aggregate_func not in ("sum", "max") or not kwargs["input"].is_cuda
+                or (self.aggregate_func == "max" and (torch.is_grad_enabled() or edge_keep))
                 or (torch.is_grad_enabled() and (kwargs["input"].requires_grad or kwargs["relation"].requires_grad
                                                  or kwargs["boundary"].requires_grad))):
             kwargs["boundary"] = kwargs["boundary"].dense()     # paths that need the boundary as a tensor
@@ -210,7 +219,7 @@ class GeneralizedRelationalConv(nn.Module):
         """Aggregate + update in one launch on the reference-order plan of a sparse graph (the entity graph): the workgroup
         that sums a row also applies the layer update to it (ultra_rspmm_forward_update).  Same bits as the two launches."""
         input, relation, boundary = kwargs["input"], kwargs["relation"], kwargs["boundary"]
-        if not (FUSED_SPARSE_LAYER and kwargs["edge_weight"] is None and self.aggregate_func == "sum"
+        if not (FUSED_SPARSE_LAYER and kwargs["edge_weight"] is None and self.aggregate_func in ("sum", "max")
                 and self.message_func in self.message2mul and input.is_cuda and not torch.is_grad_enabled()
                 and onehot_rows is None and not edge_keep and isinstance(boundary, PointBoundary)
                 and input.dim() == 3 and relation.dtype == torch.float32 and dense.conv_update_supported(self, input, input)):
@@ -221,7 +230,8 @@ class GeneralizedRelationalConv(nn.Module):
             | (dense.CONV_RESIDUAL if residual else 0)
         return plan.forward_update(relation, input, self.linear.weight, self.linear.bias, ln.weight if ln is not None else None,
                                    ln.bias if ln is not None else None, float(ln.eps) if ln is not None else 1e-5, flags,
-                                   mul=self.message2mul[self.message_func], point=(boundary.rows, boundary.values))
+                                   mul=self.message2mul[self.message_func], point=(boundary.rows, boundary.values),
+                                   sum="add" if self.aggregate_func == "sum" else "max")
 
     # ---- unfused path: gather edge_index[0], scatter to edge_index[1] -- PyG's direction (layers.py:135-181) ----
     def _propagate_unfused(self, edge_index, size, input, relation, boundary, edge_type, edge_weight):
@@ -289,13 +299,17 @@ class GeneralizedRelationalConv(nn.Module):
         # result feeds a stochastic optimiser step -- there is no reference summation order to reproduce
         plan = rspmm.get_plan(edge_index, edge_type, num_node, relation.shape[1], exact_order=False if needs_grad else None)
 
-        point = None
-        if isinstance(boundary, PointBoundary):     # (propagate() only lets it through for the fused sum path)
-            point, boundary = (boundary.rows, boundary.values), None
+        point, point_boundary = None, None
+        if isinstance(boundary, PointBoundary):     # (propagate() only lets it through for the fused sum / max paths)
+            point, point_boundary, boundary = (boundary.rows, boundary.values), boundary, None
 
         def agg(sum, rel=relation, x=input, fuse_boundary=None):
             if point is not None:
-                return plan.forward(rel, x, edge_weight=edge_weight, sum=sum, mul=mul, point=point)
+                out = plan.forward(rel, x, edge_weight=edge_weight, sum=sum, mul=mul, point=point)
+                if out is not None:
+                    return out
+                # (a plan that does not serve the point form under min / max: the boundary as a tensor)
+                return plan.forward(rel, x, edge_weight=edge_weight, boundary=point_boundary.dense(), sum=sum, mul=mul)
             if needs_grad:
                 if sum == "add":      # boundary added in the kernel's epilogue; its gradient is the output gradient
                     return rspmm.plan_rspmm(plan, rel, x, edge_weight, sum=sum, mul=mul, boundary=fuse_boundary,

@@ -120,8 +120,11 @@ class BaseNBFNet(nn.Module):
                 layer_input = hidden
                 first = 1
             else:
-                boundary = boundary.dense()
-                layer_input = boundary
+                # (the layers still get the closed form: those that can use it -- the sum and max aggregates of the
+                # inference path -- do, the others ask it for the tensor, which is built once)
+                layer_input = boundary.dense()
+                if separate_grad or torch.is_grad_enabled():
+                    boundary = layer_input
         for i, layer in enumerate(self.layers):
             if i < first:
                 continue

@@ -170,14 +170,16 @@ class Plan(object):
             out.append(t.view(-1, 4) if which == 3 else t)
         return tuple(out)
 
-    def streams(self, nparts):
-        """(sdesc[nparts * 64, 2] = {first record, steps}, srec[n, 2] = (col, type) records, markers (row, num_relation))"""
+    def streams(self, nparts, walkers=16):
+        """(sdesc[nparts * 64, 2] = {first record, steps}, srec[n, 2] = (col, type) records, markers (row, num_relation)).
+        walkers=12: the schedule of the launches whose last four waves apply the layer update beside the walk."""
         out = []
+        nparts = int(nparts) | ((1 << 24) if walkers == 12 else 0)
         for which in (4, 5):
             n = ctypes.c_int64()
-            check(lib.ultra_plan_schedule_export(self._h, int(nparts), which, None, 0, ctypes.byref(n)))
+            check(lib.ultra_plan_schedule_export(self._h, nparts, which, None, 0, ctypes.byref(n)))
             t = torch.empty(n.value, dtype=torch.int32)
-            check(lib.ultra_plan_schedule_export(self._h, int(nparts), which, t.data_ptr(), n.value, ctypes.byref(n)))
+            check(lib.ultra_plan_schedule_export(self._h, nparts, which, t.data_ptr(), n.value, ctypes.byref(n)))
             out.append(t.view(-1, 2))
         return tuple(out)
 
@@ -204,12 +206,16 @@ class Plan(object):
     def forward(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", out=None, point=None,
                 keep=False):
         """point=(rows, values): a boundary that is zero except row rows[o] of outer slice o, where it is values[o]
-        (the NBFNet boundary condition) -- added to that row only, sum aggregate only; excludes `boundary`.
+        (the NBFNet boundary condition); excludes `boundary`.  sum="add": added to that row only.  sum="min" / "max":
+        that row meets values[o], every other row meets 0 (max(update, boundary), layers.py:206-207) -- served by
+        reference-order plans; returns None where it is not (the caller then passes the boundary as a tensor).
         keep=True: `edge_weight` is a 0/1 keep mask -- an edge with 0 is absent from the graph for this call
         (ultra_rspmm_forward_masked; differs from a zero weight under min / max only)."""
         if point is not None:
-            if boundary is not None or sum != "add":
-                raise RuntimeError("a point boundary excludes `boundary` and serves the sum aggregate only")
+            if boundary is not None:
+                raise RuntimeError("a point boundary excludes `boundary`")
+            if sum != "add" and not self.exact:
+                return None
             twin = self._twin_for(sum, mul, edge_weight, input, relation, point[1], out)
         else:
             twin = self._twin_for(sum, mul, edge_weight, input, relation, boundary, out)
@@ -247,16 +253,20 @@ class Plan(object):
                 raise RuntimeError("Expected one boundary row per outer slice (%d), got %d" % (n_outer, rows.numel()))
             _require_gpu(rows, vals)
             vals, mv = as_mat(vals)
-            check(lib.ultra_rspmm_forward_point(self._h, _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel), ctypes.byref(mx),
-                                                rows.data_ptr(), ctypes.byref(mv), ctypes.byref(mout), _stream(input)))
+            rc = lib.ultra_rspmm_forward_point(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
+                                               ctypes.byref(mx), rows.data_ptr(), ctypes.byref(mv), ctypes.byref(mout), _stream(input))
+            if rc == _lib.ULTRA_ERR_UNSUPPORTED and sum != "add":
+                return None      # (min / max: the caller passes the boundary as a tensor)
+            check(rc)
             return out
         entry = lib.ultra_rspmm_forward_masked if (keep and w is not None and sum != "add") else lib.ultra_rspmm_forward
         check(entry(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
                     ctypes.byref(mx), mb, ctypes.byref(mout), _stream(input)))
         return out
 
-    def forward_update(self, relation, input, weight, bias, ln_weight, ln_bias, eps, flags, mul="mul", point=None, timed=None):
-        """Aggregate (sum, `mul`, optional point boundary) AND the layer update
+    def forward_update(self, relation, input, weight, bias, ln_weight, ln_bias, eps, flags, mul="mul", point=None, timed=None,
+                       sum="add"):
+        """Aggregate (`sum`, `mul`, optional point boundary) AND the layer update
         `[input +] relu(layer_norm(linear(cat[input, aggregate])))` in one launch (ultra_rspmm_forward_update: the workgroup
         that aggregated a row also updates it).  Bit-equal with forward(point=...) followed by dense.conv_update.
         Returns the layer output, or None where the launch does not serve the call (the caller makes the two calls).
@@ -282,7 +292,8 @@ class Plan(object):
             vals, mvv = as_mat(vals)
             rows_ptr, mv = rows.data_ptr(), ctypes.byref(mvv)
         weight = weight.contiguous()
-        args = (self._h, _lib.MUL_CODES[mul], ctypes.byref(mrel), ctypes.byref(mx), rows_ptr, mv, ctypes.byref(magg), weight.data_ptr(),
+        args = (self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], ctypes.byref(mrel), ctypes.byref(mx), rows_ptr, mv, ctypes.byref(magg),
+                weight.data_ptr(),
                 _ptr(bias), _ptr(ln_weight), _ptr(ln_bias), float(eps), int(flags), ctypes.byref(mout), _stream(input))
         if timed is not None:
             ms, ms_kernel = ctypes.c_float(), ctypes.c_float()
@@ -671,10 +682,12 @@ class _ReferenceExports(object):
 rspmm = _ReferenceExports()
 
 
-def set_tuning(threads=0, grid=0, rel_lds=-1, x_lds=-1, unroll=0, general_walk=0, unit_walk=0):
+def set_tuning(threads=0, grid=0, rel_lds=-1, x_lds=-1, unroll=0, general_walk=0, unit_walk=0, update_form=0):
     """Kernel-launch tuning knobs (measurement / tests).  set_tuning() restores the defaults.
     general_walk: reference-order plans on the general walk kernel; unit_walk: the reference-order kernels walk units of
-    four rows (C++ loops) instead of group streams (assembly loops)."""
+    four rows (C++ loops) instead of group streams (assembly loops); update_form: where forward_update applies the layer
+    update -- 0 beside the walk where that fits (else in the kernel's tail), 1 always in the tail, 2 beside the walk or not
+    at all."""
     t = _lib.Tuning(int(threads), int(grid), int(rel_lds), int(x_lds), int(unroll),
-                    (ctypes.c_int32 * 3)(int(general_walk), int(unit_walk), 0))
+                    (ctypes.c_int32 * 3)(int(general_walk), int(unit_walk), int(update_form)))
     check(lib.ultra_set_tuning(ctypes.byref(t)))
