@@ -192,12 +192,11 @@ int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t sum, int32_t mul, in
  *   aggregate = rspmm(sum, mul)(relation, input) [+ point boundary]        -- as ultra_rspmm_forward_point / _forward
  *   output    = [input +] relu( LayerNorm( W . [input ; aggregate] + b ) ) -- as ultra_conv_update (ultra_nbfnet.h), same `flags` / `eps`
  *
- * Every workgroup of the reference-order kernel applies the update to the rows it aggregates: twelve of its sixteen waves
- * walk the graph, four multiply -- on the matrix cores, while the walk goes on -- the rows the walkers hand over through an
- * LDS queue (each row is read back from the workgroup's own L2 moments after it was written).  Where that form does not fit
- * (LDS beside the relation slice, rows per workgroup) the update runs in the kernel's tail instead.  Results are bit-equal
- * with the two separate calls in both forms.  sum: ULTRA_SUM_ADD / _MIN / _MAX (min / max with a point boundary: see
- * ultra_rspmm_forward_point).
+ * Every workgroup of the reference-order kernel applies the update to the rows it aggregates -- in the kernel's tail, once
+ * its walks have ended (the default), or beside the walk (ultra_tuning.reserved[2] == 2): twelve of its sixteen waves walk
+ * the graph, four multiply, while the walk goes on, the rows the walkers hand over through an LDS queue.  Results are
+ * bit-equal with the two separate calls in both forms.  sum: ULTRA_SUM_ADD / _MIN / _MAX (min / max with a point boundary:
+ * see ultra_rspmm_forward_point).
  * `aggregate` receives the aggregate as before (scratch for the caller); `output` must not alias it or `input`.
  * point_rows_dev / point_values: both NULL = no boundary.  Served where the stream walk serves ultra_rspmm_forward_point
  * (ULTRA_PLAN_EXACT_ORDER plan in the sparse format, 64-element rows, every stride equal): ULTRA_ERR_UNSUPPORTED
@@ -327,8 +326,8 @@ typedef struct {
     int32_t unroll;       /* edges in flight per lane group (0 -> default) */
     int32_t reserved[3];  /* [0] != 0: ULTRA_PLAN_EXACT_ORDER plans run on the general walk kernel instead of the order kernels;
                              [1] != 0: the order kernels walk units of four rows (C++ loop) instead of group streams (assembly);
-                             [2]: ultra_rspmm_forward_update -- 0 the update beside the walk where it fits, else in the kernel's tail;
-                                  1 always in the tail; 2 beside the walk or ULTRA_ERR_UNSUPPORTED */
+                             [2]: ultra_rspmm_forward_update -- 0 / 1 the update in the kernel's tail; 2 beside the walk, or
+                                  ULTRA_ERR_UNSUPPORTED where that form does not fit (LDS beside the relation slice, rows per workgroup) */
 } ultra_tuning;
 int32_t ultra_set_tuning(const ultra_tuning *t);   /* NULL restores defaults */
 int32_t ultra_get_tuning(ultra_tuning *t);

@@ -105,7 +105,6 @@ def test_one_launch_layer_against_the_oracle_chain(dev, case, form, sum):
     """Not through the two launches: the C oracle's rspmm (rspmm.cpp:50-75) on the host, the boundary as the reference
     combines it (layers.py:199-207), then torch's CPU Linear / LayerNorm / ReLU / residual (layers.py:233-240,
     models.py:158-160) -- bit for bit."""
-    import torch.nn.functional as F
     from oracle import rspmm_oracle
     from ultra_amd import rspmm
     from ultra_amd.rspmm import Plan
@@ -119,20 +118,21 @@ def test_one_launch_layer_against_the_oracle_chain(dev, case, form, sum):
     agg = rspmm_oracle.generalized_rspmm(ei, et, torch.ones(E), reln, xn, sum=sum, mul="mul")
     agg = agg + bndn if sum == "add" else torch.max(agg, bndn)
     agg = agg.view(N, batch, 64).transpose(0, 1)
-    hidden = F.linear(torch.cat([x.cpu(), agg], dim=-1), weight.cpu(), bias.cpu())
-    want = torch.relu(F.layer_norm(hidden, (64,), ln_w.cpu(), ln_b.cpu(), 1e-5)) + x.cpu()
+    # nn.Linear / nn.LayerNorm in torch's CPU operation order as restated by oracle/torch_math_oracle.c -- pinned against
+    # torch itself at the model's shapes (tests/test_torch_math.py); torch picks other GEMM kernels for the few rows of
+    # these small graphs, which is why F.linear is not called here
+    from oracle import torch_math_oracle as tm
+    hidden = tm.linear(torch.cat([x.cpu(), agg], dim=-1).contiguous(), weight.cpu(), bias.cpu())
+    want = torch.relu(tm.layer_norm(hidden, ln_w.cpu(), ln_b.cpu(), 1e-5)) + x.cpu()
     plan = Plan(ei, et, N, R, exact_order=True)
     rspmm.set_tuning(update_form=FORMS[form])
     got = plan.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7, mul="mul", point=(rows, vals), sum=sum)
     assert got is not None
-    same = (got.cpu() == want).float().mean().item()
-    # (torch's CPU GEMM may use a remainder kernel for the last rows of a thread's share: tests/test_torch_order_gpu.py)
-    assert same >= 0.999 and (got.cpu() - want).abs().max().item() <= 1e-5, (same, (got.cpu() - want).abs().max().item())
+    assert torch.equal(got.cpu(), want), ((got.cpu() == want).float().mean().item(), (got.cpu() - want).abs().max().item())
 
 
-def test_beside_the_walk_is_the_default_where_it_fits_and_repeats_its_bits(dev):
-    """update_form 0 takes the update beside the walk on a graph whose relation slice leaves the room; 200 launches of it give
-    the same bits (the hand-off of rows between waves is not a race)."""
+def test_beside_the_walk_repeats_its_bits(dev):
+    """200 launches of the update beside the walk give the same bits (the hand-off of rows between waves is not a race)."""
     from ultra_amd import dense, rspmm
     from ultra_amd.rspmm import Plan
     case = CASES[5]
@@ -143,7 +143,6 @@ def test_beside_the_walk_is_the_default_where_it_fits_and_repeats_its_bits(dev):
     want = dense._conv_update_forward(x, agg, weight, bias, ln_w, ln_b, 1e-5, 7)
     rspmm.set_tuning(update_form=2)
     assert plan.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7, point=(rows, vals)) is not None
-    rspmm.set_tuning()
     outs = [plan.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7, point=(rows, vals)) for _ in range(200)]
     torch.cuda.synchronize()
     assert all(torch.equal(o, want) for o in outs)

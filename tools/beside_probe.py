@@ -37,9 +37,12 @@ def two():
     return dense._conv_update_forward(x, agg_only(), w, b, lw, lb, 1e-5, 7)
 
 
+EXTRA = int(os.environ.get("PROBE_FLAGS", "0"))     # 256: no matrix chain, 512: the update waves only drain their queue (wrong results)
+
+
 def one(form):
     rspmm.set_tuning(update_form=form)
-    out = plan.forward_update(rel, x, w, b, lw, lb, 1e-5, 7, point=point, sum=agg_sum)
+    out = plan.forward_update(rel, x, w, b, lw, lb, 1e-5, 7 | EXTRA, point=point, sum=agg_sum)
     rspmm.set_tuning()
     return out
 

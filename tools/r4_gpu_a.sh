@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r4a
 mkdir -p $O
-timeout 120 python -m pytest tests/test_fused_update_gpu.py -x -q -k "beside_the_walk_is_the_default" > $O/first.txt 2>&1
+timeout 120 python -m pytest tests/test_fused_update_gpu.py -x -q -k "beside_the_walk_repeats" > $O/first.txt 2>&1
 rc=$?
 tail -3 $O/first.txt
 if [ $rc -eq 124 ]; then echo "HANG in the first test: stopping"; exit 1; fi

@@ -413,12 +413,15 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
                 op.upd.prow_ptr = sched->d_prow_ptr;
                 op.upd.mode = 1;
                 lds = std::max(lds, (size_t)UPDATE_LDS_FLOATS * sizeof(float));   // (the weight image takes the dead relation slice's place)
-                // The update BESIDE the walk (rspmm_order_kernel, UPDATE == 2): twelve waves walk, four multiply the rows handed
-                // over through LDS.  Needs the weight image (in the ring's place once the chain is done) and the hand-off
-                // block beside the relation slice, and update rows of the input's stride (a queue entry is a byte offset).
+                // The update BESIDE the walk (rspmm_order_kernel, UPDATE == 2; on request: ultra_tuning.reserved[2] == 2): twelve
+                // waves walk, four multiply the rows handed over through LDS.  Needs the weight image (in the ring's place
+                // once the chain is done) and the hand-off block beside the relation slice, and update rows of the input's
+                // stride (a queue entry is a byte offset).  Measured on MI355X (tools/beside_probe.py): it hides
+                // the matrix work under the walk, but the update's row loads and stores -- one 16-byte piece per lane, every
+                // lane in another row -- then compete with the gathers for the CU's texture-address path, which bounds the
+                // walk: 94.6 us per layer against the tail form's 94.0 at FB15k237 bs 8, 371 against 374 at CoDEx-L.
                 Schedule *sched12 = nullptr;
-                if (g_tuning.reserved[2] != 1 && op.nparts * op.smod == grid &&
-                    upd->out_stride_row * (int64_t)sizeof(float) == (int64_t)op.x_row_bytes) {
+                if (g_tuning.reserved[2] == 2 && upd->out_stride_row * (int64_t)sizeof(float) == (int64_t)op.x_row_bytes) {
                     if ((rc = get_schedule(p, op.nparts, &sched12, ORDER_WALKERS))) return rc;
                     const size_t image = std::max(ring_bytes, (size_t)UPDATE_LDS_FLOATS * sizeof(float));
                     const size_t need = rel_bytes + image + UPDATE_CTL_QUEUE_OFF + (size_t)sched12->max_rows * 4 + 64;
@@ -914,7 +917,8 @@ int32_t ultra_rspmm_forward_update(ultra_plan *plan, int32_t sum, int32_t mul, c
     if ((point_rows_dev == nullptr) != (point_values == nullptr)) return invalid("ultra_rspmm_forward_update: half a point boundary");
     if (!weight || !output || !output->ptr || !aggregate || !aggregate->ptr || ((flags & CONV_LN) && (!ln_weight || !ln_bias)))
         return invalid("ultra_rspmm_forward_update: NULL operand");
-    if (flags & ~(CONV_LN | CONV_RELU | CONV_RESIDUAL | CONV_DBG_NO_MATRIX)) return invalid("ultra_rspmm_forward_update: unknown flag");
+    if (flags & ~(CONV_LN | CONV_RELU | CONV_RESIDUAL | CONV_DBG_NO_MATRIX | CONV_DBG_NO_UPDATE))
+        return invalid("ultra_rspmm_forward_update: unknown flag");
     if (!plan) return invalid("plan is NULL");
     if (output->row_len != 64 || output->n_outer != aggregate->n_outer || output->n_row != aggregate->n_row ||
         output->stride_row < 64 || (output->stride_row % 4) != 0 || (output->stride_outer % 4) != 0 ||

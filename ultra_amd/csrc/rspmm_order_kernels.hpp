@@ -799,6 +799,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderP
                         }
                         n = rfl(n);
                         if (n <= 0) break;
+                        if (p.upd.flags & CONV_DBG_NO_UPDATE) continue;
                         const bool valid = ju < n;
                         const uint32_t roff = (valid ? queue[32 * t + ju] : 0u) + (uint32_t)hu * 16u;
                         const float4 *xr = reinterpret_cast<const float4 *>(xbase + roff);

@@ -17,7 +17,13 @@ namespace ultra {
 
 using f32x16 = float __attribute__((ext_vector_type(16)));
 
-enum { CONV_LN = 1, CONV_RELU = 2, CONV_RESIDUAL = 4, CONV_DBG_NO_MATRIX = 256 /* measurement: skip the matrix chain */ };
+enum {
+    CONV_LN = 1,
+    CONV_RELU = 2,
+    CONV_RESIDUAL = 4,
+    CONV_DBG_NO_MATRIX = 256,  /* measurement: skip the matrix chain */
+    CONV_DBG_NO_UPDATE = 512   /* measurement (update beside the walk): the update waves only drain their queue */
+};
 
 // feature owned by accumulator register r of feature tile m in lane half h (32x32 C/D layout)
 __device__ __forceinline__ int feat_of(int m, int r, int h) { return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h; }
