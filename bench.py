@@ -46,7 +46,10 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 L2_PEAK_GBS = 34500.0      # MI355X_MICROARCH.md: aggregate L2 bandwidth
 COPY_BYTES = 1 << 30
 ROOFLINE_POINTS = [("fb15k237", 8), ("codex_l", 8)]
-ORDER_KERNEL = "rspmm_order_kernel<float, 0, 0, true, false, true, true>"   # (..., STREAMS, UPDATE): aggregate + layer update
+ORDER_KERNEL = "rspmm_order_kernel<float, 0, 0, true, false, true, 1>"   # (..., STREAMS, UPDATE = 1: in the tail): aggregate + layer update
+# the vector L1 / texture-address path of a CU delivers 64 B per clock (MI355X_MICROARCH.md: 16-B-per-lane loads, four lanes
+# per clock); at the 2.4 GHz boost clock the 256 CUs gather 39.3 TB/s -- the roof of a kernel whose gathers hit in L2
+L1_PEAK_GBS = 256 * 64 * 2.4
 
 
 def available_cores():
@@ -194,6 +197,54 @@ def _run_pmc_pass(counters, timeout=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def trace_target(steps=40):
+    """Child process of the --kernel-trace pass: the benchmark's forward, one batch at a time (one captured hipGraph, one
+    stream), replayed `steps` times -- the per-kernel durations of the step as it runs inside the graph."""
+    from ultra_amd import models, synthetic, tasks
+    from ultra_amd.graph import GraphedForward
+    dev = torch.device("cuda:0")
+    data = synthetic.make_kg(**synthetic.SHAPES["fb15k237"], seed=1234).to(dev)
+    model = models.Ultra(**synthetic.default_model_cfg())
+    golden = os.path.join(ROOT, "tests", "golden", "ultra_3g_model.pt")
+    if os.path.exists(golden):
+        model.load_state_dict(torch.load(golden))
+    model = model.to(dev).eval()
+    triples = data.target_triples
+    fwd = GraphedForward(model, data, tasks.all_negative(data, triples[:8])[0])
+    for i in range(steps):
+        fwd(tasks.all_negative(data, triples[8 * i:8 * i + 8])[0])
+    torch.cuda.synchronize()
+
+
+def _run_trace_pass(timeout=240):
+    """rocprofv3 --kernel-trace --stats over trace_target(): {kernel name: (calls, avg us)} of the captured forward's kernels
+    (no counters in this pass); the stats CSV is kept under $ULTRA_BENCH_PMC_KEEP as bench_kernel_stats_inflight1.csv."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    tmp = tempfile.mkdtemp(prefix="ultra_trace_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "trace", "--",
+           sys.executable, os.path.abspath(__file__), "--trace-target"]
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+        files = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            raise RuntimeError("rocprofv3 trace pass failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
+        keep = os.environ.get("ULTRA_BENCH_PMC_KEEP")
+        if keep:
+            os.makedirs(keep, exist_ok=True)
+            shutil.copy(files[0], os.path.join(keep, "bench_kernel_stats_inflight1.csv"))
+        rows = {}
+        for row in csv.DictReader(open(files[0])):
+            rows[row["Name"]] = (int(row["Calls"]), float(row["AverageNs"]) / 1e3, float(row["TotalDurationNs"]) / 1e3)
+        return rows
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def measure_roofline(dev, use_pmc=True):
     from ultra_amd import _lib
     out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -255,8 +306,28 @@ def measure_roofline(dev, use_pmc=True):
             pmc_note = "PMC passes unavailable in this run (%s): traffic = null" % str(exc)[:200]
     else:
         pmc_note = "PMC passes skipped (--no-pmc)"
+    # ---- the same kernel INSIDE the captured forward (one batch at a time): a --kernel-trace pass over the benchmark's step ----
+    in_graph = None
+    if use_pmc:
+        try:
+            stats = _run_trace_pass()
+            hit = [(n, v) for n, v in stats.items() if ORDER_KERNEL in n]
+            if hit:
+                calls, avg_us, _ = hit[0][1]
+                total = sum(v[2] for v in stats.values())
+                in_graph = {"kernel_avg_us": avg_us, "calls": calls, "launches_per_forward": 5,
+                            "share_of_gpu_time": hit[0][1][2] / total if total else None,
+                            "command": "rocprofv3 --kernel-trace --stats -- python bench.py --trace-target  (the benchmark's "
+                                       "forward as one hipGraph on one stream, 40 replays)",
+                            "top_kernels_us": [[n.split("(")[0][-90:], c, round(a, 2)] for n, (c, a, t) in
+                                               sorted(stats.items(), key=lambda kv: -kv[1][2])[:8]]}
+        except Exception as exc:
+            in_graph = {"unavailable": str(exc)[:200]}
     for pt in points:
         t = pt["ms_per_launch"] * 1e-3
+        # gathers through the CU's vector L1: every edge's 256-B source row per sample (+ the update's row reads)
+        pt["l1_gather_bytes"] = 4 * pt["D"] * pt["E"] + 2 * 4 * pt["D"] * pt["N"]
+        pt["l1_rate_frac"] = pt["l1_gather_bytes"] / t / 1e9 / L1_PEAK_GBS
         pt["gather_model_GBps"] = pt["gather_model_bytes"] / t / 1e9
         pt["compulsory_GBps"] = pt["compulsory_bytes"] / t / 1e9
         pt["hbm_frac_compulsory"] = pt["compulsory_GBps"] / HBM_PEAK_GBS
@@ -279,6 +350,13 @@ def measure_roofline(dev, use_pmc=True):
         "algorithmic_bytes_per_launch": {"gather_model": head["gather_model_bytes"], "compulsory": head["compulsory_bytes"]},
         "gather_model_GBps": head["gather_model_GBps"],
         "hbm_frac_measured": head.get("hbm_frac_measured"), "hbm_frac_compulsory": head["hbm_frac_compulsory"],
+        "frac_compulsory": head["hbm_frac_compulsory"],
+        "traffic_over_compulsory": head.get("traffic_over_compulsory"),
+        "l1_rate_frac": head["l1_rate_frac"],
+        "l1_rate_definition": "bytes gathered through the CUs' vector L1 per launch (E x 256 B per sample + the update's row reads) "
+                              "/ kernel time / (256 CUs x 64 B/clk x 2.4 GHz = %.0f GB/s): the binding roof at this size, where "
+                              "x and the output are cache resident" % L1_PEAK_GBS,
+        "in_graph": in_graph,
         "l2_frac": head.get("l2_frac"), "l2_hit_rate": head.get("l2_hit_rate"),
         "hbm_bound_point": big,
         "points": points,
@@ -288,8 +366,10 @@ def measure_roofline(dev, use_pmc=True):
                    "(compulsory bytes: x in, layer output out, relation table, records, weights -- the aggregate's round trip "
                    "is counted as avoidable traffic).  "
                    "gather-model GB/s exceeds the HBM peak where x is cache resident (every edge re-reads a 256-B source row "
-                   "from L2 / Infinity Cache, not from HBM); `frac` is the measured HBM-side fraction.  FETCH_SIZE counts "
-                   "L2 misses, Infinity-Cache hits included (MI355X_MICROARCH.md).")
+                   "from L2 / Infinity Cache, not from HBM); `frac` is COUNTER traffic / time / 8 TB/s: FETCH_SIZE counts L2 "
+                   "misses, Infinity-Cache (MALL) hits INCLUDED (MI355X_MICROARCH.md), so it bounds the HBM fraction from above; "
+                   "`frac_compulsory` prices only the bytes the layer must move; at the headline size the binding roof is the "
+                   "CUs' vector-L1 gather rate (`l1_rate_frac`), at CoDEx-L (`hbm_bound_point`) it is the memory system.")
     if pmc_note:
         out["pmc_note"] = pmc_note
     return out
@@ -337,13 +417,17 @@ def main():
     ap.add_argument("--data-root", default=None,
                     help="directory with train.txt / valid.txt / test.txt (kg-datasets/FB15k-237 layout): score the real test "
                          "triples instead of the synthetic graph of --shape (data: \"real\")")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed loop of --steps steps runs this many times in the process: ms_per_step / value are the FIRST "
+                         "run's (the contract's exactly-K-steps figure), `repeats` carries every run, their median and spread")
     ap.add_argument("--pmc-target", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--trace-target", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    if args.pmc_target:
+    if args.pmc_target or args.trace_target:
         import __graft_entry__ as entry
         entry.build()
-        pmc_target()
+        pmc_target() if args.pmc_target else trace_target()
         return
 
     import torch.distributed as dist
@@ -390,6 +474,10 @@ def main():
         dist.barrier()
     from ultra_amd import distributed as udist
     from ultra_amd import host_order, models, rspmm, synthetic, tasks
+    if world > 1 or launched:
+        # one association of the readout's last product for the whole job: rank 0 resolves it (cache / probe), the others adopt
+        # its program, the ids are compared (no per-rank probe, no cache race)
+        udist.share_readout_order(128, device=dev)
 
     data_kind, data_name = "synthetic", "%s-shaped synthetic KG" % args.shape
     if args.data_root:
@@ -473,7 +561,11 @@ def main():
             torch.cuda.synchronize()
             return time.perf_counter() - t0
 
-    elapsed = timed_run(make_forward(), world > 1 or launched)
+    forward = make_forward()
+    elapsed = timed_run(forward, world > 1 or launched)
+    # the same K steps again, `--repeats` runs in all: box-to-box and run-to-run spread is of the size of a small kernel gain,
+    # so the line carries the median and the extremes beside the first run's figure
+    runs = [elapsed] + [timed_run(forward, world > 1 or launched) for _ in range(max(args.repeats, 1) - 1)]
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     per_rank = None
     if world > 1 or launched:
@@ -481,12 +573,16 @@ def main():
         # the digests and the ranks' own clocks are gathered over RCCL and compared on rank 0
         with torch.no_grad():
             probe = model(data, tasks.all_negative(data, triples[:bs])[0]).double()
-        digest = torch.stack([probe.sum(), probe.abs().max(), probe[:, ::97].sum(), el[0]])
+        order_word = float(int(host_order.order_id(host_order.readout_stages(128)[0]).split("-")[1], 16))
+        digest = torch.stack([probe.sum(), probe.abs().max(), probe[:, ::97].sum(), el[0],
+                              torch.tensor(order_word, device=dev, dtype=torch.float64)])
         gathered = [torch.empty_like(digest) for _ in range(dist.get_world_size())]
         dist.all_gather(gathered, digest)
         g = torch.stack(gathered).cpu()
         per_rank = {"ms_per_step": [1e3 * v / args.steps for v in g[:, 3].tolist()],
-                    "probe_scores_identical": bool((g[:, :3] == g[0, :3]).all())}
+                    "probe_scores_identical": bool((g[:, :3] == g[0, :3]).all()),
+                    "readout_order_id": ["order-%08x" % int(v) for v in g[:, 4].tolist()],
+                    "readout_order_identical": bool((g[:, 4] == g[0, 4]).all())}
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
     triples_per_s = world * bs * N * args.steps / elapsed
@@ -495,6 +591,11 @@ def main():
         "metric": "triples scored/sec (all-tail ranking) on FB15k237",
         "value": triples_per_s, "unit": "triples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "repeats": {"runs": len(runs), "steps_per_run": args.steps,
+                    "ms_per_step": [round(1e3 * r / args.steps, 5) for r in runs],
+                    "median": 1e3 * sorted(runs)[len(runs) // 2] / args.steps,
+                    "min": 1e3 * min(runs) / args.steps, "max": 1e3 * max(runs) / args.steps,
+                    "note": "this rank's clock; `ms_per_step` / `value` above are the first run (max over ranks)"},
         "vs_baseline": None, "dtype": "f32", "data": data_kind,
         "config": {"workload": "ultra_3g architecture zero-shot all-tail ranking, %s "
                                "(N=%d, E=%d, R=%d), distmult+sum rspmm, batch %d queries/GPU, query-sharded"

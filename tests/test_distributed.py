@@ -82,6 +82,63 @@ def test_query_sharded_evaluation_matches_single_process(tmp_path):
     assert outs[0]["shard"] == (0, 19) and outs[1]["shard"] == (19, 37)
 
 
+def _order_worker(rank, world, port, out_dir):
+    """(a) rank 0's readout association reaches every rank; (b) the collectives a PipelinedForward issues from its
+    alternating slots pair up across ranks in program order."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    # the ranks start out DISAGREEING: rank 0 adds in a two-lane association read from a file, rank 1 sequentially
+    os.environ["ULTRA_READOUT_ORDER"] = os.path.join(out_dir, "order.json") if rank == 0 else "sequential"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ultra_amd import distributed as udist
+    from ultra_amd import graph as ugraph
+    from ultra_amd import host_order
+    before = host_order.order_id(host_order.readout_stages(128)[0])
+    shared = udist.share_readout_order(128)
+    after = host_order.order_id(host_order.readout_stages(128)[0])
+
+    class Slot(object):          # a stub forward with its own output buffer, like a captured forward
+        def __init__(self, k):
+            self.k, self.out = k, torch.zeros(2, 3)
+
+        def __call__(self, batch):
+            self.out.copy_(batch * 100 + rank)
+            return self.out
+
+    made = []
+    pf = ugraph.PipelinedForward(None, None, torch.zeros(2, 3), depth=2,
+                                 slot_factory=lambda: made.append(Slot(len(made))) or made[-1])
+    gathered = []
+    for i in range(7):
+        batch = torch.full((2, 3), float(i))
+        gathered.append(pf(batch, post=lambda score: udist.all_gather_scores(score).clone()))
+    pf.join()
+    torch.save(dict(before=before, shared=shared, after=after, gathered=torch.stack(gathered), source=host_order.readout_stages(128)[1]),
+               os.path.join(out_dir, "o%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_share_one_readout_order_and_pipelined_collectives_stay_in_program_order(tmp_path):
+    sys.path.insert(0, ROOT)
+    from ultra_amd import host_order
+    two_lane = [(2, False, [list(range(0, 128, 2)), list(range(1, 128, 2))])]
+    host_order.save_stages(str(tmp_path / "order.json"), two_lane, "two lanes (test)", 128)
+    world = 2
+    mp.spawn(_order_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "o%d.pt" % r)) for r in range(world)]
+    want = host_order.order_id(two_lane)
+    assert outs[0]["before"] == want and outs[1]["before"] == host_order.order_id(host_order.sequential_stages(128)) != want
+    for o in outs:
+        assert o["shared"] == want and o["after"] == want
+    assert "broadcast" in outs[1]["source"]
+    # step i's all-gather met step i's all-gather of the other rank, slots alternating: rows (rank 0's, rank 1's) = 100 i + rank
+    for o in outs:
+        for i in range(7):
+            assert o["gathered"][i][:2].eq(100.0 * i).all() and o["gathered"][i][2:].eq(100.0 * i + 1).all()
+
+
 def test_shard_range_is_a_partition():
     from ultra_amd import distributed as udist
     for n in (0, 1, 7, 8, 20466):

@@ -45,6 +45,27 @@ def test_bench_under_torchrun_world_size_one():
     assert cfg["rccl_world_size"] == 1 and cfg["launch"].startswith("hipGraph")
     assert cfg["per_rank"]["probe_scores_identical"] is True and len(cfg["per_rank"]["ms_per_step"]) == 1
     assert cfg["readout_order_id"].startswith("order-")
+    # one association of the readout's last product for the whole job (distributed.share_readout_order)
+    assert cfg["per_rank"]["readout_order_identical"] is True and cfg["per_rank"]["readout_order_id"] == [cfg["readout_order_id"]]
+    # the timed loop is repeated in the process: the first run is the line's figure, the others show the spread
+    rep = out["repeats"]
+    assert rep["runs"] == 5 and len(rep["ms_per_step"]) == 5 and rep["min"] <= rep["median"] <= rep["max"]
+    assert rep["ms_per_step"][0] == pytest.approx(out["ms_per_step"], rel=1e-3)
+
+
+def test_bench_scores_real_triples_from_files():
+    """bench.py --data-root on the committed kg-datasets-layout fixture (tests/golden/kg_fixture): `data: real`, and the
+    parity block against the oracle flow on the same batch is green."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--data-root", os.path.join(ROOT, "tests", "golden", "kg_fixture"),
+           "--steps", "5", "--warmup", "2", "--repeats", "2", "--no-roofline", "--no-secondary", "--cpu-seconds", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["data"] == "real" and "kg_fixture" in out["config"]["workload"] and "N=300" in out["config"]["workload"]
+    par = out["parity"]
+    assert par["rank_mismatches"] == 0 and par["max_abs_score_diff"] <= 1e-5
+    assert par["scores_bit_equal"] >= 0.999 * par["scores"]
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
 
 
 def test_bench_refuses_more_gpus_than_visible():

@@ -8,13 +8,15 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 part="${1:-A}"
-R="${2:-r3}"
+R="${2:-r4}"
 OUT=gpurun_out/$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 if [ "$part" = "A" ]; then
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$OUT/${R}_smoke.txt" 2>&1
     ULTRA_BENCH_PMC_KEEP="$PWD/$OUT/${R}_pmc" timeout 900 python bench.py > "$OUT/${R}_bench.json" 2> "$OUT/bench.err"
+    # (bench.py's own --kernel-trace child pass: the forward as ONE captured graph on ONE stream -- the durations DESIGN.md section 4 quotes)
+    cp "$OUT/${R}_pmc/bench_kernel_stats_inflight1.csv" "$OUT/${R}_bench_kernel_stats_inflight1.csv" 2>/dev/null
     (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o run -- \
         python "$OLDPWD/bench.py" --no-cpu-baseline --no-roofline --no-secondary > /dev/null 2>&1)
     find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} "$OUT/${R}_bench_kernel_stats.csv" \;

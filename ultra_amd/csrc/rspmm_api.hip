@@ -554,12 +554,18 @@ static int ensure_backward_plans(ultra_plan *p) {
     // The backward sums are scatter-adds in the reference (atomicAdd on the GPU, rspmm.cu:153-214): no summation order
     // to reproduce, so the transposed plans are always the re-associating kind (split hub rows, balanced units).
     o.flags = p->flags & ~ULTRA_PLAN_EXACT_ORDER;
-    if (!p->tplan)
+    // (a plan derived while captured graphs hold its parent is held by the same graphs: it inherits the pin count, so the
+    // graphs' later -1 finds it pinned -- ultra_plan_pin)
+    if (!p->tplan) {
         p->tplan = build_plan(p->h_col.data(), p->h_row.data(), p->h_type.data(), p->num_edge, p->num_in, p->num_out,
                               p->num_rel, &o, false);
-    if (!p->rplan)
+        p->tplan->pinned = p->pinned;
+    }
+    if (!p->rplan) {
         p->rplan = build_plan(p->h_type.data(), p->h_col.data(), p->h_row.data(), p->num_edge, p->num_rel, p->num_in,
                               p->num_out, &o, false);
+        p->rplan->pinned = p->pinned;
+    }
     return ULTRA_OK;
 }
 
@@ -573,6 +579,7 @@ static int backward_impl(ultra_plan *p, int sum, int mul, int dtype, const void 
     if (dtype != ULTRA_F32 && dtype != ULTRA_F64) return invalid("dtype must be ULTRA_F32 or ULTRA_F64");
     if (!og || !og->ptr) return invalid("output_grad is NULL");
     const int64_t n_outer = og->n_outer, row_len = og->row_len;
+    if (n_outer <= 0 || row_len <= 0) return invalid("output_grad: empty n_outer / row_len");   // (as the forward: rspmm.cpp's checkSize)
     int rc;
     if ((rc = check_mat(rel, "relation", p->num_rel, n_outer, row_len))) return rc;
     if ((rc = check_mat(x, "input", p->num_in, n_outer, row_len))) return rc;
@@ -859,7 +866,7 @@ int32_t ultra_plan_upload(ultra_plan *plan) {
 
 int32_t ultra_plan_pin(ultra_plan *plan, int32_t delta) {
     if (!plan) return invalid("plan is NULL");
-    // (clamped at 0: a backward plan derived after the pin sees the matching -1 without ever having seen the +1)
+    // (derived backward plans inherit their parent's count when they are built: ensure_backward_plans)
     const auto bump = [&](ultra_plan *q) { q->pinned = std::max<int32_t>(0, q->pinned + delta); };
     bump(plan);
     if (plan->tplan) bump(plan->tplan);
@@ -993,9 +1000,16 @@ static int time_launches(const std::function<int()> &once, hipStream_t s, int32_
     for (int i = 0; i < warmup; ++i)
         if ((rc = once()))
             return rc;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    struct Events {   // (destroyed on every path out)
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } ev;
+    HIP_TRY(hipEventCreate(&ev.e0));
+    HIP_TRY(hipEventCreate(&ev.e1));
+    const hipEvent_t e0 = ev.e0, e1 = ev.e1;
     // (1) the whole launch sequence (weight permute + main kernel + fix-up), back to back
     HIP_TRY(hipEventRecord(e0, s));
     for (int i = 0; i < iters; ++i)
@@ -1022,8 +1036,6 @@ static int time_launches(const std::function<int()> &once, hipStream_t s, int32_
         }
         *ms_main_kernel = (float)(acc / iters);
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return ULTRA_OK;
 }
 

@@ -52,7 +52,9 @@ def load_triples_dir(root, relation_graph=True):
     tab- (or space-) separated `head relation tail` triple per line, optionally entities.dict / relations.dict (`id name`
     per line), the layout of kg-datasets/FB15k-237 (PyG RelLinkPredDataset raw files, ultra/datasets.py:186-205).  Returns
     the TEST split in the reference's format: fact graph = training triples + their inverses (edge_type r + R),
-    num_relations = 2 R, targets = test triples; `target_triples` as (h, t, r) rows like ultra_amd.synthetic.make_kg."""
+    num_relations = 2 R, targets = test triples; `target_triples` as (h, t, r) rows like ultra_amd.synthetic.make_kg.
+    `filtered_data` holds the transductive filtering graph of script/run.py:286-288 -- the target triples of ALL three
+    splits, no inverses -- which ultra_amd.eval.evaluate uses for the filtered ranking when the caller passes none."""
     import os
 
     def read_dict(name):
@@ -98,9 +100,12 @@ def load_triples_dir(root, relation_graph=True):
     R = len(rel)
     edge_index = torch.stack([torch.cat([train[:, 0], train[:, 1]]), torch.cat([train[:, 1], train[:, 0]])])
     edge_type = torch.cat([train[:, 2], train[:, 2] + R])
+    everything = torch.cat([train, valid, test])
     data = Data(edge_index=edge_index, edge_type=edge_type, num_nodes=len(ent), num_relations=2 * R,
                 target_edge_index=test[:, :2].t().contiguous(), target_edge_type=test[:, 2].contiguous(),
-                target_triples=test.contiguous(), valid_triples=valid.contiguous())
+                target_triples=test.contiguous(), valid_triples=valid.contiguous(),
+                filtered_data=Data(edge_index=everything[:, :2].t().contiguous(), edge_type=everything[:, 2].contiguous(),
+                                   num_nodes=len(ent), num_relations=2 * R))
     if relation_graph:
         from . import tasks
         tasks.build_relation_graph(data)

@@ -73,3 +73,42 @@ def all_gather_variable(t):
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
     return torch.cat([p[:s] for p, s in zip(parts, sizes)])
+
+
+def share_readout_order(K=128, device=None):
+    """One association of the readout's last product for the whole job.  The order comes from the host BLAS
+    (host_order.readout_stages: disk cache or a probe); left to themselves the ranks of a launcher each read / probe it --
+    a cache race at best, two associations (different OMP / MKL environments per rank) at worst, and then the gathered
+    score rows of one evaluation would not all be the same numbers.  Rank 0 resolves the order, its program is broadcast,
+    every other rank adopts it; the ranks then compare order ids (one small all-gather) and raise on a mismatch.
+    Returns the order id.  Call after init_process_group and before the first forward; device: where the collectives'
+    tensors live (None: cuda for nccl, cpu for gloo)."""
+    import json
+
+    from . import host_order
+    if world_size() == 1:
+        return host_order.order_id(host_order.readout_stages(K)[0])
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    payload = b""
+    if rank() == 0:
+        stages, source = host_order.readout_stages(K)
+        payload = json.dumps({"source": source, "stages": [[L, bool(carry), [list(map(int, lane)) for lane in lists]]
+                                                           for L, carry, lists in stages]}).encode()
+    n = torch.tensor([len(payload)], dtype=torch.long, device=device)
+    dist.broadcast(n, 0)
+    buf = torch.zeros(int(n.item()), dtype=torch.uint8, device=device)
+    if rank() == 0:
+        buf.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+    dist.broadcast(buf, 0)
+    if rank() != 0:
+        rec = json.loads(bytes(buf.cpu().tolist()).decode())
+        stages = [(int(L), bool(carry), [list(map(int, lane)) for lane in lists]) for L, carry, lists in rec["stages"]]
+        host_order.adopt(stages, rec["source"] + " [rank 0's, broadcast]", K)
+    mine = host_order.order_id(host_order.readout_stages(K)[0])
+    word = torch.tensor([int(mine.split("-")[1], 16)], dtype=torch.long, device=device)
+    words = [torch.zeros_like(word) for _ in range(world_size())]
+    dist.all_gather(words, word)
+    if any(int(w.item()) != int(word.item()) for w in words):
+        raise RuntimeError("readout summation order differs across ranks: %s" % [hex(int(w.item())) for w in words])
+    return mine

@@ -60,6 +60,8 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
         triples = triples[:max_triples]
     lo, hi = udist.shard_range(len(triples), rank, world)
     mine = triples[lo:hi]
+    if filtered_data is None:       # (a dataset read from triple files carries its filtering graph: data.load_triples_dir)
+        filtered_data = getattr(test_data, "filtered_data", None)
     filt = test_data if filtered_data is None else filtered_data
 
     was_training = model.training
@@ -83,8 +85,16 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
             # (a second capture costs about what it saves on a hundred batches: 130 vs 125 M scores/s on 64 batches, 170 vs 160 on 512)
             if in_flight is None:
                 in_flight = 1 if os.environ.get("ULTRA_EVAL_IN_FLIGHT", "2") == "1" or n_full < 128 * batch_size else 2
-            n_slot = 2 if (int(in_flight) >= 2 and rspmm._plan_defaults["exact_order"] and n_full >= 2 * batch_size) else 1
-            steps = [GraphedEvalStep(model, test_data, batch_size, t_index, h_index) for _ in range(n_slot)]
+            steps = [GraphedEvalStep(model, test_data, batch_size, t_index, h_index)]
+            # ... if the plans the captured step really uses are all of that kind (a max-aggregate model sends its relation
+            # graph to a re-associating plan), and if a second capture fits: it doubles the captured activation memory
+            if (int(in_flight) >= 2 and n_full >= 2 * batch_size and rspmm._plan_defaults["exact_order"]
+                    and all(p.exact for p in steps[0]._pinned)):
+                try:
+                    steps.append(GraphedEvalStep(model, test_data, batch_size, t_index, h_index))
+                except (torch.cuda.OutOfMemoryError, RuntimeError):      # one step at a time then
+                    torch.cuda.synchronize()
+            n_slot = len(steps)
             cur = torch.cuda.current_stream(mine.device)
             with torch.cuda.device(mine.device):
                 streams = [torch.cuda.Stream() for _ in steps] if n_slot > 1 else [cur]

@@ -111,13 +111,24 @@ class PipelinedForward(object):
 
     Reference-order plans only: the re-associating plans keep per-plan scratch that concurrent forwards would share."""
 
-    def __init__(self, model, data, example_batch, depth=2, warmup=3):
+    def __init__(self, model, data, example_batch, depth=2, warmup=3, slot_factory=None):
+        """slot_factory: what builds one slot's forward (default: a GraphedForward of `model`); a CPU batch gets slots without
+        streams -- the collective-ordering contract of `post=` is testable without a GPU (tests/test_distributed.py)."""
         if not rspmm._plan_defaults["exact_order"]:
             raise RuntimeError("PipelinedForward needs the reference-order plans (the re-associating plans own scratch buffers)")
-        self.slots = [GraphedForward(model, data, example_batch, warmup=warmup) for _ in range(int(depth))]
+        make = slot_factory or (lambda: GraphedForward(model, data, example_batch, warmup=warmup))
+        self.slots = []
+        for _ in range(int(depth)):
+            self.slots.append(make())
+            if not all(p.exact for p in getattr(self.slots[-1], "_pinned", [])):     # (what the capture really uses, not the default kind)
+                raise RuntimeError("PipelinedForward: this model's forward uses a re-associating plan (scratch buffers that "
+                                   "concurrent forwards would share); run its batches one at a time")
         dev = example_batch.device
-        with torch.cuda.device(dev):
-            self.streams = [torch.cuda.Stream() for _ in self.slots]
+        if dev.type == "cuda":
+            with torch.cuda.device(dev):
+                self.streams = [torch.cuda.Stream() for _ in self.slots]
+        else:
+            self.streams = [None for _ in self.slots]
         self.device = dev
         self.calls = 0
 
@@ -127,6 +138,9 @@ class PipelinedForward(object):
         k = self.calls % len(self.slots)
         self.calls += 1
         stream = self.streams[k]
+        if stream is None:      # (CPU slots: the call order IS the program order)
+            out = self.slots[k](batch)
+            return post(out) if post is not None else out
         stream.wait_stream(torch.cuda.current_stream(self.device))     # `batch` was produced on the caller's stream ...
         if batch.is_cuda:
             batch.record_stream(stream)                                 # ... and may be released by the caller right after this call
@@ -137,6 +151,8 @@ class PipelinedForward(object):
         return out
 
     def join(self):
+        if self.device.type != "cuda":
+            return
         cur = torch.cuda.current_stream(self.device)
         for s in self.streams:
             cur.wait_stream(s)

@@ -22,6 +22,7 @@ recovers it from the BLAS the process itself links:
 Only the association is taken from the host; every product and sum is an fp32 operation on the GPU.
 """
 import os
+import subprocess
 import warnings
 
 import numpy as np
@@ -352,6 +353,23 @@ def probe_host(K=128):
     return cand, "host BLAS (probed; %.2f %% of 4096 random rows bit-equal)" % (100 * match)
 
 
+def _match_fraction(stages, K=128, rows=4096):
+    """Share of random rows on which the emulated association equals this process's F.linear(x, (1, K)) bit for bit."""
+    g = torch.Generator().manual_seed(1)
+    x, w = torch.randn(rows, K, generator=g), torch.randn(1, K, generator=g)
+    want = torch.nn.functional.linear(x, w)[:, 0].numpy()
+    return float((emulate(stages, x.numpy(), w[0].numpy()) == want).mean())
+
+
+def adopt(stages, source, K=128):
+    """Use this association in this process from now on (a multi-GPU job: every rank adds in rank 0's association --
+    distributed.share_readout_order)."""
+    _check_stages(stages, K)
+    _CACHE[K] = (stages, source)
+    from . import dense
+    dense._ORDER_CACHE.clear()      # (device copies of the previous program)
+
+
 def _probe_in_subprocess(K, path):
     """The probe in a helper process: O(K^2) single-threaded GEMV calls and torch.set_num_threads(1) stay out of the
     caller's process (data-loader or OpenMP threads there keep their thread count).  The helper links the same torch, i.e.
@@ -384,8 +402,23 @@ def readout_stages(K=128):
         if mode == "host":
             key, text = _host_key(K)
             path = os.path.join(_cache_dir(), "readout_order_%s.json" % key)
+            cached = None
             if os.path.exists(path):
-                stages, source = load_stages(path, K)
+                # The key covers CPU model, torch build and BLAS -- not MKL's environment switches (MKL_ENABLE_INSTRUCTIONS,
+                # MKL_CBWR, ...), and the directory may be shared by hosts: the cached association is re-checked against
+                # this process's F.linear on random rows (cheap: one 4096-row GEMV under the current thread count, where
+                # each thread's share may end in a few remainder rows) and probed afresh when it no longer holds.
+                try:
+                    cached = load_stages(path, K)
+                    match = _match_fraction(cached[0], K)
+                    if match < 0.9:
+                        warnings.warn("ultra_amd: cached readout order %s reproduces only %.1f %% of this host's rows; probing again"
+                                      % (order_id(cached[0]), 100 * match))
+                        cached = None
+                except (OSError, ValueError, KeyError, TypeError):
+                    cached = None
+            if cached is not None:
+                stages, source = cached
                 source += " [cached]"
             else:
                 try:
@@ -401,7 +434,8 @@ def readout_stages(K=128):
         elif mode != "sequential":
             stages, source = load_stages(mode, K)
             source = "file %s (%s)" % (os.path.basename(mode), source)
-    except Exception as exc:        # noqa: BLE001 -- whatever went wrong, the sequential chain always works
+    except (OSError, ValueError, KeyError, TypeError, subprocess.SubprocessError) as exc:
+        # (an unreadable cache directory, a tree outside the family, a failed helper process: the sequential chain always works)
         warnings.warn("ultra_amd: readout summation order '%s' unavailable (%s: %s); using the sequential chain"
                       % (mode, type(exc).__name__, exc))
         stages, source = sequential_stages(K), "sequential (fallback)"

@@ -215,6 +215,13 @@ class GeneralizedRelationalConv(nn.Module):
         return plan.fused_layer(relation, input, self.linear, self.layer_norm, relu=self.activation is not None,
                                 residual=residual, boundary=None if point is not None else boundary, point=point)
 
+    def _order_free(self, edge_index, num_node):
+        """max (and min) do not depend on the order of their operands (but for the sign of a zero), so a graph whose rows are
+        mostly long -- ULTRA's relation graph: every row has hundreds of edges, each a serial chain on the reference-order
+        kernels -- goes to the re-associating plan, which splits such rows over many lanes, and still returns the
+        reference's values."""
+        return self.aggregate_func == "max" and edge_index.shape[1] >= 128 * max(int(num_node), 1)
+
     def _fused_sparse_layer(self, edge_index, kwargs, num_node, residual, onehot_rows, edge_keep):
         """Aggregate + update in one launch on the reference-order plan of a sparse graph (the entity graph): the workgroup
         that sums a row also applies the layer update to it (ultra_rspmm_forward_update).  Same bits as the two launches."""
@@ -222,7 +229,8 @@ class GeneralizedRelationalConv(nn.Module):
         if not (FUSED_SPARSE_LAYER and kwargs["edge_weight"] is None and self.aggregate_func in ("sum", "max")
                 and self.message_func in self.message2mul and input.is_cuda and not torch.is_grad_enabled()
                 and onehot_rows is None and not edge_keep and isinstance(boundary, PointBoundary)
-                and input.dim() == 3 and relation.dtype == torch.float32 and dense.conv_update_supported(self, input, input)):
+                and input.dim() == 3 and relation.dtype == torch.float32 and dense.conv_update_supported(self, input, input)
+                and not self._order_free(edge_index, num_node)):
             return None
         plan = rspmm.get_plan(edge_index, kwargs["edge_type"], num_node, relation.shape[1])
         ln = self.layer_norm
@@ -297,7 +305,8 @@ class GeneralizedRelationalConv(nn.Module):
                                                    boundary.requires_grad)
         # a differentiable call (training step) takes the re-associating plan: its backward is a scatter-add and its
         # result feeds a stochastic optimiser step -- there is no reference summation order to reproduce
-        plan = rspmm.get_plan(edge_index, edge_type, num_node, relation.shape[1], exact_order=False if needs_grad else None)
+        plan = rspmm.get_plan(edge_index, edge_type, num_node, relation.shape[1],
+                              exact_order=False if (needs_grad or self._order_free(edge_index, num_node)) else None)
 
         point, point_boundary = None, None
         if isinstance(boundary, PointBoundary):     # (propagate() only lets it through for the fused sum / max paths)
