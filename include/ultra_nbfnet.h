@@ -18,6 +18,7 @@ extern "C" {
 #define ULTRA_CONV_LAYER_NORM 1
 #define ULTRA_CONV_RELU 2
 #define ULTRA_CONV_RESIDUAL 4
+#define ULTRA_LAYER0_MAX 8      /* ultra_nbf_layer0 only: max aggregate instead of sum (layers.py:206-207) */
 
 /*
  * GeneralizedRelationalConv.update (/root/reference/ultra/layers.py:233-240) fused with the residual

@@ -212,6 +212,8 @@ int32_t ultra_rspmm_forward_update(ultra_plan *plan, int32_t sum, int32_t mul, c
  * /root/reference/ultra/layers.py:183-207, 233-240; sum aggregate, DistMult message, hidden dim 64, fp32):
  *     x0[b, n] = src_values[b] (or ones if NULL) at n == src_rows[b], else 0
  *     out = [x0 +] relu( LayerNorm_eps( weight . cat[x0, rspmm(x0) + x0] + bias ) )        flags: ULTRA_CONV_* of ultra_nbfnet.h
+ * With ULTRA_LAYER0_MAX the aggregate is max(rspmm_max(x0), x0) (layers.py:206-207) instead of the sum: the zero rows send
+ * exact zeros and the boundary tensor is zero off the source row, so the rows not reached keep the same constant output.
  * Rows that are neither src_rows[b] nor a target of one of its out-edges all equal relu(LayerNorm(bias)); they are
  * filled, the others are computed from the transposed plan.  relation: (n_outer, num_relation, 64); weight (64, 128)
  * row-major = linear.weight; output (n_outer, num_node, 64).  Needs the (row, col) plan of a square graph.

@@ -398,18 +398,21 @@ def test_point_boundary_equals_the_materialised_boundary(dev, case, opts, layout
         plan.forward(rel, x, boundary=bnd, point=(rows, vals))
 
 
-@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[6], CASES[7], CASES[5]])
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[2], CASES[3], CASES[6], CASES[7], CASES[5]])
 @pytest.mark.parametrize("layer_norm,residual,ones", [(True, True, False), (False, False, False), (True, False, True)])
 @pytest.mark.parametrize("weights", [False, True])
-def test_layer0_on_its_boundary_condition_matches_the_dense_layer(dev, case, layer_norm, residual, ones, weights):
+@pytest.mark.parametrize("aggregate", ["sum", "max"])
+def test_layer0_on_its_boundary_condition_matches_the_dense_layer(dev, case, layer_norm, residual, ones, weights, aggregate):
     """ultra_nbf_layer0 == GeneralizedRelationalConv applied to the materialised one-hot boundary (models.py:72-80,
-    150-163): constant rows everywhere but the source and the targets of its out-edges."""
+    150-163): constant rows everywhere but the source and the targets of its out-edges.  Under max (layers.py:206-207) a
+    source row meets a zero only if another node has an edge onto it (CASES[5]: one node, self loops only; CASES[2]: a
+    source without in-edges)."""
     from ultra_amd import layers as L
     ei, et = helpers.random_graph(**case)
     N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
     bs = 4
     torch.manual_seed(case["seed"])
-    layer = L.GeneralizedRelationalConv(64, 64, R, 64, "distmult", "sum", layer_norm, "relu", dependent=False).to(dev)
+    layer = L.GeneralizedRelationalConv(64, 64, R, 64, "distmult", aggregate, layer_norm, "relu", dependent=False).to(dev)
     with torch.no_grad():
         layer.linear.bias.uniform_(-1, 1)
         if layer_norm:

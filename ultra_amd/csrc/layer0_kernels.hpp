@@ -21,14 +21,18 @@
 
 namespace ultra {
 
-enum { L0_LN = 1, L0_RELU = 2, L0_RESIDUAL = 4 };
+// L0_MAX: the max aggregate (layers.py:206-207).  The messages of the zero rows are exact zeros and the boundary tensor is
+// zero off the source row, so a reached row aggregates max(0, messages from s[b]) and every other row 0 -- the same constant
+// output row as under the sum; the source row meets its boundary value q, the messages of its self loops, and a zero only
+// if some OTHER node has an edge onto it.
+enum { L0_LN = 1, L0_RELU = 2, L0_RESIDUAL = 4, L0_MAX = 8 };
 
 struct Layer0Params {
     const int32_t *trow_ptr;   // transposed plan: row = gathered source
     const int32_t *tcol;       // = aggregation target
     const int32_t *ttype;
     const int32_t *tperm;
-    const uint8_t *self_loop;  // [num_node] 1 if the node has an edge onto itself
+    const uint8_t *self_loop;  // [num_node] bit 0: the node has an edge onto itself, bit 1: an in-edge from another node
     const float *w;            // edge weights in original edge order, or NULL
     const int64_t *src;        // [n_outer] source row s[b]
     const float *q;            // [n_outer][64] boundary value of the source row, or NULL = ones (RelNBFNet)
@@ -212,7 +216,12 @@ __global__ void __launch_bounds__(1024) nbf_layer0_rows_kernel(const Layer0Param
         if (kend == k + 3 && kend < k1 && tc[3] == target) ++kend;
         if (kend == k + 4)
             while (kend < k1 && p.tcol[kend] == target) ++kend;
-        float agg[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool is_src = target == (int)s;
+        const bool use_max = (p.flags & L0_MAX) != 0;
+        // (max: the zeros a row meets anyway -- messages of zero rows, the boundary tensor off the source row; on the source
+        // row only the former, and only if another node has an edge onto it)
+        const float init = (use_max && is_src && !(p.self_loop[s] & 2)) ? -3.402823466e+38f : 0.f;
+        float agg[4] = {init, init, init, init};
         for (int kb = k; kb < kend; kb += 4) {   // edge order of the run (deterministic)
             float4 rv[4];
             float wv[4];
@@ -231,20 +240,25 @@ __global__ void __launch_bounds__(1024) nbf_layer0_rows_kernel(const Layer0Param
                     for (int e = 0; e < 4; ++e) {
                         float m = r4[e] * qv[e];
                         if (p.w) m = wv[u] * m;
-                        agg[e] += m;
+                        agg[e] = use_max ? fmaxf(agg[e], m) : agg[e] + m;
                     }
                 }
             }
         }
-        const bool is_src = target == (int)s;
-        if (is_src) {   // update + boundary (layers.py:200)
+        if (is_src) {   // update + boundary (layers.py:200), max(update, boundary) (layers.py:207)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) agg[e] += qv[e];
+            for (int e = 0; e < 4; ++e) agg[e] = use_max ? fmaxf(agg[e], qv[e]) : agg[e] + qv[e];
         }
         update_row(agg, is_src, target);
     }
-    // no edge leads back to the source row: its aggregate is the boundary value alone
-    if (grp == 0 && !p.self_loop[s]) update_row(qv, true, s);
+    // no edge leads back to the source row: its aggregate is the boundary value alone (under max: against the zero
+    // messages of its other in-edges, if it has any)
+    if (grp == 0 && !(p.self_loop[s] & 1)) {
+        float a0[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a0[e] = ((p.flags & L0_MAX) && (p.self_loop[s] & 2)) ? fmaxf(qv[e], 0.f) : qv[e];
+        update_row(a0, true, s);
+    }
 }
 
 }  // namespace ultra

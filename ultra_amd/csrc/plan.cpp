@@ -231,7 +231,7 @@ ultra_plan *build_plan(const int32_t *row, const int32_t *col, const int32_t *ty
     if (keep_edges) {
         p->self_loop.assign((size_t)std::max<int64_t>(num_out, 1), 0);
         for (int64_t e = 0; e < E; ++e)
-            if (row[e] == col[e] && row[e] < num_out) p->self_loop[(size_t)row[e]] = 1;
+            if (row[e] < num_out) p->self_loop[(size_t)row[e]] |= (row[e] == col[e]) ? 1 : 2;   // bit 0: onto itself, bit 1: from another node
         p->h_row.assign(row, row + E);
         p->h_col.assign(col, col + E);
         p->h_type.assign(type, type + E);

@@ -97,7 +97,7 @@ struct DevicePlan {
     uint8_t *a_frag = nullptr;   // ULTRA_PLAN_DENSE
     uint8_t *a16 = nullptr;         // ULTRA_PLAN_DENSE, 16-row tiles (fused layer kernel)
     uint8_t *a_ex = nullptr;        // ULTRA_PLAN_DENSE, reference-order layer kernel (dense_order_layer.hip)
-    uint8_t *self_loop = nullptr;   // per node: has an edge onto itself (layer-0 path)
+    uint8_t *self_loop = nullptr;   // per node: bit 0 = has an edge onto itself, bit 1 = has an in-edge from another node (layer-0 path)
     void *w_sorted = nullptr;
     size_t w_sorted_bytes = 0;
     void *partial = nullptr;
@@ -149,7 +149,7 @@ struct ultra_plan {
     // summation order); empty otherwise.
     std::vector<uint8_t> a_ex;
 
-    std::vector<uint8_t> self_loop;   // [num_out] built with the edge list (square graphs)
+    std::vector<uint8_t> self_loop;   // [num_out] built with the edge list (square graphs): bit 0 self loop, bit 1 in-edge from another node
 
     // original (unsorted) edges, kept to derive the backward plans lazily
     std::vector<int32_t> h_row, h_col, h_type;

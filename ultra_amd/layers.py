@@ -156,7 +156,7 @@ class GeneralizedRelationalConv(nn.Module):
     def layer0_point_supported(self, point, relation, edge_weight):
         """Can ultra_nbf_layer0 run this layer on a one-hot input?  (sum / DistMult, 64-d, fp32, inference)"""
         return (POINT_BOUNDARY_FAST_PATH and point.values.is_cuda and point.values.dtype == torch.float32
-                and not torch.is_grad_enabled() and self.aggregate_func == "sum" and self.message_func == "distmult"
+                and not torch.is_grad_enabled() and self.aggregate_func in ("sum", "max") and self.message_func == "distmult"
                 and self.input_dim == 64 and self.output_dim == 64 and self.linear.in_features == 128
                 and (self.activation is None or self.activation is F.relu)
                 and (relation is None or (relation.dtype == torch.float32 and relation.shape[-1] == 64))
@@ -171,7 +171,8 @@ class GeneralizedRelationalConv(nn.Module):
             relation = self._relation_for(query, batch_size)
         plan = rspmm.get_plan(edge_index, edge_type, num_node, relation.shape[1])
         return plan.layer0(relation, point.rows, point.values, self.linear, self.layer_norm,
-                           relu=self.activation is not None, residual=residual, edge_weight=edge_weight)
+                           relu=self.activation is not None, residual=residual, edge_weight=edge_weight,
+                           aggregate=self.aggregate_func)
 
     def propagate(self, edge_index, size=None, residual=False, onehot_rows=None, edge_keep=False, **kwargs):
         edge_weight = kwargs["edge_weight"]

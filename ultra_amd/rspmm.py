@@ -372,7 +372,8 @@ class Plan(object):
                                         _stream(input)))
         return out
 
-    def layer0(self, relation, src_rows, src_values, linear, layer_norm=None, relu=True, residual=False, edge_weight=None):
+    def layer0(self, relation, src_rows, src_values, linear, layer_norm=None, relu=True, residual=False, edge_weight=None,
+               aggregate="sum"):
         """Layer 0 of an NBFNet on its one-hot boundary condition (ultra_nbf_layer0): returns the (batch, N, 64) hidden
         state of `relu(LayerNorm(linear(cat[x0, rspmm(x0) + x0]))) [+ x0]`, x0 = src_values[b] (ones if None) at row
         src_rows[b] and zero elsewhere, without materialising x0 or the aggregate."""
@@ -386,7 +387,7 @@ class Plan(object):
             src_values = src_values.contiguous()
         if edge_weight is not None:
             edge_weight = edge_weight.to(torch.float32).contiguous()
-        flags = (1 if layer_norm is not None else 0) | (2 if relu else 0) | (4 if residual else 0)
+        flags = (1 if layer_norm is not None else 0) | (2 if relu else 0) | (4 if residual else 0) | (8 if aggregate == "max" else 0)
         check(lib.ultra_nbf_layer0(self._h, edge_weight.data_ptr() if edge_weight is not None else None, ctypes.byref(mrel),
                                    src_rows.data_ptr(), src_values.data_ptr() if src_values is not None else None,
                                    linear.weight.data_ptr(), linear.bias.data_ptr() if linear.bias is not None else None,
