@@ -420,6 +420,10 @@ def main():
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed loop of --steps steps runs this many times in the process: ms_per_step / value are the FIRST "
                          "run's (the contract's exactly-K-steps figure), `repeats` carries every run, their median and spread")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="nccl = RCCL (the measured configuration).  gloo: the N-rank code path where ranks must share a GPU "
+                         "(tests on a one-GPU box: RCCL refuses two ranks on one device); ranks then map to GPUs modulo the "
+                         "visible count and the line says so")
     ap.add_argument("--pmc-target", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--trace-target", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -444,6 +448,8 @@ def main():
         with socket.socket() as sock:
             sock.bind(("127.0.0.1", 0))
             port = sock.getsockname()[1]
+        if args.backend != "nccl":
+            sys.exit("bench.py: --backend gloo is for launcher-started test runs")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
                "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         print("[bench] launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
@@ -453,17 +459,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d does not match the launcher's world size %d" % (args.gpus, world))
-    if local_rank >= torch.cuda.device_count():
+    if local_rank >= torch.cuda.device_count() and args.backend == "nccl":
         sys.exit("bench.py: rank %d has no GPU (local rank %d, %d visible)" % (rank, local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    gpu_index = local_rank % torch.cuda.device_count()       # (gloo test mode: ranks may share a GPU)
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # started by torch.distributed.run
     if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL prints a version banner on stdout when its communicator comes up; stdout carries exactly one JSON
         # line here, so the banner goes to stderr (file-descriptor level: it is written by C code)
         with _stdout_to_stderr():
-            dist.init_process_group("nccl", device_id=dev)               # "nccl" is RCCL on ROCm
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)           # "nccl" is RCCL on ROCm
+            else:
+                dist.init_process_group("gloo")
             dist.barrier()                                                # (communicator creation happens here)
             torch.cuda.synchronize()
 
@@ -561,6 +571,11 @@ def main():
             torch.cuda.synchronize()
             return time.perf_counter() - t0
 
+    roofline = None
+    if rank == 0 and world == 1 and not launched and not args.no_roofline:
+        # the dominant kernel's own measurement (HIP events around its launches, rocprofv3 child passes) runs BEFORE the timed
+        # region: it is independent of it, and the GPU then enters the timed steps from sustained work rather than from idle
+        roofline = measure_roofline(dev, use_pmc=not args.no_pmc)
     forward = make_forward()
     elapsed = timed_run(forward, world > 1 or launched)
     # the same K steps again, `--repeats` runs in all: box-to-box and run-to-run spread is of the size of a small kernel gain,
@@ -609,13 +624,15 @@ def main():
                               (", %d batches in flight on %d streams (graph.PipelinedForward)" % (args.in_flight, args.in_flight)
                                if args.in_flight > 1 else "")),
                    "rccl_world_size": dist.get_world_size() if (world > 1 or launched) else 1,
+                   "collective_backend": ("RCCL" if args.backend == "nccl" else "gloo (test mode: ranks share GPUs, not a measurement)")
+                   if (world > 1 or launched) else None,
                    "per_rank": per_rank,
                    "parallelism": "query-shard x%d + RCCL all-gather of scores" % world if world > 1 else "single GPU"},
     }
 
     if rank == 0 and not args.no_roofline:
         # (counter passes only at N = 1: they re-run the kernels in a child process on this rank's GPU)
-        out["roofline"] = measure_roofline(dev, use_pmc=not args.no_pmc and world == 1 and not launched)
+        out["roofline"] = roofline if roofline is not None else measure_roofline(dev, use_pmc=False)
     if rank == 0 and world == 1:
 
         # ---- CPU baseline + parity on the identical batch ----

@@ -122,3 +122,73 @@ def test_ddp_step_over_rccl_equals_the_plain_step(tmp_path):
            "--master-port", str(_free_port()), str(script)]
     r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DDP_OK world 1" in r.stdout, (r.stdout + r.stderr)[-2000:]
+
+
+DDP_TWO_RANKS = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from ultra_amd import models, synthetic, tasks
+rank = int(os.environ["RANK"])
+dev = torch.device("cuda", 0)                            # both ranks on the one GPU of the box: RCCL refuses that, gloo does not
+torch.cuda.set_device(dev)
+dist.init_process_group("gloo")
+data = synthetic.make_kg(num_node=800, num_triple=8000, num_relation_base=6, num_test=16, seed=5).to(dev)
+triples = torch.stack([data.edge_index[0], data.edge_index[1], data.edge_type], dim=-1)
+torch.manual_seed(3 + rank)
+neg = tasks.negative_sampling(data, triples[rank * 4:(rank + 1) * 4], 16, strict=True)      # every rank its own shard (run.py:33)
+
+def grads(wrap):
+    torch.manual_seed(0)
+    model = models.Ultra(**synthetic.default_model_cfg()).to(dev).train()
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0]) if wrap else model   # script/run.py:44-45
+    pred = net(data, neg)
+    target = torch.zeros_like(pred)
+    target[:, 0] = 1
+    torch.nn.functional.binary_cross_entropy_with_logits(pred, target).backward()
+    return torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
+
+plain, ddp = grads(False), grads(True)
+parts = [torch.empty_like(plain) for _ in range(2)]
+dist.all_gather(parts, plain)
+mean = (parts[0] + parts[1]) / 2
+assert not torch.equal(parts[0], parts[1]), "the two ranks must see different batches"
+err = (ddp - mean).abs().max().item()
+assert err <= 1e-6 * max(1.0, mean.abs().max().item()), err      # the all-reduce averaged the two ranks' gradients
+ref = ddp.clone()
+dist.broadcast(ref, 0)
+assert torch.equal(ref, ddp), "gradients differ across ranks after the all-reduce"
+print("DDP2_OK rank %%d grads %%d err %%.3g" %% (rank, ddp.numel(), err))
+dist.destroy_process_group()
+"""
+
+
+def test_ddp_step_with_two_ranks_averages_their_gradients(tmp_path):
+    """BASELINE config 5 is data parallel (script/run.py:44-45).  One GPU per test box and RCCL refuses two ranks on one device,
+    so the TWO-rank step runs over gloo with both ranks on cuda:0: every rank a different batch, the DDP gradients must be the
+    mean of the two plain steps' gradients and identical on both ranks -- the engine's autograd nodes under DDP's bucketed
+    all-reduce hooks, at a world size where the all-reduce is not the identity."""
+    script = tmp_path / "ddp_two.py"
+    script.write_text(DDP_TWO_RANKS % ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.count("DDP2_OK") == 2, (r.stdout + r.stderr)[-3000:]
+
+
+def test_bench_with_two_ranks_sharing_the_gpu_over_gloo():
+    """The N = 2 code path of bench.py on real forwards: two ranks (both on the box's one GPU, collectives over gloo -- RCCL
+    refuses two ranks on one device), every step's score all-gather issued behind the forward of its pipeline slot, rank 0's
+    readout association shared, per-rank clocks and probe digests gathered.  Not a measurement: the line says so."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6",
+           "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--no-roofline", "--no-secondary"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-500:]
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 2 and cfg["rccl_world_size"] == 2 and "gloo" in cfg["collective_backend"]
+    per = cfg["per_rank"]
+    assert per["probe_scores_identical"] is True and per["readout_order_identical"] is True and len(per["ms_per_step"]) == 2
+    assert out["value"] == pytest.approx(2 * 8 * 14541 * 6 / (out["ms_per_step"] * 6e-3), rel=1e-6)      # whole-job aggregate

@@ -515,3 +515,43 @@ def test_operands_on_a_device_that_is_not_the_current_one():
     got = plan.forward(rel.to(dev1), x.to(dev1), sum="add", mul="mul")
     assert got.device == dev1 and torch.equal(got.cpu(), want)
     assert torch.cuda.current_device() == 0
+
+
+ALIAS_SNIPPET = r"""
+import sys, torch
+sys.path.insert(0, %r)
+if torch.cuda.device_count() < 2:
+    print("ALIAS_UNAVAILABLE devices=%%d" %% torch.cuda.device_count())
+    sys.exit(0)
+from oracle import rspmm_oracle
+from tests import helpers
+from ultra_amd.rspmm import Plan
+assert torch.cuda.current_device() == 0
+dev1 = torch.device("cuda:1")
+ei, et = helpers.random_graph(num_node=64, num_edge=400, num_relation=5, seed=3)
+rel, x, w = helpers.features(64, 5, 64, 400, dtype=torch.float32, seed=3)
+want = rspmm_oracle.generalized_rspmm(ei, et, torch.ones(400), rel, x, sum="add", mul="mul")
+got = Plan(ei, et, 64, 5, exact_order=True).forward(rel.to(dev1), x.to(dev1), sum="add", mul="mul")
+assert got.device == dev1 and torch.equal(got.cpu(), want) and torch.cuda.current_device() == 0
+print("ALIAS_OK")
+"""
+
+
+@pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="two real GPUs: test_operands_on_a_device_that_is_not_the_current_one runs")
+def test_operands_on_the_second_ordinal_of_an_aliased_gpu(tmp_path):
+    """The device-scope test above needs two GPUs.  On a one-GPU box the same GPU is listed twice (HIP_VISIBLE_DEVICES=0,0) in a
+    child process, if the runtime accepts that: cuda:1 is then a second ordinal with its own default stream and context
+    state, which is what the entry's device scope has to follow.  Where the runtime collapses the duplicate the case
+    stays untested here and the test says so."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "alias.py"
+    script.write_text(ALIAS_SNIPPET % root)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="0,0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("ROCR_VISIBLE_DEVICES", None)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    if "ALIAS_UNAVAILABLE" in r.stdout or (r.returncode != 0 and "ALIAS_OK" not in r.stdout and "invalid device" in (r.stderr + r.stdout).lower()):
+        pytest.skip("the HIP runtime does not list one GPU under two ordinals: " + (r.stdout.strip() or r.stderr.strip()[-200:]))
+    assert r.returncode == 0 and "ALIAS_OK" in r.stdout, (r.stdout + r.stderr)[-2000:]
