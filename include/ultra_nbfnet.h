@@ -19,6 +19,9 @@ extern "C" {
 #define ULTRA_CONV_RELU 2
 #define ULTRA_CONV_RESIDUAL 4
 #define ULTRA_LAYER0_MAX 8      /* ultra_nbf_layer0 only: max aggregate instead of sum (layers.py:206-207) */
+#define ULTRA_LAYER0_ONLY_FILL 16   /* ... only the constant rows (they depend on the layer's parameters alone: relation, src_rows,
+                                       src_values, weight may be NULL) -- e.g. on a side stream, beside the relation model */
+#define ULTRA_LAYER0_SKIP_FILL 32   /* ... only the special rows, into an output the caller has filled with ULTRA_LAYER0_ONLY_FILL */
 
 /*
  * GeneralizedRelationalConv.update (/root/reference/ultra/layers.py:233-240) fused with the residual

@@ -25,7 +25,9 @@ namespace ultra {
 // zero off the source row, so a reached row aggregates max(0, messages from s[b]) and every other row 0 -- the same constant
 // output row as under the sum; the source row meets its boundary value q, the messages of its self loops, and a zero only
 // if some OTHER node has an edge onto it.
-enum { L0_LN = 1, L0_RELU = 2, L0_RESIDUAL = 4, L0_MAX = 8 };
+// L0_ONLY_FILL / L0_SKIP_FILL: the constant fill depends on the layer's parameters only -- a caller may launch it ahead of
+// time (beside the relation model, whose output the special rows need) and the special rows later.
+enum { L0_LN = 1, L0_RELU = 2, L0_RESIDUAL = 4, L0_MAX = 8, L0_ONLY_FILL = 16, L0_SKIP_FILL = 32 };
 
 struct Layer0Params {
     const int32_t *trow_ptr;   // transposed plan: row = gathered source

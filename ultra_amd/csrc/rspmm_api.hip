@@ -758,7 +758,9 @@ static int layer0_impl(ultra_plan *p, const void *w, const ultra_mat *rel, const
                        const ultra_mat *out, hipStream_t stream) {
     if (!p) return invalid("plan is NULL");
     (void)hipGetLastError();
-    if (!out || !out->ptr || !src_rows || !weight) return invalid("ultra_nbf_layer0: NULL operand");
+    const bool only_fill = (flags & L0_ONLY_FILL) != 0;
+    if (only_fill && (flags & L0_SKIP_FILL)) return invalid("ultra_nbf_layer0: ULTRA_LAYER0_ONLY_FILL excludes ULTRA_LAYER0_SKIP_FILL");
+    if (!out || !out->ptr || (!only_fill && (!src_rows || !weight))) return invalid("ultra_nbf_layer0: NULL operand");
     if ((flags & L0_LN) && (!ln_w || !ln_b)) return invalid("ultra_nbf_layer0: LayerNorm needs its weight and bias");
     if (p->flags & (ULTRA_PLAN_TYPE_RUNS | ULTRA_PLAN_DENSE)) return invalid("use the (row, col) plan for the layer-0 path");
     if (out->row_len != 64) {
@@ -768,26 +770,28 @@ static int layer0_impl(ultra_plan *p, const void *w, const ultra_mat *rel, const
     const int64_t n_outer = out->n_outer;
     int rc;
     if ((rc = check_mat(out, "output", p->num_out, n_outer, 64))) return rc;
-    if ((rc = check_mat(rel, "relation", p->num_rel, n_outer, 64))) return rc;
+    if (!only_fill && (rc = check_mat(rel, "relation", p->num_rel, n_outer, 64))) return rc;
     if (p->num_out != p->num_in) return invalid("layer-0 path needs a square graph (source rows are output rows)");
-    if (!mat_vec_ok(out, 4) || !mat_vec_ok(rel, 4) || !aligned16(weight) || (src_vals && !aligned16(src_vals)))
+    if (!mat_vec_ok(out, 4) || (!only_fill && (!mat_vec_ok(rel, 4) || !aligned16(weight) || (src_vals && !aligned16(src_vals)))))
         return invalid("ultra_nbf_layer0: operands must be 16-byte aligned with strides that are multiples of 4");
     if (n_outer == 0 || p->num_out == 0) return ULTRA_OK;
-    if ((rc = ensure_backward_plans(p))) return rc;
-    if ((rc = upload_plan(p->tplan))) return rc;
-    if ((rc = upload_plan(p))) return rc;
-    if (!p->d.self_loop) return invalid("plan was built without its edge list; layer-0 path unavailable");
     Layer0Params lp;
     std::memset(&lp, 0, sizeof(lp));
-    lp.trow_ptr = p->tplan->d.row_ptr;
-    lp.tcol = p->tplan->d.col;
-    lp.ttype = p->tplan->d.type;
-    lp.tperm = p->tplan->d.perm;
-    lp.self_loop = p->d.self_loop;
+    if (!only_fill) {
+        if ((rc = ensure_backward_plans(p))) return rc;
+        if ((rc = upload_plan(p->tplan))) return rc;
+        if ((rc = upload_plan(p))) return rc;
+        if (!p->d.self_loop) return invalid("plan was built without its edge list; layer-0 path unavailable");
+        lp.trow_ptr = p->tplan->d.row_ptr;
+        lp.tcol = p->tplan->d.col;
+        lp.ttype = p->tplan->d.type;
+        lp.tperm = p->tplan->d.perm;
+        lp.self_loop = p->d.self_loop;
+        lp.rel = MatArg{rel->ptr, rel->stride_outer, rel->stride_row};
+    }
     lp.w = static_cast<const float *>(w);
     lp.src = src_rows;
     lp.q = static_cast<const float *>(src_vals);
-    lp.rel = MatArg{rel->ptr, rel->stride_outer, rel->stride_row};
     lp.weight = static_cast<const float *>(weight);
     lp.bias = static_cast<const float *>(bias);
     lp.ln_w = static_cast<const float *>(ln_w);
@@ -801,10 +805,14 @@ static int layer0_impl(ultra_plan *p, const void *w, const ultra_mat *rel, const
     lp.flags = flags;
     const long long rows = (long long)n_outer * p->num_out;
     const int fill_blocks = (int)std::min<long long>((rows + 15) / 16, 1024);
-    hipLaunchKernelGGL(nbf_layer0_fill_kernel, dim3(fill_blocks), dim3(256), 0, stream, lp);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(nbf_layer0_rows_kernel, dim3(32, (unsigned)n_outer), dim3(1024), 0, stream, lp);
-    HIP_TRY(hipGetLastError());
+    if (!(flags & L0_SKIP_FILL)) {
+        hipLaunchKernelGGL(nbf_layer0_fill_kernel, dim3(fill_blocks), dim3(256), 0, stream, lp);
+        HIP_TRY(hipGetLastError());
+    }
+    if (!only_fill) {
+        hipLaunchKernelGGL(nbf_layer0_rows_kernel, dim3(32, (unsigned)n_outer), dim3(1024), 0, stream, lp);
+        HIP_TRY(hipGetLastError());
+    }
     return ULTRA_OK;
 }
 

@@ -63,6 +63,10 @@ class GraphedForward(object):
             with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"), \
                     dense.own_prologue_scratch(self._scratch):
                 self.static_out = model(data, self.static_batch)
+            # the first launch of an instantiated graph also uploads it (kernel arguments, node descriptors): done here, as
+            # part of building the graph, not by the caller's first batch
+            self.graph.replay()
+            torch.cuda.synchronize()
         self.valid = getattr(model.entity_model, "_pending_valid", None) if hasattr(model, "entity_model") else None
         self._params = self._param_state()
 

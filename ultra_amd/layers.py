@@ -162,8 +162,16 @@ class GeneralizedRelationalConv(nn.Module):
                 and (relation is None or (relation.dtype == torch.float32 and relation.shape[-1] == 64))
                 and (edge_weight is None or not edge_weight.requires_grad))
 
+    def layer0_fill(self, edge_index, edge_type, num_node, num_relation, batch_size):
+        """The constant rows of forward_layer0_point (every row that layer 0 cannot reach: relu(LayerNorm(bias))) as a fresh
+        (batch, N, 64) tensor on the CURRENT stream -- they depend on this layer's parameters only, so a model may launch
+        them beside whatever produces the layer's other operands and pass the tensor as `out`."""
+        plan = rspmm.get_plan(edge_index, edge_type, num_node, num_relation)
+        return plan.layer0_fill(batch_size, self.linear, self.layer_norm, relu=self.activation is not None,
+                                device=edge_index.device)
+
     def forward_layer0_point(self, point, query, edge_index, edge_type, num_node, edge_weight=None, residual=False,
-                             relation=None):
+                             relation=None, out=None):
         """This layer applied to the boundary condition itself (what layer 0 of every NBFNet does, models.py:72-80,
         150-163), evaluated only where the result differs from relu(LayerNorm(bias))."""
         batch_size = len(point.rows)
@@ -172,7 +180,7 @@ class GeneralizedRelationalConv(nn.Module):
         plan = rspmm.get_plan(edge_index, edge_type, num_node, relation.shape[1])
         return plan.layer0(relation, point.rows, point.values, self.linear, self.layer_norm,
                            relu=self.activation is not None, residual=residual, edge_weight=edge_weight,
-                           aggregate=self.aggregate_func)
+                           aggregate=self.aggregate_func, out=out)
 
     def propagate(self, edge_index, size=None, residual=False, onehot_rows=None, edge_keep=False, **kwargs):
         edge_weight = kwargs["edge_weight"]

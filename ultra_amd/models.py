@@ -17,6 +17,8 @@ from . import dense, layers, tasks
 
 # inference fast path of EntityNBFNet.forward: fused batch prologue + readout from the raw batch (A/B switch for tests)
 PROLOGUE_FAST_PATH = True
+# the constant rows of the entity model's layer 0 are written on a side stream beside the relation model (EntityNBFNet.prefill_layer0)
+PREFILL_LAYER0 = True
 
 
 class NotOnFusedPath(RuntimeError):
@@ -97,7 +99,7 @@ class BaseNBFNet(nn.Module):
         return new_h_index, new_t_index, new_r_index
 
     def _propagate_layers(self, data, layer_input, query, boundary, separate_grad=False, relations=None,
-                          edge_weight=None, onehot_rows=None, edge_keep=False):
+                          edge_weight=None, onehot_rows=None, edge_keep=False, prefilled=None):
         """The Bellman-Ford loop shared by every model (models.py:72-80, 150-163, 233-246).
         `relations`: optional per-layer relation features computed up front (EntityNBFNet batches the six
         relation_projection MLPs, which all read the same relation representations).
@@ -113,8 +115,9 @@ class BaseNBFNet(nn.Module):
                 # layer 0 on its one-hot input: constant fill + the rows reached from the source (ultra_nbf_layer0);
                 # the boundary condition never becomes a (batch, N, d) tensor on this path
                 residual = self.short_cut and layer.output_dim == layer.input_dim
+                # (prefilled: layer 0's constant rows, written ahead of time by EntityNBFNet.prefill_layer0)
                 hidden = layer.forward_layer0_point(boundary, query, data.edge_index, data.edge_type, data.num_nodes,
-                                                    edge_weight=edge_weight, residual=residual, relation=rel0)
+                                                    edge_weight=edge_weight, residual=residual, relation=rel0, out=prefilled)
                 hiddens.append(hidden)
                 edge_weights.append(edge_weight)
                 layer_input = hidden
@@ -222,7 +225,32 @@ class EntityNBFNet(BaseNBFNet):
         mlp.append(nn.Linear(feature_dim, 1))
         self.mlp = nn.Sequential(*mlp)
 
-    def _bellmanford_hidden(self, data, h_index, r_index, separate_grad=False, edge_weight=None, edge_keep=False):
+    _side_streams = {}
+
+    def prefill_layer0(self, data, batch_size):
+        """Layer 0 of the entity model leaves all but a few thousand rows at one constant value that depends on its parameters
+        alone (layers.forward_layer0_point): the 30 MB fill is launched here, on a side stream, BEFORE the relation model
+        runs -- whose launches are latency bound and leave the memory system idle -- instead of behind it.  Returns
+        (tensor, stream) for forward(prefill=...), or None where layer 0 will not take that path."""
+        layer = self.layers[0]
+        dev = data.edge_index.device
+        if not (layers.POINT_BOUNDARY_FAST_PATH and dev.type == "cuda" and not torch.is_grad_enabled() and not self.training
+                and layer.aggregate_func in ("sum", "max") and layer.message_func == "distmult" and layer.input_dim == 64
+                and layer.output_dim == 64 and layer.linear.in_features == 128
+                and (layer.activation is None or layer.activation is torch.nn.functional.relu)
+                and layer.linear.weight.dtype == torch.float32):
+            return None
+        key = str(dev)
+        side = EntityNBFNet._side_streams.get(key)
+        if side is None:
+            with torch.cuda.device(dev):
+                side = EntityNBFNet._side_streams[key] = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            out = layer.layer0_fill(data.edge_index, data.edge_type, data.num_nodes, int(data.num_relations), batch_size)
+        return out, side
+
+    def _bellmanford_hidden(self, data, h_index, r_index, separate_grad=False, edge_weight=None, edge_keep=False, prefilled=None):
         batch_size = len(r_index)
         # query = representation of each sample's query relation, scattered to its head node
         fused = (dense.boundary_supported(h_index, self.query) and self.query.dim() == 3
@@ -241,7 +269,8 @@ class EntityNBFNet(BaseNBFNet):
             boundary.scatter_add_(1, index.unsqueeze(1), query.unsqueeze(1))
         hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad,
                                                        relations=self._project_relations_batched(),
-                                                       edge_weight=edge_weight, onehot_rows=h_index, edge_keep=edge_keep)
+                                                       edge_weight=edge_weight, onehot_rows=h_index, edge_keep=edge_keep,
+                                                       prefilled=prefilled)
         return hiddens, edge_weights, query
 
     def _project_relations_batched(self):
@@ -285,8 +314,14 @@ class EntityNBFNet(BaseNBFNet):
             "edge_weights": edge_weights,
         }
 
-    def forward(self, data, relation_representations, batch):
+    def forward(self, data, relation_representations, batch, prefill=None):
         h_index, t_index, r_index = batch.unbind(-1)
+        prefilled = None
+        if prefill is not None:       # (prefill_layer0: the side stream joins here, whatever path the forward takes)
+            prefilled, side = prefill
+            torch.cuda.current_stream(prefilled.device).wait_stream(side)
+            if tuple(prefilled.shape) != (batch.shape[0], data.num_nodes, 64):
+                prefilled = None
 
         self.query = relation_representations
         for layer in self.layers:
@@ -310,7 +345,7 @@ class EntityNBFNet(BaseNBFNet):
             # inference fast path: one prologue kernel (row uniformity, head->tail conversion, validity flag) and
             # a readout that picks its candidate column straight from the raw batch
             batch_c, h0, r0, side, valid = dense.batch_prologue(batch, data.num_relations // 2)
-            hiddens, _, query = self._bellmanford_hidden(data, h0, r0)
+            hiddens, _, query = self._bellmanford_hidden(data, h0, r0, prefilled=prefilled)
             if dense.readout_supported(self, hiddens[-1]):
                 score = dense.readout_batch(self, hiddens[-1], query, batch_c, side).view(shape)
                 self._check_valid(valid)
@@ -399,6 +434,10 @@ class Ultra(nn.Module):
     def forward(self, data, batch):
         # batch: (bs, 1 + num_negs, 3); the relation is shared by every triple of a row
         query_rels = batch[:, 0, 2]
+        prefill = None
+        if PREFILL_LAYER0 and batch.is_cuda and batch.dim() == 3 and hasattr(self.entity_model, "prefill_layer0"):
+            prefill = self.entity_model.prefill_layer0(data, batch.shape[0])
         relation_representations = self.relation_model(data.relation_graph, query=query_rels)
-        score = self.entity_model(data, relation_representations, batch)
-        return score
+        if prefill is not None:
+            return self.entity_model(data, relation_representations, batch, prefill=prefill)
+        return self.entity_model(data, relation_representations, batch)

@@ -372,22 +372,43 @@ class Plan(object):
                                         _stream(input)))
         return out
 
+    def layer0_fill(self, batch_size, linear, layer_norm=None, relu=True, device=None):
+        """The constant rows of layer0() -- relu(LayerNorm(bias)) everywhere -- into a fresh (batch, N, 64) tensor: they depend
+        on the layer's parameters only, so a caller may launch this early (on a side stream, beside the relation model) and
+        hand the tensor to layer0(out=...) for the special rows."""
+        device = device if device is not None else linear.weight.device
+        out = torch.empty(batch_size, self.num_node, 64, dtype=torch.float32, device=device)
+        _, mout = as_mat(out)
+        flags = (1 if layer_norm is not None else 0) | (2 if relu else 0) | 16
+        check(lib.ultra_nbf_layer0(self._h, None, None, None, None, linear.weight.data_ptr(),
+                                   linear.bias.data_ptr() if linear.bias is not None else None,
+                                   layer_norm.weight.data_ptr() if layer_norm is not None else None,
+                                   layer_norm.bias.data_ptr() if layer_norm is not None else None,
+                                   float(layer_norm.eps) if layer_norm is not None else 1e-5, flags, ctypes.byref(mout),
+                                   _stream(out)))
+        return out
+
     def layer0(self, relation, src_rows, src_values, linear, layer_norm=None, relu=True, residual=False, edge_weight=None,
-               aggregate="sum"):
+               aggregate="sum", out=None):
         """Layer 0 of an NBFNet on its one-hot boundary condition (ultra_nbf_layer0): returns the (batch, N, 64) hidden
         state of `relu(LayerNorm(linear(cat[x0, rspmm(x0) + x0]))) [+ x0]`, x0 = src_values[b] (ones if None) at row
         src_rows[b] and zero elsewhere, without materialising x0 or the aggregate."""
         _require_gpu(relation, src_rows, src_values, edge_weight)
         relation, mrel = as_mat(relation)
         bs = relation.shape[0]
-        out = torch.empty(bs, self.num_node, 64, dtype=torch.float32, device=relation.device)
+        prefilled = out is not None       # (layer0_fill wrote the constant rows already)
+        if out is None:
+            out = torch.empty(bs, self.num_node, 64, dtype=torch.float32, device=relation.device)
+        elif tuple(out.shape) != (bs, self.num_node, 64) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise RuntimeError("layer0(out=...): expected the (batch, num_node, 64) fp32 tensor of layer0_fill")
         _, mout = as_mat(out)
         src_rows = src_rows.to(torch.int64).contiguous()
         if src_values is not None:
             src_values = src_values.contiguous()
         if edge_weight is not None:
             edge_weight = edge_weight.to(torch.float32).contiguous()
-        flags = (1 if layer_norm is not None else 0) | (2 if relu else 0) | (4 if residual else 0) | (8 if aggregate == "max" else 0)
+        flags = (1 if layer_norm is not None else 0) | (2 if relu else 0) | (4 if residual else 0) | (8 if aggregate == "max" else 0) \
+            | (32 if prefilled else 0)
         check(lib.ultra_nbf_layer0(self._h, edge_weight.data_ptr() if edge_weight is not None else None, ctypes.byref(mrel),
                                    src_rows.data_ptr(), src_values.data_ptr() if src_values is not None else None,
                                    linear.weight.data_ptr(), linear.bias.data_ptr() if linear.bias is not None else None,
