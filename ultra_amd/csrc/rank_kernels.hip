@@ -51,75 +51,71 @@ __global__ void __launch_bounds__(256) filtered_rank_kernel(const float *__restr
 //   h0[b], r0[b] = source node and query relation of the row after that conversion;
 //   valid[b] = the row really shares its source node and its relation (the reference's two asserts), per row:
 //              no initialisation pass / memset node is needed (hipGraph friendly).
-// PROLOGUE_SPLIT workgroups scan one row of the batch each (a single workgroup per row left 248 CUs idle).  They meet in
-// `scratch` (4 ints per row: violations of h / t / r uniformity, arrival ticket): the last workgroup to arrive writes the
-// row's results and puts the four ints back to zero, so the buffer needs zeroing once at allocation and never inside a
-// captured graph.  The row is read as a flat int64 array with 16-byte loads (two consecutive elements per lane, fully
-// coalesced; an element's column is its index mod 3) -- the first version read the three columns of a candidate with
-// three 8-byte loads at a 24-byte lane stride: 15.6 us for the 2.8 MB of the benchmark batch.
-constexpr int PROLOGUE_SPLIT = 64;
-__global__ void __launch_bounds__(256) batch_prologue_kernel(const int64_t *__restrict__ batch, long long n_cand,
-                                                            long long num_direct_rel, int64_t *h0, int64_t *r0,
-                                                            int32_t *side, int32_t *valid, int32_t *scratch) {
-    const int b = blockIdx.y, part = blockIdx.x;
+// One 1024-thread workgroup per row of the batch, no meeting of workgroups: the row is read as a flat int64 array with
+// 16-byte loads (two consecutive elements per lane, fully coalesced, eight in flight per thread; an element's column is
+// its index mod 3) and the verdicts are combined inside the workgroup.  History, measured in the captured forward at the
+// benchmark point (2.8 MB): three 8-byte loads per candidate at a 24-byte lane stride, 16 workgroups per row meeting
+// through device-scope atomics -- 15.6 us; 64 workgroups per row with coalesced loads -- 38.7 us: the 64 arrival tickets of
+// a row are atomics on ONE address issued from eight XCDs, which the memory side serialises at ~0.5 us apiece.  `scratch`
+// (the former meeting buffer) is unused and kept in the signature for the ABI.
+constexpr int PROLOGUE_THREADS = 1024;
+__global__ void __launch_bounds__(PROLOGUE_THREADS) batch_prologue_kernel(const int64_t *__restrict__ batch, long long n_cand,
+                                                                         long long num_direct_rel, int64_t *h0, int64_t *r0,
+                                                                         int32_t *side, int32_t *valid, int32_t *scratch) {
+    (void)scratch;
+    __shared__ int lds_bad[3];
+    const int b = blockIdx.x;
     const long long L = 3 * n_cand;
     const int64_t *row = batch + (long long)b * L;
     const int64_t fh = row[0], ft = row[1], fr = row[2];
+    if (threadIdx.x < 3) lds_bad[threadIdx.x] = 0;
     int bad_h = 0, bad_t = 0, bad_r = 0;      // some element of the column differs from the row's first
     const auto check = [&](const unsigned c, const int64_t v) {     // (selects, no indexed private array)
         bad_h |= (c == 0u && v != fh);
         bad_t |= (c == 1u && v != ft);
         bad_r |= (c == 2u && v != fr);
     };
-    const long long per = (((L + PROLOGUE_SPLIT - 1) / PROLOGUE_SPLIT) + 1) & ~1ll;
-    long long lo = part * per, hi = lo + per < L ? lo + per : L;
-    if (lo < hi) {
-        if (((uintptr_t)(row + lo) & 15u) != 0) {     // (an odd row start: one element by itself, the rest in aligned pairs)
-            if (threadIdx.x == 0) check((unsigned)(lo % 3), row[lo]);
-            ++lo;
-        }
-        const long long n2 = (hi - lo) >> 1;
-        const ulonglong2 *row2 = reinterpret_cast<const ulonglong2 *>(row + lo);
-        const unsigned c_lo = (unsigned)(lo % 3);
-        // 4 pairs (64 bytes) in flight per thread
-        long long i = threadIdx.x;
-        for (; i + 3 * (long long)blockDim.x < n2; i += 4 * (long long)blockDim.x) {
-            ulonglong2 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = row2[i + u * (long long)blockDim.x];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned c0 = (c_lo + 2u * (unsigned)((i + u * (long long)blockDim.x) % 3)) % 3u, c1 = c0 == 2u ? 0u : c0 + 1u;
-                check(c0, (int64_t)v[u].x);
-                check(c1, (int64_t)v[u].y);
-            }
-        }
-        for (; i < n2; i += blockDim.x) {
-            const ulonglong2 v = row2[i];
-            const unsigned c0 = (c_lo + 2u * (unsigned)(i % 3)) % 3u, c1 = c0 == 2u ? 0u : c0 + 1u;
-            check(c0, (int64_t)v.x);
-            check(c1, (int64_t)v.y);
-        }
-        if (((hi - lo) & 1) && threadIdx.x == 0) check((unsigned)((hi - 1) % 3), row[hi - 1]);
+    long long lo = 0;
+    const long long hi = L;
+    if (((uintptr_t)row & 15u) != 0) {     // (an odd row start: one element by itself, the rest in aligned pairs)
+        if (threadIdx.x == 0) check(0u, row[0]);
+        lo = 1;
     }
-    const int same_h = !bad_h, same_t = !bad_t, same_r = !bad_r;
-    int32_t *sc = scratch + 4 * b;
-    const bool wave_h = __all(same_h), wave_t = __all(same_t), wave_r = __all(same_r);
-    if ((threadIdx.x & 63) == 0) {
-        if (!wave_h) atomicAdd(&sc[0], 1);
-        if (!wave_t) atomicAdd(&sc[1], 1);
-        if (!wave_r) atomicAdd(&sc[2], 1);
+    const long long n2 = (hi - lo) >> 1;
+    const ulonglong2 *row2 = reinterpret_cast<const ulonglong2 *>(row + lo);
+    // column of the first element of pair i: (lo + 2 i) mod 3, stepped without divisions: PROLOGUE_THREADS = 1024 = 1 mod 3
+    unsigned c = (unsigned)((lo + 2 * (long long)(threadIdx.x % 3)) % 3);   // pair i = threadIdx.x
+    long long i = threadIdx.x;
+    for (; i + 7 * (long long)PROLOGUE_THREADS < n2; i += 8 * (long long)PROLOGUE_THREADS) {
+        ulonglong2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = row2[i + u * (long long)PROLOGUE_THREADS];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            check(c, (int64_t)v[u].x);
+            check(c == 2u ? 0u : c + 1u, (int64_t)v[u].y);
+            c = (c + 2u) % 3u;      // pair index + 1024: element index + 2048 = + 2 mod 3
+        }
     }
-    __threadfence();
+    for (; i < n2; i += PROLOGUE_THREADS) {
+        const ulonglong2 v = row2[i];
+        check(c, (int64_t)v.x);
+        check(c == 2u ? 0u : c + 1u, (int64_t)v.y);
+        c = (c + 2u) % 3u;
+    }
+    if (((hi - lo) & 1) && threadIdx.x == 0) check((unsigned)((hi - 1) % 3), row[hi - 1]);
     __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(&sc[3], 1) == PROLOGUE_SPLIT - 1) {
-        const int bad_h = atomicAdd(&sc[0], 0), bad_t = atomicAdd(&sc[1], 0), bad_r = atomicAdd(&sc[2], 0);
-        const int tail_row = bad_h == 0;     // base_nbfnet.py:82 is_t_neg
+    if (__any(bad_h) && (threadIdx.x & 63) == 0) atomicOr(&lds_bad[0], 1);
+    if (__any(bad_t) && (threadIdx.x & 63) == 0) atomicOr(&lds_bad[1], 1);
+    if (__any(bad_r) && (threadIdx.x & 63) == 0) atomicOr(&lds_bad[2], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int any_h = lds_bad[0], any_t = lds_bad[1], any_r = lds_bad[2];
+        const int tail_row = any_h == 0;     // base_nbfnet.py:82 is_t_neg
         side[b] = tail_row;
         h0[b] = tail_row ? fh : ft;
         r0[b] = tail_row ? fr : fr + num_direct_rel;
-        valid[b] = ((bad_h == 0 || bad_t == 0) && bad_r == 0) ? 1 : 0;
-        sc[0] = sc[1] = sc[2] = sc[3] = 0;      // ready for the next launch (or graph replay)
+        valid[b] = ((any_h == 0 || any_t == 0) && any_r == 0) ? 1 : 0;
     }
 }
 
@@ -136,7 +132,7 @@ extern "C" int32_t ultra_batch_prologue(const int64_t *batch, int64_t batch_size
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (batch_size == 0) return ULTRA_OK;
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
-    hipLaunchKernelGGL(ultra::batch_prologue_kernel, dim3(ultra::PROLOGUE_SPLIT, (unsigned)batch_size), dim3(256), 0, s, batch, (long long)n_cand,
+    hipLaunchKernelGGL(ultra::batch_prologue_kernel, dim3((unsigned)batch_size), dim3(ultra::PROLOGUE_THREADS), 0, s, batch, (long long)n_cand,
                        (long long)num_direct_rel, h0, r0, side, valid, scratch);
     if (hipGetLastError() != hipSuccess) {
         ultra::set_error("batch_prologue_kernel launch failed");
