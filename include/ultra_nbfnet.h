@@ -80,13 +80,12 @@ int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1
  *             into a tail query with the inverse relation r + num_direct_rel);
  *   h0[b], r0[b] = source node / query relation of row b after that conversion;
  *   valid[b] = 1 iff row b shares its source node and its relation (the reference's two asserts), else 0  (int32 [batch]).
- * scratch: 4 int32 per batch row, ZERO on entry and left zero on exit (16 workgroups per row meet there; the last one to
- * arrive writes the results and clears it): zero it once at allocation, never inside a captured graph; one buffer per
- * stream that may run a prologue concurrently.
+ * rel_first (optional, int64 [batch]): row b's relation as given, triples[b, 0, 2] -- the relation model's query
+ * (/root/reference/ultra/models.py:20).  One workgroup per row: no scratch, any number of prologues may run concurrently.
  * ultra_readout_batch is ultra_readout reading the candidate node straight from `triples` (column 1 or 0 by side[b]).
  */
 int32_t ultra_batch_prologue(const int64_t *triples, int64_t batch, int64_t n_cand, int64_t num_direct_rel, int64_t *h0,
-                             int64_t *r0, int32_t *side, int32_t *valid, int32_t *scratch, void *stream);
+                             int64_t *r0, int32_t *side, int32_t *valid, int64_t *rel_first, void *stream);
 int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const int32_t *side, const void *w1, const void *query,
                             const void *b1, const void *w2, const void *b2, const int32_t *order_dev, int64_t order_len,
                             void *score, int64_t batch, int64_t num_node, int64_t n_cand, int32_t hidden_dim,

@@ -104,24 +104,3 @@ def test_raw_triples_reader_builds_the_reference_fact_graph(tmp_path):
     assert d3.relation_graph.num_nodes == 4
 
 
-def test_own_prologue_scratch_is_scoped_to_the_block_and_the_thread():
-    """dense.own_prologue_scratch: captured forwards that may run concurrently each bring their own meeting buffer for the batch
-    prologue's workgroups; outside the block (and on other threads) the device-wide buffer is used again."""
-    import threading
-    from ultra_amd import dense
-    a = torch.zeros(1024, dtype=torch.int32)
-    b = torch.zeros(2048, dtype=torch.int32)
-    assert getattr(dense._PROLOGUE_SCRATCH_OWNER, "buf", None) is None
-    with dense.own_prologue_scratch(a):
-        assert dense._prologue_scratch(a.device, 8) is a
-        with dense.own_prologue_scratch(b):
-            assert dense._prologue_scratch(b.device, 8) is b
-        assert dense._prologue_scratch(a.device, 8) is a
-        seen = []
-        t = threading.Thread(target=lambda: seen.append(getattr(dense._PROLOGUE_SCRATCH_OWNER, "buf", None)))
-        t.start()
-        t.join()
-        assert seen == [None]
-        with pytest.raises(RuntimeError):
-            dense._prologue_scratch(a.device, 1000)          # 4 * 1000 words do not fit
-    assert getattr(dense._PROLOGUE_SCRATCH_OWNER, "buf", None) is None

@@ -1,0 +1,45 @@
+"""The benchmark step, measured for A/B comparisons on one box: captured Ultra.forward on the FB15k237 shape, batch 8, one
+batch at a time and two in flight; `reps` runs of `steps` steps each, median / min / max of ms per step.
+    python tools/step_probe.py [reps] [steps]      env: ULTRA_NO_PREFILL=1 (entity layer-0 fill behind the relation model)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ultra_amd import models, synthetic, tasks
+from ultra_amd.graph import GraphedForward, PipelinedForward
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 9
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+if os.environ.get("ULTRA_NO_PREFILL"):
+    models.PREFILL_LAYER0 = False
+dev = torch.device("cuda:0")
+shape = os.environ.get("PROBE_SHAPE", "fb15k237")
+data = synthetic.make_kg(**synthetic.SHAPES[shape], seed=1234).to(dev)
+model = models.Ultra(**synthetic.default_model_cfg())
+model.load_state_dict(torch.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ultra_3g_model.pt")))
+model = model.to(dev).eval()
+triples = data.target_triples
+inputs = [tasks.all_negative(data, triples[8 * i:8 * i + 8])[0] for i in range(16)]
+
+
+def measure(fwd, join):
+    out = []
+    with torch.no_grad():
+        for _ in range(5):
+            fwd(inputs[0])
+        for r in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                fwd(inputs[i % 16])
+            join()
+            torch.cuda.synchronize()
+            out.append((time.perf_counter() - t0) / steps * 1e3)
+    out.sort()
+    return out[len(out) // 2], out[0], out[-1]
+
+
+one = GraphedForward(model, data, inputs[0])
+print("one batch at a time: median %.4f  min %.4f  max %.4f ms per step" % measure(one, lambda: None))
+del one
+two = PipelinedForward(model, data, inputs[0], depth=2)
+print("two in flight:       median %.4f  min %.4f  max %.4f ms per step" % measure(two, two.join))

@@ -56,13 +56,12 @@ __global__ void __launch_bounds__(256) filtered_rank_kernel(const float *__restr
 // its index mod 3) and the verdicts are combined inside the workgroup.  History, measured in the captured forward at the
 // benchmark point (2.8 MB): three 8-byte loads per candidate at a 24-byte lane stride, 16 workgroups per row meeting
 // through device-scope atomics -- 15.6 us; 64 workgroups per row with coalesced loads -- 38.7 us: the 64 arrival tickets of
-// a row are atomics on ONE address issued from eight XCDs, which the memory side serialises at ~0.5 us apiece.  `scratch`
-// (the former meeting buffer) is unused and kept in the signature for the ABI.
+// a row are atomics on ONE address issued from eight XCDs, which the memory side serialises at ~0.5 us apiece.
+// rel_first[b] (optional) = the row's relation as given, triples[b, 0, 2]: the relation model's query (models.py:20).
 constexpr int PROLOGUE_THREADS = 1024;
 __global__ void __launch_bounds__(PROLOGUE_THREADS) batch_prologue_kernel(const int64_t *__restrict__ batch, long long n_cand,
                                                                          long long num_direct_rel, int64_t *h0, int64_t *r0,
-                                                                         int32_t *side, int32_t *valid, int32_t *scratch) {
-    (void)scratch;
+                                                                         int32_t *side, int32_t *valid, int64_t *rel_first) {
     __shared__ int lds_bad[3];
     const int b = blockIdx.x;
     const long long L = 3 * n_cand;
@@ -116,16 +115,17 @@ __global__ void __launch_bounds__(PROLOGUE_THREADS) batch_prologue_kernel(const 
         h0[b] = tail_row ? fh : ft;
         r0[b] = tail_row ? fr : fr + num_direct_rel;
         valid[b] = ((any_h == 0 || any_t == 0) && any_r == 0) ? 1 : 0;
+        if (rel_first) rel_first[b] = fr;
     }
 }
 
 }  // namespace ultra
 
 extern "C" int32_t ultra_batch_prologue(const int64_t *batch, int64_t batch_size, int64_t n_cand, int64_t num_direct_rel,
-                                        int64_t *h0, int64_t *r0, int32_t *side, int32_t *valid, int32_t *scratch,
+                                        int64_t *h0, int64_t *r0, int32_t *side, int32_t *valid, int64_t *rel_first,
                                         void *stream) {
     ULTRA_DEVICE_SCOPE(stream, batch);
-    if (!batch || !h0 || !r0 || !side || !valid || !scratch || batch_size < 0 || n_cand <= 0) {
+    if (!batch || !h0 || !r0 || !side || !valid || batch_size < 0 || n_cand <= 0) {
         ultra::set_error("ultra_batch_prologue: NULL operand or empty candidate set");
         return ULTRA_ERR_INVALID;
     }
@@ -133,7 +133,7 @@ extern "C" int32_t ultra_batch_prologue(const int64_t *batch, int64_t batch_size
     if (batch_size == 0) return ULTRA_OK;
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
     hipLaunchKernelGGL(ultra::batch_prologue_kernel, dim3((unsigned)batch_size), dim3(ultra::PROLOGUE_THREADS), 0, s, batch, (long long)n_cand,
-                       (long long)num_direct_rel, h0, r0, side, valid, scratch);
+                       (long long)num_direct_rel, h0, r0, side, valid, rel_first);
     if (hipGetLastError() != hipSuccess) {
         ultra::set_error("batch_prologue_kernel launch failed");
         return ULTRA_ERR_HIP;

@@ -2,7 +2,6 @@
 torch op chains `cat -> Linear -> LayerNorm -> ReLU (-> + residual)` (layers.py:233-240, models.py:158-160)
 and `cat -> gather -> Linear -> ReLU -> Linear` (models.py:166-170, 202-209) on the inference path."""
 import ctypes
-import threading
 
 import torch
 from torch.autograd.function import once_differentiable
@@ -148,65 +147,26 @@ def readout(model, hidden, query, t_index, order=None):
     return score
 
 
-_PROLOGUE_SCRATCH = {}
-_PROLOGUE_SCRATCH_RETIRED = []   # outgrown buffers: never freed (a captured hipGraph may still point at one)
-
-
-_PROLOGUE_SCRATCH_OWNER = threading.local()   # .buf: a caller-owned meeting buffer (graph.GraphedForward: one per captured forward)
-
-
-class own_prologue_scratch(object):
-    """with own_prologue_scratch(buf): ...   -- prologues launched by this thread inside the block meet in `buf` (int32 zeros,
-    >= 4 * batch words) instead of the device-wide buffer: forwards that may run concurrently on different streams (two captured
-    forwards in flight) must not share a meeting point."""
-
-    def __init__(self, buf):
-        self.buf = buf
-
-    def __enter__(self):
-        self.prev = getattr(_PROLOGUE_SCRATCH_OWNER, "buf", None)
-        _PROLOGUE_SCRATCH_OWNER.buf = self.buf
-        return self.buf
-
-    def __exit__(self, *exc):
-        _PROLOGUE_SCRATCH_OWNER.buf = self.prev
-        return False
-
-
-def _prologue_scratch(device, bs):
-    """The meeting point of the prologue's workgroups: zero on entry, left zero on exit.  One per device, allocated by the
-    first (eager) call so that a later hipGraph capture finds it in place; prologues of one device are expected on one
-    stream at a time (the C entry takes the buffer as an argument for callers that need more).  A buffer that was handed
-    out once stays allocated for the life of the process: a GraphedForward captured earlier keeps its raw pointer, and the
-    kernel increments and re-zeroes words of it on every replay."""
-    own = getattr(_PROLOGUE_SCRATCH_OWNER, "buf", None)
-    if own is not None:
-        if own.numel() < 4 * bs or own.device != torch.device(device):
-            raise RuntimeError("own_prologue_scratch: the buffer holds %d words on %s, the batch needs %d on %s"
-                               % (own.numel(), own.device, 4 * bs, device))
-        return own
-    key = str(device)
-    buf = _PROLOGUE_SCRATCH.get(key)
-    if buf is None or buf.numel() < 4 * bs:
-        if buf is not None:
-            _PROLOGUE_SCRATCH_RETIRED.append(buf)
-        buf = torch.zeros(4 * max(bs, 256), dtype=torch.int32, device=device)
-        _PROLOGUE_SCRATCH[key] = buf
-    return buf
+class Prologue(tuple):
+    """(batch, h0, r0, side, valid) of batch_prologue, plus .rel_first: every row's relation as given (the relation model's
+    query, models.py:20) -- Ultra.forward runs the prologue once, ahead of the relation model, and hands it on."""
+    rel_first = None
 
 
 def batch_prologue(batch, num_direct_rel):
-    """(h0, r0, side, valid) of a (bs, n_cand, 3) GPU batch in one kernel (models.py:190-197, base_nbfnet.py:79-86)."""
+    """(batch, h0, r0, side, valid) of a (bs, n_cand, 3) GPU batch in one kernel (models.py:190-197, base_nbfnet.py:79-86)."""
     batch = batch.contiguous()
     bs, n_cand = batch.shape[:2]
-    scratch = _prologue_scratch(batch.device, bs)
     h0 = torch.empty(bs, dtype=torch.long, device=batch.device)
     r0 = torch.empty_like(h0)
+    rel_first = torch.empty_like(h0)
     side = torch.empty(bs, dtype=torch.int32, device=batch.device)
     valid = torch.empty(bs, dtype=torch.int32, device=batch.device)
     check(lib.ultra_batch_prologue(batch.data_ptr(), bs, n_cand, int(num_direct_rel), h0.data_ptr(), r0.data_ptr(),
-                                   side.data_ptr(), valid.data_ptr(), scratch.data_ptr(), _stream(batch)))
-    return batch, h0, r0, side, valid
+                                   side.data_ptr(), valid.data_ptr(), rel_first.data_ptr(), _stream(batch)))
+    out = Prologue((batch, h0, r0, side, valid))
+    out.rel_first = rel_first
+    return out
 
 
 def readout_batch(model, hidden, query, batch, side, order=None):

@@ -29,9 +29,6 @@ class GraphedForward(object):
         self.warmup = warmup
         self.static_batch = example_batch.clone()
         self._pinned = []
-        # this forward's own meeting buffer for the batch prologue's workgroups (dense.own_prologue_scratch): captured forwards
-        # may be replayed concurrently on different streams (PipelinedForward)
-        self._scratch = torch.zeros(4 * max(int(example_batch.shape[0]), 256), dtype=torch.int32, device=example_batch.device)
         self._capture()
 
     def _param_state(self):
@@ -49,7 +46,7 @@ class GraphedForward(object):
         with torch.cuda.device(self.static_batch.device):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.no_grad(), torch.cuda.stream(side), rspmm.record_plans() as used, dense.own_prologue_scratch(self._scratch):
+            with torch.no_grad(), torch.cuda.stream(side), rspmm.record_plans() as used:
                 for _ in range(self.warmup):
                     model(data, self.static_batch)
             torch.cuda.current_stream().wait_stream(side)
@@ -60,8 +57,7 @@ class GraphedForward(object):
             self.graph = torch.cuda.CUDAGraph()
             # thread-local capture mode: helper threads of the process (RCCL's watchdog polls events) must not be able to
             # invalidate the capture; everything captured here is enqueued by this thread
-            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"), \
-                    dense.own_prologue_scratch(self._scratch):
+            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.static_out = model(data, self.static_batch)
             # the first launch of an instantiated graph also uploads it (kernel arguments, node descriptors): done here, as
             # part of building the graph, not by the caller's first batch
@@ -183,8 +179,6 @@ class GraphedEvalStep(object):
         self.rows[:batch_size, 2] = 1
         self._pinned = []
         n = data.num_nodes
-        # own meeting point of the batch prologues (see GraphedForward): two captured steps may be in flight on two streams
-        self._scratch = torch.zeros(4 * max(int(batch_size), 256), dtype=torch.int32, device=dev)
 
         def step():
             t_batch, h_batch = tasks.all_negative(data, self.batch)
@@ -203,7 +197,7 @@ class GraphedEvalStep(object):
         with torch.cuda.device(dev):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.no_grad(), torch.cuda.stream(side), rspmm.record_plans() as used, dense.own_prologue_scratch(self._scratch):
+            with torch.no_grad(), torch.cuda.stream(side), rspmm.record_plans() as used:
                 for _ in range(warmup):
                     step()
             torch.cuda.current_stream().wait_stream(side)
@@ -212,8 +206,7 @@ class GraphedEvalStep(object):
             for plan in self._pinned:
                 plan.pin(+1)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"), \
-                    dense.own_prologue_scratch(self._scratch):
+            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 step()
 
     def __call__(self, batch, t_ptr, h_ptr):

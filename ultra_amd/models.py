@@ -18,7 +18,9 @@ from . import dense, layers, tasks
 # inference fast path of EntityNBFNet.forward: fused batch prologue + readout from the raw batch (A/B switch for tests)
 PROLOGUE_FAST_PATH = True
 # the constant rows of the entity model's layer 0 are written on a side stream beside the relation model (EntityNBFNet.prefill_layer0)
-PREFILL_LAYER0 = True
+# (measured on MI355X, tools/step_probe.py: the fork / join of the side stream inside the captured graph costs more than the
+# 11 us of fill it hides -- 0.717 vs 0.687 ms per step one batch at a time, 0.631 vs 0.621 two in flight -- so: off)
+PREFILL_LAYER0 = False
 
 
 class NotOnFusedPath(RuntimeError):
@@ -314,7 +316,12 @@ class EntityNBFNet(BaseNBFNet):
             "edge_weights": edge_weights,
         }
 
-    def forward(self, data, relation_representations, batch, prefill=None):
+    def prologue_supported(self, batch):
+        """The inference fast path of forward(): one prologue kernel instead of the index arithmetic of models.py:190-197."""
+        return (PROLOGUE_FAST_PATH and not self.training and not torch.is_grad_enabled() and batch.is_cuda
+                and batch.dtype == torch.long and batch.dim() == 3 and not self.concat_hidden)
+
+    def forward(self, data, relation_representations, batch, prefill=None, prologue=None):
         h_index, t_index, r_index = batch.unbind(-1)
         prefilled = None
         if prefill is not None:       # (prefill_layer0: the side stream joins here, whatever path the forward takes)
@@ -340,11 +347,10 @@ class EntityNBFNet(BaseNBFNet):
                 data = self.remove_easy_edges(data, h_index, t_index, r_index)
 
         shape = h_index.shape
-        if (PROLOGUE_FAST_PATH and edge_weight is None and not self.training and not torch.is_grad_enabled() and batch.is_cuda
-                and batch.dtype == torch.long and batch.dim() == 3 and not self.concat_hidden):
+        if edge_weight is None and self.prologue_supported(batch):
             # inference fast path: one prologue kernel (row uniformity, head->tail conversion, validity flag) and
             # a readout that picks its candidate column straight from the raw batch
-            batch_c, h0, r0, side, valid = dense.batch_prologue(batch, data.num_relations // 2)
+            batch_c, h0, r0, side, valid = prologue if prologue is not None else dense.batch_prologue(batch, data.num_relations // 2)
             hiddens, _, query = self._bellmanford_hidden(data, h0, r0, prefilled=prefilled)
             if dense.readout_supported(self, hiddens[-1]):
                 score = dense.readout_batch(self, hiddens[-1], query, batch_c, side).view(shape)
@@ -433,11 +439,18 @@ class Ultra(nn.Module):
 
     def forward(self, data, batch):
         # batch: (bs, 1 + num_negs, 3); the relation is shared by every triple of a row
-        query_rels = batch[:, 0, 2]
+        prologue = None
+        if getattr(self.entity_model, "prologue_supported", lambda b: False)(batch):
+            # the batch prologue first: it also hands out every row's relation as a contiguous vector -- the relation model's
+            # query -- which otherwise costs a strided 8-element copy kernel (6 us in the captured forward)
+            prologue = dense.batch_prologue(batch, data.num_relations // 2)
+            query_rels = prologue.rel_first
+        else:
+            query_rels = batch[:, 0, 2]
         prefill = None
         if PREFILL_LAYER0 and batch.is_cuda and batch.dim() == 3 and hasattr(self.entity_model, "prefill_layer0"):
             prefill = self.entity_model.prefill_layer0(data, batch.shape[0])
         relation_representations = self.relation_model(data.relation_graph, query=query_rels)
-        if prefill is not None:
-            return self.entity_model(data, relation_representations, batch, prefill=prefill)
+        if prefill is not None or prologue is not None:
+            return self.entity_model(data, relation_representations, batch, prefill=prefill, prologue=prologue)
         return self.entity_model(data, relation_representations, batch)
