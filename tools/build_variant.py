@@ -24,7 +24,7 @@ def main():
     procs = []
     for src in B._sources():
         base = os.path.basename(src)
-        if base.startswith("rspmm_order_") or base in ("rspmm_api.hip", "plan.cpp", "dense_kernels.hip"):
+        if base.startswith("rspmm_order_") or base in ("rspmm_api.hip", "plan.cpp", "dense_kernels.hip", "dense_order_layer.hip"):
             obj = os.path.join(odir, base + ".o")
             cmd = [B.HIPCC] + B.CFLAGS + flags + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
             procs.append((subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), src))

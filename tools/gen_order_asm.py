@@ -297,7 +297,9 @@ def gen_stream(sum_code, mul_code, rec_policy, post=False):
 # neighbouring workgroup's chunk -- valid addresses whose data nobody consumes.
 PROD_D = 8
 PROD_CLOBBER_LO, PROD_CLOBBER_HI = 44, 127
-RING_HALF_BYTES = 15 * 64 * 16
+# (ULTRA_GEN_WAVES: waves per workgroup of the build the header is generated for -- plan.hpp ULTRA_ORDER_WAVES)
+GEN_WAVES = int(os.environ.get("ULTRA_GEN_WAVES", "16"))
+RING_HALF_BYTES = (GEN_WAVES - 1) * 64 * 16
 
 
 def gen_producer(mul_code, rec_policy):

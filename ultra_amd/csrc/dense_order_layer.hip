@@ -50,7 +50,14 @@ constexpr int DOL_ROW_STRIDE = 68;   // floats per LDS tile row (see dense_layer
 
 __device__ __forceinline__ float byte_of(uint32_t w, int q) { return (float)((w >> (8 * q)) & 0xffu); }
 
-__global__ void __launch_bounds__(256) dense_order_layer_kernel(const DenseOrderParams p) {
+// ULTRA_DOL_VGPR_CAP (measurement builds): keep the kernel to 128 registers per lane, so that one of its workgroups (one wave
+// per SIMD) fits beside a 12-wave reference-order workgroup of ANOTHER launch on the same CU (plan.hpp ULTRA_ORDER_WAVES)
+#ifdef ULTRA_DOL_VGPR_CAP
+#define ULTRA_DOL_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define ULTRA_DOL_ATTR
+#endif
+__global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(const DenseOrderParams p) {
     __shared__ __attribute__((aligned(16))) float x_lds[16 * DOL_ROW_STRIDE];     // this tile's own rows of x
     __shared__ __attribute__((aligned(16))) float agg_lds[16 * DOL_ROW_STRIDE];
     __shared__ float ln_mom[16][8][2];

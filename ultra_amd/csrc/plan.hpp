@@ -36,8 +36,15 @@ struct Chunk {
     int32_t row, begin, count, flags;   // flags: CHUNK_FIRST / CHUNK_LAST chunk of its row; a first chunk: | row length << 2
 };
 enum { CHUNK_FIRST = 1, CHUNK_LAST = 2, CHUNK_LEN_SHIFT = 2 };
-constexpr int CHAIN_SLOTS = 60;          // producer groups of a 1024-thread workgroup (15 waves x 4)
-constexpr int ORDER_GROUPS = 64;        // 16-lane groups of a 1024-thread workgroup
+// ULTRA_ORDER_WAVES: waves per workgroup of the reference-order kernels (16 = 1024 threads: a workgroup owns its CU).  12
+// (768 threads, 44-edge chunks) leaves a CU four wave slots, a quarter of its registers and ~20 KB of LDS: room for the
+// latency-bound kernels of ANOTHER batch's forward (the relation-graph layers) to run beside the walk -- see DESIGN.md 3.9.
+#ifndef ULTRA_ORDER_WAVES
+#define ULTRA_ORDER_WAVES 16
+#endif
+constexpr int ORDER_WAVES = ULTRA_ORDER_WAVES;
+constexpr int CHAIN_SLOTS = 4 * (ORDER_WAVES - 1);   // producer groups of a workgroup (every wave but the consumer, x 4)
+constexpr int ORDER_GROUPS = 4 * ORDER_WAVES;        // 16-lane groups of a workgroup
 // Chain and stream phases side by side (the fp32 stream kernels): wave 0 consumes, waves 1..ORDER_OV_PRODUCERS produce two
 // messages per chunk each (half-chunks: slots 0..31, then 32..59), the remaining waves walk their streams from the start.
 // MEASUREMENT BUILD (-DULTRA_CHAIN_OVERLAP=1), not the default: bit-exact (tests/test_order_gpu.py), the average workgroup

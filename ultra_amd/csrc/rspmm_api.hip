@@ -421,7 +421,7 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
                 // lane in another row -- then compete with the gathers for the CU's texture-address path, which bounds the
                 // walk: 94.6 us per layer against the tail form's 94.0 at FB15k237 bs 8, 371 against 374 at CoDEx-L.
                 Schedule *sched12 = nullptr;
-                if (g_tuning.reserved[2] == 2 && upd->out_stride_row * (int64_t)sizeof(float) == (int64_t)op.x_row_bytes) {
+                if (g_tuning.reserved[2] == 2 && ORDER_WAVES == 16 && upd->out_stride_row * (int64_t)sizeof(float) == (int64_t)op.x_row_bytes) {
                     if ((rc = get_schedule(p, op.nparts, &sched12, ORDER_WALKERS))) return rc;
                     const size_t image = std::max(ring_bytes, (size_t)UPDATE_LDS_FLOATS * sizeof(float));
                     const size_t need = rel_bytes + image + UPDATE_CTL_QUEUE_OFF + (size_t)sched12->max_rows * 4 + 64;

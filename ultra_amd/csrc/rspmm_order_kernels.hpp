@@ -35,7 +35,7 @@
 
 namespace ultra {
 
-constexpr int ORDER_THREADS = 1024;
+constexpr int ORDER_THREADS = 64 * ORDER_WAVES;
 // UPDATE == 2 (the layer update runs BESIDE the walk): waves [0, ORDER_WALKERS) walk the streams, the last ORDER_UPDATERS
 // waves -- one per SIMD -- multiply the rows the walkers hand over.  Hand-off block in LDS (the generator's HANDOFF_*
 // constants are the same numbers): word 0 queue tail, 1 walkers done, 2 weight image ready, 3 chain done, then
@@ -377,8 +377,15 @@ __device__ __forceinline__ void post_row(const uint32_t ctl_addr, const uint32_t
 // BESIDE the walk -- the last ORDER_UPDATERS waves do not walk: they wait for rows the walkers hand over through an LDS
 // queue and multiply them on the matrix cores while the walk goes on (what is left when the walks end is at most one
 // tile per update wave).
+// (a workgroup of fewer than sixteen waves still keeps to 128 registers per lane: the wave slots it leaves are meant for
+// workgroups of other kernels, which need their share of the register file)
+#if ULTRA_ORDER_WAVES < 16
+#define ULTRA_ORDER_VGPR_CAP __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define ULTRA_ORDER_VGPR_CAP
+#endif
 template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED, bool STREAMS, int UPDATE = 0>
-__global__ void __launch_bounds__(ORDER_THREADS) rspmm_order_kernel(const OrderParams p) {
+__global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_order_kernel(const OrderParams p) {
     static_assert(!STREAMS || OrderAsm<T, MUL, REL_LDS, WEIGHTED>::value, "group streams exist for the assembly configurations only");
     static_assert(!UPDATE || (STREAMS && sizeof(T) == 4), "the layer update follows the fp32 stream walk");
     constexpr int SPAN = 64;
