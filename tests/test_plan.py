@@ -358,3 +358,12 @@ def test_generated_assembly_header_is_in_sync_with_its_generator(tmp_path, monke
     assert fresh.count("asm volatile(") == 18 and fresh.count('"memory"') == 18
     for block in fresh.split("asm volatile(")[1:]:
         assert "s_waitcnt vmcnt(0)" in block.split(");")[0]
+    # ... and the relation-graph layer's chain (a measurement build: csrc/dense_order_asm.hpp, tools/gen_dense_order_asm.py)
+    for k in ("ULTRA_GEN_DOL_NS", "ULTRA_GEN_DOL_TOUCH"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("ULTRA_GEN_DENSE_OUT", str(tmp_path / "dense_asm.hpp"))
+    spec = importlib.util.spec_from_file_location("gen_dense_order_asm", os.path.join(root, "tools", "gen_dense_order_asm.py"))
+    gen2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen2)
+    gen2.main()
+    assert (tmp_path / "dense_asm.hpp").read_text() == open(os.path.join(root, "ultra_amd", "csrc", "dense_order_asm.hpp")).read()

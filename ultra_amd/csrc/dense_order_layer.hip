@@ -24,8 +24,23 @@
 #include <cstdint>
 #include <string>
 
+#ifdef ULTRA_DOL_ASM_HEADER   // measurement builds: a header generated with other switches (tools/build_variant.py)
+#include ULTRA_DOL_ASM_HEADER
+#else
+#include "dense_order_asm.hpp"
+#endif
 #include "plan.hpp"
 #include "torch_math.hpp"
+
+// MEASUREMENT BUILD (-DULTRA_DOL_ASM=1): the chain of phase 1 as generated assembly (tools/gen_dense_order_asm.py) -- four
+// stages of operands in flight, every wait counted, optionally a touch of the whole x slice up front.  hipcc's loop (below: three
+// stages) drains its load queue once per iteration (s_waitcnt vmcnt(0) a third into the body), which looked like the reason
+// why the chain runs at 67 cycles per column against the instruction's 32-36.  It is not: bit-exact, and 21.7 us per layer
+// against the C++ loop's 21.5 (with the touch: 22.6) on one box (round 4, tools/dense_order_probe.py) -- the chain does not wait
+// for memory; the byte -> float conversion, the product and the load issue of a column do not hide under its matrix instruction.
+#ifndef ULTRA_DOL_ASM
+#define ULTRA_DOL_ASM 0
+#endif
 
 #pragma clang fp contract(off)
 
@@ -79,6 +94,7 @@ __global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(c
     const char *xbase = reinterpret_cast<const char *>(xo);
     const uint32_t x_row_bytes = (uint32_t)p.x_sr * 4u;
     const uint32_t lane_bytes = (uint32_t)(c0 + i16) * 4u;       // B operand: lane (kk, n) reads x[j][c0 + n]
+#if !ULTRA_DOL_ASM
     uint32_t voff[16], voff_last[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -103,6 +119,7 @@ __global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(c
     fetch(0, st0);
     fetch(1, st1);
     fetch(2, st2);
+#endif
     const float relv = kk < p.n_rel ? p.rel[(long long)outer * p.rel_so + (long long)kk * p.rel_sr + c0 + i16] : 0.f;
 
     // the tile's own x rows (update input and residual), the update weights of this wave's feature tile and the small
@@ -138,6 +155,9 @@ __global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(c
     f32x4 acc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = 0.f;
+#if ULTRA_DOL_ASM
+    dense_order_chain_asm(acc, p.n_jc, p.n_in, (uint32_t)lane * 16u, ap, xbase, lane_bytes, x_row_bytes, relv, (uint32_t)tid * 128u);
+#else
     const auto chain = [&](const Stage &cur, const int jc) {
         // (stages past the graph chain zeros: fma(0, b, acc) = acc exactly -- rounds have no conditional exit, which
         // would be a join where the compiler stops counting outstanding loads and drains the queue)
@@ -158,6 +178,7 @@ __global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(c
         chain(st2, jc + 2);
         fetch(jc + 5, st2);
     }
+#endif
 
     // ---- phase 2: + boundary (layers.py:199-200), aggregate tile and x tile to LDS ----
     // D layout: lane l, reg r -> tile row 4 (l >> 4) + r, column l & 15
