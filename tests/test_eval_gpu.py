@@ -64,6 +64,35 @@ def test_evaluate_matches_reference_protocol(dev):
     assert res["mrr-tail"] == pytest.approx((1 / tail).mean().item())
 
 
+def test_cached_relation_representations_give_the_same_bits(dev):
+    """Ultra.cache_relation_representations: the relation model's output depends on the query relation only (models.py:20-21),
+    so a table of all of them, computed once, serves every batch -- same scores bit for bit, same metrics from evaluate();
+    a table whose weights have moved is dropped, not used."""
+    from tests.test_oracle_model import load_golden
+    from ultra_amd import eval as ueval
+    from ultra_amd import models, synthetic, tasks
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    data = synthetic.make_kg(num_node=400, num_triple=3000, num_relation_base=5, num_test=40, seed=3).to(dev)
+    model = models.Ultra(**cfg)
+    model.load_state_dict(state)
+    model = model.to(dev).eval()
+    t_batch, h_batch = tasks.all_negative(data, data.target_triples[:8])
+    with torch.no_grad():
+        plain_t, plain_h = model(data, t_batch), model(data, h_batch)
+        table = model.cache_relation_representations(data)
+        assert tuple(table.shape) == (data.num_relations, data.num_relations, 64)
+        assert torch.equal(model(data, t_batch), plain_t) and torch.equal(model(data, h_batch), plain_h)
+        # stale table: a weight of the relation model changes -> the next forward recomputes (and equals an uncached run)
+        model.relation_model.layers[0].linear.bias.add_(0.25)
+        moved = model(data, t_batch)
+        assert getattr(model, "_rel_table", None) is None and not torch.equal(moved, plain_t)
+        model.relation_model.layers[0].linear.bias.sub_(0.25)
+    names = ("mr", "mrr", "hits@1", "hits@10", "mrr-tail")
+    with_table = ueval.evaluate(model, data, batch_size=8, metrics=names, cache_relations=True)
+    without = ueval.evaluate(model, data, batch_size=8, metrics=names, cache_relations=False)
+    assert with_table == without and getattr(model, "_rel_table", None) is None
+
+
 def test_graph_replay_stays_correct_when_interleaved_with_eager_work(dev):
     """Regression: hipGraph replays of the forward interleaved with eager forwards / ranking kernels must keep
     matching the eager scores (memset NODES captured from hipMemsetAsync were observed to go stale on ROCm 7.2

@@ -50,10 +50,13 @@ def metrics_from_rankings(ranking, num_negative, metric_names):
 
 @torch.no_grad()
 def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", "mrr", "hits@1", "hits@3", "hits@10"),
-             max_triples=None, use_graph=True, in_flight=None):
+             max_triples=None, use_graph=True, in_flight=None, cache_relations=None):
     """Returns {metric: value} on every rank (the reference only fills it on rank 0).
     in_flight: captured evaluation steps replayed round-robin on as many streams (1 or 2; None: 2 for shards of 128 full
-    batches or more, where the second capture pays for itself)."""
+    batches or more, where the second capture pays for itself).
+    cache_relations: compute the relation model's output for every relation once (Ultra.cache_relation_representations: it
+    depends on the query relation only) instead of once per batch and direction; same bits, same metrics.  None: when the
+    shard has at least as many batches as the graph has relation chunks (then the table costs less than it saves)."""
     world, rank = udist.world_size(), udist.rank()
     triples = torch.cat([test_data.target_edge_index, test_data.target_edge_type.unsqueeze(0)]).t()
     if max_triples is not None:
@@ -67,6 +70,15 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
     was_training = model.training
     model.eval()
     rows = []
+    made_table = False
+    if hasattr(model, "cache_relation_representations") and mine.is_cuda and getattr(test_data, "relation_graph", None) is not None \
+            and getattr(model, "_rel_table", None) is None:
+        num_rel = int(test_data.relation_graph.num_nodes)
+        if cache_relations is None:
+            cache_relations = 2 * len(mine) // max(batch_size, 1) >= (num_rel + batch_size - 1) // batch_size
+        if cache_relations:
+            model.cache_relation_representations(test_data, chunk=batch_size)
+            made_table = True
     n_full = (len(mine) // batch_size) * batch_size
     start = 0
     if use_graph and mine.is_cuda and n_full >= 4 * batch_size:
@@ -136,6 +148,8 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
     else:
         local = torch.zeros(0, 3, dtype=torch.long, device=triples.device)
     flat = udist.all_gather_shards(local, len(triples), rows_per_item=2)     # the single collective of the evaluation
+    if made_table:
+        model.drop_relation_cache()
     model.train(was_training)
 
     ranking, num_neg, is_tail = flat[:, 0], flat[:, 1], flat[:, 2].bool()

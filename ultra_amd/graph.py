@@ -54,6 +54,8 @@ class GraphedForward(object):
             self._pinned = used.plans                 # exactly the plans the warm-up runs asked for
             for plan in self._pinned:
                 plan.pin(+1)
+            # (a table of cached relation representations the capture reads from stays alive with the capture)
+            self._rel_table_ref = getattr(model, "_rel_table", None)
             self.graph = torch.cuda.CUDAGraph()
             # thread-local capture mode: helper threads of the process (RCCL's watchdog polls events) must not be able to
             # invalidate the capture; everything captured here is enqueued by this thread

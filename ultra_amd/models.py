@@ -450,6 +450,48 @@ class Ultra(nn.Module):
         self.relation_model = globals()[rel_model_cfg.pop('class')](**rel_model_cfg)
         self.entity_model = globals()[entity_model_cfg.pop('class')](**entity_model_cfg)
 
+    # ---- relation representations of every query relation, computed once (opt-in) ----
+    # The relation model sees the relation graph and the query RELATION only (models.py:20-21): its output for relation r
+    # does not depend on the batch's heads, tails or candidates.  A job that scores many batches over one graph with fixed
+    # weights -- the filtered-ranking protocol: thousands of test triples over a few hundred relations -- may compute the
+    # (num_relations, num_relations, dim) table once and pick rows from it: the same kernels on the same inputs, hence the
+    # same bits.  NOT used by the benchmark's timed step (every step there runs the relation model, like the reference).
+    def cache_relation_representations(self, data, chunk=8):
+        """Fill the table for `data.relation_graph` under the current parameters (inference only); forward() then gathers
+        from it while the graph object and the parameters stay the same.  Returns the table."""
+        rg = data.relation_graph
+        dev = rg.edge_index.device
+        num_rel = int(rg.num_nodes)
+        was_training = self.training
+        self.eval()
+        rows = []
+        with torch.no_grad():
+            for lo in range(0, num_rel, chunk):
+                ids = torch.arange(lo, min(lo + chunk, num_rel), device=dev)
+                if ids.numel() < chunk:      # (one batch shape for every call: plans and kernels see what a forward shows them)
+                    ids = torch.cat([ids, ids.new_zeros(chunk - ids.numel())])
+                rows.append(self.relation_model(rg, query=ids)[: min(chunk, num_rel - lo)].clone())
+        self.train(was_training)
+        self._rel_table = torch.cat(rows)
+        self._rel_table_key = (id(rg), self._relation_param_state())
+        return self._rel_table
+
+    def drop_relation_cache(self):
+        self._rel_table = None
+        self._rel_table_key = None
+
+    def _relation_param_state(self):
+        return tuple((p.data_ptr(), p._version) for p in self.relation_model.parameters())
+
+    def _cached_relations(self, data, query_rels):
+        table = getattr(self, "_rel_table", None)
+        if table is None or self.training or torch.is_grad_enabled():
+            return None
+        if self._rel_table_key != (id(data.relation_graph), self._relation_param_state()):
+            self.drop_relation_cache()       # another graph, or the weights moved: the table is stale
+            return None
+        return table.index_select(0, query_rels)
+
     def forward(self, data, batch):
         # batch: (bs, 1 + num_negs, 3); the relation is shared by every triple of a row
         prologue = None
@@ -463,7 +505,9 @@ class Ultra(nn.Module):
         prefill = None
         if PREFILL_LAYER0 and batch.is_cuda and batch.dim() == 3 and hasattr(self.entity_model, "prefill_layer0"):
             prefill = self.entity_model.prefill_layer0(data, batch.shape[0])
-        relation_representations = self.relation_model(data.relation_graph, query=query_rels)
+        relation_representations = self._cached_relations(data, query_rels)
+        if relation_representations is None:
+            relation_representations = self.relation_model(data.relation_graph, query=query_rels)
         if prefill is not None or prologue is not None:
             return self.entity_model(data, relation_representations, batch, prefill=prefill, prologue=prologue)
         return self.entity_model(data, relation_representations, batch)
