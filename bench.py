@@ -797,6 +797,20 @@ def main():
                         "note": "--in-flight 1: every batch waits for its predecessor's readout (DESIGN.md 3.9)"}
                 finally:
                     args.in_flight = keep
+            # ---- NOT the timed mode: the relation model's output for every query relation computed once (it depends on the
+            # query relation only; Ultra.cache_relation_representations, what evaluate() does for long shards) ----
+            try:
+                model.cache_relation_representations(data, chunk=bs)
+                el5 = min(timed_run(make_forward(), False) for _ in range(2))
+                with torch.no_grad():
+                    got5 = model(data, t_batch_cpu.to(dev)).cpu()
+                out.setdefault("modes", {})["relation_table"] = {
+                    "timed": False, "triples_per_s": bs * N * args.steps / el5, "ms_per_step": 1e3 * el5 / args.steps,
+                    "scores_bit_equal_with_the_timed_mode": bool(torch.equal(got5, got)),
+                    "note": "work the timed step does is SKIPPED here (the relation model runs once per relation, not once per "
+                            "step): an engine feature for jobs that score many batches over one graph, not a benchmark figure"}
+            finally:
+                model.drop_relation_cache()
     if rank == 0 and world == 1 and not launched and not args.no_secondary:
         # ---- BASELINE.json config 5 (fine-tuning): fwd + bwd + AdamW per step, beside the headline ----
         sys.path.insert(0, os.path.join(ROOT, "tools"))

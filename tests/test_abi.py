@@ -121,7 +121,7 @@ def test_bench_names_the_timed_kernel_with_all_its_template_arguments():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = open(os.path.join(root, "ultra_amd", "csrc", "rspmm_order_kernels.hpp")).read()
-    m = re.search(r"template <([^>]*)>\s*__global__ void __launch_bounds__\(ORDER_THREADS\) rspmm_order_kernel", src)
+    m = re.search(r"template <([^>]*)>\s*__global__ void __launch_bounds__\(ORDER_THREADS\)(?: ULTRA_ORDER_VGPR_CAP)? rspmm_order_kernel", src)
     assert m, "kernel declaration not found"
     n_params = len(m.group(1).split(","))
     bench = open(os.path.join(root, "bench.py")).read()
