@@ -328,8 +328,10 @@ typedef struct {
     int32_t unroll;       /* edges in flight per lane group (0 -> default) */
     int32_t reserved[3];  /* [0] != 0: ULTRA_PLAN_EXACT_ORDER plans run on the general walk kernel instead of the order kernels;
                              [1] != 0: the order kernels walk units of four rows (C++ loop) instead of group streams (assembly);
-                             [2]: ultra_rspmm_forward_update -- 0 / 1 the update in the kernel's tail; 2 beside the walk, or
-                                  ULTRA_ERR_UNSUPPORTED where that form does not fit (LDS beside the relation slice, rows per workgroup) */
+                             [2]: ultra_rspmm_forward_update -- 0 / 1 the update in the kernel's tail; 2 beside the walk (finished rows
+                                  handed over by reference and read back from memory), 3 beside the walk with the aggregate passing
+                                  through LDS tiles (`aggregate` is then scratch: its contents are unspecified on return), or
+                                  ULTRA_ERR_UNSUPPORTED where the form does not fit (LDS beside the relation slice, rows per workgroup) */
 } ultra_tuning;
 int32_t ultra_set_tuning(const ultra_tuning *t);   /* NULL restores defaults */
 int32_t ultra_get_tuning(ultra_tuning *t);

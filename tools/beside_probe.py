@@ -81,21 +81,27 @@ def graphed(fn, n=20, reps=10):
 
 want = two()
 served = one(2) is not None
-print("%s bs %d %s: tail == two launches %s | beside == two launches %s" %
-      (shape, bs, agg_sum, torch.equal(one(1), want), torch.equal(one(2), want) if served else "not served"))
+served3 = one(3) is not None
+nan = float("nan")
+print("%s bs %d %s: tail == two launches %s | beside == two launches %s | beside through LDS == two launches %s" %
+      (shape, bs, agg_sum, torch.equal(one(1), want), torch.equal(one(2), want) if served else "not served",
+       torch.equal(one(3), want) if served3 else "not served"))
 for k in range(2):
-    print("back to back: aggregate %.1f us | two launches %.1f | tail %.1f | beside %.1f" %
-          (timed(agg_only), timed(two), timed(lambda: one(1)), timed(lambda: one(2)) if served else float("nan")))
-print("in a hipGraph of 20: aggregate %.1f us | two launches %.1f | tail %.1f | beside %.1f" %
-      (graphed(agg_only), graphed(two), graphed(lambda: one(1)), graphed(lambda: one(2)) if served else float("nan")))
+    print("back to back: aggregate %.1f us | two launches %.1f | tail %.1f | beside %.1f | beside through LDS %.1f" %
+          (timed(agg_only), timed(two), timed(lambda: one(1)), timed(lambda: one(2)) if served else nan,
+           timed(lambda: one(3)) if served3 else nan))
+print("in a hipGraph of 20: aggregate %.1f us | two launches %.1f | tail %.1f | beside %.1f | beside through LDS %.1f" %
+      (graphed(agg_only), graphed(two), graphed(lambda: one(1)), graphed(lambda: one(2)) if served else nan,
+       graphed(lambda: one(3)) if served3 else nan))
 # repeatability of the hand-off: 100 launches, every output compared
-if served:
-    outs = [one(2) for _ in range(100)]
-    torch.cuda.synchronize()
-    print("beside, 100 launches all equal to the two launches: %s" % all(torch.equal(o, want) for o in outs))
+for form, ok in ((2, served), (3, served3)):
+    if ok:
+        outs = [one(form) for _ in range(100)]
+        torch.cuda.synchronize()
+        print("form %d, 100 launches all equal to the two launches: %s" % (form, all(torch.equal(o, want) for o in outs)))
 
 if served:
-    for form in (1, 2):
+    for form in (1, 2) + ((3,) if served3 else ()):
         trace = torch.zeros(grid * 32, dtype=torch.int64, device=dev)
         one(form)
         torch.cuda.synchronize()

@@ -102,6 +102,57 @@ HANDOFF_TILE_OFF = 16
 HANDOFF_QUEUE_OFF = HANDOFF_TILE_OFF + 4 * HANDOFF_TILES
 
 
+# ---- hand-off form 2 (POST == 2): the flushed row itself goes to the update waves through LDS ----
+# Tiles of 16 rows x (256 + 16 pad) bytes, HANDOFF2_NT of them, reused round-robin by "generations" of 16 rows: slot g (from
+# the atomic tail) belongs to generation g / 16, tile buffer (g / 16) % NT, row g % 16.  Control block (byte offsets behind
+# qctl; rspmm_order_kernels.hpp has the same numbers): 0 tail, 4 walkers done, 8 update-wave barrier, 12 chain done,
+# 16 generations consumed, 32 + 4 buf: rows posted into buffer buf (monotonic: generation G is complete at 16 (G / NT + 1)),
+# 64 + 4 i: byte offset of the node row parked in tile row i (i < 16 NT).
+HANDOFF2_NT = 4
+HANDOFF2_ROW_BYTES = 272
+HANDOFF2_CONSUMED_OFF, HANDOFF2_POSTED_OFF, HANDOFF2_ROWID_OFF = 16, 32, 64
+
+
+def stream_park(a, ob_q, tag):
+    """Flush of form 2, for the lanes in %[mk] (the 16-lane groups at a marker): accumulator (boundary already applied) ->
+    a row of the current tile.  One lane per group takes the slot and later writes the row's id and bumps the buffer's
+    count; all 16 write their 16 bytes.  A slot of generation G may be written once generation G - NT has been consumed
+    (the update waves never wait for a walker that waits for them: the slots of the NT generations they may be working on
+    are all writable).  LDS operations of a wave execute in order: who sees the count sees the row.  Ends with every LDS
+    operation collected (the chunk's relation rows too: the counted waits of the remaining steps then pass at once)."""
+    a("v_cmp_eq_u32_e32 vcc, 0, %[lb]", "lane 0 of each group (whole-span rows: lb = 16 (lane % 16))")
+    a("s_and_b64 exec, %[mk], vcc")
+    a("ds_add_rtn_u32 v123, v124, v125", "slot = tail++")
+    a("s_mov_b64 exec, %[mk]")
+    a("s_waitcnt lgkmcnt(0)")
+    a("ds_swizzle_b32 v123, v123 offset:swizzle(BROADCAST,16,0)")
+    a("s_waitcnt lgkmcnt(0)")
+    a("v_lshrrev_b32_e32 v122, 4, v123", "generation")
+    a.label(".Lpark_wait_%s_%%=" % tag)
+    a("ds_read_b32 v126, v124 offset:%d" % HANDOFF2_CONSUMED_OFF)
+    a("s_waitcnt lgkmcnt(0)")
+    a("v_add_u32_e32 v126, %d, v126" % HANDOFF2_NT)
+    a("v_cmp_gt_u32_e32 vcc, v126, v122", "consumed + NT > generation: the buffer is free")
+    a("s_andn2_b64 vcc, exec, vcc")
+    a("s_cbranch_vccz .Lpark_go_%s_%%=" % tag)
+    a("s_sleep 2")
+    a("s_branch .Lpark_wait_%s_%%=" % tag)
+    a.label(".Lpark_go_%s_%%=" % tag)
+    a("v_and_b32_e32 v122, %d, v123" % (16 * HANDOFF2_NT - 1), "tile row among the NT buffers")
+    a("v_mad_u32_u24 v126, v122, %[rowpitch], %[lb]")
+    a("v_add_u32_e32 v126, %[qtile], v126")
+    a("ds_write_b128 v126, %s" % vr(ACC, 4))
+    a("v_cmp_eq_u32_e32 vcc, 0, %[lb]")
+    a("s_and_b64 exec, %[mk], vcc")
+    a("v_lshl_add_u32 v126, v122, 2, v124")
+    a("ds_write_b32 v126, v%d offset:%d" % (ob_q, HANDOFF2_ROWID_OFF), "which node row it is (byte offset)")
+    a("v_lshrrev_b32_e32 v122, 4, v122")
+    a("v_lshl_add_u32 v126, v122, 2, v124")
+    a("ds_add_u32 v126, v125 offset:%d" % HANDOFF2_POSTED_OFF)
+    a("s_mov_b64 exec, %[mk]")
+    a("s_waitcnt lgkmcnt(0)", "(also: the row's 16 bytes have left the accumulator registers)")
+
+
 def stream_post(a, tag):
     """Hand the rows flushed during the PREVIOUS chunk to the update waves.  Placed right behind a vmcnt wait that leaves
     only requests issued after those flush stores outstanding: completion is reported to a wave in issue order, so the
@@ -151,7 +202,7 @@ def stream_rel_reads(a, tb):
         a("ds_read_b128 %s, v%d" % (vr(RV[q], 4), tb + q))
 
 
-def stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag, post=False):
+def stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag, post=0):
     """The chunk's four steps in order.  Fast form: every stream of the wave still has the whole chunk (uniform test
     against nf) and none of the 16 (group, step) slots is a marker (the marker's LDS address is the largest there is).
     General form, per step: live = consts[q] < rem; marker = live and relation address == mark; edges accumulate in the
@@ -197,8 +248,11 @@ def stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag, post
             for e in range(4):
                 a("v_cndmask_b32_e32 v122, %%[bz], %%[b%d], vcc" % e)
                 a("%s v%d, v%d, v122" % (op, ACC + e, ACC + e))
-        a("global_store_dwordx4 v%d, %s, %%[ob]%s" % (ob + q, vr(ACC, 4), POST_OUT_POLICY if post else OUT_POLICY))
-        if post:
+        if post == 2:
+            stream_park(a, ob + q, "%s%d" % (tag, q))
+        else:
+            a("global_store_dwordx4 v%d, %s, %%[ob]%s" % (ob + q, vr(ACC, 4), POST_OUT_POLICY if post else OUT_POLICY))
+        if post == 1:
             a("v_mov_b32_e32 v%d, v%d" % (PEND + q, ob + q), "posted behind the next vmcnt wait (stream_post)")
             a("s_mov_b32 %[pf], 1")
         a("s_nop 2", "gfx940+: a VALU write of the data registers of a > 8-byte store needs 2 wait states behind the store "
@@ -210,7 +264,7 @@ def stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag, post
     a.label(".Lstream_summed_%s_%%=" % tag)
 
 
-def gen_stream(sum_code, mul_code, rec_policy, post=False):
+def gen_stream(sum_code, mul_code, rec_policy, post=0):
     a = Asm()
     binop = BINOPS[mul_code]
     A, B, TA, TB, OA, OB = 64, 80, 96, 100, 104, 108
@@ -221,7 +275,7 @@ def gen_stream(sum_code, mul_code, rec_policy, post=False):
         a("v_cndmask_b32_e32 v115, 0, v%d, vcc" % (rec + 1), "... multiply by relation 0, are no marker, and are masked out of the sum")
 
     def compute(xb, tb, ob, consts, first_step, tag):
-        if post:
+        if post == 1:
             stream_post(a, tag)
         stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag, post)
 
@@ -229,10 +283,11 @@ def gen_stream(sum_code, mul_code, rec_policy, post=False):
     a("s_mov_b32 %[kb], 0")
     for e in range(4):
         a("v_mov_b32_e32 v%d, %s" % (ACC + e, IDENT[sum_code]))
-    if post:
+    if post == 1:
         a("s_mov_b32 %[pf], 0")
         for q in range(4):
             a("v_mov_b32_e32 v%d, -1" % (PEND + q))
+    if post:
         a("v_mov_b32_e32 v124, %[qctl]")
         a("v_mov_b32_e32 v125, 1")
     a("global_load_dwordx2 v[120:121], %%[roff], %%[rb]%s" % rec_policy, "records of round 0")
@@ -274,7 +329,7 @@ def gen_stream(sum_code, mul_code, rec_policy, post=False):
     compute(B, TB, OB, (4, 5, 6, 7), 4, "lb")
     a.label(".Lstream_done_%=")
     a("s_waitcnt vmcnt(0)", "flush stores")
-    if post:
+    if post == 1:
         stream_post(a, "end")
     return a
 
@@ -560,29 +615,32 @@ def main():
                  "// boundary row's part of this lane (0xffffffff: none), b = its boundary values, bz = what a row other than the boundary\n"
                  "// row meets at its flush under min / max (0: the boundary tensor's zeros; -+inf: nothing), ns / nf = steps of the wave's\n"
                  "// longest / shortest stream (ns > 0, wave-uniform), xb / rb / ob = source slice, stream records, output slice.\n"
-                 "// POST: every flushed row is also handed to the workgroup's update waves through the LDS block at byte address qctl\n"
-                 "// (stream_post in the generator; whole-span rows only: lb = 16 (lane % 16)).\n"
-                 "template <int SUM, int MUL, bool POST>\n"
+                 "// POST == 1: every flushed row is also handed to the workgroup's update waves through the LDS block at byte address qctl\n"
+                 "// (stream_post in the generator; whole-span rows only: lb = 16 (lane % 16)).  POST == 2: the row itself goes to them, into\n"
+                 "// the LDS tiles at byte address qtile, and not to memory (stream_park).\n"
+                 "template <int SUM, int MUL, int POST>\n"
                  "__device__ __forceinline__ void order_stream_asm(int rem, uint32_t roff, const int l8, const uint32_t lb, const uint32_t lds,\n"
                  "                                                 const uint32_t mark, const uint32_t bndoff, const float (&b)[4], const float bz,\n"
                  "                                                 const int ns, const int nf, const char *xb, const char *rb, const char *ob,\n"
-                 "                                                 const uint32_t xrb, const uint32_t qctl) {\n"
-                 "    int kb, t0, t1, pf;\n    unsigned long long ex, mk;\n    (void)pf;\n")
+                 "                                                 const uint32_t xrb, const uint32_t qctl, const uint32_t qtile) {\n"
+                 "    int kb, t0, t1, pf;\n    unsigned long long ex, mk;\n    (void)pf, (void)qtile;\n"
+                 "    const uint32_t rowpitch = " + str(HANDOFF2_ROW_BYTES) + "u;\n    (void)rowpitch;\n")
     first = True
-    for post in (False, True):
+    for post in (0, 1, 2):
         for sum_code in (0, 1, 2):
             for mul_code in (0, 1):
                 a = gen_stream(sum_code, mul_code, REC_POLICY, post)
-                cond = "SUM == %d && MUL == %d && %sPOST" % (sum_code, mul_code, "" if post else "!")
+                cond = "SUM == %d && MUL == %d && POST == %d" % (sum_code, mul_code, post)
                 parts.append("    %sif constexpr (%s) {\n" % ("" if first else "else ", cond))
                 first = False
                 parts.append("        asm volatile(\n" + a.render("            ") + "\n")
                 parts.append('            : [rem] "+v"(rem), [roff] "+v"(roff), [kb] "=&s"(kb), [t0] "=&s"(t0), [t1] "=&s"(t1), [ex] "=&s"(ex),\n'
-                             '              [mk] "=&s"(mk)%s\n' % (', [pf] "=&s"(pf)' if post else ''))
+                             '              [mk] "=&s"(mk)%s\n' % (', [pf] "=&s"(pf)' if post == 1 else ''))
                 parts.append('            : [l8] "v"(l8), [lb] "v"(lb), [lds] "v"(lds), [mark] "v"(mark), [bndoff] "v"(bndoff), [b0] "v"(b[0]),\n'
                              '              [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [ns] "s"(ns), [nf] "s"(nf), [xb] "s"(xb), [rb] "s"(rb),\n'
-                             '              [ob] "s"(ob), [xrb] "s"(xrb)%s%s\n' % (', [bz] "v"(bz)' if sum_code else '', ', [qctl] "s"(qctl)' if post else ''))
-                lo, hi = (POST_CLOBBER_LO, POST_CLOBBER_HI) if post else (STREAM_CLOBBER_LO, STREAM_CLOBBER_HI)
+                             '              [ob] "s"(ob), [xrb] "s"(xrb)%s%s%s\n' % (', [bz] "v"(bz)' if sum_code else '', ', [qctl] "s"(qctl)' if post else '',
+                                                                                       ', [qtile] "s"(qtile), [rowpitch] "s"(rowpitch)' if post == 2 else ''))
+                lo, hi = (POST_CLOBBER_LO, POST_CLOBBER_HI) if post == 1 else ((STREAM_CLOBBER_LO, 126) if post == 2 else (STREAM_CLOBBER_LO, STREAM_CLOBBER_HI))
                 parts.append('            : "memory", "vcc", "scc", %s);\n' % clobbers(lo, hi))
                 parts.append("    }\n")
     parts.append("}\n\n")

@@ -438,6 +438,7 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
             while (s->prow.size() % 32) s->prow.push_back(-1);
             s->prow_ptr[(size_t)q + 1] = (int32_t)s->prow.size();
             s->max_rows = std::max<int32_t>(s->max_rows, (int32_t)mine.size());
+            s->max_chain_rows = std::max<int32_t>(s->max_chain_rows, (int32_t)part_chain[(size_t)q].size());
         }
     }
     // the chain producers request descriptors a fixed number of chunks ahead without a bounds test: readable, harmless

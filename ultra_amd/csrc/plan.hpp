@@ -93,6 +93,7 @@ struct Schedule {
     Chunk *d_chunks = nullptr;
     double max_cost = 0.0, mean_cost = 0.0;             // cost model's load of the fullest / average workgroup
     int32_t max_rows = 0;                               // most rows any one workgroup aggregates
+    int32_t max_chain_rows = 0;                         // most chain rows any one workgroup walks
 };
 
 struct DevicePlan {

@@ -433,7 +433,23 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
                         lds = need;
                     }
                 }
-                if (g_tuning.reserved[2] == 2 && op.upd.mode != 2) {
+                // Form 3 (ultra_tuning.reserved[2] == 3): beside the walk with the aggregate passing through LDS tiles; the update
+                // waves keep the weight matrix in registers, so the room is there even beside a 474-relation slice
+                if (g_tuning.reserved[2] == 3 && ORDER_WAVES == 16 && upd->out_stride_row * (int64_t)sizeof(float) == (int64_t)op.x_row_bytes) {
+                    if ((rc = get_schedule(p, op.nparts, &sched12, ORDER_WALKERS))) return rc;
+                    const size_t overlay = std::max(ring_bytes, (size_t)UPD2_OVERLAY_BYTES);
+                    const size_t need = rel_bytes + overlay + UPD2_CTL_BYTES;
+                    if (need <= di.lds_optin && sched12->max_chain_rows <= UPD2_MAX_CHAIN_ROWS) {
+                        op.upd.mode = 3;
+                        op.upd.ctl_off = (uint32_t)(rel_bytes + overlay);
+                        op.srec = sched12->d_srec;
+                        op.sdesc = reinterpret_cast<const int2 *>(sched12->d_sdesc);
+                        op.chunk_ptr = sched12->d_chunk_ptr;      // (the chain work of the twelve-walker schedule is the same list)
+                        op.chunks = reinterpret_cast<const int4 *>(sched12->d_chunks);
+                        lds = need;
+                    }
+                }
+                if (g_tuning.reserved[2] >= 2 && op.upd.mode != g_tuning.reserved[2]) {
                     set_error("ultra_rspmm_forward_update: the update beside the walk does not fit this call (LDS / rows per workgroup)");
                     return ULTRA_ERR_UNSUPPORTED;
                 }

@@ -88,7 +88,7 @@ struct OrderParams {
         const int32_t *prow, *prow_ptr;              // plan.hpp Schedule
         float eps;
         int32_t flags;                               // CONV_LN | CONV_RELU | CONV_RESIDUAL
-        int32_t mode;                                // 1: in the kernel's tail, 2: beside the walk (rspmm_order_kernel, UPDATE)
+        int32_t mode;                                // 1: in the kernel's tail, 2 / 3: beside the walk (rspmm_order_kernel, UPDATE)
         uint32_t ctl_off;                            // mode 2: byte offset of the hand-off block in LDS
     } upd;
 };
@@ -376,7 +376,9 @@ __device__ __forceinline__ void post_row(const uint32_t ctl_addr, const uint32_t
 // UPDATE: 0 none; 1 the layer update of the workgroup's rows in the kernel's TAIL (after every walk has ended); 2 the update
 // BESIDE the walk -- the last ORDER_UPDATERS waves do not walk: they wait for rows the walkers hand over through an LDS
 // queue and multiply them on the matrix cores while the walk goes on (what is left when the walks end is at most one
-// tile per update wave).
+// tile per update wave); 3 beside the walk with the aggregate passing THROUGH LDS: walkers park finished rows in 16-row tiles,
+// the update waves keep their slice of the weight matrix in registers and split every tile by features (update_tile.hpp,
+// UPD2_*) -- the aggregate never goes to memory, x and the output move as whole 256-byte rows.
 // (a workgroup of fewer than sixteen waves still keeps to 128 registers per lane: the wave slots it leaves are meant for
 // workgroups of other kernels, which need their share of the register file)
 #if ULTRA_ORDER_WAVES < 16
@@ -388,6 +390,7 @@ template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED, bool STREAM
 __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_order_kernel(const OrderParams p) {
     static_assert(!STREAMS || OrderAsm<T, MUL, REL_LDS, WEIGHTED>::value, "group streams exist for the assembly configurations only");
     static_assert(!UPDATE || (STREAMS && sizeof(T) == 4), "the layer update follows the fp32 stream walk");
+    static_assert(UPDATE != 3 || ORDER_UPDATERS == 4, "form 3 splits the 64 output features over four update waves");
     constexpr int SPAN = 64;
     using P = Pack<T, 4>;
     using V = typename VecOf<T, 4>::type;
@@ -407,7 +410,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
     if (part >= p.nparts) return;
     const T *wt = reinterpret_cast<const T *>(p.w);
     // UPDATE == 2: the hand-off block (see ORDER_UPDATERS); the weight image takes the ring's place once the chain is done
-    volatile uint32_t *ctl = reinterpret_cast<volatile uint32_t *>(smem + (UPDATE == 2 ? p.upd.ctl_off : 0));
+    volatile uint32_t *ctl = reinterpret_cast<volatile uint32_t *>(smem + (UPDATE >= 2 ? p.upd.ctl_off : 0));
     const T fill = (SUM != 0 && p.bnd_fill_on) ? (T)p.bnd_fill : nary_zero<T, SUM>();   // (what a non-boundary row meets under min / max)
 
     if (p.trace && tid == 0) p.trace[3 * blockIdx.x + 0] = clock64();
@@ -449,6 +452,9 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
             if constexpr (UPDATE == 2) {
                 if (tid < 4 + UPDATE_CTL_TILES) ctl[tid] = 0;
             }
+            if constexpr (UPDATE == 3) {
+                if (tid < UPD2_CTL_CTILE_BYTES / 4) ctl[tid] = 0;
+            }
             int tid_stage = tid;
             asm volatile("" : "+v"(tid_stage));
             stage_slice<T, 4>(lds_rel, reinterpret_cast<const T *>(p.rel.ptr) + outer * p.rel.stride_outer, p.rel.stride_row,
@@ -478,6 +484,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                 __builtin_amdgcn_s_setprio(3);   // the chain is the launch's critical path: win VALU / LDS issue arbitration
 #endif
                 const int d = inner * SPAN + chain_element(lane);
+                int n_listed = 0;            // UPDATE == 3: chain rows listed for the update waves (they fetch them from memory)
                 long long posted_off = -1;   // UPDATE == 2: the row stored last, not yet handed to the update waves
                 const auto post_pending = [&]() {
                     if constexpr (UPDATE == 2) {
@@ -500,6 +507,10 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                         reinterpret_cast<T *>(p.out)[outer * p.out_stride_outer + (long long)row * p.out_stride_row + d] = v;
                     }
                     posted_off = (long long)row * (long long)p.x_row_bytes;
+                    if constexpr (UPDATE == 3) {
+                        if (lane == 0) ctl[UPD2_CTL_CROW + min(n_listed, UPD2_MAX_CHAIN_ROWS - 1)] = (uint32_t)posted_off;
+                        ++n_listed;      // (the host does not pick this form for a schedule with more chain rows per workgroup)
+                    }
                 };
                 const v4i *chunks = reinterpret_cast<const v4i *>(p.chunks);
                 const V *ring_lane = reinterpret_cast<const V *>(ring) + lane;
@@ -617,6 +628,14 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                     // (behind the last post in this wave's LDS order; the ring is free: its last reads have been added)
                     asm volatile("" ::: "memory");
                     if (lane == 0) ctl[3] = 1;
+                }
+                if constexpr (UPDATE == 3) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chain rows are in memory: the update waves read them there
+                    if (lane == 0) {
+                        ctl[UPD2_CTL_NCHAIN] = (uint32_t)n_listed;
+                        asm volatile("" ::: "memory");
+                        ctl[3] = 1;       // ... and the ring is free: tiles may take its place
+                    }
                 }
 #if ULTRA_DBG_CHAIN == 3
                 if (p.trace && lane == 0) p.trace[3 * gridDim.x + blockIdx.x] = bar_cycles;
@@ -737,8 +756,13 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
         const uint32_t lane_bytes = ug.lane_bytes;
         const T *lds_rel_lane = ug.lds_rel_lane;
         if constexpr (STREAMS) {
-            if (UPDATE != 2 || wave < ORDER_WALKERS) {
+            if (UPDATE < 2 || wave < ORDER_WALKERS) {
                 // ---- group streams: one continuous walk per 16-lane group (rspmm_order_asm.hpp) ----
+                if constexpr (UPDATE == 3) {   // (the tiles the walk parks its rows in take the ring's place)
+                    if (c1 > c0) {
+                        while (ctl[3] == 0) __builtin_amdgcn_s_sleep(2);
+                    }
+                }
                 const int2 sd = p.sdesc[(part * nwave + wave) * 4 + grp];
                 const int len = sd.y;
                 const int m01 = max(__shfl(len, 0), __shfl(len, 16)), m23 = max(__shfl(len, 32), __shfl(len, 48));
@@ -755,16 +779,123 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                 // (min / max: a flushed row other than the boundary row meets `bz`: the fill, or the value that changes nothing)
                 const float bz = (SUM != 0 && p.bnd_fill_on) ? p.bnd_fill : (SUM == 1 ? __builtin_inff() : -__builtin_inff());
                 if (ns > 0)
-                    order_stream_asm<SUM, MUL, UPDATE == 2>(len, (uint32_t)(sd.x + (l16 & 7)) * 8u, l16 & 7, lane_bytes, lds_addr(lds_rel_lane),
+                    order_stream_asm<SUM, MUL, (UPDATE >= 2 ? UPDATE - 1 : 0)>(len, (uint32_t)(sd.x + (l16 & 7)) * 8u, l16 & 7, lane_bytes, lds_addr(lds_rel_lane),
                                                             lds_addr(lds_rel_lane) + (uint32_t)p.num_rel * 256u, bndoff, bv, bz, ns, nf, xbase,
                                                             reinterpret_cast<const char *>(p.srec),
                                                             reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.out) + outer * p.out_stride_outer),
-                                                            p.x_row_bytes, lds_addr(const_cast<uint32_t *>(ctl)));
-                if constexpr (UPDATE == 2) {
+                                                            p.x_row_bytes, lds_addr(const_cast<uint32_t *>(ctl)), lds_addr(ring));
+                if constexpr (UPDATE >= 2) {
                     // this wave has posted all its rows (the walk ends on vmcnt(0) + its last posts; LDS operations of a
                     // wave execute in order)
                     asm volatile("" ::: "memory");
                     if (lane == 0) __hip_atomic_fetch_add(const_cast<uint32_t *>(ctl) + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            if constexpr (UPDATE == 3) {
+                if (wave >= ORDER_WALKERS) {
+                    // ---- update waves, form 3 (update_tile.hpp UPD2_*): wave u owns output features [16 u, 16 u + 16) ----
+                    using f32x4m = float __attribute__((ext_vector_type(4)));
+                    int lane_u = lane;
+                    asm volatile("" : "+v"(lane_u));
+                    const int u = wave - ORDER_WALKERS;
+                    const int i16 = lane_u & 15, kk = lane_u >> 4;
+                    float *tiles = reinterpret_cast<float *>(ring);                         // [NT][16][68]
+                    float *x_tile = tiles + UPD2_NT * UPD2_TILE_FLOATS, *y_tile = x_tile + UPD2_TILE_FLOATS;
+                    float *moments = y_tile + UPD2_TILE_FLOATS;                             // [16 rows][16]
+                    float *c_tile = reinterpret_cast<float *>(const_cast<uint32_t *>(ctl)) + UPD2_CTL_CTILE_BYTES / 4;
+                    // A operands: this wave's 16 rows of W (lane (i, kk) holds W[16 u + i][4 s + kk]); small vectors
+                    float wfrag[32];
+#pragma unroll
+                    for (int s = 0; s < 32; ++s) wfrag[s] = p.upd.weight[(16 * u + i16) * 128 + 4 * s + kk];
+                    const int f0 = 16 * u + 4 * kk;      // D: lane l, reg r -> feature 16 u + 4 (l >> 4) + r of tile row l & 15
+                    float biasv[4], lnw[4], lnb[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        biasv[r] = p.upd.bias ? p.upd.bias[f0 + r] : 0.f;
+                        lnw[r] = (p.upd.flags & CONV_LN) ? p.upd.ln_w[4 * i16 + r] : 1.f;      // (LayerNorm phase: lane l16 owns features 4 l16 + e)
+                        lnb[r] = (p.upd.flags & CONV_LN) ? p.upd.ln_b[4 * i16 + r] : 0.f;
+                    }
+                    if (c1 > c0) {
+                        while (ctl[3] == 0) __builtin_amdgcn_s_sleep(4);   // the chain consumer still reads the ring
+                    }
+                    const char *aggbase = reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.out) + outer * p.out_stride_outer);
+                    char *ubase = reinterpret_cast<char *>(p.upd.out + outer * p.upd.out_stride_outer);
+                    uint32_t epoch = 0;
+                    const auto upd_barrier = [&]() {     // the four update waves meet (s_barrier would count the walkers too)
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        epoch += (uint32_t)ORDER_UPDATERS;
+                        if (lane == 0) __hip_atomic_fetch_add(const_cast<uint32_t *>(ctl) + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        while (ctl[2] < epoch) __builtin_amdgcn_s_sleep(1);
+                        asm volatile("" ::: "memory");
+                    };
+                    // one tile: n rows (1..16); row r's aggregate in a_tile (from_memory: fetched here from the aggregate matrix),
+                    // its node row at byte offset rowoff[r]
+                    const auto process = [&](float *a_tile, const volatile uint32_t *rowoff, const int n, const bool from_memory) {
+                        upd_barrier();                                   // everybody is done with the x / pre-norm tiles
+                        const int r_mine = 4 * u + kk;                   // staging and finishing: a 16-lane group per row
+                        const bool have = r_mine < n;
+                        const uint32_t off_mine = have ? rowoff[r_mine] : 0u;
+                        *reinterpret_cast<float4 *>(x_tile + r_mine * UPD2_ROW_FLOATS + 4 * i16) =
+                            *reinterpret_cast<const float4 *>(xbase + off_mine + 16u * (uint32_t)i16);
+                        if (from_memory)
+                            *reinterpret_cast<float4 *>(a_tile + r_mine * UPD2_ROW_FLOATS + 4 * i16) =
+                                *reinterpret_cast<const float4 *>(aggbase + off_mine + 16u * (uint32_t)i16);
+                        upd_barrier();
+                        f32x4m d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int s = 0; s < 16; ++s)
+                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[s], x_tile[i16 * UPD2_ROW_FLOATS + 4 * s + kk], d, 0, 0, 0);
+#pragma unroll
+                        for (int s = 0; s < 16; ++s)
+                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[16 + s], a_tile[i16 * UPD2_ROW_FLOATS + 4 * s + kk], d, 0, 0, 0);
+                        *reinterpret_cast<float4 *>(y_tile + i16 * UPD2_ROW_FLOATS + f0) =
+                            make_float4(d[0] + biasv[0], d[1] + biasv[1], d[2] + biasv[2], d[3] + biasv[3]);   // bias after the chain, like addmm
+                        upd_barrier();
+                        float y[4];
+                        {
+                            const float4 v = *reinterpret_cast<const float4 *>(y_tile + r_mine * UPD2_ROW_FLOATS + 4 * i16);
+                            y[0] = v.x, y[1] = v.y, y[2] = v.z, y[3] = v.w;
+                        }
+                        if (p.upd.flags & CONV_LN)
+                            ln_row_group(y, y_tile + r_mine * UPD2_ROW_FLOATS, moments + r_mine * 16, i16, p.upd.eps, lnw, lnb);
+                        if (p.upd.flags & CONV_RELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+                        }
+                        if (p.upd.flags & CONV_RESIDUAL) {
+                            const float4 xi = *reinterpret_cast<const float4 *>(x_tile + r_mine * UPD2_ROW_FLOATS + 4 * i16);
+                            y[0] += xi.x, y[1] += xi.y, y[2] += xi.z, y[3] += xi.w;
+                        }
+                        if (have) *reinterpret_cast<float4 *>(ubase + off_mine + 16u * (uint32_t)i16) = make_float4(y[0], y[1], y[2], y[3]);
+                    };
+                    // the workgroup's chain rows: listed by the chain consumer, their aggregates are in memory
+                    const int n_chain_rows = (c1 > c0) ? min((int)ctl[UPD2_CTL_NCHAIN], UPD2_MAX_CHAIN_ROWS) : 0;
+                    for (int base = 0; base < n_chain_rows; base += 16)
+                        process(c_tile, ctl + UPD2_CTL_CROW + base, min(16, n_chain_rows - base), true);
+                    // the walkers' rows: generation G sits in tile buffer G % NT
+                    for (int G = 0;; ++G) {
+                        const int buf = G & (UPD2_NT - 1);
+                        int n;
+                        for (;;) {
+                            const uint32_t walked = ctl[1];   // (read FIRST: with every walker done, the reads below see the final state)
+                            asm volatile("" ::: "memory");
+                            const uint32_t have = ctl[UPD2_CTL_POSTED + buf];
+                            if (have >= 16u * (uint32_t)(G / UPD2_NT + 1)) {
+                                n = 16;
+                                break;
+                            }
+                            if (walked == (uint32_t)ORDER_WALKERS) {
+                                n = min(16, (int)ctl[0] - 16 * G);
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(4);
+                        }
+                        n = rfl(n);
+                        if (n <= 0) break;
+                        process(tiles + buf * UPD2_TILE_FLOATS, ctl + UPD2_CTL_ROWID + 16 * buf, n, false);
+                        // (every update wave has read the tile: its third barrier lies behind the matrix phase) -> the buffer may be refilled
+                        if (u == 0 && lane == 0) ctl[UPD2_CTL_CONSUMED] = (uint32_t)(G + 1);
+                    }
                 }
             }
             if constexpr (UPDATE == 2) {
@@ -942,8 +1073,9 @@ inline hipError_t launch_order_one(const OrderParams &p, int grid, size_t lds, h
     if constexpr (OrderAsm<T, MUL, REL_LDS, WEIGHTED>::value) {
         if constexpr (sizeof(T) == 4) {
             if (p.use_streams && p.upd.weight)
-                return p.upd.mode == 2 ? launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true, 2>(p, grid, lds, s)
-                                       : launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true, 1>(p, grid, lds, s);
+                return p.upd.mode == 3   ? launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true, 3>(p, grid, lds, s)
+                       : p.upd.mode == 2 ? launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true, 2>(p, grid, lds, s)
+                                         : launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true, 1>(p, grid, lds, s);
         }
         if (p.use_streams) return launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true>(p, grid, lds, s);
     }

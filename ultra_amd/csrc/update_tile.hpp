@@ -64,6 +64,47 @@ __device__ __forceinline__ void row_moments_pair(const float (&v)[2][16], const 
     merge8(all, eps, mean, rstd);
 }
 
+// ---- the update on 16-row tiles held in LDS, the feature axis split over four waves (rspmm_order_kernel, UPDATE == 3) ----
+// Hand-off form 2 of the order kernel: walkers park finished aggregate rows in LDS tiles (16 rows x UPD2_ROW_FLOATS floats: 64 +
+// 4 pad -- lane (row n, k-quarter q) reading element 4 s + q of row n hits 64 distinct banks); each of the four update waves
+// keeps ITS 16 features of W in 32 registers (A operand of v_mfma_f32_16x16x4_f32: lane (i, q) holds W[16 u + i][4 s + q]) and
+// multiplies every tile -- the products are k-ascending fmaf chains, the reference's nn.Linear order (the same arrangement as
+// phase 3 of dense_order_layer.hip, pinned there bit for bit); the pre-norm tile meets in LDS, then every wave finishes four
+// rows: LayerNorm in torch's operation order by a 16-lane group per row (as layer0_kernels.hpp), ReLU, residual, one
+// coalesced 256-byte store per row.
+constexpr int UPD2_NT = 4;                       // aggregate tiles the walkers fill round-robin (the generator's HANDOFF2_NT)
+constexpr int UPD2_ROW_FLOATS = 68;              // 272 bytes (HANDOFF2_ROW_BYTES)
+constexpr int UPD2_TILE_FLOATS = 16 * UPD2_ROW_FLOATS;
+constexpr int UPD2_MAX_CHAIN_ROWS = 64;          // chain rows of a workgroup the control block can list
+// overlay (in the ring's place once the chain is done): NT aggregate tiles | x tile | pre-norm tile | LayerNorm moments (16 x 16)
+constexpr int UPD2_OVERLAY_BYTES = (UPD2_NT + 2) * UPD2_TILE_FLOATS * 4 + 16 * 16 * 4;
+// control block (behind ring / overlay; bytes): 0 tail, 4 walkers done, 8 update-wave barrier, 12 chain done, 16 generations
+// consumed, 20 chain rows listed, 32 posted[NT], 64 rowid[16 NT], 320 chain row offsets[64], 576 chain tile
+constexpr int UPD2_CTL_CONSUMED = 4, UPD2_CTL_NCHAIN = 5, UPD2_CTL_POSTED = 8, UPD2_CTL_ROWID = 16, UPD2_CTL_CROW = 80;   // (word offsets)
+constexpr int UPD2_CTL_CTILE_BYTES = 576, UPD2_CTL_BYTES = UPD2_CTL_CTILE_BYTES + UPD2_TILE_FLOATS * 4;
+
+// LayerNorm (torch's operation order, torch_math.hpp) of a 64-feature row held by a 16-lane group, feature 4 l16 + e in y[e].
+// `row`: the row's 64 floats in LDS (already there); `mom`: 16 floats of LDS private to the group.  LDS operations of one wave
+// execute in order: no barrier between the group's writes and reads.
+__device__ __forceinline__ void ln_row_group(float (&y)[4], const float *row, float *mom, const int l16, const float eps,
+                                             const float (&gamma)[4], const float (&beta)[4]) {
+    float xv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xv[j] = row[8 * j + (l16 & 7)];
+    const Moments w = welford8(xv);
+    if (l16 < 8) {
+        mom[2 * l16] = w.m1;
+        mom[2 * l16 + 1] = w.m2;
+    }
+    Moments all[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) all[i] = Moments{mom[2 * i], mom[2 * i + 1]};
+    float mean, rstd;
+    merge8(all, eps, mean, rstd);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = ln_apply(y[e], mean, rstd, gamma[e], beta[e]);
+}
+
 // ---- the tile as a unit (the rspmm tail; 8 weight registers instead of 16: it runs under a 128-register cap) ----
 constexpr int UPDATE_LDS_FLOATS = 32 * 64 * 4 + 3 * 64;   // weight image + {bias, LayerNorm weight, LayerNorm bias}
 
