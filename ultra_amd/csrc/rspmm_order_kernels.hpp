@@ -800,8 +800,8 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                     const int u = wave - ORDER_WALKERS;
                     const int i16 = lane_u & 15, kk = lane_u >> 4;
                     float *tiles = reinterpret_cast<float *>(ring);                         // [NT][16][68]
-                    float *x_tile = tiles + UPD2_NT * UPD2_TILE_FLOATS, *y_tile = x_tile + UPD2_TILE_FLOATS;
-                    float *moments = y_tile + UPD2_TILE_FLOATS;                             // [16 rows][16]
+                    float *x_tiles = tiles + UPD2_NT * UPD2_TILE_FLOATS, *y_tiles = x_tiles + 2 * UPD2_TILE_FLOATS;   // [2][16][68] each
+                    float *moments = y_tiles + 2 * UPD2_TILE_FLOATS;                        // [16 rows][16]
                     float *c_tile = reinterpret_cast<float *>(const_cast<uint32_t *>(ctl)) + UPD2_CTL_CTILE_BYTES / 4;
                     // A operands: this wave's 16 rows of W (lane (i, kk) holds W[16 u + i][4 s + kk]); small vectors
                     float wfrag[32];
@@ -825,32 +825,102 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         epoch += (uint32_t)ORDER_UPDATERS;
                         if (lane == 0) __hip_atomic_fetch_add(const_cast<uint32_t *>(ctl) + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        while (ctl[2] < epoch) __builtin_amdgcn_s_sleep(1);
+                        while (ctl[2] < epoch) __builtin_amdgcn_s_sleep(0);
                         asm volatile("" ::: "memory");
                     };
-                    // one tile: n rows (1..16); row r's aggregate in a_tile (from_memory: fetched here from the aggregate matrix),
-                    // its node row at byte offset rowoff[r]
-                    const auto process = [&](float *a_tile, const volatile uint32_t *rowoff, const int n, const bool from_memory) {
-                        upd_barrier();                                   // everybody is done with the x / pre-norm tiles
-                        const int r_mine = 4 * u + kk;                   // staging and finishing: a 16-lane group per row
-                        const bool have = r_mine < n;
-                        const uint32_t off_mine = have ? rowoff[r_mine] : 0u;
-                        *reinterpret_cast<float4 *>(x_tile + r_mine * UPD2_ROW_FLOATS + 4 * i16) =
-                            *reinterpret_cast<const float4 *>(xbase + off_mine + 16u * (uint32_t)i16);
-                        if (from_memory)
-                            *reinterpret_cast<float4 *>(a_tile + r_mine * UPD2_ROW_FLOATS + 4 * i16) =
-                                *reinterpret_cast<const float4 *>(aggbase + off_mine + 16u * (uint32_t)i16);
+                    const int r_mine = 4 * u + kk;       // staging and finishing: a 16-lane group per tile row
+                    // Tiles are numbered t = 0, 1, ...: first the workgroup's chain rows (listed by the chain consumer, aggregates in
+                    // memory: staged like x), then the walkers' generations.  Tile t multiplies out of x / pre-norm buffer t & 1; while
+                    // it does, the x rows of tile t + 1 -- if that tile is already complete, which update wave 0 decides for all
+                    // four -- are on their way from memory and are parked in the other buffer: two barriers per tile, no memory
+                    // round trip on the tile's own path.
+                    const int n_chain_rows = (c1 > c0) ? min((int)ctl[UPD2_CTL_NCHAIN], UPD2_MAX_CHAIN_ROWS) : 0;
+                    const int n_ctile = (n_chain_rows + 15) >> 4;
+                    // rows of tile t as (count, offsets, aggregate tile, from memory?) -- blocks until the tile is complete when `wait`
+                    struct Tile {
+                        int n;
+                        const volatile uint32_t *rowoff;
+                        float *agg;
+                        bool from_memory;
+                    };
+                    const auto tile_of = [&](const int t, const bool wait) {
+                        Tile tl;
+                        if (t < n_ctile) {
+                            tl.n = min(16, n_chain_rows - 16 * t);
+                            tl.rowoff = ctl + UPD2_CTL_CROW + 16 * t;
+                            tl.agg = c_tile;
+                            tl.from_memory = true;
+                            return tl;
+                        }
+                        const int G = t - n_ctile, buf = G & (UPD2_NT - 1);
+                        tl.rowoff = ctl + UPD2_CTL_ROWID + 16 * buf;
+                        tl.agg = tiles + buf * UPD2_TILE_FLOATS;
+                        tl.from_memory = false;
+                        for (;;) {
+                            const uint32_t walked = ctl[1];   // (read FIRST: with every walker done, the reads below see the final state)
+                            asm volatile("" ::: "memory");
+                            const uint32_t have = ctl[UPD2_CTL_POSTED + buf];
+                            if (have >= 16u * (uint32_t)(G / UPD2_NT + 1)) {
+                                tl.n = 16;
+                                break;
+                            }
+                            if (walked == (uint32_t)ORDER_WALKERS) {
+                                tl.n = min(16, (int)ctl[0] - 16 * G);
+                                break;
+                            }
+                            if (!wait) {
+                                tl.n = -1;      // not complete yet
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                        tl.n = rfl(tl.n);
+                        return tl;
+                    };
+                    bool staged = false;        // the x rows (and memory aggregates) of the current tile are in its buffers already
+                    for (int t = 0;; ++t) {
+                        const Tile cur = tile_of(t, true);
+                        if (cur.n <= 0) break;
+                        float *x_tile = x_tiles + (t & 1) * UPD2_TILE_FLOATS, *y_tile = y_tiles + (t & 1) * UPD2_TILE_FLOATS;
+                        float *x_next = x_tiles + ((t + 1) & 1) * UPD2_TILE_FLOATS;
+                        const bool have = r_mine < cur.n;
+                        const uint32_t off_mine = have ? cur.rowoff[r_mine] : 0u;
+                        if (!staged) {
+                            *reinterpret_cast<float4 *>(x_tile + r_mine * UPD2_ROW_FLOATS + 4 * i16) =
+                                *reinterpret_cast<const float4 *>(xbase + off_mine + 16u * (uint32_t)i16);
+                            if (cur.from_memory)
+                                *reinterpret_cast<float4 *>(cur.agg + r_mine * UPD2_ROW_FLOATS + 4 * i16) =
+                                    *reinterpret_cast<const float4 *>(aggbase + off_mine + 16u * (uint32_t)i16);
+                        }
+                        // is the next tile complete already?  (update wave 0 looks, everybody acts on its verdict behind the barrier;
+                        // a chain tile's aggregate buffer is single: its successor is staged when its turn comes)
+                        if (u == 0) {
+                            Tile peek = tile_of(t + 1, false);
+                            if (t + 1 < n_ctile || cur.from_memory) peek.n = -1;
+                            if (lane == 0) ctl[UPD2_CTL_NEXT] = (uint32_t)(peek.n > 0 ? peek.n : 0);
+                        }
                         upd_barrier();
+                        const int n_next = rfl((int)ctl[UPD2_CTL_NEXT]);
+                        float4 x_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (n_next > 0) {       // (its rows are listed: the tile is complete)
+                            const Tile nxt = tile_of(t + 1, false);
+                            const uint32_t off_next = r_mine < n_next ? nxt.rowoff[r_mine] : 0u;
+                            x_pre = *reinterpret_cast<const float4 *>(xbase + off_next + 16u * (uint32_t)i16);
+                        }
                         f32x4m d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int s = 0; s < 16; ++s)
                             d = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[s], x_tile[i16 * UPD2_ROW_FLOATS + 4 * s + kk], d, 0, 0, 0);
 #pragma unroll
                         for (int s = 0; s < 16; ++s)
-                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[16 + s], a_tile[i16 * UPD2_ROW_FLOATS + 4 * s + kk], d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[16 + s], cur.agg[i16 * UPD2_ROW_FLOATS + 4 * s + kk], d, 0, 0, 0);
                         *reinterpret_cast<float4 *>(y_tile + i16 * UPD2_ROW_FLOATS + f0) =
                             make_float4(d[0] + biasv[0], d[1] + biasv[1], d[2] + biasv[2], d[3] + biasv[3]);   // bias after the chain, like addmm
+                        if (n_next > 0) *reinterpret_cast<float4 *>(x_next + r_mine * UPD2_ROW_FLOATS + 4 * i16) = x_pre;
+                        staged = n_next > 0;
                         upd_barrier();
+                        // (every update wave is done with the aggregate tile) -> the walkers may refill the buffer
+                        if (!cur.from_memory && u == 0 && lane == 0) ctl[UPD2_CTL_CONSUMED] = (uint32_t)(t - n_ctile + 1);
                         float y[4];
                         {
                             const float4 v = *reinterpret_cast<const float4 *>(y_tile + r_mine * UPD2_ROW_FLOATS + 4 * i16);
@@ -867,34 +937,6 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                             y[0] += xi.x, y[1] += xi.y, y[2] += xi.z, y[3] += xi.w;
                         }
                         if (have) *reinterpret_cast<float4 *>(ubase + off_mine + 16u * (uint32_t)i16) = make_float4(y[0], y[1], y[2], y[3]);
-                    };
-                    // the workgroup's chain rows: listed by the chain consumer, their aggregates are in memory
-                    const int n_chain_rows = (c1 > c0) ? min((int)ctl[UPD2_CTL_NCHAIN], UPD2_MAX_CHAIN_ROWS) : 0;
-                    for (int base = 0; base < n_chain_rows; base += 16)
-                        process(c_tile, ctl + UPD2_CTL_CROW + base, min(16, n_chain_rows - base), true);
-                    // the walkers' rows: generation G sits in tile buffer G % NT
-                    for (int G = 0;; ++G) {
-                        const int buf = G & (UPD2_NT - 1);
-                        int n;
-                        for (;;) {
-                            const uint32_t walked = ctl[1];   // (read FIRST: with every walker done, the reads below see the final state)
-                            asm volatile("" ::: "memory");
-                            const uint32_t have = ctl[UPD2_CTL_POSTED + buf];
-                            if (have >= 16u * (uint32_t)(G / UPD2_NT + 1)) {
-                                n = 16;
-                                break;
-                            }
-                            if (walked == (uint32_t)ORDER_WALKERS) {
-                                n = min(16, (int)ctl[0] - 16 * G);
-                                break;
-                            }
-                            __builtin_amdgcn_s_sleep(4);
-                        }
-                        n = rfl(n);
-                        if (n <= 0) break;
-                        process(tiles + buf * UPD2_TILE_FLOATS, ctl + UPD2_CTL_ROWID + 16 * buf, n, false);
-                        // (every update wave has read the tile: its third barrier lies behind the matrix phase) -> the buffer may be refilled
-                        if (u == 0 && lane == 0) ctl[UPD2_CTL_CONSUMED] = (uint32_t)(G + 1);
                     }
                 }
             }

@@ -76,11 +76,14 @@ constexpr int UPD2_NT = 4;                       // aggregate tiles the walkers 
 constexpr int UPD2_ROW_FLOATS = 68;              // 272 bytes (HANDOFF2_ROW_BYTES)
 constexpr int UPD2_TILE_FLOATS = 16 * UPD2_ROW_FLOATS;
 constexpr int UPD2_MAX_CHAIN_ROWS = 64;          // chain rows of a workgroup the control block can list
-// overlay (in the ring's place once the chain is done): NT aggregate tiles | x tile | pre-norm tile | LayerNorm moments (16 x 16)
-constexpr int UPD2_OVERLAY_BYTES = (UPD2_NT + 2) * UPD2_TILE_FLOATS * 4 + 16 * 16 * 4;
+// overlay (in the ring's place once the chain is done): NT aggregate tiles | two x tiles | two pre-norm tiles (tile G uses
+// buffer G & 1: the next tile's x rows are staged while this one is multiplied) | LayerNorm moments (16 x 16)
+constexpr int UPD2_OVERLAY_BYTES = (UPD2_NT + 4) * UPD2_TILE_FLOATS * 4 + 16 * 16 * 4;
 // control block (behind ring / overlay; bytes): 0 tail, 4 walkers done, 8 update-wave barrier, 12 chain done, 16 generations
-// consumed, 20 chain rows listed, 32 posted[NT], 64 rowid[16 NT], 320 chain row offsets[64], 576 chain tile
-constexpr int UPD2_CTL_CONSUMED = 4, UPD2_CTL_NCHAIN = 5, UPD2_CTL_POSTED = 8, UPD2_CTL_ROWID = 16, UPD2_CTL_CROW = 80;   // (word offsets)
+// consumed, 20 chain rows listed, 24 "the next generation is complete: its x rows are being staged" (update wave 0's verdict
+// for all four), 32 posted[NT], 64 rowid[16 NT], 320 chain row offsets[64], 576 chain tile
+constexpr int UPD2_CTL_CONSUMED = 4, UPD2_CTL_NCHAIN = 5, UPD2_CTL_NEXT = 6, UPD2_CTL_POSTED = 8, UPD2_CTL_ROWID = 16,
+              UPD2_CTL_CROW = 80;   // (word offsets)
 constexpr int UPD2_CTL_CTILE_BYTES = 576, UPD2_CTL_BYTES = UPD2_CTL_CTILE_BYTES + UPD2_TILE_FLOATS * 4;
 
 // LayerNorm (torch's operation order, torch_math.hpp) of a 64-feature row held by a 16-lane group, feature 4 l16 + e in y[e].
