@@ -353,9 +353,10 @@ def test_generated_assembly_header_is_in_sync_with_its_generator(tmp_path, monke
     committed = open(os.path.join(root, "ultra_amd", "csrc", "rspmm_order_asm.hpp")).read()
     assert fresh == committed
     # every path out of a statement drains the vector-memory queue, and the statements declare what they clobber
-    # 2 x 3 sums x 2 messages (stream walk, without / with the hand-off of finished rows to the update waves) + 2 messages
-    # (producers) + 2 x 2 messages (producers of the measurement builds: LDS-word hand-off)
-    assert fresh.count("asm volatile(") == 18 and fresh.count('"memory"') == 18
+    # 3 x 3 sums x 2 messages (stream walk: plain, with the hand-off of finished rows' offsets to the update waves, with the rows
+    # themselves parked in LDS for them) + 2 messages (producers) + 2 x 2 messages (producers of the measurement builds: LDS-word
+    # hand-off)
+    assert fresh.count("asm volatile(") == 24 and fresh.count('"memory"') == 24
     for block in fresh.split("asm volatile(")[1:]:
         assert "s_waitcnt vmcnt(0)" in block.split(");")[0]
     # ... and the relation-graph layer's chain (a measurement build: csrc/dense_order_asm.hpp, tools/gen_dense_order_asm.py)

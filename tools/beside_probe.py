@@ -118,3 +118,7 @@ if served:
               (form, chain.mean(), end.mean(), end.max()))
         print("  end of work per wave (mean over workgroups): " + " ".join("%6.0f" % v for v in wave_end.mean(dim=0).tolist()))
         print("  ... max over workgroups:                     " + " ".join("%6.0f" % v for v in wave_end.max(dim=0)[0].tolist()))
+        if form == 3:
+            phases = t[3 * grid:7 * grid].view(grid, 4).double().mean(dim=0).tolist()
+            print("  update wave 0, cycles (mean over workgroups): waiting for a block %.0f | multiplying %.0f | until the pre-norm rows "
+                  "are all written %.0f | finishing %.0f" % tuple(phases))

@@ -106,42 +106,45 @@ HANDOFF_QUEUE_OFF = HANDOFF_TILE_OFF + 4 * HANDOFF_TILES
 # Tiles of 16 rows x (256 + 16 pad) bytes, HANDOFF2_NT of them, reused round-robin by "generations" of 16 rows: slot g (from
 # the atomic tail) belongs to generation g / 16, tile buffer (g / 16) % NT, row g % 16.  Control block (byte offsets behind
 # qctl; rspmm_order_kernels.hpp has the same numbers): 0 tail, 4 walkers done, 8 update-wave barrier, 12 chain done,
-# 16 generations consumed, 32 + 4 buf: rows posted into buffer buf (monotonic: generation G is complete at 16 (G / NT + 1)),
+# 16 update waves done with a block (two generations; four per block), 32 + 4 buf: rows posted into buffer buf (monotonic: generation G is complete at 16 (G / NT + 1)),
 # 64 + 4 i: byte offset of the node row parked in tile row i (i < 16 NT).
 HANDOFF2_NT = 4
 HANDOFF2_ROW_BYTES = 272
 HANDOFF2_CONSUMED_OFF, HANDOFF2_POSTED_OFF, HANDOFF2_ROWID_OFF = 16, 32, 64
+HANDOFF2_X_OFF = HANDOFF2_NT * 16 * HANDOFF2_ROW_BYTES     # the x rows' ring sits behind the aggregates'
 
 
-def stream_park(a, ob_q, tag):
+def stream_park(a, ob_q, x_q, tag):
     """Flush of form 2, for the lanes in %[mk] (the 16-lane groups at a marker): accumulator (boundary already applied) ->
-    a row of the current tile.  One lane per group takes the slot and later writes the row's id and bumps the buffer's
+    a row of the current tile, and beside it the row's x (registers x_q..: a marker step gathers at its own row's offset).  One lane per group takes the slot and later writes the row's id and bumps the buffer's
     count; all 16 write their 16 bytes.  A slot of generation G may be written once generation G - NT has been consumed
     (the update waves never wait for a walker that waits for them: the slots of the NT generations they may be working on
-    are all writable).  LDS operations of a wave execute in order: who sees the count sees the row.  Ends with every LDS
-    operation collected (the chunk's relation rows too: the counted waits of the remaining steps then pass at once)."""
+    are all writable).  LDS operations of a wave execute in order: who sees the count sees the row."""
     a("v_cmp_eq_u32_e32 vcc, 0, %[lb]", "lane 0 of each group (whole-span rows: lb = 16 (lane % 16))")
     a("s_and_b64 exec, %[mk], vcc")
     a("ds_add_rtn_u32 v123, v124, v125", "slot = tail++")
     a("s_mov_b64 exec, %[mk]")
+    a("ds_read_b32 v126, v124 offset:%d" % HANDOFF2_CONSUMED_OFF, "(with the slot: ONE LDS round trip per flush -- they cost hundreds of cycles here)")
     a("s_waitcnt lgkmcnt(0)")
-    a("ds_swizzle_b32 v123, v123 offset:swizzle(BROADCAST,16,0)")
-    a("s_waitcnt lgkmcnt(0)")
+    a("s_nop 4")
+    a("v_mov_b32_dpp v123, v123 row_newbcast:0 row_mask:0xf bank_mask:0xf", "the group's slot to its 16 lanes, in registers")
     a("v_lshrrev_b32_e32 v122, 4, v123", "generation")
     a.label(".Lpark_wait_%s_%%=" % tag)
-    a("ds_read_b32 v126, v124 offset:%d" % HANDOFF2_CONSUMED_OFF)
-    a("s_waitcnt lgkmcnt(0)")
-    a("v_add_u32_e32 v126, %d, v126" % HANDOFF2_NT)
+    a("v_lshrrev_b32_e32 v126, 2, v126", "(the word counts the update waves that are done with a block of two generations: four per block)")
+    a("v_lshl_add_u32 v126, v126, 1, %d" % HANDOFF2_NT)
     a("v_cmp_gt_u32_e32 vcc, v126, v122", "consumed + NT > generation: the buffer is free")
     a("s_andn2_b64 vcc, exec, vcc")
     a("s_cbranch_vccz .Lpark_go_%s_%%=" % tag)
     a("s_sleep 2")
+    a("ds_read_b32 v126, v124 offset:%d" % HANDOFF2_CONSUMED_OFF)
+    a("s_waitcnt lgkmcnt(0)")
     a("s_branch .Lpark_wait_%s_%%=" % tag)
     a.label(".Lpark_go_%s_%%=" % tag)
     a("v_and_b32_e32 v122, %d, v123" % (16 * HANDOFF2_NT - 1), "tile row among the NT buffers")
     a("v_mad_u32_u24 v126, v122, %[rowpitch], %[lb]")
     a("v_add_u32_e32 v126, %[qtile], v126")
     a("ds_write_b128 v126, %s" % vr(ACC, 4))
+    a("ds_write_b128 v126, %s offset:%d" % (vr(x_q, 4), HANDOFF2_X_OFF), "... and x[row]: what the marker's gather brought")
     a("v_cmp_eq_u32_e32 vcc, 0, %[lb]")
     a("s_and_b64 exec, %[mk], vcc")
     a("v_lshl_add_u32 v126, v122, 2, v124")
@@ -150,7 +153,8 @@ def stream_park(a, ob_q, tag):
     a("v_lshl_add_u32 v126, v122, 2, v124")
     a("ds_add_u32 v126, v125 offset:%d" % HANDOFF2_POSTED_OFF)
     a("s_mov_b64 exec, %[mk]")
-    a("s_waitcnt lgkmcnt(0)", "(also: the row's 16 bytes have left the accumulator registers)")
+    # (no wait: LDS instructions take their operands at issue, and they complete in order -- the counted waits of the steps
+    # below only ever wait longer for it)
 
 
 def stream_post(a, tag):
@@ -225,12 +229,17 @@ def stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag, post
     for q in range(4):
         a("s_waitcnt lgkmcnt(%d)" % (3 - q))
         x = xb + 4 * q
-        a("%s %s, %s, %s" % (binop, vr(x, 2), vr(RV[q], 2), vr(x, 2)))
-        a("%s %s, %s, %s" % (binop, vr(x + 2, 2), vr(RV[q] + 2, 2), vr(x + 2, 2)))
+        if post != 2:
+            a("%s %s, %s, %s" % (binop, vr(x, 2), vr(RV[q], 2), vr(x, 2)))
+            a("%s %s, %s, %s" % (binop, vr(x + 2, 2), vr(RV[q] + 2, 2), vr(x + 2, 2)))
         a("v_cmp_lt_i32_e32 vcc, %d, %%[rem]" % consts[q], "live")
         a("v_cmp_eq_u32_e64 %%[mk], v%d, %%[mark]" % (tb + q))
         a("s_and_b64 %[mk], %[mk], vcc", "marker")
         a("s_andn2_b64 exec, vcc, %[mk]", "edges")
+        if post == 2:
+            # (a marker's gather offset is its own row's: its lanes hold x[row] -- left as it is, parked with the aggregate)
+            a("%s %s, %s, %s" % (binop, vr(x, 2), vr(RV[q], 2), vr(x, 2)))
+            a("%s %s, %s, %s" % (binop, vr(x + 2, 2), vr(RV[q] + 2, 2), vr(x + 2, 2)))
         nary(a, sum_code, ACC, x)
         a("s_mov_b64 exec, %[mk]")
         a("s_cbranch_execz .Lstream_noflush_%s%d_%%=" % (tag, q))
@@ -249,7 +258,7 @@ def stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag, post
                 a("v_cndmask_b32_e32 v122, %%[bz], %%[b%d], vcc" % e)
                 a("%s v%d, v%d, v122" % (op, ACC + e, ACC + e))
         if post == 2:
-            stream_park(a, ob + q, "%s%d" % (tag, q))
+            stream_park(a, ob + q, xb + 4 * q, "%s%d" % (tag, q))
         else:
             a("global_store_dwordx4 v%d, %s, %%[ob]%s" % (ob + q, vr(ACC, 4), POST_OUT_POLICY if post else OUT_POLICY))
         if post == 1:

@@ -257,6 +257,15 @@ __device__ __forceinline__ Pack<T, 4> walk_row_in_order(const OrderParams &p, co
 #ifndef ULTRA_DBG_CHAIN
 #define ULTRA_DBG_CHAIN 0
 #endif
+#ifndef ULTRA_UPD_PRIO
+#define ULTRA_UPD_PRIO 3     /* s_setprio of the form-3 update waves */
+#endif
+#ifndef ULTRA_UPD_SKIP
+#define ULTRA_UPD_SKIP 0     /* measurement builds: 1 = the form-3 update waves skip operand reads and matrix chains (wrong results) */
+#endif
+#ifndef ULTRA_SPIN_GUARD
+#define ULTRA_SPIN_GUARD 0   /* debugging: the form-3 update waves' spins give up after 2^20 turns and report (trace[24 grid + ..]) */
+#endif
 #ifndef ULTRA_ASM_PRODUCE
 #define ULTRA_ASM_PRODUCE 1
 #endif
@@ -799,144 +808,261 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                     asm volatile("" : "+v"(lane_u));
                     const int u = wave - ORDER_WALKERS;
                     const int i16 = lane_u & 15, kk = lane_u >> 4;
-                    float *tiles = reinterpret_cast<float *>(ring);                         // [NT][16][68]
-                    float *x_tiles = tiles + UPD2_NT * UPD2_TILE_FLOATS, *y_tiles = x_tiles + 2 * UPD2_TILE_FLOATS;   // [2][16][68] each
-                    float *moments = y_tiles + 2 * UPD2_TILE_FLOATS;                        // [16 rows][16]
-                    float *c_tile = reinterpret_cast<float *>(const_cast<uint32_t *>(ctl)) + UPD2_CTL_CTILE_BYTES / 4;
+                    // the walkers' ring: 64 aggregate rows [64][68], behind them the same rows' x [64][68] -- a block's pre-norm rows
+                    // later take the place of its x rows
+                    // (typed LDS pointers: through generic ones every access here becomes a FLAT instruction -- the texture-address path
+                    // the walkers saturate -- instead of a DS one)
+                    using lds_f = __attribute__((address_space(3))) float;
+                    using lds_f4 = __attribute__((address_space(3))) f32x4m;     // (the native vector: HIP's float4 class has no address-space overloads)
+                    using lds_vu = volatile __attribute__((address_space(3))) uint32_t;
+                    using lds_u = __attribute__((address_space(3))) uint32_t;
+                    lds_vu *const lctl = (lds_vu *)ctl;
+                    lds_f *const tiles = (lds_f *)reinterpret_cast<float *>(ring), *const xring = tiles + UPD2_NT * UPD2_TILE_FLOATS;
+                    lds_f *const c_tile = (lds_f *)reinterpret_cast<float *>(const_cast<uint32_t *>(ctl)) + UPD2_CTL_CTILE_BYTES / 4;
                     // A operands: this wave's 16 rows of W (lane (i, kk) holds W[16 u + i][4 s + kk]); small vectors
                     float wfrag[32];
 #pragma unroll
                     for (int s = 0; s < 32; ++s) wfrag[s] = p.upd.weight[(16 * u + i16) * 128 + 4 * s + kk];
                     const int f0 = 16 * u + 4 * kk;      // D: lane l, reg r -> feature 16 u + 4 (l >> 4) + r of tile row l & 15
-                    float biasv[4], lnw[4], lnb[4];
+                    float biasv[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        biasv[r] = p.upd.bias ? p.upd.bias[f0 + r] : 0.f;
-                        lnw[r] = (p.upd.flags & CONV_LN) ? p.upd.ln_w[4 * i16 + r] : 1.f;      // (LayerNorm phase: lane l16 owns features 4 l16 + e)
-                        lnb[r] = (p.upd.flags & CONV_LN) ? p.upd.ln_b[4 * i16 + r] : 0.f;
-                    }
+                    for (int r = 0; r < 4; ++r) biasv[r] = p.upd.bias ? p.upd.bias[f0 + r] : 0.f;
                     if (c1 > c0) {
-                        while (ctl[3] == 0) __builtin_amdgcn_s_sleep(4);   // the chain consumer still reads the ring
+                        while (lctl[3] == 0) __builtin_amdgcn_s_sleep(4);   // the chain consumer still reads the ring
                     }
                     const char *aggbase = reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.out) + outer * p.out_stride_outer);
                     char *ubase = reinterpret_cast<char *>(p.upd.out + outer * p.upd.out_stride_outer);
                     uint32_t epoch = 0;
-                    const auto upd_barrier = [&]() {     // the four update waves meet (s_barrier would count the walkers too)
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if ULTRA_SPIN_GUARD   /* debugging build: a spin that does not end reports where it stood (trace[24 grid + 16 workgroup + 4 u ..]) and lets go */
+                    int t_now = 0;
+                    bool tripped = false;
+                    const auto spin_guard = [&](uint32_t &n, const int code) {
+                        if (++n < (1u << 20)) return false;
+                        if (p.trace && lane == 0 && !tripped) {
+                            long long *dst = p.trace + 24 * gridDim.x + 16 * blockIdx.x + 4 * u;
+                            dst[0] = ((long long)code << 48) | ((long long)t_now << 32) | epoch;
+                            dst[1] = ((long long)lctl[0] << 32) | lctl[1];
+                            dst[2] = ((long long)lctl[2] << 32) | lctl[UPD2_CTL_CONSUMED];
+                            dst[3] = ((long long)lctl[UPD2_CTL_POSTED] << 32) | lctl[UPD2_CTL_POSTED + 1];
+                        }
+                        tripped = true;
+                        lctl[UPD2_CTL_CONSUMED] = 0x3fffffffu;     // the walkers are let through
+                        return true;
+                    };
+#define ULTRA_SPIN(n, code) if (spin_guard(n, code)) break
+#else
+#define ULTRA_SPIN(n, code)
+#endif
+                    // The four update waves meet in two halves (s_barrier would count the walkers too): `arrive` costs nothing -- LDS
+                    // operations of a wave execute in order, so everything this wave did to LDS before is done when its arrival shows --
+                    // and between arriving and `meet` the wave does work that does not depend on the others.  One counter serves every
+                    // meeting: nobody arrives at meeting m + 1 before everybody has arrived at m.
+                    const auto arrive = [&]() {
+                        asm volatile("" ::: "memory");
                         epoch += (uint32_t)ORDER_UPDATERS;
-                        if (lane == 0) __hip_atomic_fetch_add(const_cast<uint32_t *>(ctl) + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        while (ctl[2] < epoch) __builtin_amdgcn_s_sleep(0);
+                        if (lane == 0) __hip_atomic_fetch_add((lds_u *)lctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    };
+                    const auto meet = [&]() {
+                        uint32_t spins = 0;
+                        (void)spins;
+                        while (lctl[2] < epoch) {
+                            ULTRA_SPIN(spins, 2);
+                        }
                         asm volatile("" ::: "memory");
                     };
-                    const int r_mine = 4 * u + kk;       // staging and finishing: a 16-lane group per tile row
-                    // Tiles are numbered t = 0, 1, ...: first the workgroup's chain rows (listed by the chain consumer, aggregates in
-                    // memory: staged like x), then the walkers' generations.  Tile t multiplies out of x / pre-norm buffer t & 1; while
-                    // it does, the x rows of tile t + 1 -- if that tile is already complete, which update wave 0 decides for all
-                    // four -- are on their way from memory and are parked in the other buffer: two barriers per tile, no memory
-                    // round trip on the tile's own path.
-                    const int n_chain_rows = (c1 > c0) ? min((int)ctl[UPD2_CTL_NCHAIN], UPD2_MAX_CHAIN_ROWS) : 0;
-                    const int n_ctile = (n_chain_rows + 15) >> 4;
-                    // rows of tile t as (count, offsets, aggregate tile, from memory?) -- blocks until the tile is complete when `wait`
-                    struct Tile {
-                        int n;
-                        const volatile uint32_t *rowoff;
-                        float *agg;
-                        bool from_memory;
+                    // An update wave's time is LDS round trips (several hundred cycles each while twelve waves walk: the LDS serves
+                    // requests in arrival order) and it takes no memory round trip at all: the walkers park x[row] beside the row's
+                    // aggregate (a marker step of a stream gathers at its own row's offset), so a complete block is ready to multiply.
+                    // The unit of work is a BLOCK of 32 rows -- two of the walkers' generations, two independent matrix chains.  Per
+                    // block: every wave sees for itself that the block is complete; reads its B operands; the waves meet once the x
+                    // rows are read (under the matrix chains) -- then the pre-norm rows take the x rows' place -- and once those are
+                    // written; every wave finishes 8 rows and, its LDS reads done, counts itself out of the block: at four the walkers
+                    // may reuse its rows.  Blocks t = 0, 1, ...: first the workgroup's chain rows, 8 to a block (listed by the chain
+                    // consumer, aggregates in memory: staged with their x into the control block's tile), then the walkers' generations
+                    // in pairs.  Lane (kk, i16) of update wave u finishes 16 bytes of rows rr and 16 + rr of a block.
+                    const int rr = 4 * u + kk;
+                    const int n_chain_rows = (c1 > c0) ? min((int)lctl[UPD2_CTL_NCHAIN], UPD2_MAX_CHAIN_ROWS) : 0;
+                    const int n_ctile = (n_chain_rows + 7) >> 3;
+                    struct Block {              // (small on purpose: `next` lives across the finishing of `cur`; tile addresses follow from b0)
+                        int n0, n1;             // rows of its two halves (n0 < 0: not complete yet; n0 == 0: there is none)
+                        uint32_t off0, off1;    // byte offsets of this lane's two rows inside a batch slice
+                        int b0;                 // first of its two ring tiles; -1: a chain block (8 rows, from memory, in the control block's tile)
                     };
-                    const auto tile_of = [&](const int t, const bool wait) {
-                        Tile tl;
-                        if (t < n_ctile) {
-                            tl.n = min(16, n_chain_rows - 16 * t);
-                            tl.rowoff = ctl + UPD2_CTL_CROW + 16 * t;
-                            tl.agg = c_tile;
-                            tl.from_memory = true;
-                            return tl;
-                        }
-                        const int G = t - n_ctile, buf = G & (UPD2_NT - 1);
-                        tl.rowoff = ctl + UPD2_CTL_ROWID + 16 * buf;
-                        tl.agg = tiles + buf * UPD2_TILE_FLOATS;
-                        tl.from_memory = false;
+                    const auto chain_block = [&](const int t) {
+                        Block bl;
+                        bl.n0 = min(8, n_chain_rows - 8 * t), bl.n1 = 0;
+                        bl.off0 = lctl[UPD2_CTL_CROW + 8 * t + (rr & 7)], bl.off1 = 0u;
+                        bl.b0 = -1;
+                        return bl;
+                    };
+                    // generations 2 B and 2 B + 1 of the walkers' rows (`wait`: blocks until they are complete)
+                    const auto look = [&](const int B, const bool wait) {
+                        const int b0 = (2 * B) & (UPD2_NT - 1);
+                        const uint32_t need = 16u * (uint32_t)(B / (UPD2_NT / 2) + 1);
+                        Block bl;
+                        bl.b0 = b0;
+                        uint32_t spins = 0;
+                        (void)spins;
                         for (;;) {
-                            const uint32_t walked = ctl[1];   // (read FIRST: with every walker done, the reads below see the final state)
-                            asm volatile("" ::: "memory");
-                            const uint32_t have = ctl[UPD2_CTL_POSTED + buf];
-                            if (have >= 16u * (uint32_t)(G / UPD2_NT + 1)) {
-                                tl.n = 16;
+                            // (`walked` is read FIRST and the row lists last: with every walker done the counts are final, and with
+                            // a generation's count full its list is)
+                            const uint32_t walked = lctl[1], have0 = lctl[UPD2_CTL_POSTED + b0], have1 = lctl[UPD2_CTL_POSTED + b0 + 1], tail = lctl[0];
+                            bl.off0 = lctl[UPD2_CTL_ROWID + 16 * b0 + rr], bl.off1 = lctl[UPD2_CTL_ROWID + 16 * b0 + 16 + rr];
+                            if (have0 >= need && have1 >= need) {
+                                bl.n0 = bl.n1 = 16;
                                 break;
                             }
                             if (walked == (uint32_t)ORDER_WALKERS) {
-                                tl.n = min(16, (int)ctl[0] - 16 * G);
+                                const int rem = (int)tail - 32 * B;
+                                bl.n0 = max(0, min(16, rem)), bl.n1 = max(0, min(16, rem - 16));
                                 break;
                             }
-                            if (!wait) {
-                                tl.n = -1;      // not complete yet
-                                break;
-                            }
-                            __builtin_amdgcn_s_sleep(2);
+                            bl.n0 = bl.n1 = -1;
+                            if (!wait) break;
+                            ULTRA_SPIN(spins, 1);
+                            __builtin_amdgcn_s_sleep(1);
                         }
-                        tl.n = rfl(tl.n);
-                        return tl;
+                        bl.n0 = rfl(bl.n0), bl.n1 = rfl(bl.n1);
+                        return bl;
                     };
-                    bool staged = false;        // the x rows (and memory aggregates) of the current tile are in its buffers already
+                    __builtin_amdgcn_s_setprio(ULTRA_UPD_PRIO);   // (the youngest waves of their SIMDs: without it every walker instruction goes first)
+                    // measurement hook (trace[3 grid + 4 workgroup + k]): cycles update wave 0 spends k = 0 waiting for a block (and
+                    // staging a chain block), 1 multiplying, 2 until the pre-norm rows are all written, 3 finishing
+                    long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, t_ph = p.trace ? clock64() : 0;
+                    const auto lap = [&](long long &ph) {
+                        if (p.trace) {
+                            const long long now = clock64();
+                            ph += now - t_ph;
+                            t_ph = now;
+                        }
+                    };
+                    bool ahead = false;         // `next` was seen complete while the previous block's pre-norm rows were being written
+                    int next_n0 = 0, next_n1 = 0, next_b0 = 0;
                     for (int t = 0;; ++t) {
-                        const Tile cur = tile_of(t, true);
-                        if (cur.n <= 0) break;
-                        float *x_tile = x_tiles + (t & 1) * UPD2_TILE_FLOATS, *y_tile = y_tiles + (t & 1) * UPD2_TILE_FLOATS;
-                        float *x_next = x_tiles + ((t + 1) & 1) * UPD2_TILE_FLOATS;
-                        const bool have = r_mine < cur.n;
-                        const uint32_t off_mine = have ? cur.rowoff[r_mine] : 0u;
-                        if (!staged) {
-                            *reinterpret_cast<float4 *>(x_tile + r_mine * UPD2_ROW_FLOATS + 4 * i16) =
-                                *reinterpret_cast<const float4 *>(xbase + off_mine + 16u * (uint32_t)i16);
-                            if (cur.from_memory)
-                                *reinterpret_cast<float4 *>(cur.agg + r_mine * UPD2_ROW_FLOATS + 4 * i16) =
-                                    *reinterpret_cast<const float4 *>(aggbase + off_mine + 16u * (uint32_t)i16);
+#if ULTRA_SPIN_GUARD
+                        t_now = t;
+                        if (tripped) break;
+#endif
+                        Block cur;
+                        if (ahead) {
+                            // (only what is uniform was kept; the rows' offsets are needed at the very end: read again, never waited for)
+                            cur.n0 = next_n0, cur.n1 = next_n1, cur.b0 = next_b0;
+                            cur.off0 = lctl[UPD2_CTL_ROWID + 16 * cur.b0 + rr], cur.off1 = lctl[UPD2_CTL_ROWID + 16 * cur.b0 + 16 + rr];
+                        } else {
+                            cur = t < n_ctile ? chain_block(t) : look(t - n_ctile, true);
+                            if (cur.n0 <= 0) break;
                         }
-                        // is the next tile complete already?  (update wave 0 looks, everybody acts on its verdict behind the barrier;
-                        // a chain tile's aggregate buffer is single: its successor is staged when its turn comes)
-                        if (u == 0) {
-                            Tile peek = tile_of(t + 1, false);
-                            if (t + 1 < n_ctile || cur.from_memory) peek.n = -1;
-                            if (lane == 0) ctl[UPD2_CTL_NEXT] = (uint32_t)(peek.n > 0 ? peek.n : 0);
+                        const bool have0 = rr < cur.n0, have1 = rr < cur.n1;
+                        const bool from_memory = cur.b0 < 0;
+                        const int rowmask = from_memory ? 7 : 15;     // (a chain block: tile rows 8..15 repeat 0..7)
+                        const int tile0 = rfl(max(cur.b0, 0)) * UPD2_TILE_FLOATS;
+                        lds_f *const px0 = from_memory ? c_tile : xring + tile0, *const px1 = from_memory ? c_tile : px0 + UPD2_TILE_FLOATS;
+                        lds_f *const pa0 = from_memory ? c_tile + 8 * UPD2_ROW_FLOATS : tiles + tile0;
+                        lds_f *const pa1 = from_memory ? pa0 : pa0 + UPD2_TILE_FLOATS;
+                        if (from_memory) {
+                            // update waves 0, 1: the 8 x rows; 2, 3: the 8 aggregate rows (16 lanes a row)
+                            const int j = 4 * (u & 1) + kk;
+                            const uint32_t off = j < cur.n0 ? lctl[UPD2_CTL_CROW + 8 * t + j] : 0u;
+                            *reinterpret_cast<lds_f4 *>((u < 2 ? px0 : pa0) + j * UPD2_ROW_FLOATS + 4 * i16) =
+                                *reinterpret_cast<const f32x4m *>((u < 2 ? xbase : aggbase) + off + 16u * (uint32_t)i16);
+                            arrive();
+                            meet();
                         }
-                        upd_barrier();
-                        const int n_next = rfl((int)ctl[UPD2_CTL_NEXT]);
-                        float4 x_pre = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (n_next > 0) {       // (its rows are listed: the tile is complete)
-                            const Tile nxt = tile_of(t + 1, false);
-                            const uint32_t off_next = r_mine < n_next ? nxt.rowoff[r_mine] : 0u;
-                            x_pre = *reinterpret_cast<const float4 *>(xbase + off_next + 16u * (uint32_t)i16);
-                        }
-                        f32x4m d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int s = 0; s < 16; ++s)
-                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[s], x_tile[i16 * UPD2_ROW_FLOATS + 4 * s + kk], d, 0, 0, 0);
-#pragma unroll
-                        for (int s = 0; s < 16; ++s)
-                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[16 + s], cur.agg[i16 * UPD2_ROW_FLOATS + 4 * s + kk], d, 0, 0, 0);
-                        *reinterpret_cast<float4 *>(y_tile + i16 * UPD2_ROW_FLOATS + f0) =
-                            make_float4(d[0] + biasv[0], d[1] + biasv[1], d[2] + biasv[2], d[3] + biasv[3]);   // bias after the chain, like addmm
-                        if (n_next > 0) *reinterpret_cast<float4 *>(x_next + r_mine * UPD2_ROW_FLOATS + 4 * i16) = x_pre;
-                        staged = n_next > 0;
-                        upd_barrier();
-                        // (every update wave is done with the aggregate tile) -> the walkers may refill the buffer
-                        if (!cur.from_memory && u == 0 && lane == 0) ctl[UPD2_CTL_CONSUMED] = (uint32_t)(t - n_ctile + 1);
-                        float y[4];
+                        lap(ph0);
+                        const int ri = i16 & rowmask, rf = rr & rowmask;
+                        f32x4m d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+                        f32x4m x0, x1;      // this lane's 16 bytes of the x rows it finishes (the residual)
+#if !ULTRA_UPD_SKIP
                         {
-                            const float4 v = *reinterpret_cast<const float4 *>(y_tile + r_mine * UPD2_ROW_FLOATS + 4 * i16);
-                            y[0] = v.x, y[1] = v.y, y[2] = v.z, y[3] = v.w;
+                            // four quarters of operands (x and aggregate of half 0, of half 1), each requested while the quarter
+                            // before it is multiplied: one LDS round trip in the open instead of two, 32 operand registers.  (One
+                            // chain at a time keeps the matrix pipe as busy as two interleaved: an instruction occupies it for its
+                            // 8 passes.)
+                            float q0[16], q1[16];
+#pragma unroll
+                            for (int s = 0; s < 16; ++s) q0[s] = px0[ri * UPD2_ROW_FLOATS + 4 * s + kk];
+#pragma unroll
+                            for (int s = 0; s < 16; ++s) q1[s] = pa0[ri * UPD2_ROW_FLOATS + 4 * s + kk];
+                            x0 = *reinterpret_cast<const lds_f4 *>(px0 + rf * UPD2_ROW_FLOATS + 4 * i16);
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (int s = 0; s < 16; ++s) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[s], q0[s], d0, 0, 0, 0);
+#pragma unroll
+                            for (int s = 0; s < 16; ++s) q0[s] = px1[ri * UPD2_ROW_FLOATS + 4 * s + kk];
+                            x1 = *reinterpret_cast<const lds_f4 *>(px1 + rf * UPD2_ROW_FLOATS + 4 * i16);
+                            arrive();       // (this wave's reads of the x rows are served before its arrival shows)
+#pragma unroll
+                            for (int s = 0; s < 16; ++s) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[16 + s], q1[s], d0, 0, 0, 0);
+#pragma unroll
+                            for (int s = 0; s < 16; ++s) q1[s] = pa1[ri * UPD2_ROW_FLOATS + 4 * s + kk];
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (int s = 0; s < 16; ++s) d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[s], q0[s], d1, 0, 0, 0);
+#pragma unroll
+                            for (int s = 0; s < 16; ++s) d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[16 + s], q1[s], d1, 0, 0, 0);
                         }
-                        if (p.upd.flags & CONV_LN)
-                            ln_row_group(y, y_tile + r_mine * UPD2_ROW_FLOATS, moments + r_mine * 16, i16, p.upd.eps, lnw, lnb);
+#else
+                        x0 = x1 = f32x4m{0.f, 0.f, 0.f, 0.f};
+                        arrive();
+#endif
+                        lap(ph1);
+                        meet();     // everybody has read the block's x rows: the pre-norm rows take their place (bias after the chain, like addmm)
+                        if (i16 <= rowmask)
+                            *reinterpret_cast<lds_f4 *>(px0 + i16 * UPD2_ROW_FLOATS + f0) =
+                                f32x4m{d0[0] + biasv[0], d0[1] + biasv[1], d0[2] + biasv[2], d0[3] + biasv[3]};
+                        if (cur.n1 > 0)
+                            *reinterpret_cast<lds_f4 *>(px1 + i16 * UPD2_ROW_FLOATS + f0) =
+                                f32x4m{d1[0] + biasv[0], d1[1] + biasv[1], d1[2] + biasv[2], d1[3] + biasv[3]};
+                        arrive();
+                        // (LayerNorm's weights of this lane's features 4 i16 + e: fetched per block, here, where the operand registers
+                        // have just come free -- kept across the loop they would spill)
+                        float lnw[4] = {1.f, 1.f, 1.f, 1.f}, lnb[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (p.upd.flags & CONV_LN) {
+                            using glb_f4 = const __attribute__((address_space(1))) f32x4m;
+                            const float *gw = p.upd.ln_w, *gb = p.upd.ln_b;
+                            asm volatile("" : "+s"(gw), "+s"(gb));
+                            const f32x4m vw = *((glb_f4 *)gw + i16), vb = *((glb_f4 *)gb + i16);
+                            lnw[0] = vw.x, lnw[1] = vw.y, lnw[2] = vw.z, lnw[3] = vw.w;
+                            lnb[0] = vb.x, lnb[1] = vb.y, lnb[2] = vb.z, lnb[3] = vb.w;
+                        }
+                        // while the others arrive: is the next block complete already?
+                        ahead = false;
+                        if (t + 1 >= n_ctile) {
+                            const Block next = look(t + 1 - n_ctile, false);
+                            ahead = next.n0 > 0;
+                            next_n0 = next.n0, next_n1 = next.n1, next_b0 = rfl(next.b0);
+                        }
+                        meet();
+                        lap(ph2);
+                        float ya[4], yb[4];
+                        const lds_f *row_a = px0 + rf * UPD2_ROW_FLOATS, *row_b = px1 + rf * UPD2_ROW_FLOATS;
+                        {
+                            const f32x4m va = *reinterpret_cast<const lds_f4 *>(row_a + 4 * i16), vb = *reinterpret_cast<const lds_f4 *>(row_b + 4 * i16);
+                            ya[0] = va.x, ya[1] = va.y, ya[2] = va.z, ya[3] = va.w;
+                            yb[0] = vb.x, yb[1] = vb.y, yb[2] = vb.z, yb[3] = vb.w;
+                        }
+                        if (p.upd.flags & CONV_LN) ln_row_group2(ya, yb, row_a, row_b, i16, p.upd.eps, lnw, lnb);
+                        // this wave is done with the block's rows in LDS (its reads above are served before the count shows): at four
+                        // the walkers may reuse them
+                        asm volatile("" ::: "memory");
+                        if (!from_memory && lane == 0)
+                            __hip_atomic_fetch_add((lds_u *)lctl + UPD2_CTL_CONSUMED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (p.upd.flags & CONV_RELU) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+                            for (int e = 0; e < 4; ++e) ya[e] = fmaxf(ya[e], 0.f), yb[e] = fmaxf(yb[e], 0.f);
                         }
                         if (p.upd.flags & CONV_RESIDUAL) {
-                            const float4 xi = *reinterpret_cast<const float4 *>(x_tile + r_mine * UPD2_ROW_FLOATS + 4 * i16);
-                            y[0] += xi.x, y[1] += xi.y, y[2] += xi.z, y[3] += xi.w;
+                            ya[0] += x0.x, ya[1] += x0.y, ya[2] += x0.z, ya[3] += x0.w;
+                            yb[0] += x1.x, yb[1] += x1.y, yb[2] += x1.z, yb[3] += x1.w;
                         }
-                        if (have) *reinterpret_cast<float4 *>(ubase + off_mine + 16u * (uint32_t)i16) = make_float4(y[0], y[1], y[2], y[3]);
+                        if (have0) *reinterpret_cast<float4 *>(ubase + cur.off0 + 16u * (uint32_t)i16) = make_float4(ya[0], ya[1], ya[2], ya[3]);
+                        if (have1) *reinterpret_cast<float4 *>(ubase + cur.off1 + 16u * (uint32_t)i16) = make_float4(yb[0], yb[1], yb[2], yb[3]);
+                        lap(ph3);
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                    if (p.trace && u == 0 && lane == 0) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) p.trace[3 * gridDim.x + 4 * blockIdx.x + k] = k == 0 ? ph0 : k == 1 ? ph1 : k == 2 ? ph2 : ph3;
                     }
                 }
             }

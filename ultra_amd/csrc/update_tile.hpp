@@ -76,13 +76,13 @@ constexpr int UPD2_NT = 4;                       // aggregate tiles the walkers 
 constexpr int UPD2_ROW_FLOATS = 68;              // 272 bytes (HANDOFF2_ROW_BYTES)
 constexpr int UPD2_TILE_FLOATS = 16 * UPD2_ROW_FLOATS;
 constexpr int UPD2_MAX_CHAIN_ROWS = 64;          // chain rows of a workgroup the control block can list
-// overlay (in the ring's place once the chain is done): NT aggregate tiles | two x tiles | two pre-norm tiles (tile G uses
-// buffer G & 1: the next tile's x rows are staged while this one is multiplied) | LayerNorm moments (16 x 16)
-constexpr int UPD2_OVERLAY_BYTES = (UPD2_NT + 4) * UPD2_TILE_FLOATS * 4 + 16 * 16 * 4;
-// control block (behind ring / overlay; bytes): 0 tail, 4 walkers done, 8 update-wave barrier, 12 chain done, 16 generations
-// consumed, 20 chain rows listed, 24 "the next generation is complete: its x rows are being staged" (update wave 0's verdict
-// for all four), 32 posted[NT], 64 rowid[16 NT], 320 chain row offsets[64], 576 chain tile
-constexpr int UPD2_CTL_CONSUMED = 4, UPD2_CTL_NCHAIN = 5, UPD2_CTL_NEXT = 6, UPD2_CTL_POSTED = 8, UPD2_CTL_ROWID = 16,
+// overlay (in the ring's place once the chain is done): NT aggregate tiles (a ring of 64 rows) | the x rows of a 32-row block
+// (k-permuted: element k of a row at (k % 4) * 16 + k / 4, so that a lane's sixteen B operands are four 16-byte reads) | its
+// pre-norm rows
+constexpr int UPD2_OVERLAY_BYTES = (UPD2_NT + 4) * UPD2_TILE_FLOATS * 4;
+// control block (behind ring / overlay; bytes): 0 tail, 4 walkers done, 8 update-wave barrier (arrivals), 12 chain done, 16
+// generations consumed, 20 chain rows listed, 32 posted[NT], 64 rowid[16 NT], 320 chain row offsets[64], 576 chain tile
+constexpr int UPD2_CTL_CONSUMED = 4, UPD2_CTL_NCHAIN = 5, UPD2_CTL_NEXT = 6 /* and 7 */, UPD2_CTL_POSTED = 8, UPD2_CTL_ROWID = 16,
               UPD2_CTL_CROW = 80;   // (word offsets)
 constexpr int UPD2_CTL_CTILE_BYTES = 576, UPD2_CTL_BYTES = UPD2_CTL_CTILE_BYTES + UPD2_TILE_FLOATS * 4;
 
@@ -106,6 +106,45 @@ __device__ __forceinline__ void ln_row_group(float (&y)[4], const float *row, fl
     merge8(all, eps, mean, rstd);
 #pragma unroll
     for (int e = 0; e < 4; ++e) y[e] = ln_apply(y[e], mean, rstd, gamma[e], beta[e]);
+}
+
+// lane I of this lane's row of 16 lanes (DPP row_share: no LDS round trip)
+template <int I>
+__device__ __forceinline__ float row_share(const float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + I, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ void gather_moments8(const Moments w, Moments (&all)[8]) {
+    all[0] = Moments{row_share<0>(w.m1), row_share<0>(w.m2)};
+    all[1] = Moments{row_share<1>(w.m1), row_share<1>(w.m2)};
+    all[2] = Moments{row_share<2>(w.m1), row_share<2>(w.m2)};
+    all[3] = Moments{row_share<3>(w.m1), row_share<3>(w.m2)};
+    all[4] = Moments{row_share<4>(w.m1), row_share<4>(w.m2)};
+    all[5] = Moments{row_share<5>(w.m1), row_share<5>(w.m2)};
+    all[6] = Moments{row_share<6>(w.m1), row_share<6>(w.m2)};
+    all[7] = Moments{row_share<7>(w.m1), row_share<7>(w.m2)};
+}
+
+// two rows at once (rows a and b of one 16-lane group), the eight partial moments of a row exchanged between lanes in registers:
+// one LDS round trip for the pair -- an update wave's time is LDS round trips
+template <class RowPtr>      // (an LDS-typed pointer: DS instructions, not FLAT ones)
+__device__ __forceinline__ void ln_row_group2(float (&ya)[4], float (&yb)[4], const RowPtr row_a, const RowPtr row_b, const int l16,
+                                              const float eps, const float (&gamma)[4], const float (&beta)[4]) {
+    float xa[8], xb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xa[j] = row_a[8 * j + (l16 & 7)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xb[j] = row_b[8 * j + (l16 & 7)];
+    float mean, rstd;
+    Moments all[8];
+    gather_moments8(welford8(xa), all);
+    merge8(all, eps, mean, rstd);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ya[e] = ln_apply(ya[e], mean, rstd, gamma[e], beta[e]);
+    gather_moments8(welford8(xb), all);
+    merge8(all, eps, mean, rstd);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) yb[e] = ln_apply(yb[e], mean, rstd, gamma[e], beta[e]);
 }
 
 // ---- the tile as a unit (the rspmm tail; 8 weight registers instead of 16: it runs under a 128-register cap) ----
