@@ -46,10 +46,12 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 L2_PEAK_GBS = 34500.0      # MI355X_MICROARCH.md: aggregate L2 bandwidth
 COPY_BYTES = 1 << 30
 ROOFLINE_POINTS = [("fb15k237", 8), ("codex_l", 8)]
-# measurement switch: ULTRA_BENCH_UPDATE_FORM=2 runs every one-launch layer of this process with the update BESIDE the walk
-# (ultra_tuning.reserved[2]) instead of in the kernel's tail -- the roofline block then describes that kernel
-UPDATE_FORM = 2 if os.environ.get("ULTRA_BENCH_UPDATE_FORM") == "2" else 1
-ORDER_KERNEL = "rspmm_order_kernel<float, 0, 0, true, false, true, %d>" % UPDATE_FORM   # (..., STREAMS, UPDATE): aggregate + layer update
+# measurement switch: ULTRA_BENCH_UPDATE_FORM=1 / 2 / 3 runs every one-launch layer of this process with the update in the
+# kernel's tail / beside the walk (rows by reference) / beside the walk (rows through LDS) -- ultra_tuning.reserved[2], DESIGN.md
+# 3.8 -- instead of the library's choice (form 3 on graphs of 10+ steps a row, which both roofline points are); the roofline
+# block then describes that kernel
+UPDATE_FORM = int(os.environ.get("ULTRA_BENCH_UPDATE_FORM") or 0)
+ORDER_KERNEL = "rspmm_order_kernel<float, 0, 0, true, false, true, %d>" % (UPDATE_FORM or 3)   # (..., STREAMS, UPDATE): aggregate + layer update
 # the vector L1 / texture-address path of a CU delivers 64 B per clock (MI355X_MICROARCH.md: 16-B-per-lane loads, four lanes
 # per clock); at the 2.4 GHz boost clock the 256 CUs gather 39.3 TB/s -- the roof of a kernel whose gathers hit in L2
 L1_PEAK_GBS = 256 * 64 * 2.4
@@ -119,8 +121,8 @@ def _stdout_to_stderr():
 # ---------------------------------------------------------------------------------------------------------------------
 def _point_operands(shape, bs, dev):
     from ultra_amd import rspmm, synthetic
-    if UPDATE_FORM == 2:
-        rspmm.set_tuning(update_form=2)
+    if UPDATE_FORM:
+        rspmm.set_tuning(update_form=UPDATE_FORM)
     data = synthetic.make_kg(**synthetic.SHAPES[shape], seed=1234, relation_graph=False)
     N, R = data.num_nodes, data.num_relations
     g = torch.Generator().manual_seed(0)
@@ -207,8 +209,8 @@ def trace_target(steps=40):
     stream), replayed `steps` times -- the per-kernel durations of the step as it runs inside the graph."""
     from ultra_amd import models, rspmm, synthetic, tasks
     from ultra_amd.graph import GraphedForward
-    if UPDATE_FORM == 2:
-        rspmm.set_tuning(update_form=2)
+    if UPDATE_FORM:
+        rspmm.set_tuning(update_form=UPDATE_FORM)
     dev = torch.device("cuda:0")
     data = synthetic.make_kg(**synthetic.SHAPES["fb15k237"], seed=1234).to(dev)
     model = models.Ultra(**synthetic.default_model_cfg())
@@ -489,9 +491,9 @@ def main():
         entry.build()
     if world > 1:
         dist.barrier()
-    if UPDATE_FORM == 2:
+    if UPDATE_FORM:
         from ultra_amd import rspmm as _r
-        _r.set_tuning(update_form=2)
+        _r.set_tuning(update_form=UPDATE_FORM)
     from ultra_amd import distributed as udist
     from ultra_amd import host_order, models, rspmm, synthetic, tasks
     if world > 1 or launched:

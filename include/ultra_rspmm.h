@@ -192,12 +192,20 @@ int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t sum, int32_t mul, in
  *   aggregate = rspmm(sum, mul)(relation, input) [+ point boundary]        -- as ultra_rspmm_forward_point / _forward
  *   output    = [input +] relu( LayerNorm( W . [input ; aggregate] + b ) ) -- as ultra_conv_update (ultra_nbfnet.h), same `flags` / `eps`
  *
- * Every workgroup of the reference-order kernel applies the update to the rows it aggregates -- in the kernel's tail, once
- * its walks have ended (the default), or beside the walk (ultra_tuning.reserved[2] == 2): twelve of its sixteen waves walk
- * the graph, four multiply, while the walk goes on, the rows the walkers hand over through an LDS queue.  Results are
- * bit-equal with the two separate calls in both forms.  sum: ULTRA_SUM_ADD / _MIN / _MAX (min / max with a point boundary:
- * see ultra_rspmm_forward_point).
- * `aggregate` receives the aggregate as before (scratch for the caller); `output` must not alias it or `input`.
+ * Every workgroup of the reference-order kernel applies the update to the rows it aggregates, in one of three forms
+ * (ultra_tuning.reserved[2]; 0 = the library chooses: form 3 where it fits and the graph has 10+ steps -- edges + rows --
+ * a row, the tail form otherwise):
+ *   1  in the kernel's tail, once its walks have ended;
+ *   2  beside the walk, rows by reference: twelve of the sixteen waves walk the graph, four multiply, while the walk goes
+ *      on, the rows the walkers stored and handed over through an LDS queue;
+ *   3  beside the walk, rows through LDS: the walkers park every finished aggregate row and its input row in a ring in
+ *      LDS, the four update waves (the weight matrix split over their registers) take them from there -- no aggregate
+ *      ever travels through memory.
+ * Results are bit-equal with the two separate calls in every form.  sum: ULTRA_SUM_ADD / _MIN / _MAX (min / max with a
+ * point boundary: see ultra_rspmm_forward_point).  A form asked for explicitly (2, 3) that does not fit the call (LDS, rows
+ * per workgroup) is ULTRA_ERR_UNSUPPORTED.
+ * `aggregate` is scratch for the caller (forms 1 and 2 leave the aggregate there; form 3 writes only the rows of its
+ * chains); `output` must not alias it or `input`.
  * point_rows_dev / point_values: both NULL = no boundary.  Served where the stream walk serves ultra_rspmm_forward_point
  * (ULTRA_PLAN_EXACT_ORDER plan in the sparse format, 64-element rows, every stride equal): ULTRA_ERR_UNSUPPORTED
  * otherwise, nothing launched -- the caller then makes the two calls.
@@ -328,10 +336,11 @@ typedef struct {
     int32_t unroll;       /* edges in flight per lane group (0 -> default) */
     int32_t reserved[3];  /* [0] != 0: ULTRA_PLAN_EXACT_ORDER plans run on the general walk kernel instead of the order kernels;
                              [1] != 0: the order kernels walk units of four rows (C++ loop) instead of group streams (assembly);
-                             [2]: ultra_rspmm_forward_update -- 0 / 1 the update in the kernel's tail; 2 beside the walk (finished rows
-                                  handed over by reference and read back from memory), 3 beside the walk with the aggregate passing
-                                  through LDS tiles (`aggregate` is then scratch: its contents are unspecified on return), or
-                                  ULTRA_ERR_UNSUPPORTED where the form does not fit (LDS beside the relation slice, rows per workgroup) */
+                             [2]: ultra_rspmm_forward_update -- 0 the library's choice (3 where it fits and the graph has 10+ steps a
+                                  row, else 1); 1 the update in the kernel's tail; 2 beside the walk (finished rows handed over by
+                                  reference and read back from memory); 3 beside the walk with the rows passing through LDS
+                                  (`aggregate` is then scratch: its contents are unspecified on return); 2 / 3 where the form
+                                  does not fit (LDS beside the relation slice, rows per workgroup): ULTRA_ERR_UNSUPPORTED */
 } ultra_tuning;
 int32_t ultra_set_tuning(const ultra_tuning *t);   /* NULL restores defaults */
 int32_t ultra_get_tuning(ultra_tuning *t);

@@ -186,7 +186,25 @@ def stream_post(a, tag):
     a.label(".Lstream_nopost_%s_%%=" % tag)
 
 
+# How a step's (col, type) gets from the lane that holds the record to the 16 lanes of its group: DPP row broadcast (a VALU move:
+# "row_newbcast" is the assembler's name of row_share on gfx90a+) instead of ds_swizzle -- the swizzles were 8 of the 12 LDS
+# instructions of a chunk, and the LDS pipe of the CU, shared by all sixteen waves, is what the walk keeps busiest.
+DPP_BCAST = os.environ.get("ULTRA_GEN_DPP_BCAST", "1") == "1"
+
+
 def stream_fetch(a, xb, tb, ob, J):
+    if DPP_BCAST:
+        a("s_nop 1", "(a VALU write of v114 / v115 needs two wait states before a DPP read)")
+        for q in range(4):
+            a("v_mov_b32_dpp v%d, v114 row_newbcast:%d row_mask:0xf bank_mask:0xf" % (ob + q, J + q))
+        for q in range(4):
+            a("v_mov_b32_dpp v%d, v115 row_newbcast:%d row_mask:0xf bank_mask:0xf" % (tb + q, J + q))
+        for q in range(4):
+            a("v_mad_u32_u24 v%d, v%d, %%[xrb], %%[lb]" % (ob + q, ob + q))
+            a("global_load_dwordx4 %s, v%d, %%[xb]" % (vr(xb + 4 * q, 4), ob + q))
+        for q in range(4):
+            a("v_lshl_add_u32 v%d, v%d, 8, %%[lds]" % (tb + q, tb + q))
+        return
     for q in range(4):
         a("ds_swizzle_b32 v%d, v114 offset:swizzle(BROADCAST,16,%d)" % (ob + q, J + q))
     for q in range(4):

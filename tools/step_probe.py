@@ -1,6 +1,7 @@
 """The benchmark step, measured for A/B comparisons on one box: captured Ultra.forward on the FB15k237 shape, batch 8, one
 batch at a time and two in flight; `reps` runs of `steps` steps each, median / min / max of ms per step.
-    python tools/step_probe.py [reps] [steps]      env: ULTRA_NO_PREFILL=1 (entity layer-0 fill behind the relation model)"""
+    python tools/step_probe.py [reps] [steps]      env: ULTRA_NO_PREFILL=1 (entity layer-0 fill behind the relation model),
+                                                        PROBE_UPDATE_FORM=1|2|3 (rspmm.set_tuning(update_form=...))"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +10,9 @@ from ultra_amd.graph import GraphedForward, PipelinedForward
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+if os.environ.get("PROBE_UPDATE_FORM"):
+    from ultra_amd import rspmm
+    rspmm.set_tuning(update_form=int(os.environ["PROBE_UPDATE_FORM"]))
 if os.environ.get("ULTRA_NO_PREFILL"):
     models.PREFILL_LAYER0 = False
 dev = torch.device("cuda:0")

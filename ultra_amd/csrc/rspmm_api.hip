@@ -433,9 +433,16 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
                         lds = need;
                     }
                 }
-                // Form 3 (ultra_tuning.reserved[2] == 3): beside the walk with the aggregate passing through LDS tiles; the update
-                // waves keep the weight matrix in registers, so the room is there even beside a 474-relation slice
-                if (g_tuning.reserved[2] == 3 && ORDER_WAVES == 16 && upd->out_stride_row * (int64_t)sizeof(float) == (int64_t)op.x_row_bytes) {
+                // Form 3: beside the walk with the rows passing through LDS -- the walkers park every finished aggregate row AND its x
+                // row (a marker step gathers at its own row's offset) in a 64-row ring; the update waves keep the weight matrix in
+                // registers, so the room is there even beside a 474-relation slice, and they take no memory round trip (DESIGN.md
+                // 3.8c).  Measured on MI355X, layer in a hipGraph, against the tail form: FB15k237 bs 8 85.7 us vs 94.4, bs 16 166 vs
+                // 192, bs 4 68.5 vs 69.6, max aggregate 110.6 vs 113.7, CoDEx-L bs 8 324 vs 375 -- but WN18RR bs 8 141 vs 128: with 5
+                // steps a row the update is most of the work, and here only four of the sixteen waves do it.  So: on request
+                // (ultra_tuning.reserved[2] == 3) always, by default (0) from 10 steps a row up; 1 asks for the tail form.
+                const bool walk_heavy = (double)(p->num_edge + p->num_out) >= 10.0 * (double)p->num_out;
+                const bool want3 = g_tuning.reserved[2] == 3 || (g_tuning.reserved[2] == 0 && walk_heavy);
+                if (want3 && ORDER_WAVES == 16 && upd->out_stride_row * (int64_t)sizeof(float) == (int64_t)op.x_row_bytes) {
                     if ((rc = get_schedule(p, op.nparts, &sched12, ORDER_WALKERS))) return rc;
                     const size_t overlay = std::max(ring_bytes, (size_t)UPD2_OVERLAY_BYTES);
                     const size_t need = rel_bytes + overlay + UPD2_CTL_BYTES;

@@ -261,7 +261,7 @@ __device__ __forceinline__ Pack<T, 4> walk_row_in_order(const OrderParams &p, co
 #define ULTRA_UPD_PRIO 3     /* s_setprio of the form-3 update waves */
 #endif
 #ifndef ULTRA_UPD_SKIP
-#define ULTRA_UPD_SKIP 0     /* measurement builds: 1 = the form-3 update waves skip operand reads and matrix chains (wrong results) */
+#define ULTRA_UPD_SKIP 0     /* measurement builds (wrong results): the form-3 update waves skip 1 = operand reads and matrix chains, 2 = the matrix chains (a VALU add per operand instead), 3 = the operand reads */
 #endif
 #ifndef ULTRA_SPIN_GUARD
 #define ULTRA_SPIN_GUARD 0   /* debugging: the form-3 update waves' spins give up after 2^20 turns and report (trace[24 grid + ..]) */
@@ -972,7 +972,17 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                         const int ri = i16 & rowmask, rf = rr & rowmask;
                         f32x4m d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
                         f32x4m x0, x1;      // this lane's 16 bytes of the x rows it finishes (the residual)
-#if !ULTRA_UPD_SKIP
+#if ULTRA_UPD_SKIP != 1
+#if ULTRA_UPD_SKIP == 2
+#define UPD_MFMA(a, b, c) f32x4m{(c)[0] + (b), (c)[1], (c)[2], (c)[3]}
+#define UPD_OP(expr) (expr)
+#elif ULTRA_UPD_SKIP == 3
+#define UPD_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+#define UPD_OP(expr) (wfrag[s])
+#else
+#define UPD_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+#define UPD_OP(expr) (expr)
+#endif
                         {
                             // four quarters of operands (x and aggregate of half 0, of half 1), each requested while the quarter
                             // before it is multiplied: one LDS round trip in the open instead of two, 32 operand registers.  (One
@@ -980,26 +990,26 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                             // 8 passes.)
                             float q0[16], q1[16];
 #pragma unroll
-                            for (int s = 0; s < 16; ++s) q0[s] = px0[ri * UPD2_ROW_FLOATS + 4 * s + kk];
+                            for (int s = 0; s < 16; ++s) q0[s] = UPD_OP(px0[ri * UPD2_ROW_FLOATS + 4 * s + kk]);
 #pragma unroll
-                            for (int s = 0; s < 16; ++s) q1[s] = pa0[ri * UPD2_ROW_FLOATS + 4 * s + kk];
+                            for (int s = 0; s < 16; ++s) q1[s] = UPD_OP(pa0[ri * UPD2_ROW_FLOATS + 4 * s + kk]);
                             x0 = *reinterpret_cast<const lds_f4 *>(px0 + rf * UPD2_ROW_FLOATS + 4 * i16);
                             asm volatile("" ::: "memory");
 #pragma unroll
-                            for (int s = 0; s < 16; ++s) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[s], q0[s], d0, 0, 0, 0);
+                            for (int s = 0; s < 16; ++s) d0 = UPD_MFMA(wfrag[s], q0[s], d0);
 #pragma unroll
-                            for (int s = 0; s < 16; ++s) q0[s] = px1[ri * UPD2_ROW_FLOATS + 4 * s + kk];
+                            for (int s = 0; s < 16; ++s) q0[s] = UPD_OP(px1[ri * UPD2_ROW_FLOATS + 4 * s + kk]);
                             x1 = *reinterpret_cast<const lds_f4 *>(px1 + rf * UPD2_ROW_FLOATS + 4 * i16);
                             arrive();       // (this wave's reads of the x rows are served before its arrival shows)
 #pragma unroll
-                            for (int s = 0; s < 16; ++s) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[16 + s], q1[s], d0, 0, 0, 0);
+                            for (int s = 0; s < 16; ++s) d0 = UPD_MFMA(wfrag[16 + s], q1[s], d0);
 #pragma unroll
-                            for (int s = 0; s < 16; ++s) q1[s] = pa1[ri * UPD2_ROW_FLOATS + 4 * s + kk];
+                            for (int s = 0; s < 16; ++s) q1[s] = UPD_OP(pa1[ri * UPD2_ROW_FLOATS + 4 * s + kk]);
                             asm volatile("" ::: "memory");
 #pragma unroll
-                            for (int s = 0; s < 16; ++s) d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[s], q0[s], d1, 0, 0, 0);
+                            for (int s = 0; s < 16; ++s) d1 = UPD_MFMA(wfrag[s], q0[s], d1);
 #pragma unroll
-                            for (int s = 0; s < 16; ++s) d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[16 + s], q1[s], d1, 0, 0, 0);
+                            for (int s = 0; s < 16; ++s) d1 = UPD_MFMA(wfrag[16 + s], q1[s], d1);
                         }
 #else
                         x0 = x1 = f32x4m{0.f, 0.f, 0.f, 0.f};
