@@ -2,11 +2,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r4w
 mkdir -p $O
-ULTRA_AMD_LIB=ultra_amd/lib/variants/libultra_amd_guard.so timeout 90 python tools/spin_guard_probe.py > $O/guard.txt 2>&1
-tail -2 $O/guard.txt
-if ! grep -q "^0 reports" $O/guard.txt; then echo "a spin gave up: stopping"; exit 1; fi
-echo "== library's choice"; timeout 200 python tools/step_probe.py 2>&1 | tail -2
-echo "== tail form";        PROBE_UPDATE_FORM=1 timeout 200 python tools/step_probe.py 2>&1 | tail -2
-echo "== library's choice"; timeout 200 python tools/step_probe.py 2>&1 | tail -2
-timeout 1500 python -m pytest tests -x -q -m gpu > $O/tests_gpu.txt 2>&1
-tail -5 $O/tests_gpu.txt
+timeout 600 python -m pytest tests/test_rspmm_gpu.py tests/test_models_gpu.py -x -q -k "layer0 or forward or bit" > $O/tests_l0.txt 2>&1
+tail -3 $O/tests_l0.txt
+echo "== step"; timeout 200 python tools/step_probe.py 2>&1 | tail -2
+FORMS=0 bash tools/r4_gpu_x.sh 2>&1 | grep -A24 "== ULTRA_BENCH" | head -26

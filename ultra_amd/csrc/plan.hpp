@@ -126,6 +126,7 @@ struct ultra_plan {
     int32_t seg_len = 256, g_max = 64, flags = 0;
     int32_t type_bits = 0;
     bool packed_ok = false;
+    int32_t max_row_len = -1;     // longest row (edges); computed on first use (the layer-0 launch sizes its grid with it)
 
     std::vector<int32_t> row_ptr, col, type, perm, erow;  // erow: output row of each sorted edge
     std::vector<uint32_t> packed;

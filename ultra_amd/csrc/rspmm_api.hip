@@ -833,7 +833,18 @@ static int layer0_impl(ultra_plan *p, const void *w, const ultra_mat *rel, const
         HIP_TRY(hipGetLastError());
     }
     if (!only_fill) {
-        hipLaunchKernelGGL(nbf_layer0_rows_kernel, dim3(32, (unsigned)n_outer), dim3(1024), 0, stream, lp);
+        // one 16-lane group per out-edge of the source, 64 groups a workgroup: enough workgroups that the hub with the most
+        // out-edges is served in ONE pass (a pass is a chain of three dependent loads + the 128-term update: 3+ us; the FB15k237
+        // shape's 9,067-edge hub took five of them on the former 32 workgroups a sample); workgroups past a source's last edge
+        // leave at once
+        ultra_plan *tp = p->tplan;
+        if (tp->max_row_len < 0) {
+            int32_t m = 0;
+            for (size_t r = 0; r + 1 < tp->row_ptr.size(); ++r) m = std::max(m, tp->row_ptr[r + 1] - tp->row_ptr[r]);
+            tp->max_row_len = m;
+        }
+        const unsigned l0_blocks = (unsigned)std::min(std::max((tp->max_row_len + 63) / 64, 32), 256);
+        hipLaunchKernelGGL(nbf_layer0_rows_kernel, dim3(l0_blocks, (unsigned)n_outer), dim3(1024), 0, stream, lp);
         HIP_TRY(hipGetLastError());
     }
     return ULTRA_OK;

@@ -469,6 +469,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
             stage_slice<T, 4>(lds_rel, reinterpret_cast<const T *>(p.rel.ptr) + outer * p.rel.stride_outer, p.rel.stride_row,
                               p.num_rel, inner, p.row_len, tid_stage, ORDER_THREADS);
             __syncthreads();
+            if (p.trace && tid == 0) p.trace[7 * gridDim.x + blockIdx.x] = clock64();   // (measurement hook: the relation slice is staged)
         }
 
         // ================= chain rows of this workgroup =================
