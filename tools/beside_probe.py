@@ -116,6 +116,25 @@ if served:
         end = main[:, 2] - main[:, 0]
         print("form %d: cycles since the workgroup's start -- chains done %.0f, end mean %.0f max %.0f" %
               (form, chain.mean(), end.mean(), end.max()))
+        late = end.argsort(descending=True)[:6].tolist()
+        print("  the six workgroups that end last (end | chains done | walkers' last end): " +
+              "  ".join("%.0f | %.0f | %.0f" % (end[i], chain[i], wave_end[i, :12].max()) for i in late))
+        if form == 3:
+            # workgroup b serves partition b // bs for sample b % bs: the same work eight times over
+            per = end.view(-1, bs)
+            pm = per.mean(dim=1)
+            print("  per partition (mean over its %d samples): min %.0f max %.0f, std across partitions %.0f; std inside a partition %.0f (mean)"
+                  % (bs, pm.min(), pm.max(), pm.std(), per.std(dim=1).mean()))
+            order = pm.argsort(descending=True).tolist()
+            wl = wave_end[:, :12].max(dim=1)[0].view(-1, bs).mean(dim=1)
+            print("  partitions, last to first (end | chains done | walkers' last end): " +
+                  "  ".join("%d: %.0f | %.0f | %.0f" % (q, pm[q], chain.view(-1, bs).mean(dim=1)[q], wl[q]) for q in order[:5] + order[-3:]))
+        if form == 3 and os.environ.get("PROBE_DUMP_PARTS"):
+            print("PARTS end " + " ".join("%.0f" % v for v in pm.tolist()))
+            print("PARTS chain " + " ".join("%.0f" % v for v in chain.view(-1, bs).mean(dim=1).tolist()))
+            print("PARTS walk " + " ".join("%.0f" % v for v in wl.tolist()))
+        early = end.argsort()[:3].tolist()
+        print("  the three that end first: " + "  ".join("%.0f | %.0f | %.0f" % (end[i], chain[i], wave_end[i, :12].max()) for i in early))
         print("  end of work per wave (mean over workgroups): " + " ".join("%6.0f" % v for v in wave_end.mean(dim=0).tolist()))
         print("  ... max over workgroups:                     " + " ".join("%6.0f" % v for v in wave_end.max(dim=0)[0].tolist()))
         if form == 3:
