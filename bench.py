@@ -152,22 +152,25 @@ def pmc_target():
         _stream_copy(dst, src)
     torch.cuda.synchronize()
     del src, dst
+    from ultra_amd import rspmm
+    grid = int(os.environ.get("ULTRA_BENCH_LAUNCH_GRID") or 0)     # (the timed region's launch size: CUs / batches in flight)
     for shape, bs in ROOFLINE_POINTS:
         _, plan, rel, x, point, upd = _point_operands(shape, bs, dev)
-        for _ in range(4):
-            if plan.forward_update(rel, x, upd[0], upd[1], upd[2], upd[3], 1e-5, 7, point=point) is None:
-                raise RuntimeError("the one-launch layer does not serve this point")
+        with rspmm.tuning_scope(grid=grid if shape == ROOFLINE_POINTS[0][0] else 0):   # (the second point: whole-chip launches)
+            for _ in range(4):
+                if plan.forward_update(rel, x, upd[0], upd[1], upd[2], upd[3], 1e-5, 7, point=point) is None:
+                    raise RuntimeError("the one-launch layer does not serve this point")
         torch.cuda.synchronize()
         del plan, rel, x
 
 
-def _run_pmc_pass(counters, timeout=240):
+def _run_pmc_pass(counters, timeout=240, launch_grid=0):
     """One rocprofv3 counter pass over pmc_target(); returns {counter: {"copy": [..], "points": [[..], [..]]}} or raises."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         raise RuntimeError("rocprofv3 not found")
     tmp = tempfile.mkdtemp(prefix="ultra_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", ULTRA_BENCH_LAUNCH_GRID=str(launch_grid))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
     cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--",
@@ -205,10 +208,11 @@ def _run_pmc_pass(counters, timeout=240):
 
 
 def trace_target(steps=40):
-    """Child process of the --kernel-trace pass: the benchmark's forward, one batch at a time (one captured hipGraph, one
-    stream), replayed `steps` times -- the per-kernel durations of the step as it runs inside the graph."""
+    """Child process of the --kernel-trace passes: the benchmark's forward replayed `steps` times -- one batch at a time (one
+    captured hipGraph, one stream), or with ULTRA_BENCH_TRACE_IN_FLIGHT=n as the timed region runs it (n captures on n
+    streams, their aggregation kernels on CUs / n workgroups each) -- for the per-kernel durations inside the graph."""
     from ultra_amd import models, rspmm, synthetic, tasks
-    from ultra_amd.graph import GraphedForward
+    from ultra_amd.graph import GraphedForward, PipelinedForward
     if UPDATE_FORM:
         rspmm.set_tuning(update_form=UPDATE_FORM)
     dev = torch.device("cuda:0")
@@ -219,20 +223,25 @@ def trace_target(steps=40):
         model.load_state_dict(torch.load(golden))
     model = model.to(dev).eval()
     triples = data.target_triples
-    fwd = GraphedForward(model, data, tasks.all_negative(data, triples[:8])[0])
-    for i in range(steps):
-        fwd(tasks.all_negative(data, triples[8 * i:8 * i + 8])[0])
+    n_flight = int(os.environ.get("ULTRA_BENCH_TRACE_IN_FLIGHT") or 1)
+    example = tasks.all_negative(data, triples[:8])[0]
+    fwd = PipelinedForward(model, data, example, depth=n_flight) if n_flight > 1 else GraphedForward(model, data, example)
+    inputs = [tasks.all_negative(data, triples[8 * i:8 * i + 8])[0] for i in range(16)]
+    for i in range(steps * n_flight):
+        fwd(inputs[i % 16])
+    if n_flight > 1:
+        fwd.join()
     torch.cuda.synchronize()
 
 
-def _run_trace_pass(timeout=240):
+def _run_trace_pass(timeout=240, in_flight=1):
     """rocprofv3 --kernel-trace --stats over trace_target(): {kernel name: (calls, avg us)} of the captured forward's kernels
-    (no counters in this pass); the stats CSV is kept under $ULTRA_BENCH_PMC_KEEP as bench_kernel_stats_inflight1.csv."""
+    (no counters in this pass); the stats CSV is kept under $ULTRA_BENCH_PMC_KEEP as bench_kernel_stats_inflight<n>.csv."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         raise RuntimeError("rocprofv3 not found")
     tmp = tempfile.mkdtemp(prefix="ultra_trace_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", ULTRA_BENCH_TRACE_IN_FLIGHT=str(in_flight))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
     cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "trace", "--",
@@ -245,7 +254,7 @@ def _run_trace_pass(timeout=240):
         keep = os.environ.get("ULTRA_BENCH_PMC_KEEP")
         if keep:
             os.makedirs(keep, exist_ok=True)
-            shutil.copy(files[0], os.path.join(keep, "bench_kernel_stats_inflight1.csv"))
+            shutil.copy(files[0], os.path.join(keep, "bench_kernel_stats_inflight%d.csv" % in_flight))
         rows = {}
         for row in csv.DictReader(open(files[0])):
             rows[row["Name"]] = (int(row["Calls"]), float(row["AverageNs"]) / 1e3, float(row["TotalDurationNs"]) / 1e3)
@@ -254,8 +263,40 @@ def _run_trace_pass(timeout=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def measure_roofline(dev, use_pmc=True):
+def _regime_ms(plan, rel, x, point, upd, n_flight, grid, iters=30):
+    """The one-launch layer as the timed region runs it: `n_flight` streams, each launching it `iters` times back to back with
+    `grid` workgroups (CUs / n_flight), all streams at once.  Returns ms per launch on a stream (HIP events on that stream
+    around its `iters` launches; mean over the streams)."""
+    from ultra_amd import rspmm
+    streams = [torch.cuda.Stream() for _ in range(n_flight)]
+    args = (rel, x, upd[0], upd[1], upd[2], upd[3], 1e-5, 7)
+    with rspmm.tuning_scope(grid=grid):
+        for s_ in streams:
+            s_.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s_):
+                for _ in range(5):
+                    plan.forward_update(*args, point=point)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in streams]
+        for s_, (e0, _) in zip(streams, ev):
+            e0.record(s_)
+        for _ in range(iters):
+            for s_ in streams:
+                with torch.cuda.stream(s_):
+                    plan.forward_update(*args, point=point)
+        for s_, (_, e1) in zip(streams, ev):
+            e1.record(s_)
+        torch.cuda.synchronize()
+    return sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev) / iters
+
+
+def measure_roofline(dev, use_pmc=True, in_flight=1):
+    """in_flight: batches the timed region keeps in flight -- its aggregation kernels run with CUs / in_flight workgroups, that
+    many launches side by side (graph.PipelinedForward); the block describes the kernel in THAT regime and keeps the
+    whole-chip launch beside it."""
     from ultra_amd import _lib
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    launch_grid = max(n_cu // in_flight, 1) if in_flight > 1 else 0
     out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "kernel": "ultra::" + ORDER_KERNEL + " (entity layer in one launch: rspmm add_mul with point boundary, relation slice "
                      "in LDS, then Linear(128->64) + LayerNorm + ReLU + residual on the rows each workgroup aggregated)"}
@@ -286,10 +327,16 @@ def measure_roofline(dev, use_pmc=True):
         # captured forward (five in a row).  timed[1] has the other regime for the record: events right around ONE launch with a
         # host synchronisation after each, i.e. every launch starts on an idle chip (form 3 of the layer -- twelve waves walking
         # while four multiply -- is the one that shows the difference: ~ 100 us against ~ 87).
-        ms = timed[0]
+        ms_whole = timed[0]
+        # (the second point is not the timed workload: it stays a whole-chip launch -- PipelinedForward shares the chip only
+        # where the activations fit the last-level cache)
+        shared = in_flight > 1 and shape == ROOFLINE_POINTS[0][0]
+        ms = _regime_ms(plan, rel, x, point, upd, in_flight, launch_grid) if shared else ms_whole
         plan.forward_timed(rel, x, point=point, warmup=5, iters=30)      # (the aggregate alone, for the record)
         info = plan.info()
         points.append({"shape": shape, "batch": bs, "N": N, "E": E, "R": R, "D": D, "ms_per_launch": ms,
+                       "launches_side_by_side": in_flight if shared else 1, "workgroups_per_launch": (launch_grid or n_cu) if shared else n_cu,
+                       "ms_per_launch_alone_on_the_whole_chip": ms_whole,
                        "ms_per_launch_each_on_an_idle_chip": timed[1],
                        "ms_per_launch_aggregate_only": plan.last_main_kernel_ms,
                        "x_plus_out_MB": 2 * 4 * D * N / 1e6, "chain_rows": info["n_chain_row"],
@@ -300,9 +347,9 @@ def measure_roofline(dev, use_pmc=True):
     pmc_note = None
     if use_pmc:
         try:
-            fetch = _run_pmc_pass(["FETCH_SIZE"])["FETCH_SIZE"]
-            write = _run_pmc_pass(["WRITE_SIZE"])["WRITE_SIZE"]
-            tcc = _run_pmc_pass(["TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"])
+            fetch = _run_pmc_pass(["FETCH_SIZE"], launch_grid=launch_grid)["FETCH_SIZE"]
+            write = _run_pmc_pass(["WRITE_SIZE"], launch_grid=launch_grid)["WRITE_SIZE"]
+            tcc = _run_pmc_pass(["TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"], launch_grid=launch_grid)
             f_unit, w_unit = COPY_BYTES / fetch["copy"], COPY_BYTES / write["copy"]
             req_unit = 2 * COPY_BYTES / tcc["TCC_REQ_sum"]["copy"]
             out["pmc_calibration"] = {"fetch_bytes_per_FETCH_SIZE_unit": f_unit, "write_bytes_per_WRITE_SIZE_unit": w_unit,
@@ -324,21 +371,26 @@ def measure_roofline(dev, use_pmc=True):
     in_graph = None
     if use_pmc:
         try:
-            stats = _run_trace_pass()
-            hit = [(n, v) for n, v in stats.items() if ORDER_KERNEL in n]
-            if hit:
+            def digest(stats, what):
+                hit = [(n, v) for n, v in stats.items() if ORDER_KERNEL in n]
+                if not hit:
+                    return None
                 calls, avg_us, _ = hit[0][1]
                 total = sum(v[2] for v in stats.values())
-                in_graph = {"kernel_avg_us": avg_us, "calls": calls, "launches_per_forward": 5,
-                            "share_of_gpu_time": hit[0][1][2] / total if total else None,
-                            "command": "rocprofv3 --kernel-trace --stats -- python bench.py --trace-target  (the benchmark's "
-                                       "forward as one hipGraph on one stream, 40 replays)",
-                            "top_kernels_us": [[n.split("(")[0][-90:], c, round(a, 2)] for n, (c, a, t) in
-                                               sorted(stats.items(), key=lambda kv: -kv[1][2])[:8]]}
+                return {"kernel_avg_us": avg_us, "calls": calls, "launches_per_forward": 5,
+                        "share_of_gpu_time": hit[0][1][2] / total if total else None,
+                        "command": "rocprofv3 --kernel-trace --stats -- python bench.py --trace-target  (%s)" % what,
+                        "top_kernels_us": [[n.split("(")[0][-90:], c, round(a, 2)] for n, (c, a, t) in
+                                           sorted(stats.items(), key=lambda kv: -kv[1][2])[:8]]}
+            in_graph = digest(_run_trace_pass(), "the benchmark's forward as one hipGraph on one stream, 40 replays: whole-chip launches")
+            if in_flight > 1 and in_graph is not None:
+                in_graph["as_timed"] = digest(_run_trace_pass(in_flight=in_flight),
+                                              "ULTRA_BENCH_TRACE_IN_FLIGHT=%d: %d captures on %d streams as in the timed region, the "
+                                              "aggregation kernels on %d workgroups each" % (in_flight, in_flight, in_flight, launch_grid))
         except Exception as exc:
             in_graph = {"unavailable": str(exc)[:200]}
     for pt in points:
-        t = pt["ms_per_launch"] * 1e-3
+        t = pt["ms_per_launch"] * 1e-3 / pt["launches_side_by_side"]     # (chip time per launch: that many run at once)
         # gathers through the CU's vector L1: every edge's 256-B source row per sample (+ the update's row reads)
         pt["l1_gather_bytes"] = 4 * pt["D"] * pt["E"] + 2 * 4 * pt["D"] * pt["N"]
         pt["l1_rate_frac"] = pt["l1_gather_bytes"] / t / 1e9 / L1_PEAK_GBS
@@ -357,9 +409,14 @@ def measure_roofline(dev, use_pmc=True):
         "point": "%s shape, batch %d (the benchmark's call; x + out = %.0f MB: L2 / Infinity-Cache resident)"
                  % (head["shape"], head["batch"], head["x_plus_out_MB"]),
         "ms_per_launch": head["ms_per_launch"],
+        "launches_side_by_side": head["launches_side_by_side"], "workgroups_per_launch": head["workgroups_per_launch"],
+        "ms_per_launch_alone_on_the_whole_chip": head["ms_per_launch_alone_on_the_whole_chip"],
         "achieved": head["hbm_GBps_measured"] if measured else head["compulsory_GBps"],
-        "achieved_definition": ("HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated) / kernel time" if measured
-                                else "compulsory-model bytes / kernel time (no counters in this run)"),
+        "achieved_definition": (("HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated) x launches side by side / "
+                                 "duration of a launch" if measured else
+                                 "compulsory-model bytes x launches side by side / duration of a launch (no counters in this run)")
+                                + ": the timed region keeps %d batches in flight, each one's entity layers on %d of the %d CUs"
+                                % (head["launches_side_by_side"], head["workgroups_per_launch"], n_cu)),
         "traffic": head.get("hbm_bytes"),
         "algorithmic_bytes_per_launch": {"gather_model": head["gather_model_bytes"], "compulsory": head["compulsory_bytes"]},
         "gather_model_GBps": head["gather_model_GBps"],
@@ -376,9 +433,8 @@ def measure_roofline(dev, use_pmc=True):
         "points": points,
     })
     out["frac"] = out["achieved"] / HBM_PEAK_GBS
-    out["note"] = ("the kernel is the whole entity layer: aggregate, then the update of the same rows in the kernel's tail "
-                   "(compulsory bytes: x in, layer output out, relation table, records, weights -- the aggregate's round trip "
-                   "is counted as avoidable traffic).  "
+    out["note"] = ("the kernel is the whole entity layer: twelve waves of a workgroup aggregate, four apply the update to the rows "
+                   "they hand over through LDS (compulsory bytes: x in, layer output out, relation table, records, weights).  "
                    "gather-model GB/s exceeds the HBM peak where x is cache resident (every edge re-reads a 256-B source row "
                    "from L2 / Infinity Cache, not from HBM); `frac` is COUNTER traffic / time / 8 TB/s: FETCH_SIZE counts L2 "
                    "misses, Infinity-Cache (MALL) hits INCLUDED (MI355X_MICROARCH.md), so it bounds the HBM fraction from above; "
@@ -602,7 +658,7 @@ def main():
     if rank == 0 and world == 1 and not launched and not args.no_roofline:
         # the dominant kernel's own measurement (HIP events around its launches, rocprofv3 child passes) runs BEFORE the timed
         # region: it is independent of it, and the GPU then enters the timed steps from sustained work rather than from idle
-        roofline = measure_roofline(dev, use_pmc=not args.no_pmc)
+        roofline = measure_roofline(dev, use_pmc=not args.no_pmc, in_flight=1 if args.no_graph else args.in_flight)
     forward = make_forward()
     elapsed = timed_run(forward, world > 1 or launched)
     # the same K steps again, `--repeats` runs in all: box-to-box and run-to-run spread is of the size of a small kernel gain,
@@ -649,7 +705,8 @@ def main():
                    "readout_order_id": host_order.order_id(host_order.readout_stages(128)[0]),
                    "launch": ("eager" if args.no_graph else
                               "hipGraph replay of the captured forward" +
-                              (", %d batches in flight on %d streams (graph.PipelinedForward)" % (args.in_flight, args.in_flight)
+                              (", %d batches in flight on %d streams, the aggregation kernels of each on 1 / %d of the CUs "
+                               "(graph.PipelinedForward)" % (args.in_flight, args.in_flight, args.in_flight)
                                if args.in_flight > 1 else "")),
                    "rccl_world_size": dist.get_world_size() if (world > 1 or launched) else 1,
                    "collective_backend": ("RCCL" if args.backend == "nccl" else "gloo (test mode: ranks share GPUs, not a measurement)")
@@ -660,7 +717,8 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         # (counter passes only at N = 1: they re-run the kernels in a child process on this rank's GPU)
-        out["roofline"] = roofline if roofline is not None else measure_roofline(dev, use_pmc=False)
+        out["roofline"] = roofline if roofline is not None else measure_roofline(dev, use_pmc=False,
+                                                                               in_flight=1 if args.no_graph else args.in_flight)
     if rank == 0 and world == 1:
 
         # ---- CPU baseline + parity on the identical batch ----
@@ -815,6 +873,18 @@ def main():
                         "note": "--in-flight 1: every batch waits for its predecessor's readout (DESIGN.md 3.9)"}
                 finally:
                     args.in_flight = keep
+                # ---- the batches in flight with whole-chip launches (round 3's form of the timed mode) ----
+                try:
+                    from ultra_amd.graph import PipelinedForward
+                    piped = PipelinedForward(model, data, tasks.all_negative(data, batch_for(0))[0], depth=args.in_flight, share_chip=False)
+                    el6 = timed_run(lambda data_, batch_, post=None: piped(batch_, post=post), False)
+                    out.setdefault("modes", {})["in_flight_whole_chip_launches"] = {
+                        "timed": False, "triples_per_s": bs * N * args.steps / el6, "ms_per_step": 1e3 * el6 / args.steps,
+                        "note": "PipelinedForward(share_chip=False): every aggregation kernel with one workgroup per CU, so the entity "
+                                "layers of the batches in flight follow one another (DESIGN.md 3.9)"}
+                    del piped
+                except Exception as exc:
+                    out.setdefault("modes", {})["in_flight_whole_chip_launches"] = {"unavailable": str(exc)[:200]}
             # ---- NOT the timed mode: the relation model's output for every query relation computed once (it depends on the
             # query relation only; Ultra.cache_relation_representations, what evaluate() does for long shards) ----
             try:

@@ -1,7 +1,7 @@
 """The benchmark step, measured for A/B comparisons on one box: captured Ultra.forward on the FB15k237 shape, batch 8, one
 batch at a time and two in flight; `reps` runs of `steps` steps each, median / min / max of ms per step.
     python tools/step_probe.py [reps] [steps]      env: ULTRA_NO_PREFILL=1 (entity layer-0 fill behind the relation model),
-                                                        PROBE_UPDATE_FORM=1|2|3 (rspmm.set_tuning(update_form=...))"""
+                                                        PROBE_UPDATE_FORM=1|2|3, PROBE_GRID=n (rspmm.set_tuning(update_form=..., grid=...))"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,9 +10,9 @@ from ultra_amd.graph import GraphedForward, PipelinedForward
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-if os.environ.get("PROBE_UPDATE_FORM"):
+if os.environ.get("PROBE_UPDATE_FORM") or os.environ.get("PROBE_GRID"):
     from ultra_amd import rspmm
-    rspmm.set_tuning(update_form=int(os.environ["PROBE_UPDATE_FORM"]))
+    rspmm.set_tuning(update_form=int(os.environ.get("PROBE_UPDATE_FORM", "0")), grid=int(os.environ.get("PROBE_GRID", "0")))
 if os.environ.get("ULTRA_NO_PREFILL"):
     models.PREFILL_LAYER0 = False
 dev = torch.device("cuda:0")
@@ -45,5 +45,6 @@ def measure(fwd, join):
 one = GraphedForward(model, data, inputs[0])
 print("one batch at a time: median %.4f  min %.4f  max %.4f ms per step" % measure(one, lambda: None))
 del one
-two = PipelinedForward(model, data, inputs[0], depth=2)
-print("two in flight:       median %.4f  min %.4f  max %.4f ms per step" % measure(two, two.join))
+depth = int(os.environ.get("PROBE_DEPTH", "2"))
+two = PipelinedForward(model, data, inputs[0], depth=depth, share_chip=os.environ.get("PROBE_SHARE", "1") == "1")
+print("%d in flight:         median %%.4f  min %%.4f  max %%.4f ms per step" % depth % measure(two, two.join))

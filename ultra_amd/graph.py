@@ -22,11 +22,14 @@ from . import dense, rspmm
 class GraphedForward(object):
     """score = GraphedForward(model, data, example_batch)(batch) for batches of example_batch's shape."""
 
-    def __init__(self, model, data, example_batch, warmup=3):
+    def __init__(self, model, data, example_batch, warmup=3, launch_grid=0):
+        """launch_grid > 0: the aggregation kernels of this capture are launched with that many workgroups instead of one per
+        CU (rspmm.tuning_scope(grid=...) around warm-up and capture) -- see PipelinedForward."""
         assert example_batch.is_cuda, "graph capture needs GPU tensors"
         self.model = model
         self.data = data
         self.warmup = warmup
+        self.launch_grid = int(launch_grid)
         self.static_batch = example_batch.clone()
         self._pinned = []
         self._capture()
@@ -40,6 +43,13 @@ class GraphedForward(object):
         self._pinned = []
 
     def _capture(self):
+        if self.launch_grid > 0:
+            with rspmm.tuning_scope(grid=self.launch_grid):
+                self._capture_now()
+        else:
+            self._capture_now()
+
+    def _capture_now(self):
         model, data = self.model, self.data
         self._release()
         model.eval()
@@ -105,6 +115,14 @@ class PipelinedForward(object):
     consecutive batches are independent, so the launches of one batch that leave the chip idle (relation model, glue) run
     beside the entity layers of its neighbour -- 0.69 -> 0.62 ms per batch at the benchmark point with two in flight.
 
+    share_chip (True; "auto", the default: where the layers' activations fit the last-level cache): the aggregation kernels of each
+    capture are launched with CUs / depth workgroups instead of one per CU.  A reference-order workgroup owns its CU (160 KB of LDS), so two full-size launches can only follow one another; at
+    half size the entity layers of two batches run side by side, each workgroup with twice the rows -- its fixed costs (the
+    relation slice staged, the chain pipeline filled, the last block drained) paid once for them -- and the other batch's
+    short, latency-bound launches find free CUs at any time: 0.623 -> 0.592 ms per batch at the benchmark point (grid 128;
+    192: 0.603; three in flight at 128: 0.590; four at 64: 0.655 -- tools/step_probe.py, profiles/r4_experiments.txt).
+    The sums do not depend on the split: the schedule only decides WHICH workgroup walks a row, never the order inside it.
+
         pf = PipelinedForward(model, data, example_batch)
         for batch in batches:
             score = pf(batch)        # enqueued; `score` is that slot's output buffer ...
@@ -113,12 +131,21 @@ class PipelinedForward(object):
 
     Reference-order plans only: the re-associating plans keep per-plan scratch that concurrent forwards would share."""
 
-    def __init__(self, model, data, example_batch, depth=2, warmup=3, slot_factory=None):
+    def __init__(self, model, data, example_batch, depth=2, warmup=3, slot_factory=None, share_chip="auto"):
         """slot_factory: what builds one slot's forward (default: a GraphedForward of `model`); a CPU batch gets slots without
         streams -- the collective-ordering contract of `post=` is testable without a GPU (tests/test_distributed.py)."""
         if not rspmm._plan_defaults["exact_order"]:
             raise RuntimeError("PipelinedForward needs the reference-order plans (the re-associating plans own scratch buffers)")
-        make = slot_factory or (lambda: GraphedForward(model, data, example_batch, warmup=warmup))
+        grid = 0
+        if share_chip == "auto":
+            # measured (tools/step_probe.py, two in flight, ms per batch, shared / whole-chip launches): FB15k237 shape 0.592 / 0.623,
+            # WN18RR 0.795 / 0.781, CoDEx-L 1.967 / 1.905 -- it pays where a layer's input and output of all samples stay in the
+            # last-level cache (60 MB at the first, 167 and 319 MB at the others); two launches side by side thrash it otherwise
+            share_chip = 2 * example_batch.shape[0] * int(data.num_nodes) * 256 <= 128 << 20
+        if share_chip and int(depth) > 1 and example_batch.is_cuda:
+            grid = max(torch.cuda.get_device_properties(example_batch.device).multi_processor_count // int(depth), 1)
+        self.launch_grid = grid
+        make = slot_factory or (lambda: GraphedForward(model, data, example_batch, warmup=warmup, launch_grid=grid))
         self.slots = []
         for _ in range(int(depth)):
             self.slots.append(make())

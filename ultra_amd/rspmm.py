@@ -704,6 +704,31 @@ class _ReferenceExports(object):
 rspmm = _ReferenceExports()
 
 
+class tuning_scope(object):
+    """with tuning_scope(grid=128): ... -- the launches inside run (and a capture inside records them) with the given knobs changed,
+    every other knob as it was; the former tuning is back afterwards."""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        self.was = _lib.Tuning()
+        check(lib.ultra_get_tuning(ctypes.byref(self.was)))
+        t = _lib.Tuning()
+        ctypes.memmove(ctypes.byref(t), ctypes.byref(self.was), ctypes.sizeof(t))
+        for k, v in self.knobs.items():
+            if k in ("general_walk", "unit_walk", "update_form"):
+                t.reserved[("general_walk", "unit_walk", "update_form").index(k)] = int(v)
+            else:
+                setattr(t, k, int(v))
+        check(lib.ultra_set_tuning(ctypes.byref(t)))
+        return self
+
+    def __exit__(self, *exc):
+        check(lib.ultra_set_tuning(ctypes.byref(self.was)))
+        return False
+
+
 def set_tuning(threads=0, grid=0, rel_lds=-1, x_lds=-1, unroll=0, general_walk=0, unit_walk=0, update_form=0):
     """Kernel-launch tuning knobs (measurement / tests).  set_tuning() restores the defaults.
     general_walk: reference-order plans on the general walk kernel; unit_walk: the reference-order kernels walk units of
