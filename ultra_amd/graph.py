@@ -141,7 +141,8 @@ class PipelinedForward(object):
             # measured (tools/step_probe.py, two in flight, ms per batch, shared / whole-chip launches): FB15k237 shape 0.592 / 0.623,
             # WN18RR 0.795 / 0.781, CoDEx-L 1.967 / 1.905 -- it pays where a layer's input and output of all samples stay in the
             # last-level cache (60 MB at the first, 167 and 319 MB at the others); two launches side by side thrash it otherwise
-            share_chip = 2 * example_batch.shape[0] * int(data.num_nodes) * 256 <= 128 << 20
+            share_chip = example_batch.is_cuda and data is not None and \
+                2 * example_batch.shape[0] * int(data.num_nodes) * 256 <= 128 << 20
         if share_chip and int(depth) > 1 and example_batch.is_cuda:
             grid = max(torch.cuda.get_device_properties(example_batch.device).multi_processor_count // int(depth), 1)
         self.launch_grid = grid
