@@ -263,40 +263,14 @@ def _run_trace_pass(timeout=240, in_flight=1):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def _regime_ms(plan, rel, x, point, upd, n_flight, grid, iters=30):
-    """The one-launch layer as the timed region runs it: `n_flight` streams, each launching it `iters` times back to back with
-    `grid` workgroups (CUs / n_flight), all streams at once.  Returns ms per launch on a stream (HIP events on that stream
-    around its `iters` launches; mean over the streams)."""
-    from ultra_amd import rspmm
-    streams = [torch.cuda.Stream() for _ in range(n_flight)]
-    args = (rel, x, upd[0], upd[1], upd[2], upd[3], 1e-5, 7)
-    with rspmm.tuning_scope(grid=grid):
-        for s_ in streams:
-            s_.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s_):
-                for _ in range(5):
-                    plan.forward_update(*args, point=point)
-        torch.cuda.synchronize()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in streams]
-        for s_, (e0, _) in zip(streams, ev):
-            e0.record(s_)
-        for _ in range(iters):
-            for s_ in streams:
-                with torch.cuda.stream(s_):
-                    plan.forward_update(*args, point=point)
-        for s_, (_, e1) in zip(streams, ev):
-            e1.record(s_)
-        torch.cuda.synchronize()
-    return sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev) / iters
-
-
 def measure_roofline(dev, use_pmc=True, in_flight=1):
-    """in_flight: batches the timed region keeps in flight -- its aggregation kernels run with CUs / in_flight workgroups, that
-    many launches side by side (graph.PipelinedForward); the block describes the kernel in THAT regime and keeps the
-    whole-chip launch beside it."""
-    from ultra_amd import _lib
+    """in_flight: batches the timed region keeps in flight -- with more than one its aggregation kernels are launched with three
+    quarters of the CUs as workgroups (graph.PipelinedForward, shared_launch_grid): the block describes the kernel as launched
+    THERE and keeps the whole-chip launch beside it."""
+    from ultra_amd import _lib, rspmm
+    from ultra_amd.graph import shared_launch_grid
     n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-    launch_grid = max(n_cu // in_flight, 1) if in_flight > 1 else 0
+    launch_grid = shared_launch_grid(dev) if in_flight > 1 else 0
     out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "kernel": "ultra::" + ORDER_KERNEL + " (entity layer in one launch: rspmm add_mul with point boundary, relation slice "
                      "in LDS, then Linear(128->64) + LayerNorm + ReLU + residual on the rows each workgroup aggregated)"}
@@ -331,11 +305,14 @@ def measure_roofline(dev, use_pmc=True, in_flight=1):
         # (the second point is not the timed workload: it stays a whole-chip launch -- PipelinedForward shares the chip only
         # where the activations fit the last-level cache)
         shared = in_flight > 1 and shape == ROOFLINE_POINTS[0][0]
-        ms = _regime_ms(plan, rel, x, point, upd, in_flight, launch_grid) if shared else ms_whole
+        ms = ms_whole
+        if shared:
+            with rspmm.tuning_scope(grid=launch_grid):
+                ms = plan.forward_update(rel, x, upd[0], upd[1], upd[2], upd[3], 1e-5, 7, point=point, timed=(5, 30))[0]
         plan.forward_timed(rel, x, point=point, warmup=5, iters=30)      # (the aggregate alone, for the record)
         info = plan.info()
         points.append({"shape": shape, "batch": bs, "N": N, "E": E, "R": R, "D": D, "ms_per_launch": ms,
-                       "launches_side_by_side": in_flight if shared else 1, "workgroups_per_launch": (launch_grid or n_cu) if shared else n_cu,
+                       "workgroups_per_launch": (launch_grid or n_cu) if shared else n_cu,
                        "ms_per_launch_alone_on_the_whole_chip": ms_whole,
                        "ms_per_launch_each_on_an_idle_chip": timed[1],
                        "ms_per_launch_aggregate_only": plan.last_main_kernel_ms,
@@ -386,11 +363,12 @@ def measure_roofline(dev, use_pmc=True, in_flight=1):
             if in_flight > 1 and in_graph is not None:
                 in_graph["as_timed"] = digest(_run_trace_pass(in_flight=in_flight),
                                               "ULTRA_BENCH_TRACE_IN_FLIGHT=%d: %d captures on %d streams as in the timed region, the "
-                                              "aggregation kernels on %d workgroups each" % (in_flight, in_flight, in_flight, launch_grid))
+                                              "aggregation kernels on %d workgroups each; a kernel's duration there includes what "
+                                              "the other stream's launches cost it" % (in_flight, in_flight, in_flight, launch_grid))
         except Exception as exc:
             in_graph = {"unavailable": str(exc)[:200]}
     for pt in points:
-        t = pt["ms_per_launch"] * 1e-3 / pt["launches_side_by_side"]     # (chip time per launch: that many run at once)
+        t = pt["ms_per_launch"] * 1e-3
         # gathers through the CU's vector L1: every edge's 256-B source row per sample (+ the update's row reads)
         pt["l1_gather_bytes"] = 4 * pt["D"] * pt["E"] + 2 * 4 * pt["D"] * pt["N"]
         pt["l1_rate_frac"] = pt["l1_gather_bytes"] / t / 1e9 / L1_PEAK_GBS
@@ -409,14 +387,13 @@ def measure_roofline(dev, use_pmc=True, in_flight=1):
         "point": "%s shape, batch %d (the benchmark's call; x + out = %.0f MB: L2 / Infinity-Cache resident)"
                  % (head["shape"], head["batch"], head["x_plus_out_MB"]),
         "ms_per_launch": head["ms_per_launch"],
-        "launches_side_by_side": head["launches_side_by_side"], "workgroups_per_launch": head["workgroups_per_launch"],
+        "workgroups_per_launch": head["workgroups_per_launch"],
         "ms_per_launch_alone_on_the_whole_chip": head["ms_per_launch_alone_on_the_whole_chip"],
         "achieved": head["hbm_GBps_measured"] if measured else head["compulsory_GBps"],
-        "achieved_definition": (("HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated) x launches side by side / "
-                                 "duration of a launch" if measured else
-                                 "compulsory-model bytes x launches side by side / duration of a launch (no counters in this run)")
-                                + ": the timed region keeps %d batches in flight, each one's entity layers on %d of the %d CUs"
-                                % (head["launches_side_by_side"], head["workgroups_per_launch"], n_cu)),
+        "achieved_definition": (("HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated) / duration of a launch" if measured
+                                 else "compulsory-model bytes / duration of a launch (no counters in this run)")
+                                + ": launched as the timed region launches it, on %d workgroups (%d CUs; the rest serve the other batch "
+                                "in flight)" % (head["workgroups_per_launch"], n_cu)),
         "traffic": head.get("hbm_bytes"),
         "algorithmic_bytes_per_launch": {"gather_model": head["gather_model_bytes"], "compulsory": head["compulsory_bytes"]},
         "gather_model_GBps": head["gather_model_GBps"],
@@ -705,8 +682,8 @@ def main():
                    "readout_order_id": host_order.order_id(host_order.readout_stages(128)[0]),
                    "launch": ("eager" if args.no_graph else
                               "hipGraph replay of the captured forward" +
-                              (", %d batches in flight on %d streams, the aggregation kernels of each on 1 / %d of the CUs "
-                               "(graph.PipelinedForward)" % (args.in_flight, args.in_flight, args.in_flight)
+                              (", %d batches in flight on %d streams, the aggregation kernels of each on three quarters of the CUs "
+                               "(graph.PipelinedForward)" % (args.in_flight, args.in_flight)
                                if args.in_flight > 1 else "")),
                    "rccl_world_size": dist.get_world_size() if (world > 1 or launched) else 1,
                    "collective_backend": ("RCCL" if args.backend == "nccl" else "gloo (test mode: ranks share GPUs, not a measurement)")

@@ -110,24 +110,27 @@ class GraphedForward(object):
         return self.static_out
 
 
+def shared_launch_grid(device):
+    """Workgroups of an aggregation launch that leaves a quarter of the chip to the other batch in flight (whole XCD-sized
+    multiples: 192 of 256 -- 200 and 208 measured 4 % slower than either neighbour)."""
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    return max((3 * cus // 4) // 64 * 64, 3 * cus // 4 if cus < 86 else 64)
+
+
 class PipelinedForward(object):
     """`depth` captured forwards (own input, activation and output buffers each) replayed round-robin on `depth` streams:
     consecutive batches are independent, so the launches of one batch that leave the chip idle (relation model, glue) run
     beside the entity layers of its neighbour -- 0.69 -> 0.62 ms per batch at the benchmark point with two in flight.
 
     share_chip (True; "auto", the default: where the layers' activations fit the last-level cache): the aggregation kernels of each
-    capture are launched with CUs / depth workgroups instead of one per CU.  A reference-order workgroup owns its CU (160 KB of LDS), so two full-size launches can only follow one another; at
-    half size the entity layers of two batches run side by side, each workgroup with twice the rows -- its fixed costs (the
-    relation slice staged, the chain pipeline filled, the last block drained) paid once for them -- and the other batch's
-    short, latency-bound launches find free CUs at any time: 0.623 -> 0.592 ms per batch at the benchmark point (grid 128;
-    192: 0.603; three in flight at 128: 0.590; four at 64: 0.655 -- tools/step_probe.py, profiles/r4_experiments.txt).
-    The sums do not depend on the split: the schedule only decides WHICH workgroup walks a row, never the order inside it.
-
-        pf = PipelinedForward(model, data, example_batch)
-        for batch in batches:
-            score = pf(batch)        # enqueued; `score` is that slot's output buffer ...
-            ...                      # ... readable after pf.join(), and until the slot's next call (`depth` calls later)
-        pf.join()                    # the caller's stream waits for everything in flight
+    capture are launched with three quarters of the chip's CUs as workgroups instead of one per CU.  A reference-order
+    workgroup owns its CU (160 KB of LDS), so behind a full-size launch nothing else starts; at 192 of 256 the entity layers of
+    the batches in flight still follow one another, but the other batch's short, latency-bound launches (relation-graph layers,
+    layer 0, projections, readout) find 64 free CUs at any time.  tools/share_probe.py, twelve runs of 20 steps, ms per batch
+    (median; first run): 256 workgroups 0.614; 0.641 -- 224: 0.616; 0.635 -- 192: 0.603; 0.627 -- 128: 0.599; 0.610, but there
+    two entity layers run side by side (199 us each against 152 alone on half a chip) and how the two streams' phases fall decides
+    between 0.60 and 0.65 (bench.py's repeats alternated between the two).  The sums do not depend on the split: the schedule
+    only decides WHICH workgroup walks a row, never the order inside it.
 
     Reference-order plans only: the re-associating plans keep per-plan scratch that concurrent forwards would share."""
 
@@ -138,13 +141,13 @@ class PipelinedForward(object):
             raise RuntimeError("PipelinedForward needs the reference-order plans (the re-associating plans own scratch buffers)")
         grid = 0
         if share_chip == "auto":
-            # measured (tools/step_probe.py, two in flight, ms per batch, shared / whole-chip launches): FB15k237 shape 0.592 / 0.623,
-            # WN18RR 0.795 / 0.781, CoDEx-L 1.967 / 1.905 -- it pays where a layer's input and output of all samples stay in the
-            # last-level cache (60 MB at the first, 167 and 319 MB at the others); two launches side by side thrash it otherwise
+            # measured with half-chip launches (tools/step_probe.py, two in flight, ms per batch, shared / whole-chip): FB15k237
+            # shape 0.592 / 0.623, WN18RR 0.795 / 0.781, CoDEx-L 1.967 / 1.905 -- it pays where a layer's input and output of all
+            # samples stay in the last-level cache (60 MB at the first, 167 and 319 MB at the others)
             share_chip = example_batch.is_cuda and data is not None and \
                 2 * example_batch.shape[0] * int(data.num_nodes) * 256 <= 128 << 20
         if share_chip and int(depth) > 1 and example_batch.is_cuda:
-            grid = max(torch.cuda.get_device_properties(example_batch.device).multi_processor_count // int(depth), 1)
+            grid = shared_launch_grid(example_batch.device)
         self.launch_grid = grid
         make = slot_factory or (lambda: GraphedForward(model, data, example_batch, warmup=warmup, launch_grid=grid))
         self.slots = []
