@@ -1,8 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-for shape in codex_l wn18rr; do
-for sh in 1 0; do
-    echo "=== $shape share_chip=$sh"
-    PROBE_SHAPE=$shape PROBE_SHARE=$sh timeout 280 python tools/step_probe.py 3 24 2>&1 | tail -2
-done
-done
+timeout 300 python -m pytest tests/test_eval_gpu.py -x -q 2>&1 | tail -2
+timeout 300 python tools/eval_speed.py 4096 2>&1 | grep evaluate
+timeout 300 python tools/eval_speed.py 512 2>&1 | grep evaluate

@@ -97,15 +97,23 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
             # (a second capture costs about what it saves on a hundred batches: 130 vs 125 M scores/s on 64 batches, 170 vs 160 on 512)
             if in_flight is None:
                 in_flight = 1 if os.environ.get("ULTRA_EVAL_IN_FLIGHT", "2") == "1" or n_full < 128 * batch_size else 2
-            steps = [GraphedEvalStep(model, test_data, batch_size, t_index, h_index)]
-            # ... if the plans the captured step really uses are all of that kind (a max-aggregate model sends its relation
-            # graph to a re-associating plan), and if a second capture fits: it doubles the captured activation memory
-            if (int(in_flight) >= 2 and n_full >= 2 * batch_size and rspmm._plan_defaults["exact_order"]
-                    and all(p.exact for p in steps[0]._pinned)):
-                try:
-                    steps.append(GraphedEvalStep(model, test_data, batch_size, t_index, h_index))
-                except (torch.cuda.OutOfMemoryError, RuntimeError):      # one step at a time then
-                    torch.cuda.synchronize()
+            # (two steps in flight share the chip like graph.PipelinedForward: the aggregation launches of each capture on three
+            # quarters of the CUs, where a layer's activations fit the last-level cache)
+            from .graph import shared_launch_grid
+            want_two = int(in_flight) >= 2 and n_full >= 2 * batch_size and rspmm._plan_defaults["exact_order"]
+            share = want_two and 2 * batch_size * int(test_data.num_nodes) * 256 <= 128 << 20
+            scope = (lambda: rspmm.tuning_scope(grid=shared_launch_grid(mine.device))) if share else (lambda: rspmm.tuning_scope())
+            with scope():
+                steps = [GraphedEvalStep(model, test_data, batch_size, t_index, h_index)]
+                # ... if the plans the captured step really uses are all of that kind (a max-aggregate model sends its relation
+                # graph to a re-associating plan), and if a second capture fits: it doubles the captured activation memory
+                if want_two and all(p.exact for p in steps[0]._pinned):
+                    try:
+                        steps.append(GraphedEvalStep(model, test_data, batch_size, t_index, h_index))
+                    except (torch.cuda.OutOfMemoryError, RuntimeError):      # one step at a time then
+                        torch.cuda.synchronize()
+            if share and len(steps) == 1:       # (alone after all: it gets the whole chip)
+                steps = [GraphedEvalStep(model, test_data, batch_size, t_index, h_index)]
             n_slot = len(steps)
             cur = torch.cuda.current_stream(mine.device)
             with torch.cuda.device(mine.device):
