@@ -49,12 +49,12 @@ def _operands(case, batch, dev, seed):
     return rel, x, rows, vals, weight, bias, ln_w, ln_b
 
 
-FORMS = {"tail": 1, "beside": 2, "lds": 3}     # rspmm.set_tuning(update_form=...): in the kernel's tail / beside the walk (by reference / through LDS tiles)
+FORMS = {"library": 0, "tail": 1, "beside": 2, "lds": 3}     # rspmm.set_tuning(update_form=...): the library's choice (3 from 10 steps a row up, else 1) / in the kernel's tail / beside the walk (by reference / through LDS)
 
 
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("mul", ["mul", "add"])
-@pytest.mark.parametrize("form", ["tail", "beside", "lds"])
+@pytest.mark.parametrize("form", ["library", "tail", "beside", "lds"])
 @pytest.mark.parametrize("batch,flags,point", [(8, 7, True), (3, 7, False), (1, 3, True), (2, 4, True), (5, 0, True), (16, 6, True)])
 def test_one_launch_equals_the_two_launches(dev, case, mul, batch, flags, point, form):
     from ultra_amd import dense, rspmm

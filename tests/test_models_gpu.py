@@ -385,10 +385,12 @@ def test_relation_projection_matches_reference_golden(dev, threshold, key):
     assert (got - g[key]).abs().max().item() <= 1e-5, (got - g[key]).abs().max().item()
 
 
-def test_two_batches_in_flight_score_like_one_at_a_time(dev):
-    """graph.PipelinedForward: captured forwards replayed round-robin on two streams (own buffers and own prologue meeting
-    point each) return, batch for batch, the bits of the one-at-a-time forward."""
-    from ultra_amd import graph as ugraph, models, synthetic, tasks
+@pytest.mark.parametrize("share_chip", ["auto", True, False])
+def test_two_batches_in_flight_score_like_one_at_a_time(dev, share_chip):
+    """graph.PipelinedForward: captured forwards replayed round-robin on two streams (own buffers each) return, batch for
+    batch, the bits of the one-at-a-time forward -- with whole-chip aggregation launches and with the shared-chip ones (three
+    quarters of the CUs as workgroups: the schedule for fewer partitions moves rows between workgroups, not inside their sums)."""
+    from ultra_amd import graph as ugraph, models, rspmm, synthetic, tasks
     data = synthetic.make_kg(num_node=900, num_triple=6000, num_relation_base=11, seed=5).to(dev)
     torch.manual_seed(3)
     model = models.Ultra(**synthetic.default_model_cfg()).to(dev).eval()
@@ -396,7 +398,12 @@ def test_two_batches_in_flight_score_like_one_at_a_time(dev):
     batches = [tasks.all_negative(data, data.target_triples[i * bs:(i + 1) * bs])[0] for i in range(6)]
     with torch.no_grad():
         want = [model(data, b).clone() for b in batches]
-    piped = ugraph.PipelinedForward(model, data, batches[0], depth=2)
+    piped = ugraph.PipelinedForward(model, data, batches[0], depth=2, share_chip=share_chip)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    assert piped.launch_grid == (0 if share_chip is False else ugraph.shared_launch_grid(dev))      # (a small graph: "auto" shares)
+    assert 0 < ugraph.shared_launch_grid(dev) < cus
+    t = rspmm.get_tuning()
+    assert t["grid"] == 0, "the launch size of the captures must not leak into the process's tuning"
     for rep in range(3):
         got = []
         for i, b in enumerate(batches):

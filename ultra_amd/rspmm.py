@@ -704,9 +704,18 @@ class _ReferenceExports(object):
 rspmm = _ReferenceExports()
 
 
+def get_tuning():
+    """The launch knobs in force (ultra_get_tuning) as a dict."""
+    t = _lib.Tuning()
+    check(lib.ultra_get_tuning(ctypes.byref(t)))
+    return {"threads": t.threads, "grid": t.grid, "rel_lds": t.rel_lds, "x_lds": t.x_lds, "unroll": t.unroll,
+            "general_walk": t.reserved[0], "unit_walk": t.reserved[1], "update_form": t.reserved[2]}
+
+
 class tuning_scope(object):
-    """with tuning_scope(grid=128): ... -- the launches inside run (and a capture inside records them) with the given knobs changed,
-    every other knob as it was; the former tuning is back afterwards."""
+    """with tuning_scope(grid=192): ... -- the launches inside run (and a capture inside records them) with the given knobs changed,
+    every other knob as it was; the former tuning is back afterwards.  The knobs are process-wide (ultra_set_tuning): not for
+    threads that launch at the same time with different ones."""
 
     def __init__(self, **knobs):
         self.knobs = knobs
