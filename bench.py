@@ -389,6 +389,14 @@ def measure_roofline(dev, use_pmc=True, in_flight=1):
         "ms_per_launch": head["ms_per_launch"],
         "workgroups_per_launch": head["workgroups_per_launch"],
         "ms_per_launch_alone_on_the_whole_chip": head["ms_per_launch_alone_on_the_whole_chip"],
+        # (the same fractions for the launch with one workgroup per CU: what the kernel does with the whole chip -- the launch
+        # of the timed region occupies only `workgroups_per_launch` of the 256 CUs, the peaks above are the whole chip's)
+        "whole_chip_launch": {
+            "ms_per_launch": head["ms_per_launch_alone_on_the_whole_chip"],
+            "frac_compulsory": head["compulsory_bytes"] / (head["ms_per_launch_alone_on_the_whole_chip"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "l1_rate_frac": head["l1_gather_bytes"] / (head["ms_per_launch_alone_on_the_whole_chip"] * 1e-3) / 1e9 / L1_PEAK_GBS,
+            "frac_of_counter_traffic": (head["hbm_bytes"] / (head["ms_per_launch_alone_on_the_whole_chip"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                        if "hbm_bytes" in head else None)},
         "achieved": head["hbm_GBps_measured"] if measured else head["compulsory_GBps"],
         "achieved_definition": (("HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated) / duration of a launch" if measured
                                  else "compulsory-model bytes / duration of a launch (no counters in this run)")
