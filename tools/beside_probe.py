@@ -26,7 +26,7 @@ point = (torch.arange(bs, device=dev) * 7 % N, torch.randn(bs, 64, generator=g).
 w = (torch.randn(64, 128, generator=g) / 11).to(dev)
 b, lw, lb = (torch.randn(64, generator=g).to(dev) for _ in range(3))
 plan = rspmm.Plan(data.edge_index, data.edge_type, N, R, exact_order=True)
-grid = 256
+grid = int(os.environ.get("PROBE_GRID", "256"))      # workgroups per launch (256: one per CU)
 
 
 def agg_only():
@@ -41,7 +41,7 @@ EXTRA = int(os.environ.get("PROBE_FLAGS", "0"))     # 256: no matrix chain, 512:
 
 
 def one(form):
-    rspmm.set_tuning(update_form=form)
+    rspmm.set_tuning(update_form=form, grid=grid if grid != 256 else 0)
     out = plan.forward_update(rel, x, w, b, lw, lb, 1e-5, 7 | EXTRA, point=point, sum=agg_sum)
     rspmm.set_tuning()
     return out

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (one gpurun call: /usr/local/graft/bin/gpurun --timeout 900 -- "bash tools/gpu_collect.sh"; writes under gpurun_out/)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 part="${1:-A}"
 bash tools/collect_profiles.sh $part r4 > /dev/null 2>&1

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (one gpurun call: /usr/local/graft/bin/gpurun --timeout 900 -- "bash tools/gpu_form3_check.sh"; writes under gpurun_out/)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r4s
 mkdir -p $O
