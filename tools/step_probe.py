@@ -13,6 +13,9 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 if os.environ.get("PROBE_UPDATE_FORM") or os.environ.get("PROBE_GRID"):
     from ultra_amd import rspmm
     rspmm.set_tuning(update_form=int(os.environ.get("PROBE_UPDATE_FORM", "0")), grid=int(os.environ.get("PROBE_GRID", "0")))
+if os.environ.get("PROBE_SEG_LEN"):        # rows longer than this are chain rows of the reference-order plans (default 256)
+    from ultra_amd import rspmm as _r
+    _r.set_plan_defaults(seg_len=int(os.environ["PROBE_SEG_LEN"]))
 if os.environ.get("ULTRA_NO_PREFILL"):
     models.PREFILL_LAYER0 = False
 dev = torch.device("cuda:0")

@@ -259,6 +259,13 @@ static double WAVE_SHARE[4] = {1.7, 1.3, 0.7, 0.3};
 // ... and when the youngest quartet does not walk at all (its waves apply the layer update beside the walk:
 // rspmm_order_kernel, UPDATE == 2): the same age effect among the three walking quartets
 static double WAVE_SHARE_12[4] = {1.5, 1.2, 0.7, 0.0};
+// A row the plan lists as a chain row (> chain_min = 256 edges) is still better off as ONE group stream's row when the streams
+// of the launch are long enough to take it: the chain sums an edge in 11 workgroup-cycles, a stream in 6-8.  In the schedules of
+// the update-beside-the-walk launches (twelve walkers; nothing else reads them) chain rows of up to CHAIN_LIMIT_FACTOR x the mean
+// stream length go to the streams.  tools/step_probe.py PROBE_SEG_LEN (FB15k237 shape, ms per step, one batch at a time with 32
+// partitions a sample: mean stream 364 steps / two in flight with 24: 485 steps): threshold 256: 0.667 / 0.605, 384: 0.661 /
+// 0.596, 512: 0.655 / 0.595, 768: 0.648 / 0.590, 1,024: 0.705 / 0.580, 1,536: 0.837 / 0.597 -- the best is at 2.1 x in both.
+static double CHAIN_LIMIT_FACTOR = 2.1;
 // ULTRA_CHAIN_OVERLAP: cycles one walking stream needs per step while the chain crew is still busy (fewer streams share the
 // vector L1 then: a stream steps faster than the 64 x COST_S_STEP of the all-streams phase)
 static double COST_S_STEP_SIDE = 252.0, SIDE_TAPER = 0.6;   // (SIDE_TAPER: share of T above which a chain stays classic)
@@ -279,6 +286,8 @@ static void read_cost_override() {   // calibration runs only: ULTRA_SCHED_COSTS
         for (int k = 0; k < 3; ++k) WAVE_SHARE_12[k] = v[k];
         WAVE_SHARE_12[3] = 0.0;
     }
+    env = std::getenv("ULTRA_CHAIN_LIMIT_FACTOR");   // calibration runs (0: every listed chain row stays one)
+    if (env && std::sscanf(env, "%lf", &v[0]) == 1) CHAIN_LIMIT_FACTOR = v[0];
     env = std::getenv("ULTRA_STREAM_COSTS");
     if (env) {
         const int n = std::sscanf(env, "%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4]);
@@ -299,9 +308,19 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
         double cost;
         int32_t id;   // chain item index, or n_chain + unit id
     };
+    // chain rows that this launch size's streams take as plain rows (twelve-walker schedules only: the sixteen-walker ones also
+    // serve the unit walk, whose units do not list them)
+    std::vector<char> to_stream((size_t)n_chain, 0);
+    if (walkers == 12 && CHAIN_LIMIT_FACTOR > 0.0) {
+        double all_steps = 0.0;
+        for (int64_t g = 0; g < n_item; ++g) all_steps += p->items[(size_t)g].len + 1;
+        const double limit = CHAIN_LIMIT_FACTOR * all_steps / ((double)nparts * 16.0 * (walkers / 4));   // x the mean stream length
+        for (int64_t c = 0; c < n_chain; ++c) to_stream[(size_t)c] = p->items[(size_t)c].len <= limit;
+    }
     std::vector<Work> work;
     work.reserve((size_t)(n_chain + n_unit));
     for (int64_t c = 0; c < n_chain; ++c) {
+        if (to_stream[(size_t)c]) continue;
         const int32_t len = p->items[(size_t)c].len;
         const int32_t nchunk = (len + CHAIN_SLOTS - 1) / CHAIN_SLOTS;
         work.push_back(Work{COST_CHAIN_ROW + COST_CHAIN_EDGE * len + COST_CHAIN_CHUNK * nchunk, (int32_t)c});
@@ -358,7 +377,8 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
             total += chain_cost[(size_t)q];
         }
         double steps = 0.0;
-        for (int64_t g = n_chain; g < n_item; ++g) steps += p->items[(size_t)g].len + 1;
+        for (int64_t g = 0; g < n_item; ++g)
+            if (g >= n_chain || to_stream[(size_t)g]) steps += p->items[(size_t)g].len + 1;
         const int64_t nstream = (int64_t)nparts * ORDER_GROUPS;
         std::vector<double> weight((size_t)nstream);
 #if ULTRA_CHAIN_OVERLAP
@@ -401,7 +421,8 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
         std::vector<std::vector<int32_t>> srows((size_t)nstream);
         for (int64_t g = 0; g < nstream; ++g)
             if (weight[(size_t)g] > 0.0) sheap.push(Slot(1.0 / weight[(size_t)g], g));   // (a stream without a share takes no rows)
-        for (int64_t g = n_chain; g < n_item; ++g) {   // group items are sorted by descending length
+        for (int64_t g = 0; g < n_item; ++g) {   // (chain items that go to the streams first: longest first throughout)
+            if (g < n_chain && !to_stream[(size_t)g]) continue;
             const Slot sl = sheap.top();
             sheap.pop();
             srows[(size_t)sl.second].push_back((int32_t)g);

@@ -430,6 +430,8 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
                         op.upd.ctl_off = (uint32_t)(rel_bytes + image);
                         op.srec = sched12->d_srec;
                         op.sdesc = reinterpret_cast<const int2 *>(sched12->d_sdesc);
+                        op.chunk_ptr = sched12->d_chunk_ptr;      // (its own chain list: shorter chain rows are stream rows there)
+                        op.chunks = reinterpret_cast<const int4 *>(sched12->d_chunks);
                         lds = need;
                     }
                 }
@@ -451,7 +453,7 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
                         op.upd.ctl_off = (uint32_t)(rel_bytes + overlay);
                         op.srec = sched12->d_srec;
                         op.sdesc = reinterpret_cast<const int2 *>(sched12->d_sdesc);
-                        op.chunk_ptr = sched12->d_chunk_ptr;      // (the chain work of the twelve-walker schedule is the same list)
+                        op.chunk_ptr = sched12->d_chunk_ptr;      // (its own chain list: shorter chain rows are stream rows there)
                         op.chunks = reinterpret_cast<const int4 *>(sched12->d_chunks);
                         lds = need;
                     }
