@@ -434,8 +434,19 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
         for (int64_t g = 0; g < nstream; ++g) {
             s->sdesc[(size_t)2 * g] = (int32_t)(s->srec.size() / 2);
             s->sdesc[(size_t)2 * g + 1] = (int32_t)sload[(size_t)g];
-            std::sort(srows[(size_t)g].begin(), srows[(size_t)g].end(),
-                      [&](int32_t a, int32_t b) { return p->items[(size_t)a].row < p->items[(size_t)b].row; });
+            // Order inside a stream: by row; in the update-beside-the-walk schedules the LONGEST ROW LAST -- every stream ends with a
+            // flush, and the fewer other flushes fall into the walk's last few thousand cycles, the shorter the queue the update
+            // waves are left with when the walkers are gone (tools/step_probe.py, one batch at a time / two in flight: by row
+            // 0.6446 / 0.5727 ms, longest last 0.6415 / 0.5664, shortest last 0.6436 / 0.5754).  ULTRA_STREAM_ROW_ORDER=0 / 1 / 2
+            // (by row / shortest last / longest last) overrides for measurements.  The sums do not depend on it.
+            static const int row_order_env = std::getenv("ULTRA_STREAM_ROW_ORDER") ? std::atoi(std::getenv("ULTRA_STREAM_ROW_ORDER")) : -1;
+            const int row_order = row_order_env >= 0 ? row_order_env : (walkers == 12 ? 2 : 0);
+            std::sort(srows[(size_t)g].begin(), srows[(size_t)g].end(), [&](int32_t a, int32_t b) {
+                const Item &ia = p->items[(size_t)a], &ib = p->items[(size_t)b];
+                if (row_order == 1 && ia.len != ib.len) return ia.len > ib.len;
+                if (row_order == 2 && ia.len != ib.len) return ia.len < ib.len;
+                return ia.row < ib.row;
+            });
             for (int32_t it : srows[(size_t)g]) {
                 const Item &row = p->items[(size_t)it];
                 for (int32_t e = row.begin; e < row.begin + row.len; ++e) {
