@@ -286,6 +286,60 @@ def test_twelve_walker_schedule_leaves_the_update_waves_without_rows():
     assert int(sdesc16[:, 1].view(nparts, 64)[:, 48:].min()) > 0
 
 
+def _schedule_array(plan, key, which):
+    import ctypes
+    from ultra_amd import _lib
+    n = ctypes.c_int64()
+    _lib.check(_lib.lib.ultra_plan_schedule_export(plan._h, key, which, None, 0, ctypes.byref(n)))
+    t = torch.empty(n.value, dtype=torch.int32)
+    _lib.check(_lib.lib.ultra_plan_schedule_export(plan._h, key, which, t.data_ptr(), n.value, ctypes.byref(n)))
+    return t
+
+
+def test_twelve_walker_schedule_walks_shorter_chain_rows_as_stream_rows_longest_last():
+    """plan.cpp CHAIN_LIMIT_FACTOR: in the schedules of the update-beside-the-walk launches a row the plan lists as a chain row
+    (> 256 edges) is a stream row if it is at most 2.1 x the mean stream length; longer rows stay chains; every row is still
+    served exactly once; inside a stream the rows come shortest first (the longest last).  The sixteen-walker schedule of the
+    same plan keeps every listed chain row a chain row (it also serves the unit walk)."""
+    from ultra_amd.rspmm import Plan
+    from ultra_amd import _lib
+    N, R = 3000, 9
+    ei, et = helpers.random_graph(num_node=N, num_edge=40000, num_relation=R, seed=8, hub=(11, 700))
+    extra_rows = torch.cat([torch.full((300,), 5), torch.full((6000,), 7)])            # a 300-odd and a 6,000-odd edge row too
+    g = torch.Generator().manual_seed(1)
+    ei = torch.cat([ei, torch.stack([extra_rows, torch.randint(0, N, (6300,), generator=g)])], dim=1)
+    et = torch.cat([et, torch.randint(0, R, (6300,), generator=g)])
+    plan = Plan(ei, et, N, R, exact_order=True)
+    n_chain = plan.info()["n_chain_row"]
+    items = plan.export(_lib.ARR_ITEM).view(-1, 4)
+    listed = {int(r): int(l) for r, l in zip(items[:n_chain, 0].tolist(), items[:n_chain, 2].tolist())}
+    assert {5, 7, 11} <= set(listed)
+    nparts = 1
+    key12 = nparts | (1 << 24)
+    sdesc, srec = plan.streams(nparts, walkers=12)
+    steps_all = ei.shape[1] + N
+    limit = 2.1 * steps_all / (nparts * 48)
+    assert listed[5] < limit and listed[11] < limit < listed[7]                      # (what the graph was built for)
+    chunks = _schedule_array(plan, key12, 3).view(-1, 4)
+    n_chunk = int(_schedule_array(plan, key12, 0)[-1])
+    chain12 = set(chunks[:n_chunk][(chunks[:n_chunk, 3] & 1) != 0, 0].tolist())        # rows with a CHUNK_FIRST chunk
+    assert chain12 == {r for r, l in listed.items() if l > limit} and 7 in chain12
+    markers = srec[srec[:, 1] == R, 0].tolist()
+    assert len(markers) == len(set(markers)) and set(markers) == set(range(N)) - chain12
+    assert {5, 11} <= set(markers)
+    # inside every stream: row lengths ascending
+    deg = torch.bincount(ei[0], minlength=N)
+    for g_ in range(nparts * 64):
+        begin, steps = sdesc[g_].tolist()
+        rows = srec[begin:begin + steps][srec[begin:begin + steps, 1] == R, 0]
+        lens = deg[rows.long()]
+        assert bool((lens[1:] >= lens[:-1]).all())
+    # the sixteen-walker schedule: every listed chain row is a chain row
+    chunks16 = _schedule_array(plan, nparts, 3).view(-1, 4)
+    n16 = int(_schedule_array(plan, nparts, 0)[-1])
+    assert set(chunks16[:n16][(chunks16[:n16, 3] & 1) != 0, 0].tolist()) == set(listed)
+
+
 def test_stream_work_follows_the_wave_age_shares():
     """plan.cpp WAVE_SHARE: a CU issues oldest wave first, so the schedule gives the four wave quartets of a workgroup
     1.7 / 1.3 / 0.7 / 0.3 of an even share of its stream steps (they then finish their walks together)."""
