@@ -24,6 +24,18 @@ Extra blocks of the JSON line (rank 0, N = 1):
                   present) on the host cores, same workload, bounded sample.
   parity       -- GPU scores / rankings against that CPU result on the identical batch.
 """
+import os as _os
+
+# A launcher's rank holds an RCCL communicator, i.e. more HIP streams than the plain process, and the runtime maps a process's
+# streams round-robin onto GPU_MAX_HW_QUEUES hardware queues (default 4): with the default the two pipeline slots' streams of a
+# rank end up interleaving worse than in the plain process.  Measured with one rank under torch.distributed.run, ms per step
+# first run / repeats: 4 queues 0.605 - 0.625 / 0.586 - 0.610, 2: 0.597 / 0.589 - 0.604, 3: 0.583 / 0.583 - 0.588, 5: 0.596 /
+# 0.576 - 0.590, 6: 0.616 / 0.592 - 0.609, 8: 0.773 / 0.764 (the plain process: 4 queues 0.568 / 0.566, 2: 0.607, 3: 0.599, 6:
+# 0.593).  The runtime reads the variable when it is loaded, so it is set here, before torch is imported; a value the caller
+# set stays.
+if "RANK" in _os.environ and "WORLD_SIZE" in _os.environ:
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
+
 import argparse
 import contextlib
 import csv
@@ -693,6 +705,7 @@ def main():
                               (", %d batches in flight on %d streams, the aggregation kernels of each on three quarters of the CUs "
                                "(graph.PipelinedForward)" % (args.in_flight, args.in_flight)
                                if args.in_flight > 1 else "")),
+                   "hip_hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                    "rccl_world_size": dist.get_world_size() if (world > 1 or launched) else 1,
                    "collective_backend": ("RCCL" if args.backend == "nccl" else "gloo (test mode: ranks share GPUs, not a measurement)")
                    if (world > 1 or launched) else None,
