@@ -7,7 +7,7 @@ update wave never multiplies a row that is not the generation it believes it is,
 everybody has read them, every parked row is finished exactly once, and everybody terminates (row counts 0 .. 200: empty,
 partial and full last blocks -- the round-4 hang was a partial last tile whose row count equalled the "not complete yet" value
 of the look loop; the row counts are clamped to [0, 16] since).  No GPU needed; three sensitivity tests break one rule each and
-expect the model to notice.
+expect the model to notice."""
 import random
 
 import pytest
