@@ -21,6 +21,12 @@
 // for the launch's workgroups-per-span), chain rows first.  Every output row is written exactly once by the lanes
 // that summed it: no partial slots, no fix-up launch, no scratch memory -- a plan is immutable after upload and can be
 // shared by any number of streams.
+//
+// (Since round 3 the group items of the fp32 / unit-weight kernels are walked as STREAMS -- the rows a 16-lane group was dealt,
+// back to back, by the generated assembly loops of rspmm_order_asm.hpp, records broadcast with DPP moves -- and the UPDATE
+// instances apply the layer update to the rows a workgroup aggregated: 1 in the kernel's tail, 2 / 3 beside the walk, by waves
+// 12..15 (3: rows handed over through an LDS ring, x rows included).  In the schedules of forms
+// 2 / 3 chain rows of up to 2.1 x the mean stream length are stream rows too.)
 #pragma once
 
 #include "rspmm_kernels.hpp"
