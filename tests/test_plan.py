@@ -340,6 +340,45 @@ def test_twelve_walker_schedule_walks_shorter_chain_rows_as_stream_rows_longest_
     assert set(chunks16[:n16][(chunks16[:n16, 3] & 1) != 0, 0].tolist()) == set(listed)
 
 
+def test_schedules_serve_every_row_once_on_random_graphs():
+    """Schedule builder under random shapes (one node .. 2,000, no edges .. 30,000, hub rows of 257 .. 9,000 edges, 1 .. 32
+    partitions, twelve and sixteen walkers): every row is either one chain row -- its chunks cover its edges -- or the row of
+    exactly one stream marker; the streams' steps are their rows' edges + markers; the update waves' streams stay empty."""
+    import random
+    from ultra_amd.rspmm import Plan
+    rng = random.Random(0)
+    for it in range(14):
+        N = rng.choice([1, 2, 7, 50, 300, 2000])
+        E = rng.choice([1, 10, 500, 5000, 30000]) if N > 1 else rng.choice([1, 17])
+        R = rng.choice([1, 3, 9])
+        ei, et = helpers.random_graph(num_node=N, num_edge=E, num_relation=R, seed=it)
+        for _ in range(rng.choice([0, 1, 3])):
+            node, cnt = rng.randrange(N), rng.choice([257, 300, 700, 3000, 9000])
+            g = torch.Generator().manual_seed(it * 7 + cnt)
+            ei = torch.cat([ei, torch.stack([torch.full((cnt,), node), torch.randint(0, N, (cnt,), generator=g)])], dim=1)
+            et = torch.cat([et, torch.randint(0, R, (cnt,), generator=g)])
+        plan = Plan(ei, et, N, R, exact_order=True)
+        deg = torch.bincount(ei[0], minlength=N)
+        for nparts in (1, 24):
+            for walkers in (12, 16):
+                key = nparts | ((1 << 24) if walkers == 12 else 0)
+                sdesc, srec = plan.streams(nparts, walkers=walkers)
+                cp = _schedule_array(plan, key, 0)
+                ch = _schedule_array(plan, key, 3).view(-1, 4)[:int(cp[-1])]
+                chain_rows = ch[(ch[:, 3] & 1) != 0, 0].tolist()
+                covered = {}
+                for row, _, cnt, _ in ch.tolist():
+                    covered[row] = covered.get(row, 0) + cnt
+                markers = srec[srec[:, 1] == R, 0].tolist()
+                where = "graph %d, %d partitions, %d walkers" % (it, nparts, walkers)
+                assert len(markers) == len(set(markers)) and len(chain_rows) == len(set(chain_rows)), where
+                assert not (set(markers) & set(chain_rows)) and set(markers) | set(chain_rows) == set(range(N)), where
+                assert all(covered[r] == int(deg[r]) for r in chain_rows), where
+                assert int(sdesc[:, 1].sum()) == sum(int(deg[r]) + 1 for r in markers), where
+                if walkers == 12:
+                    assert int(sdesc[:, 1].view(nparts, 64)[:, 48:].sum()) == 0, where
+
+
 def test_stream_work_follows_the_wave_age_shares():
     """plan.cpp WAVE_SHARE: a CU issues oldest wave first, so the schedule gives the four wave quartets of a workgroup
     1.7 / 1.3 / 0.7 / 0.3 of an even share of its stream steps (they then finish their walks together)."""
