@@ -26,15 +26,15 @@ Extra blocks of the JSON line (rank 0, N = 1):
 """
 import os as _os
 
-# A launcher's rank holds an RCCL communicator, i.e. more HIP streams than the plain process, and the runtime maps a process's
-# streams round-robin onto GPU_MAX_HW_QUEUES hardware queues (default 4): with the default the two pipeline slots' streams of a
-# rank end up interleaving worse than in the plain process.  Measured with one rank under torch.distributed.run, ms per step
-# first run / repeats: 4 queues 0.605 - 0.625 / 0.586 - 0.610, 2: 0.597 / 0.589 - 0.604, 3: 0.583 / 0.583 - 0.588, 5: 0.596 /
-# 0.576 - 0.590, 6: 0.616 / 0.592 - 0.609, 8: 0.773 / 0.764 (the plain process: 4 queues 0.568 / 0.566, 2: 0.607, 3: 0.599, 6:
-# 0.593).  The runtime reads the variable when it is loaded, so it is set here, before torch is imported; a value the caller
-# set stays.
-if "RANK" in _os.environ and "WORLD_SIZE" in _os.environ:
-    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
+# Hardware queues.  The HIP runtime maps a process's streams round-robin onto GPU_MAX_HW_QUEUES hardware queues (default 4) per
+# priority level, and a launcher's rank (RCCL communicator = more streams) used to land its two pipeline slots' streams on queues
+# that interleave worse than the plain process's: round 4 pinned GPU_MAX_HW_QUEUES=3 for launched ranks (0.605 - 0.625 -> 0.583
+# ms per step).  Since round 5 the slots' streams are the only HIGH-priority streams of the process (ultra_amd/graph.py
+# slot_stream): they own two distinct queues on either path, and the override is gone -- the runtime's default applies unless the
+# caller sets the variable (ULTRA_BENCH_LAUNCHER_QUEUES=n re-creates the old override for A/B runs; the runtime reads the
+# variable when it is loaded, hence here, before torch is imported).
+if "RANK" in _os.environ and "WORLD_SIZE" in _os.environ and _os.environ.get("ULTRA_BENCH_LAUNCHER_QUEUES"):
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", _os.environ["ULTRA_BENCH_LAUNCHER_QUEUES"])
 
 import argparse
 import contextlib
@@ -394,6 +394,8 @@ def measure_roofline(dev, use_pmc=True, in_flight=1):
             pt["l2_GBps"] = pt["l2_request_bytes"] / t / 1e9
             pt["l2_frac"] = pt["l2_GBps"] / L2_PEAK_GBS
     head, big = points[0], points[1]
+    big["bound"] = "hbm"
+    big["frac"] = big.get("hbm_frac_measured")
     measured = "hbm_bytes" in head
     out.update({
         "point": "%s shape, batch %d (the benchmark's call; x + out = %.0f MB: L2 / Infinity-Cache resident)"
@@ -417,13 +419,16 @@ def measure_roofline(dev, use_pmc=True, in_flight=1):
         "traffic": head.get("hbm_bytes"),
         "algorithmic_bytes_per_launch": {"gather_model": head["gather_model_bytes"], "compulsory": head["compulsory_bytes"]},
         "gather_model_GBps": head["gather_model_GBps"],
-        "hbm_frac_measured": head.get("hbm_frac_measured"), "hbm_frac_compulsory": head["hbm_frac_compulsory"],
         "frac_compulsory": head["hbm_frac_compulsory"],
         "traffic_over_compulsory": head.get("traffic_over_compulsory"),
+        # the roof the builder argues at THIS point (x + out cache resident): the CUs' vector-L1 gather rate, not HBM.  `bound` /
+        # `achieved` / `peak` / `frac` above stay the contract's HBM quantities (counter traffic / time / 8 TB/s); at
+        # `hbm_bound_point` (CoDEx-L) the memory system is the roof and its own `bound` says "hbm"
+        "binding_roof": {"name": "l1-gather", "frac": head["l1_rate_frac"], "peak_GBps": L1_PEAK_GBS,
+                         "achieved_GBps": head["l1_gather_bytes"] / (head["ms_per_launch"] * 1e-3) / 1e9,
+                         "definition": "bytes gathered through the CUs' vector L1 per launch (E x 256 B per sample + the update's row "
+                                       "reads) / kernel time / (256 CUs x 64 B/clk x 2.4 GHz)"},
         "l1_rate_frac": head["l1_rate_frac"],
-        "l1_rate_definition": "bytes gathered through the CUs' vector L1 per launch (E x 256 B per sample + the update's row reads) "
-                              "/ kernel time / (256 CUs x 64 B/clk x 2.4 GHz = %.0f GB/s): the binding roof at this size, where "
-                              "x and the output are cache resident" % L1_PEAK_GBS,
         "in_graph": in_graph,
         "l2_frac": head.get("l2_frac"), "l2_hit_rate": head.get("l2_hit_rate"),
         "hbm_bound_point": big,
@@ -436,7 +441,7 @@ def measure_roofline(dev, use_pmc=True, in_flight=1):
                    "from L2 / Infinity Cache, not from HBM); `frac` is COUNTER traffic / time / 8 TB/s: FETCH_SIZE counts L2 "
                    "misses, Infinity-Cache (MALL) hits INCLUDED (MI355X_MICROARCH.md), so it bounds the HBM fraction from above; "
                    "`frac_compulsory` prices only the bytes the layer must move; at the headline size the binding roof is the "
-                   "CUs' vector-L1 gather rate (`l1_rate_frac`), at CoDEx-L (`hbm_bound_point`) it is the memory system.")
+                   "CUs' vector-L1 gather rate (`binding_roof`), at CoDEx-L (`hbm_bound_point`, `bound: hbm`) it is the memory system.")
     if pmc_note:
         out["pmc_note"] = pmc_note
     return out
@@ -466,6 +471,114 @@ def tie_band_mismatches(ref_score, got_rank, pos, mask, band):
     return int(((got_rank < best) | (got_rank > worst)).sum())
 
 
+def stub_main(args):
+    """`--stub-cpu`: the program of an N-rank run with everything GPU-bound replaced by a stub -- what can be checked of the
+    1 / 2 / 4 / 8-GPU half of the metric where no multi-GPU box exists.  Same control flow as main(): self-launch under
+    torch.distributed.run, process group (gloo), rank 0's readout order broadcast, two pipeline slots taking the steps alternately
+    with the step's all-gather behind each (graph.PipelinedForward(post=)), W warm-up + exactly K timed steps between barriers,
+    MAX over ranks, per-rank digests, ONE JSON line from rank 0.  The line says what it is: data = "stub"."""
+    import torch.distributed as dist
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("[bench] launching %d stub ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, OMP_NUM_THREADS="1")))
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d does not match the launcher's world size %d" % (args.gpus, world))
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world > 1 or launched:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        with _stdout_to_stderr():      # (gloo's connection banner is written to stdout by C code; stdout carries ONE line)
+            dist.init_process_group("gloo")
+            dist.barrier()
+    from ultra_amd import distributed as udist
+    from ultra_amd import host_order, synthetic, tasks
+    from ultra_amd.graph import PipelinedForward
+    if world > 1 or launched:
+        udist.share_readout_order(128, device=torch.device("cpu"))
+    data = synthetic.make_kg(num_node=512, num_triple=4000, num_relation_base=6, num_test=20466, seed=1234, relation_graph=False)
+    N, bs, triples = data.num_nodes, args.bs, data.target_triples
+    gen = torch.Generator().manual_seed(7)
+    emb, relv = torch.randn(N, 16, generator=gen), torch.randn(data.num_relations, 16, generator=gen)
+
+    def score(batch):       # (bs, N, 3) -> (bs, N): any deterministic function of the batch
+        h, t, r = batch.unbind(-1)
+        return (emb[h] * relv[r] * emb[t]).sum(-1)
+
+    class Slot(object):     # a "captured forward": own output buffer, valid until the slot's next call
+        def __init__(self):
+            self.out = torch.zeros(bs, N)
+
+        def __call__(self, batch):
+            self.out.copy_(score(batch))
+            return self.out
+
+    def batch_for(step):
+        lo = ((step * world + rank) * bs) % (triples.shape[0] - bs)
+        return triples[lo:lo + bs]
+
+    n_inputs = min(args.warmup + args.steps, 256)
+    inputs = [tasks.all_negative(data, batch_for(i))[0] for i in range(n_inputs)]
+    piped = PipelinedForward(None, None, inputs[0], depth=args.in_flight, slot_factory=Slot)
+    gather = world > 1 or launched
+    seen = []
+
+    def one_step(step):
+        out = piped(inputs[step % n_inputs], post=(lambda sc: udist.all_gather_scores(sc).clone()) if gather else None)
+        seen.append(tuple(out.shape))
+        return out
+    for i in range(args.warmup):
+        one_step(i)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = one_step(args.warmup + i)
+    piped.join()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64)
+    per_rank = None
+    if gather:
+        probe = score(tasks.all_negative(data, triples[:bs])[0]).double()
+        order_word = float(int(host_order.order_id(host_order.readout_stages(128)[0]).split("-")[1], 16))
+        digest = torch.stack([probe.sum(), probe.abs().max(), probe[:, ::97].sum(), el[0], torch.tensor(order_word, dtype=torch.float64)])
+        gathered = [torch.empty_like(digest) for _ in range(world)]
+        dist.all_gather(gathered, digest)
+        g = torch.stack(gathered)
+        # the last step's gathered rows: rank r's block must be what rank r scored for ITS batch of that step
+        step = args.warmup + args.steps - 1
+        blocks_ok = all(torch.equal(last[r * bs:(r + 1) * bs],
+                                    score(tasks.all_negative(data, triples[((step * world + r) * bs) % (triples.shape[0] - bs):][:bs])[0]))
+                        for r in range(world))
+        per_rank = {"ms_per_step": [1e3 * v / args.steps for v in g[:, 3].tolist()],
+                    "probe_scores_identical": bool((g[:, :3] == g[0, :3]).all()),
+                    "readout_order_id": ["order-%08x" % int(v) for v in g[:, 4].tolist()],
+                    "readout_order_identical": bool((g[:, 4] == g[0, 4]).all()),
+                    "gathered_rows_per_step": seen[-1][0], "gathered_blocks_in_rank_order": bool(blocks_ok)}
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = el.item()
+    out = {"metric": "triples scored/sec (all-tail ranking) on FB15k237", "value": world * bs * N * args.steps / elapsed,
+           "unit": "triples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "stub (CPU dry run of the %d-rank program over gloo: NOT a measurement)" % world,
+           "config": {"workload": "stub scorer on a 512-node synthetic graph: the N-rank control flow of bench.py without GPUs",
+                      "batch_per_gpu": bs, "triples_per_step_per_gpu": bs * N, "rccl_world_size": world if gather else 1,
+                      "collective_backend": "gloo (CPU dry run)" if gather else None, "per_rank": per_rank,
+                      "parallelism": "query-shard x%d + all-gather of scores" % world if world > 1 else "single process"}}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if gather:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -493,6 +606,10 @@ def main():
                     help="nccl = RCCL (the measured configuration).  gloo: the N-rank code path where ranks must share a GPU "
                          "(tests on a one-GPU box: RCCL refuses two ranks on one device); ranks then map to GPUs modulo the "
                          "visible count and the line says so")
+    ap.add_argument("--stub-cpu", action="store_true",
+                    help="dry run of the N-rank program WITHOUT GPUs (tests/test_bench_cpu.py): the launcher path, the gloo "
+                         "process group, the shared readout order, the per-step all-gather behind each pipeline slot, the "
+                         "barrier-fenced max-over-ranks clock and the JSON line, around a stub scorer on CPU -- not a measurement")
     ap.add_argument("--pmc-target", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--trace-target", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -504,6 +621,8 @@ def main():
         return
 
     import torch.distributed as dist
+    if args.stub_cpu:
+        return stub_main(args)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -687,6 +806,7 @@ def main():
         "value": triples_per_s, "unit": "triples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "pre_warmup_steps": max(args.pre_warm, 0),
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step_median": 1e3 * sorted(runs)[len(runs) // 2] / args.steps,
         "repeats": {"runs": len(runs), "steps_per_run": args.steps,
                     "ms_per_step": [round(1e3 * r / args.steps, 5) for r in runs],
                     "median": 1e3 * sorted(runs)[len(runs) // 2] / args.steps,
@@ -697,6 +817,10 @@ def main():
                                "(N=%d, E=%d, R=%d), distmult+sum rspmm, batch %d queries/GPU, query-sharded"
                                % (data_name, N, data.num_edges, data.num_relations, bs),
                    "batch_per_gpu": bs, "triples_per_step_per_gpu": bs * N, "weights": weights,
+                   # (what ran in front of the K timed steps of `ms_per_step`: W warm-up steps as asked for, behind
+                   # `pre_warmup_steps` untimed steps of the same loop; the sustained figure is the median of the repeats)
+                   "untimed_steps_before_the_first_run": {"warmup": args.warmup, "pre_warmup_steps": max(args.pre_warm, 0)},
+                   "ms_per_step_median_of_repeats": 1e3 * sorted(runs)[len(runs) // 2] / args.steps,
                    "summation_order": "reference (rspmm.cpp:61-72 sequential per row; nn.Linear / nn.LayerNorm in torch's CPU order; "
                                       "readout GEMV %s)" % host_order.describe(128),
                    "readout_order_id": host_order.order_id(host_order.readout_stages(128)[0]),
@@ -705,7 +829,9 @@ def main():
                               (", %d batches in flight on %d streams, the aggregation kernels of each on three quarters of the CUs "
                                "(graph.PipelinedForward)" % (args.in_flight, args.in_flight)
                                if args.in_flight > 1 else "")),
-                   "hip_hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
+                   "hip_hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),
+                   "slot_stream_priority": ("high (the pipeline slots own their hardware queues: graph.slot_stream)"
+                                            if os.environ.get("ULTRA_SLOT_STREAM_PRIORITY", "-1") != "0" else "normal"),
                    "rccl_world_size": dist.get_world_size() if (world > 1 or launched) else 1,
                    "collective_backend": ("RCCL" if args.backend == "nccl" else "gloo (test mode: ranks share GPUs, not a measurement)")
                    if (world > 1 or launched) else None,

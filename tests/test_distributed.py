@@ -82,6 +82,57 @@ def test_query_sharded_evaluation_matches_single_process(tmp_path):
     assert outs[0]["shard"] == (0, 19) and outs[1]["shard"] == (19, 37)
 
 
+WORLD8_KG = dict(num_node=48, num_triple=600, num_relation_base=4, num_test=20466, seed=9, relation_graph=False)
+WORLD8_METRICS = ("mr", "mrr", "hits@1", "hits@3", "hits@10", "mrr-tail")
+
+
+def _world8_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ultra_amd import distributed as udist
+    from ultra_amd import eval as ueval
+    from ultra_amd import synthetic
+    data = synthetic.make_kg(**WORLD8_KG)
+    model = StubScorer(data.num_nodes, data.num_relations)
+    res = ueval.evaluate(model, data, batch_size=64, metrics=WORLD8_METRICS)
+    lo, hi = udist.shard_range(data.target_triples.shape[0])
+    # the per-step collective of the benchmark at this world size: every rank's (bs, N) score rows, rank-major
+    gathered = udist.all_gather_scores(torch.full((2, 3), float(rank)))
+    torch.save(dict(res=res, shard=(lo, hi), gathered=gathered), os.path.join(out_dir, "w%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_of_eight_ranks_with_uneven_shards_matches_single_process(tmp_path):
+    """The 1 / 2 / 4 / 8-GPU half of BASELINE.json's metric has never met eight GPUs (no multi-GPU box: DESIGN.md section 7), so
+    the eight-rank program is run on CPU: FB15k237's 20,466 test triples do not divide by 8 (six ranks of 2,558, two of 2,559 --
+    script/run.py:127's DistributedSampler would pad by repeating samples), every rank evaluates its own shard through the real
+    evaluate(), the ONE all-gather of the evaluation (distributed.all_gather_shards, run.py:165-186's six all-reduces) returns
+    every ranking exactly once, and the metrics equal the single-process evaluation on every rank."""
+    world = 8
+    mp.spawn(_world8_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    from ultra_amd import eval as ueval
+    from ultra_amd import synthetic
+    data = synthetic.make_kg(**WORLD8_KG)
+    assert data.target_triples.shape[0] == 20466 and 20466 % world != 0
+    want = ueval.evaluate(StubScorer(data.num_nodes, data.num_relations), data, batch_size=64, metrics=WORLD8_METRICS)
+    assert want["_num_rankings"] == 2 * 20466
+    outs = [torch.load(os.path.join(str(tmp_path), "w%d.pt" % r)) for r in range(world)]
+    sizes = [o["shard"][1] - o["shard"][0] for o in outs]
+    assert sorted(sizes) == [2558] * 6 + [2559] * 2 and sum(sizes) == 20466
+    assert all(outs[r]["shard"][1] == outs[r + 1]["shard"][0] for r in range(world - 1))      # contiguous: no gap, no overlap
+    for o in outs:
+        assert o["res"]["_num_rankings"] == want["_num_rankings"]        # nothing padded, nothing counted twice
+        for k, v in want.items():
+            assert o["res"][k] == pytest.approx(v, rel=1e-6), k
+        assert o["gathered"].shape == (16, 3)
+        assert [float(o["gathered"][2 * r, 0]) for r in range(world)] == [float(r) for r in range(world)]
+
+
 def _order_worker(rank, world, port, out_dir):
     """(a) rank 0's readout association reaches every rank; (b) the collectives a PipelinedForward issues from its
     alternating slots pair up across ranks in program order."""

@@ -152,6 +152,36 @@ def test_point_boundary_under_min_max_meets_zero_off_the_query_rows(dev, sum, wa
     assert loose.forward(rel.to(dev), x.to(dev), sum=sum, point=(rows.to(dev), vals.to(dev))) is None
 
 
+@pytest.mark.parametrize("sum", ["max", "min"])
+@pytest.mark.parametrize("miss", ["general_walk", "row_len_30"])
+def test_point_boundary_under_min_max_is_declined_off_the_order_kernels(dev, sum, miss):
+    """a reference-order plan whose call misses the order kernels (general_walk tuning, a row length that is no
+    multiple of four elements) must not run the general walk with a point boundary under min / max -- that kernel has no fill for
+    the rows off the boundary row.  The call answers None (ULTRA_ERR_UNSUPPORTED) and the layer's route -- the boundary as a
+    tensor -- gives the reference's values."""
+    from ultra_amd import rspmm
+    case = CASES[2]
+    ei, et = helpers.random_graph(**case)
+    N, R, E = case["num_node"], case["num_relation"], ei.shape[1]
+    bs, d = 2, (30 if miss == "row_len_30" else 64)
+    g = torch.Generator().manual_seed(16)
+    x, rel = torch.randn(bs, N, d, generator=g), torch.randn(bs, R, d, generator=g)
+    rows, vals = torch.tensor([3 % N, N - 1]), torch.randn(bs, d, generator=g)
+    bnd = torch.zeros(bs, N, d)
+    bnd[torch.arange(bs), rows] = vals
+    xn, reln, bndn = (t.transpose(0, 1).flatten(1).contiguous() for t in (x, rel, bnd))
+    want = rspmm_oracle.generalized_rspmm(ei, et, torch.ones(E), reln, xn, sum=sum, mul="mul")
+    want = torch.max(want, bndn) if sum == "max" else torch.min(want, bndn)
+    plan = rspmm.Plan(ei, et, N, R, exact_order=True)
+    if miss == "general_walk":
+        rspmm.set_tuning(general_walk=1)
+    assert plan.forward(rel.to(dev), x.to(dev), sum=sum, point=(rows.to(dev), vals.to(dev))) is None
+    got = plan.forward(rel.to(dev), x.to(dev), sum=sum, boundary=bnd.to(dev))
+    assert torch.allclose(got.cpu().transpose(0, 1).flatten(1), want, rtol=1e-6, atol=1e-6)
+    # the edge-less row N - 1 meets the tensor's zero (sample 0) or its value (sample 1), never -+FLT_MAX
+    assert got[0, N - 1].abs().max().item() == 0.0
+
+
 @pytest.mark.parametrize("grid", [1, 3, 8, 77, 256, 1000])
 def test_any_grid_same_bits(dev, grid):
     """Schedules are built per workgroups-per-span; more spans than workgroups loop inside the workgroup."""

@@ -482,6 +482,15 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
         set_error("ultra_rspmm_forward_update: this call is not served by the reference-order kernels");
         return ULTRA_ERR_UNSUPPORTED;
     }
+    // The general walk below applies a point boundary at row bnd_rows[outer] only: it has no fill for the OTHER rows, which under
+    // min / max must meet the boundary tensor's zeros (layers.py:206-207).  A reference-order plan that missed the order kernels
+    // (rows not a multiple of 4 elements, misaligned strides, general_walk tuning, 2^24 rows) therefore answers UNSUPPORTED -- the
+    // layer then passes the dense boundary tensor -- instead of returning FLT_LOWEST / negative aggregates.
+    if (point_fill) {
+        set_error("a point boundary under min / max: this call is not served by the reference-order kernels (row length, "
+                  "alignment or tuning); pass the boundary as a tensor");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
     // per-call edge weights -> sorted order
     if (w && p->num_edge > 0) {
         if ((rc = ensure_scratch(&p->d.w_sorted, &p->d.w_sorted_bytes, (size_t)p->num_edge * esz, p))) return rc;

@@ -95,7 +95,7 @@ struct OrderParams {
         float eps;
         int32_t flags;                               // CONV_LN | CONV_RELU | CONV_RESIDUAL
         int32_t mode;                                // 1: in the kernel's tail, 2 / 3: beside the walk (rspmm_order_kernel, UPDATE)
-        uint32_t ctl_off;                            // mode 2: byte offset of the hand-off block in LDS
+        uint32_t ctl_off;                            // modes 2 and 3: byte offset of the hand-off / control block in LDS
     } upd;
 };
 

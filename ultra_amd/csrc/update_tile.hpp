@@ -76,9 +76,11 @@ constexpr int UPD2_NT = 4;                       // aggregate tiles the walkers 
 constexpr int UPD2_ROW_FLOATS = 68;              // 272 bytes (HANDOFF2_ROW_BYTES)
 constexpr int UPD2_TILE_FLOATS = 16 * UPD2_ROW_FLOATS;
 constexpr int UPD2_MAX_CHAIN_ROWS = 64;          // chain rows of a workgroup the control block can list
-// overlay (in the ring's place once the chain is done): NT aggregate tiles (a ring of 64 rows) | the x rows of a 32-row block
-// (k-permuted: element k of a row at (k % 4) * 16 + k / 4, so that a lane's sixteen B operands are four 16-byte reads) | its
-// pre-norm rows
+// overlay (in the ring's place once the chain is done): NT aggregate tiles (a ring of 64 rows, [64][UPD2_ROW_FLOATS]) | behind
+// them the SAME 64 rows' x, same pitch, elements in NATURAL order (the walkers' stream_park writes both with one ds_write_b128 per
+// lane each; an update lane reads element 4 s + kk of row n: 2-way bank conflicts, the minimum for 64 lanes).  A block's pre-norm
+// rows are written IN PLACE of its x rows once all four update waves have read them (rspmm_order_kernels.hpp, form-3 block) --
+// there is no separate pre-norm area: (NT + 4) tiles = NT aggregate tiles + NT x tiles
 constexpr int UPD2_OVERLAY_BYTES = (UPD2_NT + 4) * UPD2_TILE_FLOATS * 4;
 // control block (behind ring / overlay; bytes): 0 tail, 4 walkers done, 8 update-wave barrier (arrivals), 12 chain done, 16
 // generations consumed, 20 chain rows listed, 32 posted[NT], 64 rowid[16 NT], 320 chain row offsets[64], 576 chain tile

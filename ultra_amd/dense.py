@@ -117,6 +117,7 @@ def readout_supported(model, hidden):
 
 
 _ORDER_CACHE = {}
+_ORDER_RETIRED = []      # programs replaced by host_order.adopt(): kept alive for captured graphs that still point at them
 
 
 def readout_order(device):

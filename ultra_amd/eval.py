@@ -69,16 +69,44 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
 
     was_training = model.training
     model.eval()
-    rows = []
     made_table = False
     if hasattr(model, "cache_relation_representations") and mine.is_cuda and getattr(test_data, "relation_graph", None) is not None \
             and getattr(model, "_rel_table", None) is None:
         num_rel = int(test_data.relation_graph.num_nodes)
         if cache_relations is None:
             cache_relations = 2 * len(mine) // max(batch_size, 1) >= (num_rel + batch_size - 1) // batch_size
+            # (by default only where the (num_rel, num_rel, 64) fp32 table is small next to what is free: it grows with the SQUARE of
+            # the relation count -- 2.6 GB at 3,200 relations -- and a second captured step may hold its activations beside it)
+            if cache_relations and mine.is_cuda:
+                free_bytes = torch.cuda.mem_get_info(mine.device)[0]
+                cache_relations = num_rel * num_rel * 256 <= free_bytes // 8
         if cache_relations:
             model.cache_relation_representations(test_data, chunk=batch_size)
             made_table = True
+    try:
+        local = _local_rows(model, test_data, filt, mine, batch_size, use_graph, in_flight, triples.device)
+    finally:
+        if made_table:
+            model.drop_relation_cache()      # (also when an exception escapes: the table must not stay on the model)
+        model.train(was_training)
+    flat = udist.all_gather_shards(local, len(triples), rows_per_item=2)     # the single collective of the evaluation
+
+    ranking, num_neg, is_tail = flat[:, 0], flat[:, 1], flat[:, 2].bool()
+    plain = [m for m in metrics if "-tail" not in m]
+    tail = [m for m in metrics if "-tail" in m]
+    out = metrics_from_rankings(ranking, num_neg, plain)
+    for m in tail:
+        base, direction = m.split("-")
+        if direction != "tail":
+            raise ValueError("Only tail metric is supported in this mode")
+        out[m] = metrics_from_rankings(ranking[is_tail], num_neg[is_tail], [base])[base]
+    out["_num_rankings"] = int(ranking.numel())
+    return out
+
+
+def _local_rows(model, test_data, filt, mine, batch_size, use_graph, in_flight, device):
+    """(rank, #negatives, is_tail) rows of this rank's shard `mine`, tail and head direction, in shard order."""
+    rows = []
     n_full = (len(mine) // batch_size) * batch_size
     start = 0
     if use_graph and mine.is_cuda and n_full >= 4 * batch_size:
@@ -110,14 +138,14 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
                 if want_two and all(p.exact for p in steps[0]._pinned):
                     try:
                         steps.append(GraphedEvalStep(model, test_data, batch_size, t_index, h_index))
-                    except (torch.cuda.OutOfMemoryError, RuntimeError):      # one step at a time then
+                    except torch.cuda.OutOfMemoryError:      # one step at a time then (any other error is a real one: raised)
                         torch.cuda.synchronize()
             if share and len(steps) == 1:       # (alone after all: it gets the whole chip)
                 steps = [GraphedEvalStep(model, test_data, batch_size, t_index, h_index)]
             n_slot = len(steps)
             cur = torch.cuda.current_stream(mine.device)
-            with torch.cuda.device(mine.device):
-                streams = [torch.cuda.Stream() for _ in steps] if n_slot > 1 else [cur]
+            from .graph import slot_stream
+            streams = [slot_stream(mine.device) for _ in steps] if n_slot > 1 else [cur]
             out = torch.empty(n_full // batch_size, 2 * batch_size, 3, dtype=torch.long, device=mine.device)
             for s in streams:
                 if s is not cur:
@@ -152,22 +180,5 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
         rows.append(torch.stack([t_rank, t_neg, is_tail], dim=-1))
         rows.append(torch.stack([h_rank, h_neg, torch.zeros_like(is_tail)], dim=-1))
     if rows:
-        local = torch.cat(rows).long()
-    else:
-        local = torch.zeros(0, 3, dtype=torch.long, device=triples.device)
-    flat = udist.all_gather_shards(local, len(triples), rows_per_item=2)     # the single collective of the evaluation
-    if made_table:
-        model.drop_relation_cache()
-    model.train(was_training)
-
-    ranking, num_neg, is_tail = flat[:, 0], flat[:, 1], flat[:, 2].bool()
-    plain = [m for m in metrics if "-tail" not in m]
-    tail = [m for m in metrics if "-tail" in m]
-    out = metrics_from_rankings(ranking, num_neg, plain)
-    for m in tail:
-        base, direction = m.split("-")
-        if direction != "tail":
-            raise ValueError("Only tail metric is supported in this mode")
-        out[m] = metrics_from_rankings(ranking[is_tail], num_neg[is_tail], [base])[base]
-    out["_num_rankings"] = int(ranking.numel())
-    return out
+        return torch.cat(rows).long()
+    return torch.zeros(0, 3, dtype=torch.long, device=device)

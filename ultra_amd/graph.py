@@ -110,6 +110,21 @@ class GraphedForward(object):
         return self.static_out
 
 
+def slot_stream(device):
+    """A stream for one pipeline slot (PipelinedForward, evaluate()'s two captured steps).  The HIP runtime maps a process's
+    streams onto a small pool of hardware queues PER PRIORITY LEVEL (GPU_MAX_HW_QUEUES of them, round-robin in creation order), so
+    which queue a normal-priority stream lands on depends on how many streams the process made before it -- torch's side
+    streams, the capture streams, RCCL's: a launcher's rank ran the same step 6 % slower than the plain process until its queue
+    count was tuned by hand.  The slots' streams are therefore created at HIGH priority: they are the only
+    streams of that level in the process, so the two of them own two distinct hardware queues whatever else the process did
+    before -- by construction, on the plain and on the launcher's path alike.  ULTRA_SLOT_STREAM_PRIORITY=0 restores the
+    normal-priority streams (measurements)."""
+    import os
+    prio = int(os.environ.get("ULTRA_SLOT_STREAM_PRIORITY", "-1"))
+    with torch.cuda.device(device):
+        return torch.cuda.Stream(priority=prio)
+
+
 def shared_launch_grid(device):
     """Workgroups of an aggregation launch that leaves a quarter of the chip to the other batch in flight (whole XCD-sized
     multiples: 192 of 256 -- 200 and 208 measured 4 % slower than either neighbour)."""
@@ -158,8 +173,7 @@ class PipelinedForward(object):
                                    "concurrent forwards would share); run its batches one at a time")
         dev = example_batch.device
         if dev.type == "cuda":
-            with torch.cuda.device(dev):
-                self.streams = [torch.cuda.Stream() for _ in self.slots]
+            self.streams = [slot_stream(dev) for _ in self.slots]
         else:
             self.streams = [None for _ in self.slots]
         self.device = dev
@@ -238,9 +252,17 @@ class GraphedEvalStep(object):
             self._pinned = used.plans
             for plan in self._pinned:
                 plan.pin(+1)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                step()
+            try:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    step()
+            except BaseException:
+                # a capture that fails (out of memory for the second step of evaluate(), a kernel error) must not leave its plans
+                # pinned for the life of the process: __del__ of a half-built object is not something to rely on
+                for plan in self._pinned:
+                    plan.pin(-1)
+                self._pinned = []
+                raise
 
     def __call__(self, batch, t_ptr, h_ptr):
         """rows (2 bs, 3) of this batch -- a view of the static buffer: copy before the next call."""

@@ -367,7 +367,10 @@ def adopt(stages, source, K=128):
     _check_stages(stages, K)
     _CACHE[K] = (stages, source)
     from . import dense
-    dense._ORDER_CACHE.clear()      # (device copies of the previous program)
+    # device copies of the previous program: RETIRED, not freed -- a hipGraph captured before this call may still read them
+    # (share_readout_order is documented to run before the first forward; a dangling pointer must not be the price of calling it late)
+    dense._ORDER_RETIRED.extend(dense._ORDER_CACHE.values())
+    dense._ORDER_CACHE.clear()
 
 
 def _probe_in_subprocess(K, path):
@@ -434,8 +437,10 @@ def readout_stages(K=128):
         elif mode != "sequential":
             stages, source = load_stages(mode, K)
             source = "file %s (%s)" % (os.path.basename(mode), source)
-    except (OSError, ValueError, KeyError, TypeError, subprocess.SubprocessError) as exc:
-        # (an unreadable cache directory, a tree outside the family, a failed helper process: the sequential chain always works)
+    except (OSError, ValueError, KeyError, TypeError, IndexError, ArithmeticError, RuntimeError, subprocess.SubprocessError) as exc:
+        # (an unreadable cache directory, a tree outside the family, a failed helper process, an in-process probe that trips over
+        # torch / numpy: the sequential chain always works -- "anything that fails falls back", as the docstring says; only
+        # KeyboardInterrupt / SystemExit / MemoryError pass)
         warnings.warn("ultra_amd: readout summation order '%s' unavailable (%s: %s); using the sequential chain"
                       % (mode, type(exc).__name__, exc))
         stages, source = sequential_stages(K), "sequential (fallback)"

@@ -464,15 +464,18 @@ class Ultra(nn.Module):
         num_rel = int(rg.num_nodes)
         was_training = self.training
         self.eval()
-        rows = []
+        table = None      # (preallocated on the first chunk: a list of chunks + torch.cat would hold the table twice at its peak)
         with torch.no_grad():
             for lo in range(0, num_rel, chunk):
                 ids = torch.arange(lo, min(lo + chunk, num_rel), device=dev)
                 if ids.numel() < chunk:      # (one batch shape for every call: plans and kernels see what a forward shows them)
                     ids = torch.cat([ids, ids.new_zeros(chunk - ids.numel())])
-                rows.append(self.relation_model(rg, query=ids)[: min(chunk, num_rel - lo)].clone())
+                rep = self.relation_model(rg, query=ids)
+                if table is None:
+                    table = rep.new_empty((num_rel,) + tuple(rep.shape[1:]))
+                table[lo:min(lo + chunk, num_rel)] = rep[: min(chunk, num_rel - lo)]
         self.train(was_training)
-        self._rel_table = torch.cat(rows)
+        self._rel_table = table
         self._rel_table_key = (id(rg), self._relation_param_state())
         return self._rel_table
 
