@@ -29,8 +29,9 @@ import os as _os
 # Hardware queues.  The HIP runtime maps a process's streams round-robin onto GPU_MAX_HW_QUEUES hardware queues (default 4) per
 # priority level, and a launcher's rank (RCCL communicator = more streams) used to land its two pipeline slots' streams on queues
 # that interleave worse than the plain process's: round 4 pinned GPU_MAX_HW_QUEUES=3 for launched ranks (0.605 - 0.625 -> 0.583
-# ms per step).  Since round 5 the slots' streams are the only HIGH-priority streams of the process (ultra_amd/graph.py
-# slot_stream): they own two distinct queues on either path, and the override is gone -- the runtime's default applies unless the
+# ms per step).  Since round 5 the pipeline picks its slots' streams by measurement (ultra_amd/graph.py pick_slot_streams: a
+# normal- and a high-priority pair timed for a few steps when the pipeline is built; the launcher's rank ends up on the
+# high-priority pair, the plain process on the normal one), and the override is gone -- the runtime's default applies unless the
 # caller sets the variable (ULTRA_BENCH_LAUNCHER_QUEUES=n re-creates the old override for A/B runs; the runtime reads the
 # variable when it is loaded, hence here, before torch is imported).
 if "RANK" in _os.environ and "WORLD_SIZE" in _os.environ and _os.environ.get("ULTRA_BENCH_LAUNCHER_QUEUES"):
@@ -711,6 +712,8 @@ def main():
         score = model(data_, batch_)
         return post(score) if post is not None else score
 
+    slot_report = {}      # which streams the pipeline slots of the timed forward run on (graph.pick_slot_streams)
+
     def make_forward():
         if args.no_graph:
             return eager_forward
@@ -723,6 +726,8 @@ def main():
             example = tasks.all_negative(data, batch_for(0))[0]
             if args.in_flight > 1 and rspmm._plan_defaults["exact_order"]:
                 piped = PipelinedForward(model, data, example, depth=args.in_flight)
+                if not slot_report:
+                    slot_report.update(piped.stream_report or {})
                 return lambda data_, batch_, post=None: piped(batch_, post=post)
             graphed = GraphedForward(model, data, example)
 
@@ -830,8 +835,8 @@ def main():
                                "(graph.PipelinedForward)" % (args.in_flight, args.in_flight)
                                if args.in_flight > 1 else "")),
                    "hip_hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),
-                   "slot_stream_priority": ("high (the pipeline slots own their hardware queues: graph.slot_stream)"
-                                            if os.environ.get("ULTRA_SLOT_STREAM_PRIORITY", "-1") != "0" else "normal"),
+                   # (normal- or high-priority pair, whichever interleaved better in a ~ 20 ms trial when the pipeline was built)
+                   "slot_streams": slot_report or None,
                    "rccl_world_size": dist.get_world_size() if (world > 1 or launched) else 1,
                    "collective_backend": ("RCCL" if args.backend == "nccl" else "gloo (test mode: ranks share GPUs, not a measurement)")
                    if (world > 1 or launched) else None,

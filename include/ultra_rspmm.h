@@ -108,6 +108,16 @@ typedef struct {
 int32_t ultra_abi_version(void);
 const char *ultra_last_error(void);
 
+/*
+ * Errors raised ON the device.  The waits of the one-launch layer's hand-off between walking and multiplying waves
+ * (ultra_rspmm_forward_update, forms beside the walk) are bounded: a wave that has polled for >= 0.05 s stores an error word in
+ * pinned host memory, lets the other side through and ends -- a protocol error or a broken schedule is a failed call, not a hung
+ * GPU.  The word is looked at (and cleared) at the entry of every rspmm forward call and by this function: returns ULTRA_OK, or
+ * ULTRA_ERR_HIP with ultra_last_error() naming the wait and the workgroup.  Call it after synchronising the stream to learn
+ * about the launches before; no HIP call is made.
+ */
+int32_t ultra_device_error(void);
+
 /* Number of GPUs the HIP runtime sees (0 without a GPU; never fails). */
 int32_t ultra_device_count(void);
 

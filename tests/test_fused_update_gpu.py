@@ -203,3 +203,71 @@ def test_layer_takes_the_one_launch_path_and_keeps_its_bits(dev, message_func):
             finally:
                 layers.FUSED_SPARSE_LAYER = True
     assert torch.equal(outs[0], outs[1])
+
+
+def test_form_3_on_the_random_schedules_of_the_plan_tests(dev):
+    """the hand-off of form 3 on every random graph of tests/test_plan.py's schedule test (one node .. 2,000,
+    no edges .. 30,000, hub rows of 257 .. 9,000 edges), on 8 and on 192 workgroups -- not only on the six fused cases above: bit
+    for bit the two launches, and no bounded wait gave up (rspmm.check_device_error)."""
+    import random
+    from ultra_amd import dense, rspmm
+    from ultra_amd.rspmm import Plan
+    rng = random.Random(0)
+    served = 0
+    for it in range(14):
+        N = rng.choice([1, 2, 7, 50, 300, 2000])
+        E = rng.choice([1, 10, 500, 5000, 30000]) if N > 1 else rng.choice([1, 17])
+        R = rng.choice([1, 3, 9])
+        ei, et = helpers.random_graph(num_node=N, num_edge=E, num_relation=R, seed=it)
+        for _ in range(rng.choice([0, 1, 3])):
+            node, cnt = rng.randrange(N), rng.choice([257, 300, 700, 3000, 9000])
+            g = torch.Generator().manual_seed(it * 7 + cnt)
+            ei = torch.cat([ei, torch.stack([torch.full((cnt,), node), torch.randint(0, N, (cnt,), generator=g)])], dim=1)
+            et = torch.cat([et, torch.randint(0, R, (cnt,), generator=g)])
+        plan = Plan(ei, et, N, R, exact_order=True)
+        case = dict(num_node=N, num_relation=R)
+        rel, x, rows, vals, weight, bias, ln_w, ln_b = _operands(case, 8, dev, 100 + it)
+        for sum in ("add", "max"):
+            rspmm.set_tuning()
+            agg = plan.forward(rel, x, sum=sum, mul="mul", point=(rows, vals))
+            want = dense._conv_update_forward(x, agg, weight, bias, ln_w, ln_b, 1e-5, 7)
+            for grid in (8, 192):
+                rspmm.set_tuning(grid=grid, update_form=3)
+                got = plan.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7, point=(rows, vals), sum=sum)
+                if got is None:      # (a schedule with more chain rows per workgroup than the control block lists: declined)
+                    continue
+                served += 1
+                assert torch.equal(got, want), "graph %d, %s, grid %d" % (it, sum, grid)
+    torch.cuda.synchronize()
+    rspmm.check_device_error()
+    assert served >= 40
+
+
+def test_a_lost_arrival_ends_the_launch_with_an_error_not_a_hang(dev):
+    """The waits of form 3's hand-off are bounded (OrderParams::err): with one update wave that never arrives at a meeting
+    (CONV_DBG_LOSE_ARRIVAL, a fault injected for this test) the other three would spin for ever -- the launch must END, and the
+    next look at the device error word must name the wait.  A clean launch afterwards is clean."""
+    import time
+    from ultra_amd import dense, rspmm
+    from ultra_amd._lib import UltraError
+    from ultra_amd.rspmm import Plan
+    case = CASES[5]
+    ei, et = helpers.random_graph(**case)
+    plan = Plan(ei, et, case["num_node"], case["num_relation"], exact_order=True)
+    rel, x, rows, vals, weight, bias, ln_w, ln_b = _operands(case, 2, dev, 5)
+    agg = plan.forward(rel, x, sum="add", mul="mul", point=(rows, vals))
+    want = dense._conv_update_forward(x, agg, weight, bias, ln_w, ln_b, 1e-5, 7)
+    rspmm.set_tuning(update_form=3, grid=8)
+    assert torch.equal(plan.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7, point=(rows, vals)), want)
+    torch.cuda.synchronize()
+    rspmm.check_device_error()                               # nothing so far
+    t0 = time.perf_counter()
+    broken = plan.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7 | 1024, point=(rows, vals))
+    torch.cuda.synchronize()                                 # returns: the launch ended
+    assert broken is not None and time.perf_counter() - t0 < 60.0
+    with pytest.raises(UltraError, match="bounded wait"):
+        rspmm.check_device_error()
+    rspmm.check_device_error()                               # the word was cleared by the look
+    assert torch.equal(plan.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7, point=(rows, vals)), want)
+    torch.cuda.synchronize()
+    rspmm.check_device_error()

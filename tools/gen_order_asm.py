@@ -111,6 +111,9 @@ HANDOFF_QUEUE_OFF = HANDOFF_TILE_OFF + 4 * HANDOFF_TILES
 HANDOFF2_NT = 4
 HANDOFF2_ROW_BYTES = 272
 HANDOFF2_CONSUMED_OFF, HANDOFF2_POSTED_OFF, HANDOFF2_ROWID_OFF = 16, 32, 64
+# a park wait that gave up leaves a non-zero word here (UPD2_CTL_ERR in update_tile.hpp; the kernel's C++ forwards it to the host)
+HANDOFF2_ERR_OFF = 28
+PARK_SPIN_CAP = 1 << 20
 HANDOFF2_X_OFF = HANDOFF2_NT * 16 * HANDOFF2_ROW_BYTES     # the x rows' ring sits behind the aggregates'
 
 
@@ -129,6 +132,7 @@ def stream_park(a, ob_q, x_q, tag):
     a("s_nop 4")
     a("v_mov_b32_dpp v123, v123 row_newbcast:0 row_mask:0xf bank_mask:0xf", "the group's slot to its 16 lanes, in registers")
     a("v_lshrrev_b32_e32 v122, 4, v123", "generation")
+    a("s_mov_b32 %[t1], 0", "polls of this wait (bounded: OrderParams::err)")
     a.label(".Lpark_wait_%s_%%=" % tag)
     a("v_lshrrev_b32_e32 v126, 2, v126", "(the word counts the update waves that are done with a block of two generations: four per block)")
     a("v_lshl_add_u32 v126, v126, 1, %d" % HANDOFF2_NT)
@@ -136,9 +140,16 @@ def stream_park(a, ob_q, x_q, tag):
     a("s_andn2_b64 vcc, exec, vcc")
     a("s_cbranch_vccz .Lpark_go_%s_%%=" % tag)
     a("s_sleep 2")
+    a("s_add_u32 %[t1], %[t1], 1")
+    a("s_cmp_lt_u32 %%[t1], 0x%x" % PARK_SPIN_CAP)
+    a("s_cbranch_scc0 .Lpark_giveup_%s_%%=" % tag)
     a("ds_read_b32 v126, v124 offset:%d" % HANDOFF2_CONSUMED_OFF)
     a("s_waitcnt lgkmcnt(0)")
     a("s_branch .Lpark_wait_%s_%%=" % tag)
+    a.label(".Lpark_giveup_%s_%%=" % tag)
+    # the update waves have not freed a ring row in 2^20 polls (>= 0.1 s; a block takes them microseconds): leave the code for the
+    # kernel's C++ to report and park anyway -- the launch ends with an error word instead of hanging the GPU
+    a("ds_write_b32 v124, v125 offset:%d" % HANDOFF2_ERR_OFF)
     a.label(".Lpark_go_%s_%%=" % tag)
     a("v_and_b32_e32 v122, %d, v123" % (16 * HANDOFF2_NT - 1), "tile row among the NT buffers")
     a("v_mad_u32_u24 v126, v122, %[rowpitch], %[lb]")
@@ -190,9 +201,33 @@ def stream_post(a, tag):
 # "row_newbcast" is the assembler's name of row_share on gfx90a+) instead of ds_swizzle -- the swizzles were 8 of the 12 LDS
 # instructions of a chunk, and the LDS pipe of the CU, shared by all sixteen waves, is what the walk keeps busiest.
 DPP_BCAST = os.environ.get("ULTRA_GEN_DPP_BCAST", "1") == "1"
+# The walk's instruction diet (round 5; ULTRA_GEN_DIET=0 generates round 4's loops for A/B builds).  The stream phase shares its
+# SIMDs with the update waves' matrix chains, and what it loses to them is VALU issue slots: 9.4 VALU instructions per step
+# before, 6.5 now.
+#   * marker test once per ROUND of records instead of once per chunk of gathers: at promote time lane l holds the type of step
+#     l % 8, so ONE v_cmp against the marker's type gives the 64-lane mask of marker steps; folded to 32 bits (vcc_lo | vcc_hi) its
+#     nibbles say "chunk A (steps 0..3) / chunk B (steps 4..7) of some group holds a marker" -- two SALU tests where v_max3 +
+#     v_max + v_cmp ran per chunk;
+#   * live test against the step counter in an SGPR (lim = len - lane % 8 and len never change) instead of a per-lane remaining
+#     count that a v_add moved every round;
+#   * PRESHIFT (the twelve-walker schedules' records, POST variants): records hold col * 256 and type * 256 (whole-span rows of
+#     256 bytes: the only geometry the hand-off forms serve), so a step's gather offset and relation-row address are ONE VOP2 add
+#     each with the DPP row broadcast ON ITS SOURCE -- v_add_u32_dpp dst, record, lane_base row_newbcast:k -- where a DPP move
+#     plus a v_mad_u32_u24 / v_lshl_add_u32 (VOP3: no DPP on gfx950) ran before: 8 VALU instead of 16 per chunk.
+DIET = os.environ.get("ULTRA_GEN_DIET", "1") == "1"
 
 
-def stream_fetch(a, xb, tb, ob, J):
+def stream_fetch(a, xb, tb, ob, J, preshift=False):
+    if preshift:
+        a("s_nop 1", "(a VALU write of v114 / v115 needs two wait states before a DPP read)")
+        for q in range(4):
+            a("v_add_u32_dpp v%d, v114, %%[lb] row_newbcast:%d row_mask:0xf bank_mask:0xf" % (ob + q, J + q),
+              "col * 256 of step %d, broadcast inside the group, + the lane's 16 bytes" % (J + q))
+        for q in range(4):
+            a("v_add_u32_dpp v%d, v115, %%[lds] row_newbcast:%d row_mask:0xf bank_mask:0xf" % (tb + q, J + q))
+        for q in range(4):
+            a("global_load_dwordx4 %s, v%d, %%[xb]" % (vr(xb + 4 * q, 4), ob + q))
+        return
     if DPP_BCAST:
         a("s_nop 1", "(a VALU write of v114 / v115 needs two wait states before a DPP read)")
         for q in range(4):
@@ -228,14 +263,25 @@ def stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag, post
     """The chunk's four steps in order.  Fast form: every stream of the wave still has the whole chunk (uniform test
     against nf) and none of the 16 (group, step) slots is a marker (the marker's LDS address is the largest there is).
     General form, per step: live = consts[q] < rem; marker = live and relation address == mark; edges accumulate in the
-    lanes live & ~marker, markers flush."""
-    a("s_add_i32 %%[t1], %%[kb], %d" % (first_step + 4))
-    a("s_cmp_le_i32 %[t1], %[nf]")
-    a("s_cbranch_scc0 .Lstream_general_%s_%%=" % tag)
-    a("v_max3_u32 v122, v%d, v%d, v%d" % (tb, tb + 1, tb + 2))
-    a("v_max_u32_e32 v122, v122, v%d" % (tb + 3))
-    a("v_cmp_eq_u32_e32 vcc, v122, %[mark]")
-    a("s_cbranch_vccnz .Lstream_general_%s_%%=" % tag)
+    lanes live & ~marker, markers flush.
+    DIET: t0 holds kb + first_step + 4 wherever a chunk is computed; the marker test is the round's mask (m32: chunk A's nibbles,
+    mb: chunk B's, masked out before the next round's promote); live = kb + first_step + q < len with the step in an SGPR."""
+    if DIET:
+        a("s_cmp_le_i32 %[t0], %[nf]")
+        a("s_cbranch_scc0 .Lstream_general_%s_%%=" % tag)
+        if first_step == 0:
+            a("s_and_b32 %[t1], %[m32], 0x0f0f0f0f", "a marker among steps 0..3 of some group?")
+        else:
+            a("s_cmp_lg_u32 %[mb], 0", "... among steps 4..7?")
+        a("s_cbranch_scc1 .Lstream_general_%s_%%=" % tag)
+    else:
+        a("s_add_i32 %%[t1], %%[kb], %d" % (first_step + 4))
+        a("s_cmp_le_i32 %[t1], %[nf]")
+        a("s_cbranch_scc0 .Lstream_general_%s_%%=" % tag)
+        a("v_max3_u32 v122, v%d, v%d, v%d" % (tb, tb + 1, tb + 2))
+        a("v_max_u32_e32 v122, v122, v%d" % (tb + 3))
+        a("v_cmp_eq_u32_e32 vcc, v122, %[mark]")
+        a("s_cbranch_vccnz .Lstream_general_%s_%%=" % tag)
     for q in range(4):
         a("s_waitcnt lgkmcnt(%d)" % (3 - q))
         x = xb + 4 * q
@@ -250,7 +296,11 @@ def stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag, post
         if post != 2:
             a("%s %s, %s, %s" % (binop, vr(x, 2), vr(RV[q], 2), vr(x, 2)))
             a("%s %s, %s, %s" % (binop, vr(x + 2, 2), vr(RV[q] + 2, 2), vr(x + 2, 2)))
-        a("v_cmp_lt_i32_e32 vcc, %d, %%[rem]" % consts[q], "live")
+        if DIET:
+            a("s_add_i32 %%[t1], %%[kb], %d" % (first_step + q))
+            a("v_cmp_lt_i32_e32 vcc, %[t1], %[rem]", "live: this step is inside the group's stream")
+        else:
+            a("v_cmp_lt_i32_e32 vcc, %d, %%[rem]" % consts[q], "live")
         a("v_cmp_eq_u32_e64 %%[mk], v%d, %%[mark]" % (tb + q))
         a("s_and_b64 %[mk], %[mk], vcc", "marker")
         a("s_andn2_b64 exec, vcc, %[mk]", "edges")
@@ -295,11 +345,22 @@ def gen_stream(sum_code, mul_code, rec_policy, post=0):
     a = Asm()
     binop = BINOPS[mul_code]
     A, B, TA, TB, OA, OB = 64, 80, 96, 100, 104, 108
+    preshift = DIET and post != 0
 
-    def promote(rec):
-        a("v_cmp_lt_i32_e32 vcc, %[l8], %[rem]")
+    def promote(rec, step_reg=None):
+        if DIET:
+            # (%[l8] carries lim = len - lane % 8 in these variants: step kr + lane % 8 is inside the stream iff kr < lim)
+            if step_reg is None:
+                a("v_cmp_lt_i32_e32 vcc, 0, %[l8]")
+            else:
+                a("v_cmp_lt_i32_e32 vcc, %%[%s], %%[l8]" % step_reg)
+        else:
+            a("v_cmp_lt_i32_e32 vcc, %[l8], %[rem]")
         a("v_cndmask_b32_e32 v114, 0, v%d, vcc" % rec, "steps past the stream's end gather node 0 ...")
         a("v_cndmask_b32_e32 v115, 0, v%d, vcc" % (rec + 1), "... multiply by relation 0, are no marker, and are masked out of the sum")
+        if DIET:
+            a("v_cmp_eq_u32_e32 vcc, %[rmk], v115", "marker steps of this round: lane l = step l % 8 of its group")
+            a("s_or_b32 %[m32], vcc_lo, vcc_hi", "(VALU -> SGPR -> SALU: interlocked)")
 
     def compute(xb, tb, ob, consts, first_step, tag):
         if post == 1:
@@ -322,24 +383,27 @@ def gen_stream(sum_code, mul_code, rec_policy, post=0):
     a("v_add_u32_e32 %[roff], 0x80, %[roff]")
     a("s_waitcnt vmcnt(1)", "in flight: [r0, r1] -> r0")
     promote(120)
-    stream_fetch(a, A, TA, OA, 0)                                  # in flight: [r1, A x 4]
+    stream_fetch(a, A, TA, OA, 0, preshift)                        # in flight: [r1, A x 4]
     a.label(".Lstream_loop_%=")
     a("s_add_i32 %[t0], %[kb], 4")
     a("s_cmp_lt_i32 %[t0], %[ns]")
     a("s_cbranch_scc0 .Lstream_last_a_%=")
-    stream_fetch(a, B, TB, OB, 4)                                  # [r', A x 4, B x 4]
+    stream_fetch(a, B, TB, OB, 4, preshift)                        # [r', A x 4, B x 4]
     stream_rel_reads(a, TA)
     a("s_waitcnt vmcnt(4)", "[r', A x 4, B x 4] (+ flush stores, which only make the count stricter) -> r', A; the previous "
                             "chunk's flush stores are older than B x 4: complete")
     compute(A, TA, OA, (0, 1, 2, 3), 0, "a")
+    if DIET:
+        a("s_and_b32 %[mb], %[m32], 0xf0f0f0f0", "this round's markers among steps 4..7 (the next promote overwrites m32)")
     a("s_add_i32 %[t0], %[kb], 8")
     a("s_cmp_lt_i32 %[t0], %[ns]")
     a("s_cbranch_scc0 .Lstream_last_b_%=")
-    a("v_add_u32_e32 %[rem], -8, %[rem]", "rem = len - (kb + 8)")
-    promote(112)
+    if not DIET:
+        a("v_add_u32_e32 %[rem], -8, %[rem]", "rem = len - (kb + 8)")
+    promote(112, "t0")
     a("global_load_dwordx2 v[112:113], %%[roff], %%[rb]%s" % rec_policy, "records of round kb / 8 + 2: a whole round before their first use")
     a("v_add_u32_e32 %[roff], 64, %[roff]")
-    stream_fetch(a, A, TA, OA, 0)                                  # [B x 4, r'', A x 4]
+    stream_fetch(a, A, TA, OA, 0, preshift)                        # [B x 4, r'', A x 4]
     stream_rel_reads(a, TB)
     a("s_waitcnt vmcnt(5)", "[B x 4, r'', A x 4] -> B; chunk A's flush stores are older than r'', A x 4: complete")
     compute(B, TB, OB, (-4, -3, -2, -1), 4, "b")   # (rem already moved on by 8)
@@ -645,12 +709,17 @@ def main():
                  "// POST == 1: every flushed row is also handed to the workgroup's update waves through the LDS block at byte address qctl\n"
                  "// (stream_post in the generator; whole-span rows only: lb = 16 (lane % 16)).  POST == 2: the row itself goes to them, into\n"
                  "// the LDS tiles at byte address qtile, and not to memory (stream_park).\n"
+                 "// ULTRA_STREAM_DIET (generator: DIET): l8 carries lim = len - lane % 8 instead of lane % 8, rem stays the stream's length, rmk\n"
+                 "// = the type a marker record holds (num_rel; num_rel * 256 where the records are pre-shifted).  ULTRA_STREAM_PRESHIFT_GEN: the\n"
+                 "// POST variants read records (col * 256, type * 256) -- the twelve-walker schedules' format (plan.hpp ULTRA_STREAM_PRESHIFT).\n"
+                 "#define ULTRA_STREAM_DIET " + ("1" if DIET else "0") + "\n#define ULTRA_STREAM_PRESHIFT_GEN " + ("1" if DIET else "0") + "\n"
                  "template <int SUM, int MUL, int POST>\n"
                  "__device__ __forceinline__ void order_stream_asm(int rem, uint32_t roff, const int l8, const uint32_t lb, const uint32_t lds,\n"
                  "                                                 const uint32_t mark, const uint32_t bndoff, const float (&b)[4], const float bz,\n"
                  "                                                 const int ns, const int nf, const char *xb, const char *rb, const char *ob,\n"
-                 "                                                 const uint32_t xrb, const uint32_t qctl, const uint32_t qtile) {\n"
-                 "    int kb, t0, t1, pf;\n    unsigned long long ex, mk;\n    (void)pf, (void)qtile;\n"
+                 "                                                 const uint32_t xrb, const uint32_t qctl, const uint32_t qtile,\n"
+                 "                                                 const uint32_t rmk) {\n"
+                 "    int kb, t0, t1, pf, m32, mb;\n    unsigned long long ex, mk;\n    (void)pf, (void)qtile, (void)m32, (void)mb, (void)rmk;\n"
                  "    const uint32_t rowpitch = " + str(HANDOFF2_ROW_BYTES) + "u;\n    (void)rowpitch;\n")
     first = True
     for post in (0, 1, 2):
@@ -662,11 +731,13 @@ def main():
                 first = False
                 parts.append("        asm volatile(\n" + a.render("            ") + "\n")
                 parts.append('            : [rem] "+v"(rem), [roff] "+v"(roff), [kb] "=&s"(kb), [t0] "=&s"(t0), [t1] "=&s"(t1), [ex] "=&s"(ex),\n'
-                             '              [mk] "=&s"(mk)%s\n' % (', [pf] "=&s"(pf)' if post == 1 else ''))
+                             '              [mk] "=&s"(mk)%s%s\n' % (', [pf] "=&s"(pf)' if post == 1 else '',
+                                                                   ', [m32] "=&s"(m32), [mb] "=&s"(mb)' if DIET else ''))
                 parts.append('            : [l8] "v"(l8), [lb] "v"(lb), [lds] "v"(lds), [mark] "v"(mark), [bndoff] "v"(bndoff), [b0] "v"(b[0]),\n'
                              '              [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [ns] "s"(ns), [nf] "s"(nf), [xb] "s"(xb), [rb] "s"(rb),\n'
-                             '              [ob] "s"(ob), [xrb] "s"(xrb)%s%s%s\n' % (', [bz] "v"(bz)' if sum_code else '', ', [qctl] "s"(qctl)' if post else '',
-                                                                                       ', [qtile] "s"(qtile), [rowpitch] "s"(rowpitch)' if post == 2 else ''))
+                             '              [ob] "s"(ob), [xrb] "s"(xrb)%s%s%s%s\n' % (', [bz] "v"(bz)' if sum_code else '', ', [qctl] "s"(qctl)' if post else '',
+                                                                                         ', [qtile] "s"(qtile), [rowpitch] "s"(rowpitch)' if post == 2 else '',
+                                                                                         ', [rmk] "s"(rmk)' if DIET else ''))
                 lo, hi = (POST_CLOBBER_LO, POST_CLOBBER_HI) if post == 1 else ((STREAM_CLOBBER_LO, 126) if post == 2 else (STREAM_CLOBBER_LO, STREAM_CLOBBER_HI))
                 parts.append('            : "memory", "vcc", "scc", %s);\n' % clobbers(lo, hi))
                 parts.append("    }\n")

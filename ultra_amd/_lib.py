@@ -75,6 +75,7 @@ def _load():
     lib.ultra_last_error.restype = ctypes.c_char_p
     lib.ultra_abi_version.restype = ctypes.c_int32
     lib.ultra_device_count.restype = ctypes.c_int32
+    lib.ultra_device_error.restype = ctypes.c_int32
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     matp = ctypes.POINTER(UltraMat)
     lib.ultra_plan_create.argtypes = [ctypes.POINTER(vp), vp, vp, i64, i64, i64, i64, ctypes.POINTER(PlanOpts)]

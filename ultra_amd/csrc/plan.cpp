@@ -434,6 +434,7 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
         for (int64_t g = 0; g < nstream; ++g) {
             s->sdesc[(size_t)2 * g] = (int32_t)(s->srec.size() / 2);
             s->sdesc[(size_t)2 * g + 1] = (int32_t)sload[(size_t)g];
+            s->max_stream_steps = std::max<int32_t>(s->max_stream_steps, (int32_t)sload[(size_t)g]);
             // Order inside a stream: by row; in the update-beside-the-walk schedules the LONGEST ROW LAST -- every stream ends with a
             // flush, and the fewer other flushes fall into the walk's last few thousand cycles, the shorter the queue the update
             // waves are left with when the walkers are gone (tools/step_probe.py, one batch at a time / two in flight: by row
@@ -447,14 +448,18 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
                 if (row_order == 2 && ia.len != ib.len) return ia.len < ib.len;
                 return ia.row < ib.row;
             });
+            // (twelve-walker schedules: records pre-multiplied by the 256-byte row pitch, plan.hpp ULTRA_STREAM_PRESHIFT; the
+            // products fit 32 bits: the caller keeps node and relation counts below 2^24)
+            const int shift = (walkers == 12 && ULTRA_STREAM_PRESHIFT) ? 8 : 0;
+            s->rec_shift = shift;
             for (int32_t it : srows[(size_t)g]) {
                 const Item &row = p->items[(size_t)it];
                 for (int32_t e = row.begin; e < row.begin + row.len; ++e) {
-                    s->srec.push_back(p->col[(size_t)e]);
-                    s->srec.push_back(p->type[(size_t)e]);
+                    s->srec.push_back((int32_t)((uint32_t)p->col[(size_t)e] << shift));
+                    s->srec.push_back((int32_t)((uint32_t)p->type[(size_t)e] << shift));
                 }
-                s->srec.push_back(row.row);                  // marker: flush the accumulator to this row
-                s->srec.push_back((int32_t)p->num_rel);
+                s->srec.push_back((int32_t)((uint32_t)row.row << shift));     // marker: flush the accumulator to this row
+                s->srec.push_back((int32_t)((uint32_t)p->num_rel << shift));
             }
         }
         s->srec.resize(s->srec.size() + 2 * ORDER_PAD, 0);   // (records are requested two rounds ahead without a bounds test)

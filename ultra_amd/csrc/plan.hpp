@@ -64,6 +64,13 @@ constexpr int ORDER_GROUPS = 4 * ORDER_WAVES;        // 16-lane groups of a work
 constexpr int ORDER_OV_PRODUCERS = 8;
 constexpr int ORDER_OV_CREW_GROUPS = 4 * (1 + ORDER_OV_PRODUCERS);   // streams (16-lane groups) of the consumer and producer waves
 constexpr int CHUNK_PAD = 32;           // descriptors readable behind a schedule's last chunk (>= 3 x the producers' depth)
+// Record format of the group streams of the TWELVE-walker schedules (the update-beside-the-walk launches; nothing else reads
+// them): 1 = (col * 256, type * 256) -- these launches serve whole-span rows of 256 bytes only, so gather offset and relation-row
+// address are one DPP-fused add each in the generated walk (tools/gen_order_asm.py, DIET) -- 0 = (col, type) like the
+// sixteen-walker schedules, whose walks serve any row stride.  Both sides of 2^24 rows / relations are excluded by the caller.
+#ifndef ULTRA_STREAM_PRESHIFT
+#define ULTRA_STREAM_PRESHIFT 1
+#endif
 constexpr int ORDER_PAD = 128;           // the device record / perm streams are readable this many entries past the last edge
 
 // Static work assignment of one launch geometry: `nparts` workgroups share the items of a span.  Built on first use
@@ -94,6 +101,8 @@ struct Schedule {
     double max_cost = 0.0, mean_cost = 0.0;             // cost model's load of the fullest / average workgroup
     int32_t max_rows = 0;                               // most rows any one workgroup aggregates
     int32_t max_chain_rows = 0;                         // most chain rows any one workgroup walks
+    int32_t max_stream_steps = 0;                       // longest group stream in steps (edges + markers)
+    int32_t rec_shift = 0;                              // srec holds (col << rec_shift, type << rec_shift): ULTRA_STREAM_PRESHIFT
 };
 
 struct DevicePlan {

@@ -63,6 +63,36 @@ static thread_local long long *g_order_trace = nullptr;
 // set by ultra_rspmm_forward_masked around its launch: the weight stream is a 0/1 keep mask (weigh(), rspmm_kernels.hpp)
 static thread_local int g_keep_mode = 0;
 
+// ---- the device-side error word (OrderParams::err) ----
+// One word of pinned, mapped host memory per process: a kernel whose bounded spin gave up stores (code << 24 | workgroup) there
+// with a system-scope store; the host reads it without any HIP call -- at the next forward entry and in ultra_device_error().
+static uint32_t *g_dev_err = nullptr;
+static uint32_t *device_error_word() {
+    if (!g_dev_err) {
+        void *ptr = nullptr;
+        if (hipHostMalloc(&ptr, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;      // (no word: the kernels then only keep their spins bounded)
+        }
+        std::memset(ptr, 0, 64);
+        g_dev_err = static_cast<uint32_t *>(ptr);
+    }
+    return g_dev_err;
+}
+static int take_device_error() {
+    if (!g_dev_err) return ULTRA_OK;
+    const uint32_t word = __atomic_exchange_n(g_dev_err, 0u, __ATOMIC_RELAXED);
+    if (!word) return ULTRA_OK;
+    static const char *const what[] = {"?", "an update wave waiting for rows from the walkers", "an update wave waiting for the other update waves",
+                                       "a walker waiting for the chain consumer", "an update wave waiting for the chain consumer",
+                                       "a walker waiting for a free row of the hand-off ring", "an update wave waiting for its tile"};
+    const uint32_t code = word >> 24;
+    set_error(std::string("rspmm_order_kernel: a bounded wait of the hand-off between walkers and update waves gave up (") +
+              (code < 7 ? what[code] : "?") + ", workgroup " + std::to_string(word & 0xffffffu) +
+              "): the launch was ended instead of hanging; its output is incomplete");
+    return ULTRA_ERR_HIP;
+}
+
 static int hip_fail(hipError_t e, const char *what) {
     set_error(std::string(what) + ": " + hipGetErrorString(e));
     return ULTRA_ERR_HIP;
@@ -259,6 +289,7 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
                         const int64_t *bnd_rows = nullptr, const OrderParams::Update *upd = nullptr) {
     if (!p) return invalid("plan is NULL");
     (void)hipGetLastError();   // drop any stale error left by other users of the HIP runtime
+    if (int derr = take_device_error()) return derr;   // (an earlier launch ended on a bounded wait: say so now)
     if (sum < 0 || sum > 2 || mul < 0 || mul > 3) return invalid("unknown sum/mul code");
     if (dtype != ULTRA_F32 && dtype != ULTRA_F64) return invalid("dtype must be ULTRA_F32 or ULTRA_F64");
     if (!out || !out->ptr) return invalid("output is NULL");
@@ -391,6 +422,7 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
             op.keep_mode = fp.keep_mode;
             op.x_row_bytes = fp.x_row_bytes, op.rel_row_bytes = fp.rel_row_bytes;
             op.trace = g_order_trace;
+            op.err = device_error_word();
             // The group streams (assembly walk) serve the inference configuration: fp32, unit weights, relation slice in
             // LDS, mul / add messages, whole 64-element spans, no boundary or a point boundary, source and output rows of
             // one stride (a marker's gather offset is its store offset), every output row also a source row.
@@ -421,7 +453,10 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
                 // lane in another row -- then compete with the gathers for the CU's texture-address path, which bounds the
                 // walk: 94.6 us per layer against the tail form's 94.0 at FB15k237 bs 8, 371 against 374 at CoDEx-L.
                 Schedule *sched12 = nullptr;
-                if (g_tuning.reserved[2] == 2 && ORDER_WAVES == 16 && upd->out_stride_row * (int64_t)sizeof(float) == (int64_t)op.x_row_bytes) {
+                // (both forms beside the walk read the twelve-walker schedules, whose records are pre-multiplied by the 256-byte
+                // pitch of whole-span rows: plan.hpp ULTRA_STREAM_PRESHIFT)
+                const bool pitch_ok = !ULTRA_STREAM_PRESHIFT || op.x_row_bytes == 256u;
+                if (g_tuning.reserved[2] == 2 && pitch_ok && ORDER_WAVES == 16 && upd->out_stride_row * (int64_t)sizeof(float) == (int64_t)op.x_row_bytes) {
                     if ((rc = get_schedule(p, op.nparts, &sched12, ORDER_WALKERS))) return rc;
                     const size_t image = std::max(ring_bytes, (size_t)UPDATE_LDS_FLOATS * sizeof(float));
                     const size_t need = rel_bytes + image + UPDATE_CTL_QUEUE_OFF + (size_t)sched12->max_rows * 4 + 64;
@@ -444,12 +479,13 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
                 // (ultra_tuning.reserved[2] == 3) always, by default (0) from 10 steps a row up; 1 asks for the tail form.
                 const bool walk_heavy = (double)(p->num_edge + p->num_out) >= 10.0 * (double)p->num_out;
                 const bool want3 = g_tuning.reserved[2] == 3 || (g_tuning.reserved[2] == 0 && walk_heavy);
-                if (want3 && ORDER_WAVES == 16 && upd->out_stride_row * (int64_t)sizeof(float) == (int64_t)op.x_row_bytes) {
+                if (want3 && pitch_ok && ORDER_WAVES == 16 && upd->out_stride_row * (int64_t)sizeof(float) == (int64_t)op.x_row_bytes) {
                     if ((rc = get_schedule(p, op.nparts, &sched12, ORDER_WALKERS))) return rc;
                     const size_t overlay = std::max(ring_bytes, (size_t)UPD2_OVERLAY_BYTES);
                     const size_t need = rel_bytes + overlay + UPD2_CTL_BYTES;
                     if (need <= di.lds_optin && sched12->max_chain_rows <= UPD2_MAX_CHAIN_ROWS) {
                         op.upd.mode = 3;
+                        op.max_stream_steps = sched12->max_stream_steps;
                         op.upd.ctl_off = (uint32_t)(rel_bytes + overlay);
                         op.srec = sched12->d_srec;
                         op.sdesc = reinterpret_cast<const int2 *>(sched12->d_sdesc);
@@ -977,7 +1013,7 @@ int32_t ultra_rspmm_forward_update(ultra_plan *plan, int32_t sum, int32_t mul, c
     if ((point_rows_dev == nullptr) != (point_values == nullptr)) return invalid("ultra_rspmm_forward_update: half a point boundary");
     if (!weight || !output || !output->ptr || !aggregate || !aggregate->ptr || ((flags & CONV_LN) && (!ln_weight || !ln_bias)))
         return invalid("ultra_rspmm_forward_update: NULL operand");
-    if (flags & ~(CONV_LN | CONV_RELU | CONV_RESIDUAL | CONV_DBG_NO_MATRIX | CONV_DBG_NO_UPDATE))
+    if (flags & ~(CONV_LN | CONV_RELU | CONV_RESIDUAL | CONV_DBG_NO_MATRIX | CONV_DBG_NO_UPDATE | CONV_DBG_LOSE_ARRIVAL))
         return invalid("ultra_rspmm_forward_update: unknown flag");
     if (!plan) return invalid("plan is NULL");
     if (output->row_len != 64 || output->n_outer != aggregate->n_outer || output->n_row != aggregate->n_row ||
@@ -1172,10 +1208,16 @@ int32_t ultra_plan_schedule_export(ultra_plan *plan, int32_t nparts, int32_t whi
     if (dst) {
         if (capacity < n) rc = invalid("ultra_plan_schedule_export: destination too small");
         else if (n) std::memcpy(dst, src, (size_t)n * sizeof(int32_t));
+        // (the export shows LOGICAL records -- (col, type), markers (row, num_relation) -- whatever the device format of this
+        // schedule's streams is: plan.hpp ULTRA_STREAM_PRESHIFT)
+        if (rc == ULTRA_OK && which == 5 && s->rec_shift)
+            for (int64_t i = 0; i < n; ++i) dst[i] = (int32_t)((uint32_t)dst[i] >> s->rec_shift);
     }
     delete s;
     return rc;
 }
+
+int32_t ultra_device_error(void) { return take_device_error(); }
 
 int32_t ultra_set_tuning(const ultra_tuning *t) {
     if (!t) {

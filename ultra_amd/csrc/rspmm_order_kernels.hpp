@@ -37,11 +37,22 @@
 #endif
 #include "update_tile.hpp"
 
+static_assert(ULTRA_STREAM_PRESHIFT_GEN == ULTRA_STREAM_PRESHIFT,
+              "the generated walk and plan.cpp must agree on the record format of the twelve-walker schedules (plan.hpp)");
+
 #pragma clang fp contract(off)
 
 namespace ultra {
 
 constexpr int ORDER_THREADS = 64 * ORDER_WAVES;
+// bounded spins of the hand-off protocols (OrderParams::err): polls before a wait gives up, and who gave up
+constexpr uint32_t SPIN_CAP = 1u << 20;      // (a poll is an LDS round trip, 100+ cycles, mostly with an s_sleep: >= 0.05 s)
+enum { ORDER_SPIN_LOOK = 1,        // an update wave waiting for a block of rows from the walkers
+       ORDER_SPIN_MEET = 2,        // an update wave waiting for the other update waves at a meeting point
+       ORDER_SPIN_CHAIN_WALKER = 3, // a walker waiting for the chain consumer to leave the ring
+       ORDER_SPIN_CHAIN_UPDATER = 4, // an update wave waiting for the same
+       ORDER_SPIN_PARK = 5,        // a walker waiting for a free row of the hand-off ring (stream_park in the generator)
+       ORDER_SPIN_QUEUE = 6 };     // form 2: an update wave waiting for its tile / the weight image
 // UPDATE == 2 (the layer update runs BESIDE the walk): waves [0, ORDER_WALKERS) walk the streams, the last ORDER_UPDATERS
 // waves -- one per SIMD -- multiply the rows the walkers hand over.  Hand-off block in LDS (the generator's HANDOFF_*
 // constants are the same numbers): word 0 queue tail, 1 walkers done, 2 weight image ready, 3 chain done, then
@@ -86,6 +97,13 @@ struct OrderParams {
     int32_t smod, nparts;
     uint32_t x_row_bytes, rel_row_bytes;
     long long *trace;         // measurement hook (NULL in production): per workgroup {start, chains done, end} shader clocks
+    // Every wait of the hand-off protocols (forms 2 / 3: LDS words polled by one wave until another wave writes them) is BOUNDED:
+    // a wave that has polled SPIN_CAP times (+ an allowance that grows with the work the other side may legitimately still have)
+    // stores (code << 24 | workgroup) here -- a word of pinned host memory, rspmm_api.hip device_error_word() -- lets the other
+    // side through and carries on / ends, so a protocol error (or a broken schedule) is a failed call with a message
+    // (ultra_device_error, checked at the next entry), not a hung GPU.  Codes: ORDER_SPIN_*.
+    uint32_t *err;
+    int32_t max_stream_steps; // longest group stream of the schedule in steps (allowance of the update waves' wait for rows)
     // UPDATE instances: the layer update (update_tile.hpp) of the rows this workgroup aggregated, applied after its walk
     struct Update {
         const float *weight, *bias, *ln_w, *ln_b;   // Linear(128 -> 64) [+ LayerNorm(64)]
@@ -428,6 +446,11 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
     volatile uint32_t *ctl = reinterpret_cast<volatile uint32_t *>(smem + (UPDATE >= 2 ? p.upd.ctl_off : 0));
     const T fill = (SUM != 0 && p.bnd_fill_on) ? (T)p.bnd_fill : nary_zero<T, SUM>();   // (what a non-boundary row meets under min / max)
 
+    // a bounded spin gave up (OrderParams::err): one store to the host's error word, system scope
+    const auto report_spin = [&](const int code) {
+        if (p.err) __hip_atomic_store(p.err, ((uint32_t)code << 24) | (blockIdx.x & 0xffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    (void)report_spin;
     if (p.trace && tid == 0) p.trace[3 * blockIdx.x + 0] = clock64();
     for (int span = blockIdx.x % p.smod; span < p.n_span; span += p.smod) {
         const int outer = span / p.spans_per_outer;
@@ -776,7 +799,16 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                 // ---- group streams: one continuous walk per 16-lane group (rspmm_order_asm.hpp) ----
                 if constexpr (UPDATE == 3) {   // (the tiles the walk parks its rows in take the ring's place)
                     if (c1 > c0) {
-                        while (ctl[3] == 0) __builtin_amdgcn_s_sleep(2);
+                        // (bounded: a chunk of the chain takes ~ 700 cycles, a poll >= 200 -- 16 polls a chunk are a wide allowance)
+                        const uint32_t cap = SPIN_CAP + 16u * (uint32_t)(c1 - c0);
+                        uint32_t polls = 0;
+                        while (ctl[3] == 0) {
+                            if (++polls >= cap) {
+                                if (lane == 0) report_spin(ORDER_SPIN_CHAIN_WALKER);
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
                     }
                 }
                 const int2 sd = p.sdesc[(part * nwave + wave) * 4 + grp];
@@ -794,16 +826,31 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                 }
                 // (min / max: a flushed row other than the boundary row meets `bz`: the fill, or the value that changes nothing)
                 const float bz = (SUM != 0 && p.bnd_fill_on) ? p.bnd_fill : (SUM == 1 ? __builtin_inff() : -__builtin_inff());
+                // (ULTRA_STREAM_DIET, rspmm_order_asm.hpp: the walk tests "is this lane's step inside its stream" as step < lim with the
+                // step in an SGPR, lim = len - lane % 8; a marker record's type is num_rel -- times 256 in the pre-shifted records of
+                // the twelve-walker schedules, which the hand-off forms read)
+                constexpr int POST = UPDATE >= 2 ? UPDATE - 1 : 0;
+#if ULTRA_STREAM_DIET
+                const int l8_arg = len - (l16 & 7);
+                const uint32_t rmk = (uint32_t)p.num_rel << ((POST != 0 && ULTRA_STREAM_PRESHIFT_GEN) ? 8 : 0);
+#else
+                const int l8_arg = l16 & 7;
+                const uint32_t rmk = 0;
+#endif
                 if (ns > 0)
-                    order_stream_asm<SUM, MUL, (UPDATE >= 2 ? UPDATE - 1 : 0)>(len, (uint32_t)(sd.x + (l16 & 7)) * 8u, l16 & 7, lane_bytes, lds_addr(lds_rel_lane),
-                                                            lds_addr(lds_rel_lane) + (uint32_t)p.num_rel * 256u, bndoff, bv, bz, ns, nf, xbase,
-                                                            reinterpret_cast<const char *>(p.srec),
-                                                            reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.out) + outer * p.out_stride_outer),
-                                                            p.x_row_bytes, lds_addr(const_cast<uint32_t *>(ctl)), lds_addr(ring));
+                    order_stream_asm<SUM, MUL, POST>(len, (uint32_t)(sd.x + (l16 & 7)) * 8u, l8_arg, lane_bytes, lds_addr(lds_rel_lane),
+                                                     lds_addr(lds_rel_lane) + (uint32_t)p.num_rel * 256u, bndoff, bv, bz, ns, nf, xbase,
+                                                     reinterpret_cast<const char *>(p.srec),
+                                                     reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.out) + outer * p.out_stride_outer),
+                                                     p.x_row_bytes, lds_addr(const_cast<uint32_t *>(ctl)), lds_addr(ring), rmk);
                 if constexpr (UPDATE >= 2) {
                     // this wave has posted all its rows (the walk ends on vmcnt(0) + its last posts; LDS operations of a
                     // wave execute in order)
                     asm volatile("" ::: "memory");
+                    if constexpr (UPDATE == 3) {
+                        // (the generated walk cannot reach OrderParams: a park wait that gave up left its code in the control block)
+                        if (lane == 0 && ctl[UPD2_CTL_ERR] != 0) report_spin(ORDER_SPIN_PARK);
+                    }
                     if (lane == 0) __hip_atomic_fetch_add(const_cast<uint32_t *>(ctl) + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
@@ -835,45 +882,63 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
 #pragma unroll
                     for (int r = 0; r < 4; ++r) biasv[r] = p.upd.bias ? p.upd.bias[f0 + r] : 0.f;
                     if (c1 > c0) {
-                        while (lctl[3] == 0) __builtin_amdgcn_s_sleep(4);   // the chain consumer still reads the ring
+                        const uint32_t cap = SPIN_CAP + 16u * (uint32_t)(c1 - c0);
+                        uint32_t polls = 0;
+                        while (lctl[3] == 0) {   // the chain consumer still reads the ring
+                            if (++polls >= cap) {
+                                if (lane == 0) report_spin(ORDER_SPIN_CHAIN_UPDATER);
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(4);
+                        }
                     }
                     const char *aggbase = reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.out) + outer * p.out_stride_outer);
                     char *ubase = reinterpret_cast<char *>(p.upd.out + outer * p.upd.out_stride_outer);
                     uint32_t epoch = 0;
-#if ULTRA_SPIN_GUARD   /* debugging build: a spin that does not end reports where it stood (trace[24 grid + 16 workgroup + 4 u ..]) and lets go */
+                    // Bounded spins (OrderParams::err).  A wait that has polled `cap` times reports, lets the walkers through (they
+                    // never wait for a free ring row again) and ends this wave's work: the launch terminates with an error word
+                    // instead of hanging the GPU -- results of the workgroup are then incomplete, and the host says so.
+                    // ULTRA_SPIN_GUARD builds also leave the control words in the trace buffer (tools/spin_guard_probe.py).
                     int t_now = 0;
                     bool tripped = false;
-                    const auto spin_guard = [&](uint32_t &n, const int code) {
-                        if (++n < (1u << 20)) return false;
-                        if (p.trace && lane == 0 && !tripped) {
-                            long long *dst = p.trace + 24 * gridDim.x + 16 * blockIdx.x + 4 * u;
-                            dst[0] = ((long long)code << 48) | ((long long)t_now << 32) | epoch;
-                            dst[1] = ((long long)lctl[0] << 32) | lctl[1];
-                            dst[2] = ((long long)lctl[2] << 32) | lctl[UPD2_CTL_CONSUMED];
-                            dst[3] = ((long long)lctl[UPD2_CTL_POSTED] << 32) | lctl[UPD2_CTL_POSTED + 1];
+                    const uint32_t look_cap = SPIN_CAP + 16u * (uint32_t)p.max_stream_steps;   // (a walker may be inside one long row)
+                    const auto spin_guard = [&](uint32_t &n, const uint32_t cap, const int code) {
+                        if (++n < cap) return false;
+                        if (lane == 0 && !tripped) {
+                            report_spin(code);
+#if ULTRA_SPIN_GUARD
+                            if (p.trace) {
+                                long long *dst = p.trace + 24 * gridDim.x + 16 * blockIdx.x + 4 * u;
+                                dst[0] = ((long long)code << 48) | ((long long)t_now << 32) | epoch;
+                                dst[1] = ((long long)lctl[0] << 32) | lctl[1];
+                                dst[2] = ((long long)lctl[2] << 32) | lctl[UPD2_CTL_CONSUMED];
+                                dst[3] = ((long long)lctl[UPD2_CTL_POSTED] << 32) | lctl[UPD2_CTL_POSTED + 1];
+                            }
+#endif
                         }
                         tripped = true;
                         lctl[UPD2_CTL_CONSUMED] = 0x3fffffffu;     // the walkers are let through
                         return true;
                     };
-#define ULTRA_SPIN(n, code) if (spin_guard(n, code)) break
-#else
-#define ULTRA_SPIN(n, code)
-#endif
+                    (void)t_now;
+#define ULTRA_SPIN(n, cap, code) if (spin_guard(n, cap, code)) break
                     // The four update waves meet in two halves (s_barrier would count the walkers too): `arrive` costs nothing -- LDS
                     // operations of a wave execute in order, so everything this wave did to LDS before is done when its arrival shows --
                     // and between arriving and `meet` the wave does work that does not depend on the others.  One counter serves every
                     // meeting: nobody arrives at meeting m + 1 before everybody has arrived at m.
+                    // (CONV_DBG_LOSE_ARRIVAL, tests only: update wave 3 never arrives anywhere -- the protocol error the bounded
+                    // spins exist for; the launch must end with an error word, not hang)
+                    const bool lose_arrival = (p.upd.flags & CONV_DBG_LOSE_ARRIVAL) && u == 3;
                     const auto arrive = [&]() {
                         asm volatile("" ::: "memory");
                         epoch += (uint32_t)ORDER_UPDATERS;
-                        if (lane == 0) __hip_atomic_fetch_add((lds_u *)lctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (lane == 0 && !lose_arrival)
+                            __hip_atomic_fetch_add((lds_u *)lctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     };
                     const auto meet = [&]() {
                         uint32_t spins = 0;
-                        (void)spins;
-                        while (lctl[2] < epoch) {
-                            ULTRA_SPIN(spins, 2);
+                        while (!tripped && lctl[2] < epoch) {
+                            ULTRA_SPIN(spins, SPIN_CAP, ORDER_SPIN_MEET);
                         }
                         asm volatile("" ::: "memory");
                     };
@@ -909,7 +974,6 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                         Block bl;
                         bl.b0 = b0;
                         uint32_t spins = 0;
-                        (void)spins;
                         for (;;) {
                             // (`walked` is read FIRST and the row lists last: with every walker done the counts are final, and with
                             // a generation's count full its list is)
@@ -926,7 +990,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                             }
                             bl.n0 = bl.n1 = -1;
                             if (!wait) break;
-                            ULTRA_SPIN(spins, 1);
+                            ULTRA_SPIN(spins, look_cap, ORDER_SPIN_LOOK);
                             __builtin_amdgcn_s_sleep(1);
                         }
                         bl.n0 = rfl(bl.n0), bl.n1 = rfl(bl.n1);
@@ -946,10 +1010,8 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                     bool ahead = false;         // `next` was seen complete while the previous block's pre-norm rows were being written
                     int next_n0 = 0, next_n1 = 0, next_b0 = 0;
                     for (int t = 0;; ++t) {
-#if ULTRA_SPIN_GUARD
                         t_now = t;
-                        if (tripped) break;
-#endif
+                        if (tripped) break;     // (a wait of this wave gave up: see spin_guard)
                         Block cur;
                         if (ahead) {
                             // (only what is uniform was kept; the rows' offsets are needed at the very end: read again, never waited for)

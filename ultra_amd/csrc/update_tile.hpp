@@ -22,7 +22,8 @@ enum {
     CONV_RELU = 2,
     CONV_RESIDUAL = 4,
     CONV_DBG_NO_MATRIX = 256,  /* measurement: skip the matrix chain */
-    CONV_DBG_NO_UPDATE = 512   /* measurement (update beside the walk): the update waves only drain their queue */
+    CONV_DBG_NO_UPDATE = 512,  /* measurement (update beside the walk): the update waves only drain their queue */
+    CONV_DBG_LOSE_ARRIVAL = 1024 /* tests (form 3): one update wave never arrives at a meeting -- the bounded spins must end the launch */
 };
 
 // feature owned by accumulator register r of feature tile m in lane half h (32x32 C/D layout)
@@ -84,7 +85,8 @@ constexpr int UPD2_MAX_CHAIN_ROWS = 64;          // chain rows of a workgroup th
 constexpr int UPD2_OVERLAY_BYTES = (UPD2_NT + 4) * UPD2_TILE_FLOATS * 4;
 // control block (behind ring / overlay; bytes): 0 tail, 4 walkers done, 8 update-wave barrier (arrivals), 12 chain done, 16
 // generations consumed, 20 chain rows listed, 32 posted[NT], 64 rowid[16 NT], 320 chain row offsets[64], 576 chain tile
-constexpr int UPD2_CTL_CONSUMED = 4, UPD2_CTL_NCHAIN = 5, UPD2_CTL_NEXT = 6 /* and 7 */, UPD2_CTL_POSTED = 8, UPD2_CTL_ROWID = 16,
+constexpr int UPD2_CTL_CONSUMED = 4, UPD2_CTL_NCHAIN = 5, UPD2_CTL_ERR = 7 /* a park wait of the generated walk gave up (HANDOFF2_ERR_OFF) */,
+              UPD2_CTL_POSTED = 8, UPD2_CTL_ROWID = 16,
               UPD2_CTL_CROW = 80;   // (word offsets)
 constexpr int UPD2_CTL_CTILE_BYTES = 576, UPD2_CTL_BYTES = UPD2_CTL_CTILE_BYTES + UPD2_TILE_FLOATS * 4;
 

@@ -144,8 +144,21 @@ def _local_rows(model, test_data, filt, mine, batch_size, use_graph, in_flight, 
                 steps = [GraphedEvalStep(model, test_data, batch_size, t_index, h_index)]
             n_slot = len(steps)
             cur = torch.cuda.current_stream(mine.device)
-            from .graph import slot_stream
-            streams = [slot_stream(mine.device) for _ in steps] if n_slot > 1 else [cur]
+            streams = [cur]
+            if n_slot > 1:
+                # (which pair of streams interleaves is decided by a short trial: graph.pick_slot_streams)
+                from .graph import pick_slot_streams
+
+                def trial(cand, reps=6):
+                    import time
+                    torch.cuda.synchronize(mine.device)
+                    t0 = time.perf_counter()
+                    for i in range(reps):
+                        with torch.cuda.stream(cand[i % n_slot]):
+                            steps[i % n_slot](mine[:batch_size], t_ptr[:batch_size + 1], h_ptr[:batch_size + 1])
+                    torch.cuda.synchronize(mine.device)
+                    return (time.perf_counter() - t0) / reps
+                streams, _report = pick_slot_streams(mine.device, n_slot, trial)
             out = torch.empty(n_full // batch_size, 2 * batch_size, 3, dtype=torch.long, device=mine.device)
             for s in streams:
                 if s is not cur:

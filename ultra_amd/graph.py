@@ -110,19 +110,40 @@ class GraphedForward(object):
         return self.static_out
 
 
-def slot_stream(device):
-    """A stream for one pipeline slot (PipelinedForward, evaluate()'s two captured steps).  The HIP runtime maps a process's
-    streams onto a small pool of hardware queues PER PRIORITY LEVEL (GPU_MAX_HW_QUEUES of them, round-robin in creation order), so
-    which queue a normal-priority stream lands on depends on how many streams the process made before it -- torch's side
-    streams, the capture streams, RCCL's: a launcher's rank ran the same step 6 % slower than the plain process until its queue
-    count was tuned by hand.  The slots' streams are therefore created at HIGH priority: they are the only
-    streams of that level in the process, so the two of them own two distinct hardware queues whatever else the process did
-    before -- by construction, on the plain and on the launcher's path alike.  ULTRA_SLOT_STREAM_PRIORITY=0 restores the
-    normal-priority streams (measurements)."""
-    import os
-    prio = int(os.environ.get("ULTRA_SLOT_STREAM_PRIORITY", "-1"))
+def slot_stream(device, priority=0):
+    """A stream for one pipeline slot (PipelinedForward, evaluate()'s two captured steps)."""
     with torch.cuda.device(device):
-        return torch.cuda.Stream(priority=prio)
+        return torch.cuda.Stream(priority=priority)
+
+
+def pick_slot_streams(device, n, trial):
+    """The streams the pipeline slots run on, chosen by MEASUREMENT.  The HIP runtime maps a process's streams onto a small pool
+    of hardware queues per priority level (GPU_MAX_HW_QUEUES of them, in creation order), and how two slots' launches interleave
+    depends on which queues their streams land on -- i.e. on how many streams the process made before (torch's side streams, the
+    capture streams, RCCL's).  Measured on MI355X, ms per step with two captured forwards in flight (profiles/r5_slot_streams.txt):
+
+        process                         normal-priority pair      high-priority pair
+        plain bench.py                  0.573 / 0.562 - 0.567     0.573 / 0.567 - 0.573
+        one rank under torchrun (RCCL)  0.616 / 0.587 - 0.605     0.584 / 0.573 - 0.576     (round 4's remedy: GPU_MAX_HW_QUEUES=3)
+        tools/step_probe.py             0.566                     0.709
+
+    Neither level is right everywhere, and nothing the process can ask the runtime tells it which one is.  So the pipeline times a
+    few steps on each candidate pair when it is built (`trial(streams)` -> seconds; ~ 20 ms in all) and keeps the faster pair,
+    normal priority on a tie (within 1 %): the launcher's rank and the plain process both end up on a pair that interleaves, by
+    construction rather than by an environment variable.  ULTRA_SLOT_STREAM_PRIORITY=0 / -1 pins a level (measurements).
+    Returns (streams, report)."""
+    import os
+    forced = os.environ.get("ULTRA_SLOT_STREAM_PRIORITY")
+    if forced not in (None, "", "auto"):
+        prio = int(forced)
+        return [slot_stream(device, prio) for _ in range(n)], {"chosen": "high" if prio < 0 else "normal", "forced": True}
+    cands = [("normal", [slot_stream(device, 0) for _ in range(n)]), ("high", [slot_stream(device, -1) for _ in range(n)])]
+    times = {}
+    for name, streams in cands:
+        trial(streams)                                   # (first use of a stream: queue creation, not timed)
+        times[name] = min(trial(streams) for _ in range(2))
+    chosen = "high" if times["high"] < 0.99 * times["normal"] else "normal"
+    return dict(cands)[chosen], {"chosen": chosen, "forced": False, "trial_ms": {k: round(1e3 * v, 4) for k, v in times.items()}}
 
 
 def shared_launch_grid(device):
@@ -172,12 +193,26 @@ class PipelinedForward(object):
                 raise RuntimeError("PipelinedForward: this model's forward uses a re-associating plan (scratch buffers that "
                                    "concurrent forwards would share); run its batches one at a time")
         dev = example_batch.device
-        if dev.type == "cuda":
-            self.streams = [slot_stream(dev) for _ in self.slots]
-        else:
-            self.streams = [None for _ in self.slots]
         self.device = dev
         self.calls = 0
+        self.stream_report = None
+        if dev.type == "cuda" and len(self.slots) > 1:
+            def trial(streams, steps=12):
+                import time
+                self.streams = streams
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    self(example_batch)
+                self.join()
+                torch.cuda.synchronize(dev)
+                return (time.perf_counter() - t0) / steps
+            self.streams, self.stream_report = pick_slot_streams(dev, len(self.slots), trial)
+            self.calls = 0
+        elif dev.type == "cuda":
+            self.streams = [slot_stream(dev)]
+        else:
+            self.streams = [None for _ in self.slots]
 
     def __call__(self, batch, post=None):
         """Enqueue the forward of `batch` on the next slot's stream; post(score), if given, runs on that stream right behind

@@ -738,6 +738,12 @@ class tuning_scope(object):
         return False
 
 
+def check_device_error():
+    """Raise if a launch before this point ended on a bounded wait of the one-launch layer's hand-off (ultra_device_error,
+    include/ultra_rspmm.h): call after synchronising.  The same word is looked at on entry of every rspmm forward."""
+    check(lib.ultra_device_error())
+
+
 def set_tuning(threads=0, grid=0, rel_lds=-1, x_lds=-1, unroll=0, general_walk=0, unit_walk=0, update_form=0):
     """Kernel-launch tuning knobs (measurement / tests).  set_tuning() restores the defaults.
     general_walk: reference-order plans on the general walk kernel; unit_walk: the reference-order kernels walk units of
