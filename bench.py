@@ -725,7 +725,8 @@ def main():
         try:
             example = tasks.all_negative(data, batch_for(0))[0]
             if args.in_flight > 1 and rspmm._plan_defaults["exact_order"]:
-                piped = PipelinedForward(model, data, example, depth=args.in_flight)
+                piped = PipelinedForward(model, data, example, depth=args.in_flight,
+                                         trial_post=udist.all_gather_scores if (world > 1 or launched) else None)
                 if not slot_report:
                     slot_report.update(piped.stream_report or {})
                 return lambda data_, batch_, post=None: piped(batch_, post=post)

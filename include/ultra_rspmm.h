@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_ABI_VERSION 5
+#define ULTRA_ABI_VERSION 6
 
 typedef enum {
     ULTRA_OK = 0,

@@ -49,12 +49,12 @@ def _operands(case, batch, dev, seed):
     return rel, x, rows, vals, weight, bias, ln_w, ln_b
 
 
-FORMS = {"library": 0, "tail": 1, "beside": 2, "lds": 3}     # rspmm.set_tuning(update_form=...): the library's choice (3 from 10 steps a row up, else 1) / in the kernel's tail / beside the walk (by reference / through LDS)
+FORMS = {"library": 0, "tail": 1, "lds": 3}     # rspmm.set_tuning(update_form=...): the library's choice (3 from 10 steps a row up, else 1) / in the kernel's tail / beside the walk, rows through LDS  (2 -- rows by reference -- was removed in round 5)
 
 
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("mul", ["mul", "add"])
-@pytest.mark.parametrize("form", ["library", "tail", "beside", "lds"])
+@pytest.mark.parametrize("form", ["library", "tail", "lds"])
 @pytest.mark.parametrize("batch,flags,point", [(8, 7, True), (3, 7, False), (1, 3, True), (2, 4, True), (5, 0, True), (16, 6, True)])
 def test_one_launch_equals_the_two_launches(dev, case, mul, batch, flags, point, form):
     from ultra_amd import dense, rspmm
@@ -76,7 +76,7 @@ def test_one_launch_equals_the_two_launches(dev, case, mul, batch, flags, point,
 
 
 @pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[4], CASES[5]])
-@pytest.mark.parametrize("form", ["tail", "beside", "lds"])
+@pytest.mark.parametrize("form", ["tail", "lds"])
 @pytest.mark.parametrize("sum", ["max", "min"])
 def test_max_aggregate_layer_in_one_launch(dev, case, form, sum):
     """BASELINE config 3 (max aggregate): the point boundary under max -- every other row meets 0, layers.py:206-207 -- and the
@@ -99,7 +99,7 @@ def test_max_aggregate_layer_in_one_launch(dev, case, form, sum):
 
 
 @pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[3], CASES[5]])
-@pytest.mark.parametrize("form", ["tail", "beside", "lds"])
+@pytest.mark.parametrize("form", ["tail", "lds"])
 @pytest.mark.parametrize("sum", ["add", "max"])
 def test_one_launch_layer_against_the_oracle_chain(dev, case, form, sum):
     """Not through the two launches: the C oracle's rspmm (rspmm.cpp:50-75) on the host, the boundary as the reference
@@ -141,7 +141,7 @@ def test_beside_the_walk_repeats_its_bits(dev):
     rel, x, rows, vals, weight, bias, ln_w, ln_b = _operands(case, 8, dev, 77)
     agg = plan.forward(rel, x, sum="add", mul="mul", point=(rows, vals))
     want = dense._conv_update_forward(x, agg, weight, bias, ln_w, ln_b, 1e-5, 7)
-    rspmm.set_tuning(update_form=2)
+    rspmm.set_tuning(update_form=3)
     assert plan.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7, point=(rows, vals)) is not None
     outs = [plan.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7, point=(rows, vals)) for _ in range(200)]
     torch.cuda.synchronize()
@@ -149,7 +149,7 @@ def test_beside_the_walk_repeats_its_bits(dev):
 
 
 @pytest.mark.parametrize("grid", [8, 64, 256])
-@pytest.mark.parametrize("form", ["tail", "beside", "lds"])
+@pytest.mark.parametrize("form", ["tail", "lds"])
 def test_any_number_of_workgroups_per_span(dev, grid, form):
     from ultra_amd import dense, rspmm
     from ultra_amd.rspmm import Plan
@@ -177,6 +177,9 @@ def test_calls_the_launch_does_not_serve_are_declined_not_approximated(dev):
     assert exact.forward_update(torch.randn(2, case["num_relation"], 128, device=dev), wide, weight, bias, ln_w, ln_b, 1e-5, 7) is None
     strided = torch.randn(2, case["num_node"], 128, device=dev)[:, :, :64]          # row stride 128: not the aggregate's stride
     assert exact.forward_update(rel, strided, weight, bias, ln_w, ln_b, 1e-5, 7, point=(rows, vals)) is None
+    from ultra_amd import rspmm
+    rspmm.set_tuning(update_form=2)      # (round 4's by-reference form: removed in ABI 6 -- declined, never silently another form)
+    assert exact.forward_update(rel, x, weight, bias, ln_w, ln_b, 1e-5, 7, point=(rows, vals)) is None
 
 
 @pytest.mark.parametrize("message_func", ["distmult", "transe"])

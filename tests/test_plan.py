@@ -446,13 +446,12 @@ def test_generated_assembly_header_is_in_sync_with_its_generator(tmp_path, monke
     committed = open(os.path.join(root, "ultra_amd", "csrc", "rspmm_order_asm.hpp")).read()
     assert fresh == committed
     # every path out of a statement drains the vector-memory queue, and the statements declare what they clobber
-    # 3 x 3 sums x 2 messages (stream walk: plain, with the hand-off of finished rows' offsets to the update waves, with the rows
-    # themselves parked in LDS for them) + 2 messages (producers) + 2 x 2 messages (producers of the measurement builds: LDS-word
-    # hand-off)
-    assert fresh.count("asm volatile(") == 24 and fresh.count('"memory"') == 24
+    # 2 x 3 sums x 2 messages (stream walk: plain, and with the finished rows parked in LDS for the update waves) + 2 messages
+    # (chain producers)
+    assert fresh.count("asm volatile(") == 14 and fresh.count('"memory"') == 14
     for block in fresh.split("asm volatile(")[1:]:
         assert "s_waitcnt vmcnt(0)" in block.split(");")[0]
-    # ... and the relation-graph layer's chain (a measurement build: csrc/dense_order_asm.hpp, tools/gen_dense_order_asm.py)
+    # ... and the generator of the relation-graph layer's measurement build still runs (its header is not part of the tree)
     for k in ("ULTRA_GEN_DOL_NS", "ULTRA_GEN_DOL_TOUCH"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("ULTRA_GEN_DENSE_OUT", str(tmp_path / "dense_asm.hpp"))
@@ -460,4 +459,4 @@ def test_generated_assembly_header_is_in_sync_with_its_generator(tmp_path, monke
     gen2 = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen2)
     gen2.main()
-    assert (tmp_path / "dense_asm.hpp").read_text() == open(os.path.join(root, "ultra_amd", "csrc", "dense_order_asm.hpp")).read()
+    assert "v_mfma_f32_16x16x4" in (tmp_path / "dense_asm.hpp").read_text()

@@ -1,5 +1,6 @@
 """The entity layer in one launch, two forms (ultra_rspmm_forward_update): the update in the kernel's TAIL (update_form 1) vs
-BESIDE the walk (update_form 2: twelve waves walk, four multiply the rows handed over through LDS).  Prints times between
+BESIDE the walk (update_form 3: twelve waves walk, four multiply the rows handed over through an LDS ring; round 4's form 2 --
+rows by reference -- was removed in round 5 and prints as nan / "not served").  Prints times between
 HIP events (back-to-back launches and inside a hipGraph of 20 launches), bit-equality with the two launches, and the
 per-wave end-of-work clocks of one traced launch (walkers 0..11, update waves 12..15).
 
@@ -80,7 +81,7 @@ def graphed(fn, n=20, reps=10):
 
 
 want = two()
-served = one(2) is not None
+served = False      # (form 2: removed)
 served3 = one(3) is not None
 nan = float("nan")
 print("%s bs %d %s: tail == two launches %s | beside == two launches %s | beside through LDS == two launches %s" %
@@ -100,8 +101,8 @@ for form, ok in ((2, served), (3, served3)):
         torch.cuda.synchronize()
         print("form %d, 100 launches all equal to the two launches: %s" % (form, all(torch.equal(o, want) for o in outs)))
 
-if served:
-    for form in (1, 2) + ((3,) if served3 else ()):
+if served3:
+    for form in (1, 3):
         trace = torch.zeros(grid * 32, dtype=torch.int64, device=dev)
         one(form)
         torch.cuda.synchronize()

@@ -1,7 +1,9 @@
-"""Generator of ultra_amd/csrc/dense_order_asm.hpp: the matrix-instruction chain of the relation-graph layer
-(dense_order_layer.hip, phase 1) as gfx950 assembly.
+"""Generator of the MEASUREMENT build of the relation-graph layer's chain (dense_order_layer.hip, phase 1, -DULTRA_DOL_ASM=1) as
+gfx950 assembly.  Measured in round 4: bit-exact and not faster than the C++ loop (21.7 vs 21.5 us per layer), so the header is
+no longer part of the source tree; it is generated where a measurement build wants it:
 
-    python tools/gen_dense_order_asm.py
+    python tools/gen_dense_order_asm.py          # writes ultra_amd/lib/variants/dense_order_asm.hpp (git-ignored)
+    python tools/build_variant.py dolasm -DULTRA_DOL_ASM=1 '-DULTRA_DOL_ASM_HEADER="<that path>"'
 
 The chain is one dependent v_mfma_f32_16x16x4_f32 per source column (474 at FB15k237): the wave has nothing else to hide a
 memory round trip behind, so its operands -- per 16-column stage one 16-byte adjacency word and sixteen x values per lane -- must
@@ -21,7 +23,7 @@ types of a column, columns ascending -- the reference's order (see dense_order_l
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.environ.get("ULTRA_GEN_DENSE_OUT") or os.path.join(os.path.dirname(HERE), "ultra_amd", "csrc", "dense_order_asm.hpp")
+OUT = os.environ.get("ULTRA_GEN_DENSE_OUT") or os.path.join(os.path.dirname(HERE), "ultra_amd", "lib", "variants", "dense_order_asm.hpp")
 
 NS = int(os.environ.get("ULTRA_GEN_DOL_NS", "4"))         # stages in flight (measurement builds: other depths)
 TOUCH = os.environ.get("ULTRA_GEN_DOL_TOUCH", "1") == "1"  # (measurement builds: without the touch loads)
@@ -217,6 +219,7 @@ def main():
            '[touch0] "v"(touch0)', '[xlast] "s"(xlast)', '[alast] "s"(alast)', '[ntouch] "s"(ntouch)']
     clob = ", ".join('"v%d"' % r for r in range(CLOBBER_LO, CLOBBER_HI + 1))
     parts.append("        : %s\n        : %s\n        : \"memory\", \"scc\", %s);\n}\n\n}  // namespace ultra\n" % (ops_out, ", ".join(ins), clob))
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with open(OUT, "w") as f:
         f.write("".join(parts))
     print("wrote", OUT)

@@ -34,9 +34,6 @@ REC_POLICY = os.environ.get("ULTRA_GEN_REC_POLICY", "")
 # FETCH_SIZE + WRITE_SIZE): FB15k237 bs 8 180 -> 155 MB and 78.3 -> 77.5 us, CoDEx-L bs 8 1.91 -> 1.88 GB and 266 -> 257 us;
 # " sc1" the same within noise; "" = default policy.
 OUT_POLICY = os.environ.get("ULTRA_GEN_OUT_POLICY", " nt")
-# ... and in the POST variants, whose flushed rows are read back by the update waves of the same workgroup moments later:
-# default policy (measured, FB15k237 bs 8, layer in a hipGraph: "" 94.6 us, " sc1" 95.2, " nt" 98.8)
-POST_OUT_POLICY = os.environ.get("ULTRA_GEN_POST_OUT_POLICY", "")
 
 
 def vr(lo, n=1):
@@ -87,22 +84,15 @@ def nary(a, sum_code, acc, x):
 #   v112:113   records of the round after the current one (in flight)      v120:121  round 0's records (prologue)
 #   v114/v115  current round's col / type (lane l holds step l % 8)
 #   v56..v63, v48..v55  the chunk's four relation rows          v116..v119 the accumulator       v122 scratch
-#   POST variants (the walk also hands its finished rows to the workgroup's update waves, see stream_post):
-#   v44..v47   byte offset of the row flushed at step q of the previous chunk (-1: none)     v123 queue slot
-#   v124 LDS address of the hand-off block     v125 the constant 1
+#   POST == 2 (the walk parks its finished rows in LDS for the workgroup's update waves, see stream_park):
+#   v123 ring slot     v124 LDS address of the control block     v125 the constant 1     v126 scratch
 STREAM_CLOBBER_LO, STREAM_CLOBBER_HI = 48, 122
-POST_CLOBBER_LO, POST_CLOBBER_HI = 44, 125
 RV = (56, 60, 48, 52)
 ACC = 116
-PEND = 44
-# hand-off block in LDS (rspmm_order_kernels.hpp, UpdateCtl): word 0 queue tail, 1 walkers done, 2 weight image ready,
-# 3 chain done, then HANDOFF_TILES counters "rows of tile t posted", then the queue of row byte offsets
-HANDOFF_TILES = 256
-HANDOFF_TILE_OFF = 16
-HANDOFF_QUEUE_OFF = HANDOFF_TILE_OFF + 4 * HANDOFF_TILES
 
 
-# ---- hand-off form 2 (POST == 2): the flushed row itself goes to the update waves through LDS ----
+# ---- the hand-off (POST == 2): the flushed row itself goes to the update waves through LDS ----
+# (POST == 1 -- rows stored to memory and their offsets queued in LDS, round 4's by-reference form -- was removed in round 5)
 # Tiles of 16 rows x (256 + 16 pad) bytes, HANDOFF2_NT of them, reused round-robin by "generations" of 16 rows: slot g (from
 # the atomic tail) belongs to generation g / 16, tile buffer (g / 16) % NT, row g % 16.  Control block (byte offsets behind
 # qctl; rspmm_order_kernels.hpp has the same numbers): 0 tail, 4 walkers done, 8 update-wave barrier, 12 chain done,
@@ -166,35 +156,6 @@ def stream_park(a, ob_q, x_q, tag):
     a("s_mov_b64 exec, %[mk]")
     # (no wait: LDS instructions take their operands at issue, and they complete in order -- the counted waits of the steps
     # below only ever wait longer for it)
-
-
-def stream_post(a, tag):
-    """Hand the rows flushed during the PREVIOUS chunk to the update waves.  Placed right behind a vmcnt wait that leaves
-    only requests issued after those flush stores outstanding: completion is reported to a wave in issue order, so the
-    stores have reached the L2 and the rows are readable by the other waves of this CU.  One lane per 16-lane group posts:
-    slot = tail++, queue[slot] = row offset, posted[slot / 32]++ -- a wave's LDS operations execute in order, so a reader
-    that sees the tile's count complete also sees its 32 queue entries.  Ends with every LDS operation of the wave
-    collected (the chunk's relation rows included: the counted lgkm waits of the steps below then pass at once)."""
-    a("s_cmp_eq_u32 %[pf], 0")
-    a("s_cbranch_scc1 .Lstream_nopost_%s_%%=" % tag)
-    a("v_cmp_eq_u32_e64 %[mk], 0, %[lb]", "lane 0 of each group (whole-span rows: lb = 16 (lane % 16))")
-    for q in range(4):
-        a("v_cmp_ne_u32_e32 vcc, -1, v%d" % (PEND + q))
-        a("s_and_b64 exec, vcc, %[mk]")
-        a("s_cbranch_execz .Lstream_posted_%s%d_%%=" % (tag, q))
-        a("ds_add_rtn_u32 v123, v124, v125")
-        a("s_waitcnt lgkmcnt(0)")
-        a("v_lshl_add_u32 v122, v123, 2, v124")
-        a("ds_write_b32 v122, v%d offset:%d" % (PEND + q, HANDOFF_QUEUE_OFF))
-        a("v_lshrrev_b32_e32 v123, 5, v123")
-        a("v_lshl_add_u32 v122, v123, 2, v124")
-        a("ds_add_u32 v122, v125 offset:%d" % HANDOFF_TILE_OFF)
-        a.label(".Lstream_posted_%s%d_%%=" % (tag, q))
-        a("s_mov_b64 exec, %[ex]")
-        a("v_mov_b32_e32 v%d, -1" % (PEND + q))
-    a("s_mov_b32 %[pf], 0")
-    a("s_waitcnt lgkmcnt(0)")
-    a.label(".Lstream_nopost_%s_%%=" % tag)
 
 
 # How a step's (col, type) gets from the lane that holds the record to the 16 lanes of its group: DPP row broadcast (a VALU move:
@@ -328,10 +289,7 @@ def stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag, post
         if post == 2:
             stream_park(a, ob + q, xb + 4 * q, "%s%d" % (tag, q))
         else:
-            a("global_store_dwordx4 v%d, %s, %%[ob]%s" % (ob + q, vr(ACC, 4), POST_OUT_POLICY if post else OUT_POLICY))
-        if post == 1:
-            a("v_mov_b32_e32 v%d, v%d" % (PEND + q, ob + q), "posted behind the next vmcnt wait (stream_post)")
-            a("s_mov_b32 %[pf], 1")
+            a("global_store_dwordx4 v%d, %s, %%[ob]%s" % (ob + q, vr(ACC, 4), OUT_POLICY))
         a("s_nop 2", "gfx940+: a VALU write of the data registers of a > 8-byte store needs 2 wait states behind the store "
                      "(with one, v_mov v116 reached the last lanes' data first)")
         for e in range(4):
@@ -363,18 +321,12 @@ def gen_stream(sum_code, mul_code, rec_policy, post=0):
             a("s_or_b32 %[m32], vcc_lo, vcc_hi", "(VALU -> SGPR -> SALU: interlocked)")
 
     def compute(xb, tb, ob, consts, first_step, tag):
-        if post == 1:
-            stream_post(a, tag)
         stream_compute(a, xb, tb, ob, consts, binop, sum_code, first_step, tag, post)
 
     a("s_mov_b64 %[ex], exec")
     a("s_mov_b32 %[kb], 0")
     for e in range(4):
         a("v_mov_b32_e32 v%d, %s" % (ACC + e, IDENT[sum_code]))
-    if post == 1:
-        a("s_mov_b32 %[pf], 0")
-        for q in range(4):
-            a("v_mov_b32_e32 v%d, -1" % (PEND + q))
     if post:
         a("v_mov_b32_e32 v124, %[qctl]")
         a("v_mov_b32_e32 v125, 1")
@@ -420,8 +372,6 @@ def gen_stream(sum_code, mul_code, rec_policy, post=0):
     compute(B, TB, OB, (4, 5, 6, 7), 4, "lb")
     a.label(".Lstream_done_%=")
     a("s_waitcnt vmcnt(0)", "flush stores")
-    if post == 1:
-        stream_post(a, "end")
     return a
 
 
@@ -543,141 +493,6 @@ def gen_producer(mul_code, rec_policy):
     return a
 
 
-# ---- chain producers, OVERLAP form: eight producer waves, two messages per chunk each, no workgroup barrier ----
-# The other seven waves of the workgroup walk their streams while the chain runs, so s_barrier (which counts every wave) is
-# out: the hand-off goes through three LDS words behind the ring -- ready[0], ready[1] (messages parked for chunks of even /
-# odd index: every producer wave adds 1 per half-chunk, 16 per chunk) and done (chunks the consumer has read completely).
-# The producers see the chunk list as HALF-chunks (plan.cpp vchunks: slots 0..31, then 32..59 of each chunk): step v parks
-# quad (wave - 1) + 8 (v & 1) of ring half (v >> 1) & 1 (a half holds 16 quads here; quad 15 is wave 8's idle second step).
-# A producer may park chunk j only when done >= j - 1 (chunk j - 2, the previous tenant of that ring half, has been read).
-OV_RING_HALF_BYTES = 16 * 64 * 16
-OV_CLOBBER_LO = 40
-
-
-def gen_producer_overlap(mul_code, rec_policy, halves=True):
-    """halves=True: eight producer waves, two half-chunk steps per chunk (the side-by-side form).  halves=False: fifteen producer
-    waves, one step per chunk, classic ring (15 quads per half) -- the classic chain with the LDS-word hand-off in place of its
-    barrier."""
-    a = Asm()
-    D = PROD_D
-    binop = BINOPS[mul_code]
-    SETS = (120, 52, 48, 44)   # four 4-register sets: relation row (requested two steps ahead) -> message -> transposed -> parked
-
-    def xq(j):
-        return 64 + 4 * (j % D)
-
-    def rq(j):
-        return 96 + 2 * (j % D)
-
-    def tq(j):
-        return 112 + (j % D)
-
-    def bq(j):
-        return 56 + (j % D)
-
-    def begin_request_imm(j, k):
-        a("global_load_dword v%d, v127, %%[chunks] offset:%d" % (bq(j), 16 * k + 4), "B_%d: Chunk::begin" % k)
-
-    def rec_request(j):
-        a("v_lshl_add_u32 v125, v%d, 3, %%[slot8]" % bq(j))
-        a("global_load_dwordx2 %s, v125, %%[rb]%s" % (vr(rq(j), 2), rec_policy))
-
-    def row_request(j):
-        a("v_lshl_add_u32 v%d, v%d, 8, %%[lds]" % (tq(j), rq(j) + 1))
-        a("v_mad_u32_u24 v124, v%d, %%[xrb], %%[lb]" % rq(j))
-        a("global_load_dwordx4 %s, v124, %%[xb]" % vr(xq(j), 4))
-
-    def prepare(k, lgkm):
-        """message of half-chunk k (stage k % D, set k % 4; its relation row was requested two steps ago) -> transposed, in
-        registers; the stage is refilled and the relation row of half-chunk k + 2 requested.  lgkm: LDS operations this wave
-        has issued since that relation row's read (they may stay outstanding), or None when everything has been drained."""
-        m = SETS[k % 4]
-        a("s_waitcnt vmcnt(%d)" % (3 * (D - 1)))
-        if lgkm is not None:
-            a("s_waitcnt lgkmcnt(%d)" % lgkm)
-        x = xq(k)
-        a("%s %s, %s, %s" % (binop, vr(m, 2), vr(m, 2), vr(x, 2)))
-        a("%s %s, %s, %s" % (binop, vr(m + 2, 2), vr(m + 2, 2), vr(x + 2, 2)))
-        a("s_nop 1", "VALU write -> v_permlane*_swap read: 2 wait states")
-        a("v_permlane32_swap_b32_e32 v%d, v%d" % (m, m + 2))
-        a("v_permlane32_swap_b32_e32 v%d, v%d" % (m + 1, m + 3))
-        a("s_nop 1")
-        a("v_permlane16_swap_b32_e32 v%d, v%d" % (m, m + 1))
-        a("v_permlane16_swap_b32_e32 v%d, v%d" % (m + 2, m + 3))
-        row_request(k)
-        rec_request(k)
-        a("v_add_u32_e32 v127, 16, v127")
-        a("global_load_dword v%d, v127, %%[chunks]" % bq(k), "B_k+3D")
-        a("ds_read_b128 %s, v%d" % (vr(SETS[(k + 2) % 4], 4), tq(k + 2)), "relation row of half-chunk k + 2")
-
-    a("s_mov_b32 %[i], 0")
-    a("s_mov_b32 %[half], 0")
-    a("s_mov_b32 %[par], 0")
-    a("v_mov_b32_e32 v127, 0")
-    a("v_mov_b32_e32 v40, %[flags]")
-    a("v_mov_b32_e32 v41, 1")
-    for j in range(D):
-        begin_request_imm(j, j)
-    a("s_waitcnt vmcnt(0)")
-    for j in range(D):
-        rec_request(j)
-        begin_request_imm(j, D + j)
-    a("s_waitcnt vmcnt(0)")
-    for j in range(D):
-        row_request(j)
-        rec_request(j)
-        begin_request_imm(j, 2 * D + j)
-    a("v_mov_b32_e32 v127, 0x%x" % (16 * (3 * D - 1) + 4), "descriptor offset of half-chunk 3 D - 1")
-    a("ds_read_b128 %s, v%d" % (vr(SETS[0], 4), tq(0)), "relation rows of half-chunks 0 and 1")
-    a("ds_read_b128 %s, v%d" % (vr(SETS[1], 4), tq(1)))
-    a("s_waitcnt lgkmcnt(0)")
-    prepare(0, None)
-    a("ds_read_b32 v42, v40 offset:8", "done (for the first gate)")
-    a.label(".Lov_loop_%=")
-    for J in range(D):
-        first = (J % 2 == 0) or not halves     # first (or only) step of a chunk: gated
-        last = (J % 2 == 1) or not halves      # last (or only) step of a chunk: ring half and parity flip behind it
-        if first:
-            # chunk j = i / 2 (i with one step per chunk): its ring half is free once done >= j - 1.  `done` was requested at
-            # the end of the previous step; the wait also collects the relation row requested one step ago.
-            if halves:
-                a("s_lshr_b32 %[t], %[i], 1")
-            else:
-                a("s_mov_b32 %[t], %[i]")
-            a.label(".Lov_gate%d_%%=" % J)
-            a("s_waitcnt lgkmcnt(0)")
-            a("v_readfirstlane_b32 %[d], v42")
-            a("s_add_i32 %[d], %[d], 1")
-            a("s_cmp_ge_i32 %[d], %[t]")
-            a("s_cbranch_scc1 .Lov_go%d_%%=" % J)
-            a("s_sleep 1")
-            a("ds_read_b32 v42, v40 offset:8", "done")
-            a("s_branch .Lov_gate%d_%%=" % J)
-            a.label(".Lov_go%d_%%=" % J)
-        a("v_add_u32_e32 v126, %[half], %[ring]")
-        a("ds_write_b128 v126, %s%s" % (vr(SETS[J % 4], 4), " offset:8192" if (halves and J % 2) else ""))
-        a("v_add_u32_e32 v43, %[par], v40", "ready[chunk parity]")
-        a("s_mov_b64 %[ex], exec")
-        a("s_mov_b64 exec, 1")
-        a("ds_add_u32 v43, v41", "(behind the write: a wave's LDS operations execute in order)")
-        a("s_mov_b64 exec, %[ex]")
-        if last:
-            a("s_xor_b32 %%[half], %%[half], %d" % (OV_RING_HALF_BYTES if halves else RING_HALF_BYTES))
-            a("s_xor_b32 %[par], %[par], 4")
-        # LDS operations this wave has issued since the read of relation row J + 1 (two steps ago): a gated step drained
-        # everything at its gate; an ungated (second-half) step has only its own write + add outstanding behind it.
-        prepare(J + 1, None if first else 2)
-        if last:
-            a("ds_read_b32 v42, v40 offset:8", "done (for the next step's gate)")
-        a("s_add_i32 %[i], %[i], 1")
-        a("s_cmp_ge_i32 %[i], %[n]")
-        a("s_cbranch_scc1 .Lov_done_%=")
-    a("s_branch .Lov_loop_%=")
-    a.label(".Lov_done_%=")
-    a("s_waitcnt vmcnt(0) lgkmcnt(0)", "requests past the last half-chunk: nobody consumes them")
-    return a
-
-
 def clobbers(lo, hi):
     return ", ".join('"v%d"' % r for r in range(lo, hi + 1))
 
@@ -706,9 +521,8 @@ def main():
                  "// boundary row's part of this lane (0xffffffff: none), b = its boundary values, bz = what a row other than the boundary\n"
                  "// row meets at its flush under min / max (0: the boundary tensor's zeros; -+inf: nothing), ns / nf = steps of the wave's\n"
                  "// longest / shortest stream (ns > 0, wave-uniform), xb / rb / ob = source slice, stream records, output slice.\n"
-                 "// POST == 1: every flushed row is also handed to the workgroup's update waves through the LDS block at byte address qctl\n"
-                 "// (stream_post in the generator; whole-span rows only: lb = 16 (lane % 16)).  POST == 2: the row itself goes to them, into\n"
-                 "// the LDS tiles at byte address qtile, and not to memory (stream_park).\n"
+                 "// POST == 2: every flushed row goes to the workgroup's update waves, into the LDS tiles at byte address qtile (control block at\n"
+                 "// qctl), and not to memory (stream_park in the generator; whole-span rows only: lb = 16 (lane % 16)).\n"
                  "// ULTRA_STREAM_DIET (generator: DIET): l8 carries lim = len - lane % 8 instead of lane % 8, rem stays the stream's length, rmk\n"
                  "// = the type a marker record holds (num_rel; num_rel * 256 where the records are pre-shifted).  ULTRA_STREAM_PRESHIFT_GEN: the\n"
                  "// POST variants read records (col * 256, type * 256) -- the twelve-walker schedules' format (plan.hpp ULTRA_STREAM_PRESHIFT).\n"
@@ -719,10 +533,10 @@ def main():
                  "                                                 const int ns, const int nf, const char *xb, const char *rb, const char *ob,\n"
                  "                                                 const uint32_t xrb, const uint32_t qctl, const uint32_t qtile,\n"
                  "                                                 const uint32_t rmk) {\n"
-                 "    int kb, t0, t1, pf, m32, mb;\n    unsigned long long ex, mk;\n    (void)pf, (void)qtile, (void)m32, (void)mb, (void)rmk;\n"
+                 "    int kb, t0, t1, m32, mb;\n    unsigned long long ex, mk;\n    (void)qtile, (void)qctl, (void)m32, (void)mb, (void)rmk;\n"
                  "    const uint32_t rowpitch = " + str(HANDOFF2_ROW_BYTES) + "u;\n    (void)rowpitch;\n")
     first = True
-    for post in (0, 1, 2):
+    for post in (0, 2):
         for sum_code in (0, 1, 2):
             for mul_code in (0, 1):
                 a = gen_stream(sum_code, mul_code, REC_POLICY, post)
@@ -731,14 +545,13 @@ def main():
                 first = False
                 parts.append("        asm volatile(\n" + a.render("            ") + "\n")
                 parts.append('            : [rem] "+v"(rem), [roff] "+v"(roff), [kb] "=&s"(kb), [t0] "=&s"(t0), [t1] "=&s"(t1), [ex] "=&s"(ex),\n'
-                             '              [mk] "=&s"(mk)%s%s\n' % (', [pf] "=&s"(pf)' if post == 1 else '',
-                                                                   ', [m32] "=&s"(m32), [mb] "=&s"(mb)' if DIET else ''))
+                             '              [mk] "=&s"(mk)%s\n' % (', [m32] "=&s"(m32), [mb] "=&s"(mb)' if DIET else ''))
                 parts.append('            : [l8] "v"(l8), [lb] "v"(lb), [lds] "v"(lds), [mark] "v"(mark), [bndoff] "v"(bndoff), [b0] "v"(b[0]),\n'
                              '              [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [ns] "s"(ns), [nf] "s"(nf), [xb] "s"(xb), [rb] "s"(rb),\n'
                              '              [ob] "s"(ob), [xrb] "s"(xrb)%s%s%s%s\n' % (', [bz] "v"(bz)' if sum_code else '', ', [qctl] "s"(qctl)' if post else '',
                                                                                          ', [qtile] "s"(qtile), [rowpitch] "s"(rowpitch)' if post == 2 else '',
                                                                                          ', [rmk] "s"(rmk)' if DIET else ''))
-                lo, hi = (POST_CLOBBER_LO, POST_CLOBBER_HI) if post == 1 else ((STREAM_CLOBBER_LO, 126) if post == 2 else (STREAM_CLOBBER_LO, STREAM_CLOBBER_HI))
+                lo, hi = (STREAM_CLOBBER_LO, 126) if post == 2 else (STREAM_CLOBBER_LO, STREAM_CLOBBER_HI)
                 parts.append('            : "memory", "vcc", "scc", %s);\n' % clobbers(lo, hi))
                 parts.append("    }\n")
     parts.append("}\n\n")
@@ -764,43 +577,7 @@ def main():
                          '            : "memory", "scc", %s);\n' % clobbers(PROD_CLOBBER_LO, PROD_CLOBBER_HI))
             parts.append("    }\n")
     parts.append("}\n\n")
-    parts.append("// chain producers, overlap form (no barrier; see the generator): `n` HALF-chunks from descriptor `chunks` on, flags = LDS byte\n"
-                 "// address of {ready[0], ready[1], done}; ring = LDS byte address of this lane's 16 B in quad (wave - 1) of ring half 0\n"
-                 "template <int MUL>\n"
-                 "__device__ __forceinline__ void order_produce_overlap_asm(const int n, const void *chunks, const uint32_t slot8, const uint32_t lb,\n"
-                 "                                                          const uint32_t lds, const uint32_t ring, const uint32_t flags,\n"
-                 "                                                          const char *xb, const char *rb, const uint32_t xrb) {\n"
-                 "    int i, half, par, t, d;\n    unsigned long long ex;\n")
-    first = True
-    for mul_code in (0, 1):
-        a = gen_producer_overlap(mul_code, REC_POLICY)
-        parts.append("    %sif constexpr (MUL == %d) {\n" % ("" if first else "else ", mul_code))
-        first = False
-        parts.append("        asm volatile(\n" + a.render("            ") + "\n")
-        parts.append('            : [i] "=&s"(i), [half] "=&s"(half), [par] "=&s"(par), [t] "=&s"(t), [d] "=&s"(d), [ex] "=&s"(ex)\n'
-                     '            : [n] "s"(n), [chunks] "s"(chunks), [slot8] "v"(slot8), [lb] "v"(lb), [lds] "v"(lds), [ring] "v"(ring),\n'
-                     '              [flags] "s"(flags), [xb] "s"(xb), [rb] "s"(rb), [xrb] "s"(xrb)\n'
-                     '            : "memory", "scc", %s);\n' % clobbers(OV_CLOBBER_LO, PROD_CLOBBER_HI))
-        parts.append("    }\n")
-    parts.append("}\n\n")
-    parts.append("// chain producers, classic layout with the LDS-word hand-off instead of the barrier: `n` chunks, fifteen producer waves\n"
-                 "template <int MUL>\n"
-                 "__device__ __forceinline__ void order_produce_polled_asm(const int n, const void *chunks, const uint32_t slot8, const uint32_t lb,\n"
-                 "                                                         const uint32_t lds, const uint32_t ring, const uint32_t flags,\n"
-                 "                                                         const char *xb, const char *rb, const uint32_t xrb) {\n"
-                 "    int i, half, par, t, d;\n    unsigned long long ex;\n")
-    first = True
-    for mul_code in (0, 1):
-        a = gen_producer_overlap(mul_code, REC_POLICY, halves=False)
-        parts.append("    %sif constexpr (MUL == %d) {\n" % ("" if first else "else ", mul_code))
-        first = False
-        parts.append("        asm volatile(\n" + a.render("            ") + "\n")
-        parts.append('            : [i] "=&s"(i), [half] "=&s"(half), [par] "=&s"(par), [t] "=&s"(t), [d] "=&s"(d), [ex] "=&s"(ex)\n'
-                     '            : [n] "s"(n), [chunks] "s"(chunks), [slot8] "v"(slot8), [lb] "v"(lb), [lds] "v"(lds), [ring] "v"(ring),\n'
-                     '              [flags] "s"(flags), [xb] "s"(xb), [rb] "s"(rb), [xrb] "s"(xrb)\n'
-                     '            : "memory", "scc", %s);\n' % clobbers(OV_CLOBBER_LO, PROD_CLOBBER_HI))
-        parts.append("    }\n")
-    parts.append("}\n\n}  // namespace ultra\n")
+    parts.append("}  // namespace ultra\n")
     with open(OUT, "w") as f:
         f.write("".join(parts))
     print("wrote", OUT)

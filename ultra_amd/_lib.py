@@ -127,7 +127,7 @@ def _load():
 
 
 lib = _load()
-if lib.ultra_abi_version() != 5:
+if lib.ultra_abi_version() != 6:
     raise ImportError("ultra_amd: libultra_amd.so ABI version mismatch")
 
 

@@ -24,10 +24,13 @@
 #include <cstdint>
 #include <string>
 
-#ifdef ULTRA_DOL_ASM_HEADER   // measurement builds: a header generated with other switches (tools/build_variant.py)
+#ifndef ULTRA_DOL_ASM
+#define ULTRA_DOL_ASM 0
+#endif
+#if ULTRA_DOL_ASM   // measurement builds only: the header is GENERATED for them (python tools/gen_dense_order_asm.py writes
+                    // ultra_amd/lib/variants/dense_order_asm.hpp; tools/build_variant.py NAME -DULTRA_DOL_ASM=1
+                    // -DULTRA_DOL_ASM_HEADER=\"<path>\") -- it is not part of the source tree or of the default build
 #include ULTRA_DOL_ASM_HEADER
-#else
-#include "dense_order_asm.hpp"
 #endif
 #include "plan.hpp"
 #include "torch_math.hpp"
@@ -38,10 +41,6 @@
 // why the chain runs at 67 cycles per column against the instruction's 32-36.  It is not: bit-exact, and 21.7 us per layer
 // against the C++ loop's 21.5 (with the touch: 22.6) on one box (round 4, tools/dense_order_probe.py) -- the chain does not wait
 // for memory; the byte -> float conversion, the product and the load issue of a column do not hide under its matrix instruction.
-#ifndef ULTRA_DOL_ASM
-#define ULTRA_DOL_ASM 0
-#endif
-
 #pragma clang fp contract(off)
 
 namespace ultra {

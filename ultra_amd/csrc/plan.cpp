@@ -266,9 +266,12 @@ static double WAVE_SHARE_12[4] = {1.5, 1.2, 0.7, 0.0};
 // partitions a sample: mean stream 364 steps / two in flight with 24: 485 steps): threshold 256: 0.667 / 0.605, 384: 0.661 /
 // 0.596, 512: 0.655 / 0.595, 768: 0.648 / 0.590, 1,024: 0.705 / 0.580, 1,536: 0.837 / 0.597 -- the best is at 2.1 x in both.
 static double CHAIN_LIMIT_FACTOR = 2.1;
-// ULTRA_CHAIN_OVERLAP: cycles one walking stream needs per step while the chain crew is still busy (fewer streams share the
-// vector L1 then: a stream steps faster than the 64 x COST_S_STEP of the all-streams phase)
-static double COST_S_STEP_SIDE = 252.0, SIDE_TAPER = 0.6;   // (SIDE_TAPER: share of T above which a chain stays classic)
+// What a ROW costs a stream of the twelve-walker schedules beyond its edges, in steps, per wave quartet.  A flush is not a step
+// like the others: the wave parks the row in the hand-off ring -- one LDS round trip, sometimes a wait for a free ring row --
+// and the stall holds up all four streams of the wave, whatever the wave's age; the steps themselves go faster the older the
+// wave is (WAVE_SHARE_12).  Fitted from a traced launch (tools/wave_fit.py: walk = c_q steps + r rows per wave; a stream's share
+// of its wave's row stalls is 4 r / c_q steps a row).  ULTRA_STREAM_ROW_COST_12="r0,r1,r2" overrides (calibration runs).
+static double ROW_COST_12[4] = {0.0, 0.0, 0.0, 0.0};
 
 static void read_cost_override() {   // calibration runs only: ULTRA_SCHED_COSTS="edge,chunk,row,step,unit", ULTRA_STREAM_COSTS="chunk,row,step"
     const char *env = std::getenv("ULTRA_SCHED_COSTS");
@@ -286,14 +289,16 @@ static void read_cost_override() {   // calibration runs only: ULTRA_SCHED_COSTS
         for (int k = 0; k < 3; ++k) WAVE_SHARE_12[k] = v[k];
         WAVE_SHARE_12[3] = 0.0;
     }
+    env = std::getenv("ULTRA_STREAM_ROW_COST_12");
+    if (env && std::sscanf(env, "%lf,%lf,%lf", &v[0], &v[1], &v[2]) == 3) {
+        for (int k = 0; k < 3; ++k) ROW_COST_12[k] = v[k];
+    }
     env = std::getenv("ULTRA_CHAIN_LIMIT_FACTOR");   // calibration runs (0: every listed chain row stays one)
     if (env && std::sscanf(env, "%lf", &v[0]) == 1) CHAIN_LIMIT_FACTOR = v[0];
     env = std::getenv("ULTRA_STREAM_COSTS");
     if (env) {
         const int n = std::sscanf(env, "%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4]);
         if (n >= 3) COST_S_CHUNK = v[0], COST_S_ROW = v[1], COST_S_STEP = v[2];
-        if (n >= 4) COST_S_STEP_SIDE = v[3];
-        if (n >= 5) SIDE_TAPER = v[4];
     }
 }
 
@@ -381,43 +386,16 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
             if (g >= n_chain || to_stream[(size_t)g]) steps += p->items[(size_t)g].len + 1;
         const int64_t nstream = (int64_t)nparts * ORDER_GROUPS;
         std::vector<double> weight((size_t)nstream);
-#if ULTRA_CHAIN_OVERLAP
-        // Side by side: while workgroup q's chain runs (C_q cycles), its ORDER_GROUPS - ORDER_OV_CREW_GROUPS walking streams
-        // step every COST_S_STEP_SIDE cycles; afterwards all 64 streams step every 64 COST_S_STEP cycles.  Equal finishing
-        // times T for all workgroups: steps_q = (T - C_q) / COST_S_STEP + n_side C_q / COST_S_STEP_SIDE.  Walkers slow the
-        // chain they run beside (they share its LDS and its vector L1, and eight producer waves prefetch half as far ahead as
-        // fifteen), so a workgroup whose chain is most of the launch -- C_q > SIDE_TAPER x T -- keeps the classic form.
-        const double n_side = ORDER_GROUPS - ORDER_OV_CREW_GROUPS;
-        s->part_mode.assign((size_t)nparts, SIDE_TAPER < 0.0 ? 2 : 1);   // (< 0: every chain classic, with the LDS-word hand-off)
-        double T = 0.0;
-        for (int iter = 0; iter < 4; ++iter) {
-            if (SIDE_TAPER < 0.0) {
-                T = (COST_S_STEP * steps + total) / nparts;
-                break;
-            }
-            double recovered = 0.0;
-            for (int32_t q = 0; q < nparts; ++q)
-                if (s->part_mode[(size_t)q]) recovered += COST_S_STEP * n_side * chain_cost[(size_t)q] / COST_S_STEP_SIDE;
-            T = (COST_S_STEP * steps + total - recovered) / nparts;
-            for (int32_t q = 0; q < nparts; ++q) s->part_mode[(size_t)q] = chain_cost[(size_t)q] <= SIDE_TAPER * T ? 1 : 0;
-        }
-        for (int32_t q = 0; q < nparts; ++q) {
-            const double after = std::max(T - chain_cost[(size_t)q], 0.02 * T) / (COST_S_STEP * ORDER_GROUPS);   // steps per stream, all walking
-            const double side = s->part_mode[(size_t)q] == 1 ? chain_cost[(size_t)q] / COST_S_STEP_SIDE : 0.0;   // steps per walking stream, chain busy
-            for (int g = 0; g < ORDER_GROUPS; ++g)
-                weight[(size_t)q * ORDER_GROUPS + g] = after + (g >= ORDER_OV_CREW_GROUPS ? side : 0.0);
-        }
-#else
         total += COST_S_STEP * steps;
         const double T = total / nparts;
         for (int32_t q = 0; q < nparts; ++q) {
             const double budget = std::max(T - chain_cost[(size_t)q], 0.02 * T);   // (never zero: every row needs a home)
             for (int g = 0; g < ORDER_GROUPS; ++g) weight[(size_t)q * ORDER_GROUPS + g] = budget * wave_share[g / 16];
         }
-#endif
         typedef std::pair<double, int64_t> Slot;   // ((load + 1) / weight, stream): the heap's top is the relatively emptiest
         std::priority_queue<Slot, std::vector<Slot>, std::greater<Slot>> sheap;
         std::vector<int64_t> sload((size_t)nstream, 0);
+        std::vector<double> scost((size_t)nstream, 0.0);   // steps + what the rows cost beyond them (ROW_COST_12)
         std::vector<std::vector<int32_t>> srows((size_t)nstream);
         for (int64_t g = 0; g < nstream; ++g)
             if (weight[(size_t)g] > 0.0) sheap.push(Slot(1.0 / weight[(size_t)g], g));   // (a stream without a share takes no rows)
@@ -427,7 +405,8 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
             sheap.pop();
             srows[(size_t)sl.second].push_back((int32_t)g);
             sload[(size_t)sl.second] += p->items[(size_t)g].len + 1;
-            sheap.push(Slot((double)(sload[(size_t)sl.second] + 1) / weight[(size_t)sl.second], sl.second));
+            scost[(size_t)sl.second] += p->items[(size_t)g].len + 1 + (walkers == 12 ? ROW_COST_12[(sl.second % ORDER_GROUPS) / 16] : 0.0);
+            sheap.push(Slot((scost[(size_t)sl.second] + 1.0) / weight[(size_t)sl.second], sl.second));
         }
         s->sdesc.assign((size_t)nstream * 2, 0);
         s->srec.reserve((size_t)(2 * (int64_t)steps) + 2 * ORDER_PAD);
@@ -480,14 +459,7 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
     }
     // the chain producers request descriptors a fixed number of chunks ahead without a bounds test: readable, harmless
     // entries (edge 0) behind the last chunk
-    if (s->part_mode.empty()) s->part_mode.assign((size_t)nparts, 0);
-    s->vchunks.reserve(2 * s->chunks.size() + CHUNK_PAD);
-    for (const Chunk &c : s->chunks) {
-        s->vchunks.push_back(Chunk{c.row, c.begin, std::min<int32_t>(c.count, 32), 0});
-        s->vchunks.push_back(Chunk{c.row, c.begin + 32, std::max<int32_t>(c.count - 32, 0), 0});
-    }
     for (int k = 0; k < CHUNK_PAD; ++k) s->chunks.push_back(Chunk{0, 0, 0, 0});
-    for (int k = 0; k < CHUNK_PAD; ++k) s->vchunks.push_back(Chunk{0, 0, 0, 0});
     return s;
 }
 

@@ -45,24 +45,10 @@ enum { CHUNK_FIRST = 1, CHUNK_LAST = 2, CHUNK_LEN_SHIFT = 2 };
 constexpr int ORDER_WAVES = ULTRA_ORDER_WAVES;
 constexpr int CHAIN_SLOTS = 4 * (ORDER_WAVES - 1);   // producer groups of a workgroup (every wave but the consumer, x 4)
 constexpr int ORDER_GROUPS = 4 * ORDER_WAVES;        // 16-lane groups of a workgroup
-// Chain and stream phases side by side (the fp32 stream kernels): wave 0 consumes, waves 1..ORDER_OV_PRODUCERS produce two
-// messages per chunk each (half-chunks: slots 0..31, then 32..59), the remaining waves walk their streams from the start.
-// MEASUREMENT BUILD (-DULTRA_CHAIN_OVERLAP=1), not the default: bit-exact (tests/test_order_gpu.py), the average workgroup
-// finishes 8 % earlier (129 k instead of 140 k cycles at FB15k237 bs 8), but the chain itself slows from 675 to 800 cycles
-// per chunk -- eight producer waves prefetch four chunks ahead instead of eight, less than a gather's latency while 255 other
-// CUs are walking -- and the workgroup with the 9,067-edge row becomes the launch: 77.3 vs 79 us stand-alone, - 1.4 % on the
-// benchmark step.  Keeping the classic form for workgroups whose chain is most of the launch (part_mode, C_q >
-// 0.6 T) does not rescue it: the classic chain also slows (152 chunks in 147 k cycles instead of 130 k) once the other
-// workgroups walk from the start -- in the default kernel every CU is in its chain phase at the same time, i.e. the chains
-// run against a quiet memory system -- 82-85 us.  And the hand-off itself is the slower primitive: the classic chain (fifteen
-// producers, nobody walking) with the LDS words in place of its barrier (part_mode 2, ULTRA_STREAM_COSTS=...,-1) runs at 813
-// cycles per chunk against 641 with s_barrier on the same box -- with two ring halves the producer -> consumer -> producer
-// signalling round trip (two LDS polls) sits on every chunk, and a deeper ring does not fit beside the relation slice.
-#ifndef ULTRA_CHAIN_OVERLAP
-#define ULTRA_CHAIN_OVERLAP 0
-#endif
-constexpr int ORDER_OV_PRODUCERS = 8;
-constexpr int ORDER_OV_CREW_GROUPS = 4 * (1 + ORDER_OV_PRODUCERS);   // streams (16-lane groups) of the consumer and producer waves
+// (Round 3 built the chain and stream phases SIDE BY SIDE -- wave 0 consuming, eight producer waves, seven walking from the start,
+// LDS words instead of the barrier -- as a measurement build: bit-exact, the average workgroup 8 % earlier, but the chain itself
+// 675 -> 800 cycles per chunk and the 9,067-edge row's workgroup the launch: - 1.4 % on the step.  The build was removed in round
+// 5; its numbers are in DESIGN.md 8 and profiles/r3_*.)
 constexpr int CHUNK_PAD = 32;           // descriptors readable behind a schedule's last chunk (>= 3 x the producers' depth)
 // Record format of the group streams of the TWELVE-walker schedules (the update-beside-the-walk launches; nothing else reads
 // them): 1 = (col * 256, type * 256) -- these launches serve whole-span rows of 256 bytes only, so gather offset and relation-row
@@ -87,14 +73,6 @@ struct Schedule {
     // 32-row tiles: prow[prow_ptr[part] .. prow_ptr[part + 1]) -- the work list of the update the workgroup applies to its
     // own rows after the walk (rspmm_order_kernels.hpp, UPDATE).
     std::vector<int32_t> prow, prow_ptr;
-    // ULTRA_CHAIN_OVERLAP: the chunk list as half-chunks {row, begin (+ 32), count in this half, 0}, two per chunk, in chunk
-    // order (workgroup q: [2 chunk_ptr[q], 2 chunk_ptr[q + 1])), CHUNK_PAD readable entries behind the last one
-    std::vector<Chunk> vchunks;
-    Chunk *d_vchunks = nullptr;
-    // ... and per workgroup: 1 = its chain runs side by side with its walkers, 0 = classic (fifteen producers, one barrier per
-    // chunk, then the walk) -- the form kept for workgroups whose chain is the launch's critical path
-    std::vector<int32_t> part_mode;
-    int32_t *d_part_mode = nullptr;
     int32_t *d_chunk_ptr = nullptr, *d_unit_ptr = nullptr, *d_units = nullptr, *d_srec = nullptr, *d_sdesc = nullptr;
     int32_t *d_prow = nullptr, *d_prow_ptr = nullptr;
     Chunk *d_chunks = nullptr;

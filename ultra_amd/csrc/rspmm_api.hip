@@ -169,8 +169,6 @@ static void free_schedules(ultra_plan *p) {
         if (s->d_chunks) (void)hipFree(s->d_chunks);
         if (s->d_srec) (void)hipFree(s->d_srec);
         if (s->d_sdesc) (void)hipFree(s->d_sdesc);
-        if (s->d_vchunks) (void)hipFree(s->d_vchunks);
-        if (s->d_part_mode) (void)hipFree(s->d_part_mode);
         if (s->d_prow) (void)hipFree(s->d_prow);
         if (s->d_prow_ptr) (void)hipFree(s->d_prow_ptr);
         delete s;
@@ -193,8 +191,7 @@ static int get_schedule(ultra_plan *p, int32_t nparts, Schedule **out, int32_t w
     if ((rc = upload_array(&s->d_chunk_ptr, s->chunk_ptr)) || (rc = upload_array(&s->d_unit_ptr, s->unit_ptr)) ||
         (rc = upload_array(&s->d_units, s->units)) || (rc = upload_array(&s->d_chunks, s->chunks)) ||
         (rc = upload_array(&s->d_srec, s->srec)) || (rc = upload_array(&s->d_sdesc, s->sdesc)) ||
-        (rc = upload_array(&s->d_prow, s->prow)) || (rc = upload_array(&s->d_prow_ptr, s->prow_ptr)) ||
-        (rc = upload_array(&s->d_vchunks, s->vchunks)) || (rc = upload_array(&s->d_part_mode, s->part_mode))) {
+        (rc = upload_array(&s->d_prow, s->prow)) || (rc = upload_array(&s->d_prow_ptr, s->prow_ptr))) {
         delete s;
         return rc;
     }
@@ -382,11 +379,8 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
         (mul == BIN_RHS || rel->stride_row * (int64_t)esz < (1 << 24))) {
         // (+ one row: the stream walk's row markers carry relation index num_rel)
         const size_t rel_bytes = (mul != BIN_RHS) ? (size_t)(p->num_rel + 1) * 64 * esz : 0;
-        // ring: [2 halves][15 quads][64 lanes][4 messages]; the side-by-side chain of the fp32 stream kernels keeps 16 quads per
-        // half (the eighth producer wave's idle second step) and three hand-off words behind them
-        const size_t ring_bytes = p->n_chain > 0 ? ((ULTRA_CHAIN_OVERLAP && dtype == ULTRA_F32) ? (size_t)2 * 16 * 64 * 16 + 64
-                                                                                                  : (size_t)2 * CHAIN_SLOTS * 64 * esz)
-                                                 : 0;
+        // ring: [2 halves][15 quads][64 lanes][4 messages]
+        const size_t ring_bytes = p->n_chain > 0 ? (size_t)2 * CHAIN_SLOTS * 64 * esz : 0;
         if (ring_bytes <= di.lds_optin) {
             const bool rel_lds = g_tuning.rel_lds != 0 && rel_bytes > 0 && rel_bytes + ring_bytes <= di.lds_optin;
             int grid = g_tuning.grid > 0 ? g_tuning.grid : di.cu;
@@ -405,8 +399,6 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
             op.units = sched->d_units;
             op.chunk_ptr = sched->d_chunk_ptr;
             op.chunks = reinterpret_cast<const int4 *>(sched->d_chunks);
-            op.vchunks = reinterpret_cast<const int4 *>(sched->d_vchunks);
-            op.part_mode = sched->d_part_mode;
             op.n_chain = (int32_t)p->n_chain;
             op.n_item = (int32_t)p->items.size();
             op.rel = fp.rel, op.x = fp.x, op.bnd = fp.bnd;
@@ -445,31 +437,10 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
                 op.upd.prow_ptr = sched->d_prow_ptr;
                 op.upd.mode = 1;
                 lds = std::max(lds, (size_t)UPDATE_LDS_FLOATS * sizeof(float));   // (the weight image takes the dead relation slice's place)
-                // The update BESIDE the walk (rspmm_order_kernel, UPDATE == 2; on request: ultra_tuning.reserved[2] == 2): twelve
-                // waves walk, four multiply the rows handed over through LDS.  Needs the weight image (in the ring's place
-                // once the chain is done) and the hand-off block beside the relation slice, and update rows of the input's
-                // stride (a queue entry is a byte offset).  Measured on MI355X (tools/beside_probe.py): it hides
-                // the matrix work under the walk, but the update's row loads and stores -- one 16-byte piece per lane, every
-                // lane in another row -- then compete with the gathers for the CU's texture-address path, which bounds the
-                // walk: 94.6 us per layer against the tail form's 94.0 at FB15k237 bs 8, 371 against 374 at CoDEx-L.
                 Schedule *sched12 = nullptr;
-                // (both forms beside the walk read the twelve-walker schedules, whose records are pre-multiplied by the 256-byte
-                // pitch of whole-span rows: plan.hpp ULTRA_STREAM_PRESHIFT)
+                // (the form beside the walk reads the twelve-walker schedules, whose records are pre-multiplied by the 256-byte pitch
+                // of whole-span rows: plan.hpp ULTRA_STREAM_PRESHIFT)
                 const bool pitch_ok = !ULTRA_STREAM_PRESHIFT || op.x_row_bytes == 256u;
-                if (g_tuning.reserved[2] == 2 && pitch_ok && ORDER_WAVES == 16 && upd->out_stride_row * (int64_t)sizeof(float) == (int64_t)op.x_row_bytes) {
-                    if ((rc = get_schedule(p, op.nparts, &sched12, ORDER_WALKERS))) return rc;
-                    const size_t image = std::max(ring_bytes, (size_t)UPDATE_LDS_FLOATS * sizeof(float));
-                    const size_t need = rel_bytes + image + UPDATE_CTL_QUEUE_OFF + (size_t)sched12->max_rows * 4 + 64;
-                    if (need <= di.lds_optin && sched12->max_rows <= 32 * (UPDATE_CTL_TILES - 1)) {
-                        op.upd.mode = 2;
-                        op.upd.ctl_off = (uint32_t)(rel_bytes + image);
-                        op.srec = sched12->d_srec;
-                        op.sdesc = reinterpret_cast<const int2 *>(sched12->d_sdesc);
-                        op.chunk_ptr = sched12->d_chunk_ptr;      // (its own chain list: shorter chain rows are stream rows there)
-                        op.chunks = reinterpret_cast<const int4 *>(sched12->d_chunks);
-                        lds = need;
-                    }
-                }
                 // Form 3: beside the walk with the rows passing through LDS -- the walkers park every finished aggregate row AND its x
                 // row (a marker step gathers at its own row's offset) in a 64-row ring; the update waves keep the weight matrix in
                 // registers, so the room is there even beside a 474-relation slice, and they take no memory round trip (DESIGN.md
@@ -493,6 +464,11 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
                         op.chunks = reinterpret_cast<const int4 *>(sched12->d_chunks);
                         lds = need;
                     }
+                }
+                if (g_tuning.reserved[2] == 2) {
+                    set_error("ultra_rspmm_forward_update: update form 2 (rows by reference) was removed in ABI 6; ask for 0 (the library's "
+                              "choice), 1 (tail) or 3 (beside the walk, rows through LDS)");
+                    return ULTRA_ERR_UNSUPPORTED;
                 }
                 if (g_tuning.reserved[2] >= 2 && op.upd.mode != g_tuning.reserved[2]) {
                     set_error("ultra_rspmm_forward_update: the update beside the walk does not fit this call (LDS / rows per workgroup)");
@@ -1200,7 +1176,6 @@ int32_t ultra_plan_schedule_export(ultra_plan *plan, int32_t nparts, int32_t whi
         case 5: src = s->srec.data(), n = (int64_t)s->srec.size() - 2 * ORDER_PAD; break;
         case 6: src = s->prow.data(), n = (int64_t)s->prow.size(); break;
         case 7: src = s->prow_ptr.data(), n = (int64_t)s->prow_ptr.size(); break;
-        case 8: src = s->part_mode.data(), n = (int64_t)s->part_mode.size(); break;
         default: delete s; return invalid("ultra_plan_schedule_export: unknown array id");
     }
     *count = n;

@@ -51,22 +51,14 @@ enum { ORDER_SPIN_LOOK = 1,        // an update wave waiting for a block of rows
        ORDER_SPIN_MEET = 2,        // an update wave waiting for the other update waves at a meeting point
        ORDER_SPIN_CHAIN_WALKER = 3, // a walker waiting for the chain consumer to leave the ring
        ORDER_SPIN_CHAIN_UPDATER = 4, // an update wave waiting for the same
-       ORDER_SPIN_PARK = 5,        // a walker waiting for a free row of the hand-off ring (stream_park in the generator)
-       ORDER_SPIN_QUEUE = 6 };     // form 2: an update wave waiting for its tile / the weight image
-// UPDATE == 2 (the layer update runs BESIDE the walk): waves [0, ORDER_WALKERS) walk the streams, the last ORDER_UPDATERS
-// waves -- one per SIMD -- multiply the rows the walkers hand over.  Hand-off block in LDS (the generator's HANDOFF_*
-// constants are the same numbers): word 0 queue tail, 1 walkers done, 2 weight image ready, 3 chain done, then
-// UPDATE_CTL_TILES counters "rows of tile t posted", then the queue of row byte offsets in posting order.
+       ORDER_SPIN_PARK = 5 };      // a walker waiting for a free row of the hand-off ring (stream_park in the generator)
+// UPDATE == 3 (the layer update runs BESIDE the walk): waves [0, ORDER_WALKERS) walk the streams, the last ORDER_UPDATERS waves --
+// one per SIMD -- multiply the rows the walkers hand over through an LDS ring (update_tile.hpp, UPD2_*; the generator's HANDOFF2_*
+// constants are the same numbers).  (Round 4 also kept form 2 -- rows handed over BY REFERENCE, through memory and an LDS queue
+// of row offsets: bit-exact, never faster than the tail form, superseded by form 3; removed in round 5)
 constexpr int ORDER_UPDATERS = 4, ORDER_WALKERS = ORDER_THREADS / 64 - ORDER_UPDATERS;
-constexpr int UPDATE_CTL_TILES = 256, UPDATE_CTL_TILE_OFF = 16, UPDATE_CTL_QUEUE_OFF = UPDATE_CTL_TILE_OFF + 4 * UPDATE_CTL_TILES;
 #ifndef ULTRA_CHAIN_PRIO
 #define ULTRA_CHAIN_PRIO 1
-#endif
-#ifndef ULTRA_OV_SPIN
-#define ULTRA_OV_SPIN 0
-#endif
-#ifndef ULTRA_OV_PROD_PRIO
-#define ULTRA_OV_PROD_PRIO 0
 #endif
 static_assert(CHAIN_SLOTS == 4 * (ORDER_THREADS / 64 - 1), "one ring slot per producer group");
 
@@ -77,8 +69,6 @@ struct OrderParams {
     const int4 *items;        // {row, begin, len, -}; chain rows first, group items from n_chain on
     const int32_t *unit_ptr, *units, *chunk_ptr;
     const int4 *chunks;       // {row, begin, count, flags}
-    const int4 *vchunks;      // the same list as half-chunks, two per chunk (ULTRA_CHAIN_OVERLAP; plan.hpp Schedule)
-    const int32_t *part_mode; // ... and per workgroup: chain side by side with the walkers (1) or classic (0)
     const int32_t *srec;      // group streams (plan.hpp Schedule): records and {first record, steps} per (workgroup, 16-lane group)
     const int2 *sdesc;
     int32_t use_streams;
@@ -387,31 +377,13 @@ __device__ __forceinline__ T chain_add_partial(T acc, const V (&v)[N], const int
     return acc;
 }
 
-// One lane hands a finished row (its stores reported complete) to the workgroup's update waves: slot = tail++,
-// queue[slot] = byte offset of the row, posted[slot / 32]++ (the generator's stream_post is the walkers' copy of this).
-__device__ __forceinline__ void post_row(const uint32_t ctl_addr, const uint32_t row_off) {
-    uint32_t slot, a;
-    asm volatile(
-        "ds_add_rtn_u32 %0, %2, %3\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_lshl_add_u32 %1, %0, 2, %2\n"
-        "ds_write_b32 %1, %4 offset:%5\n"
-        "v_lshrrev_b32_e32 %0, 5, %0\n"
-        "v_lshl_add_u32 %1, %0, 2, %2\n"
-        "ds_add_u32 %1, %3 offset:%6\n"
-        : "=&v"(slot), "=&v"(a)
-        : "v"(ctl_addr), "v"(1u), "v"(row_off), "n"(UPDATE_CTL_QUEUE_OFF), "n"(UPDATE_CTL_TILE_OFF)
-        : "memory");
-}
-
 // STREAMS: the group rows are walked as streams by the assembly loop (its own instantiation: the C++ unit walk
 // and the assembly walk in one kernel cost each other registers around the asm statements).
-// UPDATE: 0 none; 1 the layer update of the workgroup's rows in the kernel's TAIL (after every walk has ended); 2 the update
-// BESIDE the walk -- the last ORDER_UPDATERS waves do not walk: they wait for rows the walkers hand over through an LDS
-// queue and multiply them on the matrix cores while the walk goes on (what is left when the walks end is at most one
-// tile per update wave); 3 beside the walk with the aggregate passing THROUGH LDS: walkers park finished rows in 16-row tiles,
-// the update waves keep their slice of the weight matrix in registers and split every tile by features (update_tile.hpp,
-// UPD2_*) -- the aggregate never goes to memory, x and the output move as whole 256-byte rows.
+// UPDATE: 0 none; 1 the layer update of the workgroup's rows in the kernel's TAIL (after every walk has ended); 3 the update
+// BESIDE the walk with the aggregate passing THROUGH LDS -- the last ORDER_UPDATERS waves do not walk: the walkers park every
+// finished row (and its x row) in 16-row tiles, the update waves keep their slice of the weight matrix in registers and split
+// every tile by features (update_tile.hpp, UPD2_*); the aggregate never goes to memory, x and the output move as whole 256-byte
+// rows.  (2 was round 4's by-reference form: removed.)
 // (a workgroup of fewer than sixteen waves still keeps to 128 registers per lane: the wave slots it leaves are meant for
 // workgroups of other kernels, which need their share of the register file)
 #if ULTRA_ORDER_WAVES < 16
@@ -430,10 +402,6 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *lds_rel = reinterpret_cast<T *>(smem);
     T *ring = lds_rel + ((REL_LDS && MUL != BIN_RHS) ? (size_t)(p.num_rel + 1) * SPAN : 0);   // [2][CHAIN_QUADS][64][4]; (+ 1: marker row)
-    // Chain and stream phases side by side (plan.hpp ULTRA_CHAIN_OVERLAP): the stream kernels' chain runs on nine waves and
-    // hands chunks over through LDS words instead of workgroup barriers; the other seven waves are already walking.
-    constexpr bool OVERLAP = STREAMS && ULTRA_CHAIN_OVERLAP && ULTRA_ASM_PRODUCE;
-    constexpr int OV_RING_HALF = 16 * 64;   // quads-of-lane units per ring half in that form (16 quads: see the generator)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -442,8 +410,8 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
     const int part = blockIdx.x / p.smod;
     if (part >= p.nparts) return;
     const T *wt = reinterpret_cast<const T *>(p.w);
-    // UPDATE == 2: the hand-off block (see ORDER_UPDATERS); the weight image takes the ring's place once the chain is done
-    volatile uint32_t *ctl = reinterpret_cast<volatile uint32_t *>(smem + (UPDATE >= 2 ? p.upd.ctl_off : 0));
+    // UPDATE == 3: the control block of the hand-off (update_tile.hpp UPD2_CTL_*)
+    volatile uint32_t *ctl = reinterpret_cast<volatile uint32_t *>(smem + (UPDATE == 3 ? p.upd.ctl_off : 0));
     const T fill = (SUM != 0 && p.bnd_fill_on) ? (T)p.bnd_fill : nary_zero<T, SUM>();   // (what a non-boundary row meets under min / max)
 
     // a bounded spin gave up (OrderParams::err): one store to the host's error word, system scope
@@ -482,14 +450,8 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
 
         if (REL_LDS && MUL != BIN_RHS) {
             __syncthreads();  // readers of the previous span are done with the LDS image
-            if constexpr (OVERLAP) {   // hand-off words {ready[0], ready[1], done} behind the ring (see the chain phase)
-                if (tid < 3) reinterpret_cast<volatile int *>(reinterpret_cast<char *>(ring) + 2 * OV_RING_HALF * 16)[tid] = 0;
-            }
             // (the staging addresses are recomputed per span: hoisted out of the span loop they would stay live through
             // the walks below and spill)
-            if constexpr (UPDATE == 2) {
-                if (tid < 4 + UPDATE_CTL_TILES) ctl[tid] = 0;
-            }
             if constexpr (UPDATE == 3) {
                 if (tid < UPD2_CTL_CTILE_BYTES / 4) ctl[tid] = 0;
             }
@@ -507,12 +469,8 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
         // lgkmcnt(0)), so a ring half is never overwritten early.  Producers and the consumer run separate loops with
         // the same number of barriers: one per chunk.
         const int c0 = p.has_chain ? p.chunk_ptr[part] : 0, c1 = p.has_chain ? p.chunk_ptr[part + 1] : 0;
-        // this workgroup's chain (workgroup-uniform): 0 classic (one barrier per chunk), 1 side by side with its walkers (nine-wave
-        // crew, LDS-word hand-off), 2 classic with the LDS-word hand-off
-        int ov = 0;
-        if constexpr (OVERLAP) ov = load_uniform(p.part_mode + part);
-        const int RING_HALF = ov == 1 ? OV_RING_HALF : CHAIN_QUADS * 64;   // in quads-of-lane units (V)
-        if (c1 > c0 && (ov != 1 || wave <= ORDER_OV_PRODUCERS)) {
+        constexpr int RING_HALF = CHAIN_QUADS * 64;   // in quads-of-lane units (V)
+        if (c1 > c0) {
             const LaneGeom cg = lane_geom();
             const int grp = cg.grp, l16 = cg.l16;
             const uint32_t lane_bytes = cg.lane_bytes;
@@ -524,17 +482,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
 #endif
                 const int d = inner * SPAN + chain_element(lane);
                 int n_listed = 0;            // UPDATE == 3: chain rows listed for the update waves (they fetch them from memory)
-                long long posted_off = -1;   // UPDATE == 2: the row stored last, not yet handed to the update waves
-                const auto post_pending = [&]() {
-                    if constexpr (UPDATE == 2) {
-                        if (posted_off >= 0) {
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (issued a whole row ago: no stall in practice)
-                            if (lane == 0) post_row(lds_addr(const_cast<uint32_t *>(ctl)), (uint32_t)posted_off);
-                        }
-                    }
-                };
                 const auto finish_row = [&](const int row, T v) {
-                    post_pending();
                     if (d < p.row_len) {
                         if (p.has_bnd) {
                             if (bnd_row < 0 || bnd_row == row)
@@ -545,9 +493,8 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                         }
                         reinterpret_cast<T *>(p.out)[outer * p.out_stride_outer + (long long)row * p.out_stride_row + d] = v;
                     }
-                    posted_off = (long long)row * (long long)p.x_row_bytes;
                     if constexpr (UPDATE == 3) {
-                        if (lane == 0) ctl[UPD2_CTL_CROW + min(n_listed, UPD2_MAX_CHAIN_ROWS - 1)] = (uint32_t)posted_off;
+                        if (lane == 0) ctl[UPD2_CTL_CROW + min(n_listed, UPD2_MAX_CHAIN_ROWS - 1)] = (uint32_t)((long long)row * (long long)p.x_row_bytes);
                         ++n_listed;      // (the host does not pick this form for a schedule with more chain rows per workgroup)
                     }
                 };
@@ -570,34 +517,8 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
 #else
 #define ULTRA_CHAIN_BARRIER() __syncthreads()
 #endif
-                // side-by-side form: "chunk kc is parked" = ready[kc & 1] has reached 16 per chunk of that parity (eight
-                // producer waves x two half-chunks); the consumer publishes done = kc + 1 right behind its last read of chunk
-                // kc (a wave's LDS operations execute in order), which frees that ring half for chunk kc + 2
-                volatile int *ov_flags = reinterpret_cast<volatile int *>(reinterpret_cast<char *>(ring) + 2 * OV_RING_HALF * 16);
-                int kc = 0, ready_seen = 0;   // ready_seen: ready[kc & 1] as read right behind the previous chunk's ring reads
-                const auto chunk_wait = [&]() {
-                    if (OVERLAP && ov) {
-                        const int target = (ov == 1 ? 16 : 15) * ((kc >> 1) + 1);
-                        if (ready_seen < target) {
-#if ULTRA_OV_SPIN
-                            while (ov_flags[kc & 1] < target) {}
-#else
-                            while (ov_flags[kc & 1] < target) __builtin_amdgcn_s_sleep(1);
-#endif
-                        }
-                        asm volatile("" ::: "memory");
-                    } else {
-                        ULTRA_CHAIN_BARRIER();
-                    }
-                };
-                const auto chunk_read = [&]() {
-                    if (OVERLAP && ov) {
-                        asm volatile("" ::: "memory");
-                        ov_flags[2] = ++kc;
-                        ready_seen = ov_flags[kc & 1];   // (returns behind the ring reads: off the critical path when the producers are ahead)
-                        asm volatile("" ::: "memory");
-                    }
-                };
+                const auto chunk_wait = [&]() { ULTRA_CHAIN_BARRIER(); };
+                const auto chunk_read = [&]() {};
                 for (int it = c0; it < c1;) {
                     const int row = desc[0], len = desc[3] >> 2;
                     const int nfull = len / CHAIN_SLOTS, rem = len - nfull * CHAIN_SLOTS;
@@ -662,12 +583,6 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                     finish_row(row, cacc);
                     it += nch;
                 }
-                post_pending();
-                if constexpr (UPDATE == 2) {
-                    // (behind the last post in this wave's LDS order; the ring is free: its last reads have been added)
-                    asm volatile("" ::: "memory");
-                    if (lane == 0) ctl[3] = 1;
-                }
                 if constexpr (UPDATE == 3) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chain rows are in memory: the update waves read them there
                     if (lane == 0) {
@@ -695,21 +610,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                     for (int k = c0; k < c1; ++k) __syncthreads();
                 } else
 #endif
-                if (OVERLAP && ov == 2) {
-                    order_produce_polled_asm<MUL>(c1 - c0, p.chunks + c0, (uint32_t)slot * 8u, lane_bytes, lds_addr(lds_rel_lane),
-                                                  lds_addr(ring) + (uint32_t)((wave - 1) * 64 + lane) * 16u,
-                                                  lds_addr(ring) + 2u * OV_RING_HALF * 16u, xbase, reinterpret_cast<const char *>(p.rec),
-                                                  p.x_row_bytes);
-                } else if (OVERLAP && ov == 1) {
-#if ULTRA_OV_PROD_PRIO
-                    __builtin_amdgcn_s_setprio(ULTRA_OV_PROD_PRIO);
-#endif
-                    // half-chunks: this group's slot is 4 (wave - 1) + grp of 0..31 in each; see the generator
-                    order_produce_overlap_asm<MUL>(2 * (c1 - c0), p.vchunks + 2 * c0, (uint32_t)slot * 8u, lane_bytes, lds_addr(lds_rel_lane),
-                                                   lds_addr(ring) + (uint32_t)((wave - 1) * 64 + lane) * 16u,
-                                                   lds_addr(ring) + 2u * OV_RING_HALF * 16u, xbase, reinterpret_cast<const char *>(p.rec),
-                                                   p.x_row_bytes);
-                } else if constexpr (STREAMS && ULTRA_ASM_PRODUCE) {   // (the unit-walk kernels keep the C++ producers: see STREAMS)
+                if constexpr (STREAMS && ULTRA_ASM_PRODUCE) {   // (the unit-walk kernels keep the C++ producers: see STREAMS)
                     order_produce_asm<MUL>(c1 - c0, p.chunks + c0, (uint32_t)slot * 8u, lane_bytes, lds_addr(lds_rel_lane),
                                            lds_addr(ring) + (uint32_t)((wave - 1) * 64 + lane) * 16u, xbase,
                                            reinterpret_cast<const char *>(p.rec), p.x_row_bytes);
@@ -795,7 +696,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
         const uint32_t lane_bytes = ug.lane_bytes;
         const T *lds_rel_lane = ug.lds_rel_lane;
         if constexpr (STREAMS) {
-            if (UPDATE < 2 || wave < ORDER_WALKERS) {
+            if (UPDATE != 3 || wave < ORDER_WALKERS) {
                 // ---- group streams: one continuous walk per 16-lane group (rspmm_order_asm.hpp) ----
                 if constexpr (UPDATE == 3) {   // (the tiles the walk parks its rows in take the ring's place)
                     if (c1 > c0) {
@@ -829,7 +730,7 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                 // (ULTRA_STREAM_DIET, rspmm_order_asm.hpp: the walk tests "is this lane's step inside its stream" as step < lim with the
                 // step in an SGPR, lim = len - lane % 8; a marker record's type is num_rel -- times 256 in the pre-shifted records of
                 // the twelve-walker schedules, which the hand-off forms read)
-                constexpr int POST = UPDATE >= 2 ? UPDATE - 1 : 0;
+                constexpr int POST = UPDATE == 3 ? 2 : 0;      // (the generator's POST == 2: rows parked in LDS, stream_park)
 #if ULTRA_STREAM_DIET
                 const int l8_arg = len - (l16 & 7);
                 const uint32_t rmk = (uint32_t)p.num_rel << ((POST != 0 && ULTRA_STREAM_PRESHIFT_GEN) ? 8 : 0);
@@ -843,14 +744,12 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                                                      reinterpret_cast<const char *>(p.srec),
                                                      reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.out) + outer * p.out_stride_outer),
                                                      p.x_row_bytes, lds_addr(const_cast<uint32_t *>(ctl)), lds_addr(ring), rmk);
-                if constexpr (UPDATE >= 2) {
+                if constexpr (UPDATE == 3) {
                     // this wave has posted all its rows (the walk ends on vmcnt(0) + its last posts; LDS operations of a
                     // wave execute in order)
                     asm volatile("" ::: "memory");
-                    if constexpr (UPDATE == 3) {
-                        // (the generated walk cannot reach OrderParams: a park wait that gave up left its code in the control block)
-                        if (lane == 0 && ctl[UPD2_CTL_ERR] != 0) report_spin(ORDER_SPIN_PARK);
-                    }
+                    // (the generated walk cannot reach OrderParams: a park wait that gave up left its code in the control block)
+                    if (lane == 0 && ctl[UPD2_CTL_ERR] != 0) report_spin(ORDER_SPIN_PARK);
                     if (lane == 0) __hip_atomic_fetch_add(const_cast<uint32_t *>(ctl) + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
@@ -1145,60 +1044,6 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                     }
                 }
             }
-            if constexpr (UPDATE == 2) {
-                if (wave >= ORDER_WALKERS) {
-                    // ---- update waves: rows come over the LDS queue in posting order, 32 to a tile; update wave u takes tiles
-                    // u, u + ORDER_UPDATERS, ...  A tile is ready when its 32 rows are posted -- or, once every walker has
-                    // finished, with the rows there are (the workgroup's last, partial tile). ----
-                    int tid_u = tid;
-                    asm volatile("" : "+v"(tid_u));
-                    if (c1 > c0) {
-                        while (ctl[3] == 0) __builtin_amdgcn_s_sleep(4);   // the chain consumer still reads the ring
-                    }
-                    float *lds_w = reinterpret_cast<float *>(ring);
-                    update_stage_weights(lds_w, p.upd.weight, p.upd.bias, p.upd.ln_w, p.upd.ln_b, p.upd.flags, tid_u - ORDER_WALKERS * 64,
-                                         ORDER_UPDATERS * 64);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_fetch_add(const_cast<uint32_t *>(ctl) + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    while (ctl[2] < (uint32_t)ORDER_UPDATERS) __builtin_amdgcn_s_sleep(1);
-                    asm volatile("" ::: "memory");
-                    const int lane_u = tid_u & 63, ju = lane_u & 31, hu = lane_u >> 5;
-                    const char *aggbase = reinterpret_cast<const char *>(reinterpret_cast<const T *>(p.out) + outer * p.out_stride_outer);
-                    float *ubase = p.upd.out + outer * p.upd.out_stride_outer;
-                    const volatile uint32_t *queue = ctl + UPDATE_CTL_QUEUE_OFF / 4;
-                    for (int t = wave - ORDER_WALKERS;; t += ORDER_UPDATERS) {
-                        int n;
-                        for (;;) {
-                            const uint32_t walked = ctl[1];   // (read FIRST: with every walker done, the reads below see the final state)
-                            asm volatile("" ::: "memory");
-                            const uint32_t have = ctl[UPDATE_CTL_TILE_OFF / 4 + t];
-                            if (have == 32u) {
-                                n = 32;
-                                break;
-                            }
-                            if (walked == (uint32_t)ORDER_WALKERS) {
-                                n = min(32, (int)ctl[0] - 32 * t);
-                                break;
-                            }
-                            __builtin_amdgcn_s_sleep(8);
-                        }
-                        n = rfl(n);
-                        if (n <= 0) break;
-                        if (p.upd.flags & CONV_DBG_NO_UPDATE) continue;
-                        const bool valid = ju < n;
-                        const uint32_t roff = (valid ? queue[32 * t + ju] : 0u) + (uint32_t)hu * 16u;
-                        const float4 *xr = reinterpret_cast<const float4 *>(xbase + roff);
-                        const float4 *ar = reinterpret_cast<const float4 *>(aggbase + roff);
-                        float4 b[16];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) b[i] = xr[2 * i];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) b[8 + i] = ar[2 * i];
-                        update_tile(b, lds_w, lane_u, p.upd.flags, p.upd.eps,
-                                    reinterpret_cast<float *>(reinterpret_cast<char *>(ubase) + (roff - (uint32_t)hu * 16u)), valid);
-                    }
-                }
-            }
             // (measurement hook: when each wave's walk ended, trace[8 * grid + 16 * workgroup + wave]; the buffer holds 32 * grid words)
             if (p.trace && lane == 0) p.trace[8 * gridDim.x + 16 * blockIdx.x + wave] = clock64();
             if constexpr (UPDATE == 1) {
@@ -1320,9 +1165,8 @@ inline hipError_t launch_order_one(const OrderParams &p, int grid, size_t lds, h
     if constexpr (OrderAsm<T, MUL, REL_LDS, WEIGHTED>::value) {
         if constexpr (sizeof(T) == 4) {
             if (p.use_streams && p.upd.weight)
-                return p.upd.mode == 3   ? launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true, 3>(p, grid, lds, s)
-                       : p.upd.mode == 2 ? launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true, 2>(p, grid, lds, s)
-                                         : launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true, 1>(p, grid, lds, s);
+                return p.upd.mode == 3 ? launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true, 3>(p, grid, lds, s)
+                                       : launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true, 1>(p, grid, lds, s);
         }
         if (p.use_streams) return launch_order_inst<T, SUM, MUL, REL_LDS, WEIGHTED, true>(p, grid, lds, s);
     }

@@ -170,9 +170,14 @@ class PipelinedForward(object):
 
     Reference-order plans only: the re-associating plans keep per-plan scratch that concurrent forwards would share."""
 
-    def __init__(self, model, data, example_batch, depth=2, warmup=3, slot_factory=None, share_chip="auto"):
+    def __init__(self, model, data, example_batch, depth=2, warmup=3, slot_factory=None, share_chip="auto", trial_post=None):
         """slot_factory: what builds one slot's forward (default: a GraphedForward of `model`); a CPU batch gets slots without
-        streams -- the collective-ordering contract of `post=` is testable without a GPU (tests/test_distributed.py)."""
+        streams -- the collective-ordering contract of `post=` is testable without a GPU (tests/test_distributed.py).
+        trial_post: the `post=` the caller will pass to every step (a multi-GPU step's all-gather): the short trial that picks the
+        slots' streams (pick_slot_streams) then runs the steps WITH it -- how a pair of streams interleaves depends on the
+        collective's stream too (measured: a launcher's rank whose trial left the all-gather out could not tell the pairs apart,
+        0.593 vs 0.590 ms, and then ran at 0.60 on the pair that runs at 0.574 with the other).  Every rank runs the same number of
+        trial steps, so the collectives pair up."""
         if not rspmm._plan_defaults["exact_order"]:
             raise RuntimeError("PipelinedForward needs the reference-order plans (the re-associating plans own scratch buffers)")
         grid = 0
@@ -203,7 +208,7 @@ class PipelinedForward(object):
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
                 for _ in range(steps):
-                    self(example_batch)
+                    self(example_batch, post=trial_post)
                 self.join()
                 torch.cuda.synchronize(dev)
                 return (time.perf_counter() - t0) / steps
