@@ -340,6 +340,33 @@ def test_dense_order_layer_matches_rspmm_plus_update(dev, residual, layer_norm, 
     assert (got - want).abs().max().item() <= 2e-5 * max(scale, 1.0)
 
 
+@pytest.mark.parametrize("N", [474, 40, 17, 33])
+def test_dense_order_layer_with_two_row_tiles_per_workgroup_keeps_its_bits(dev, N, monkeypatch):
+    """The relation-graph layer with TWO 16-row tiles per workgroup over one stream of B operands (dense_order_layer_kernel<2>,
+    ULTRA_DOL_TILES=2 -- VERDICT r4 item 3a: built, measured slower in the step, not the default): the same bits as one tile per
+    workgroup -- an even and an odd number of tiles, a last tile with fewer than 16 rows."""
+    from torch import nn
+    from ultra_amd.rspmm import Plan
+    ei, et = _relation_like_graph(N, 0.97, seed=N)
+    bs = 5
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(bs, N, 64, generator=g).to(dev)
+    rel = torch.randn(bs, 4, 64, generator=g).to(dev) * 0.1
+    point = (torch.arange(bs).to(dev) * 3 % N, torch.randn(bs, 64, generator=g).to(dev))
+    tensor_bnd = torch.randn(bs, N, 64, generator=g).to(dev)
+    torch.manual_seed(1)
+    lin, ln = nn.Linear(128, 64).to(dev), nn.LayerNorm(64).to(dev)
+    plan = Plan(ei, et, N, 4, exact_order=True)
+    assert plan.dense is not None
+    outs = {}
+    for tiles in ("1", "2"):
+        monkeypatch.setenv("ULTRA_DOL_TILES", tiles)
+        outs[tiles] = (plan.fused_layer(rel, x, lin, layer_norm=ln, relu=True, residual=True, point=point),
+                       plan.fused_layer(rel, x, lin, layer_norm=None, relu=False, residual=False, boundary=tensor_bnd))
+    assert all(o is not None for pair in outs.values() for o in pair)
+    assert torch.equal(outs["1"][0], outs["2"][0]) and torch.equal(outs["1"][1], outs["2"][1])
+
+
 @pytest.mark.parametrize("sum,mul", list(itertools.product(SUMS, MULS)))
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("surface", ["ctypes", "pybind"])

@@ -11,6 +11,8 @@ layer = layers.GeneralizedRelationalConv(64, 64, 4, 64, "distmult", "sum", True,
 x = torch.randn(8, rg.num_nodes, 64, device=dev)
 rel = torch.randn(8, 4, 64, device=dev)
 run = lambda: plan.fused_layer(rel, x, layer.linear, layer.layer_norm, relu=True, residual=True)
+if os.environ.get("PROBE_GRID"):       # a launch-grid tuning below the CU count: the two-tile form of the layer
+    rspmm.set_tuning(grid=int(os.environ["PROBE_GRID"]))
 for _ in range(5):
     run()
 g = torch.cuda.CUDAGraph()

@@ -75,9 +75,10 @@ main = t[:3 * grid].view(grid, 3).double()
 wave_end = t[8 * grid:24 * grid].view(grid, 16).double() - main[:, :1]
 chain = main[:, 1] - main[:, 0]
 end = main[:, 2] - main[:, 0]
-print("%s bs %d %s grid %d form %d: %.2f us (min %.2f max %.2f) equal %s | chains %.0f walkers %.0f update %.0f | end mean %.0f max %.0f"
+retries = t[24 * grid:25 * grid].double()
+print("%s bs %d %s grid %d form %d: %.2f us (min %.2f max %.2f) equal %s | chains %.0f walkers %.0f update %.0f | end mean %.0f max %.0f | ring-full retries mean %.1f max %.0f"
       % (shape, bs, agg_sum, grid, form, times[2], times[0], times[-1], equal, chain.mean(), wave_end[:, :12].max(dim=1)[0].mean(),
-         wave_end[:, 12:].max(dim=1)[0].mean(), end.mean(), end.max()))
+         wave_end[:, 12:].max(dim=1)[0].mean(), end.mean(), end.max(), retries.mean(), retries.max()))
 if os.environ.get("PROBE_DUMP_PARTS"):
     nparts = grid // bs
     print("PARTS end " + " ".join("%.0f" % v for v in end.view(nparts, bs).mean(dim=1).tolist()))

@@ -103,6 +103,8 @@ HANDOFF2_ROW_BYTES = 272
 HANDOFF2_CONSUMED_OFF, HANDOFF2_POSTED_OFF, HANDOFF2_ROWID_OFF = 16, 32, 64
 # a park wait that gave up leaves a non-zero word here (UPD2_CTL_ERR in update_tile.hpp; the kernel's C++ forwards it to the host)
 HANDOFF2_ERR_OFF = 28
+HANDOFF2_RETRY_OFF = 24     # (UPD2_CTL_RETRIES: how often a park wait found the ring full and went to sleep)
+PARK_DIAG = os.environ.get("ULTRA_GEN_PARK_DIAG", "0") == "1"     # measurement builds: count those retries (trace hook)
 PARK_SPIN_CAP = 1 << 20
 HANDOFF2_X_OFF = HANDOFF2_NT * 16 * HANDOFF2_ROW_BYTES     # the x rows' ring sits behind the aggregates'
 
@@ -130,6 +132,11 @@ def stream_park(a, ob_q, x_q, tag):
     a("s_andn2_b64 vcc, exec, vcc")
     a("s_cbranch_vccz .Lpark_go_%s_%%=" % tag)
     a("s_sleep 2")
+    if PARK_DIAG:      # (measurement builds: one count per retry and wave -- an LDS atomic by every parking lane costs the walk 50 %)
+        a("s_mov_b64 %[mk], exec")
+        a("s_mov_b64 exec, 1")
+        a("ds_add_u32 v124, v125 offset:%d" % HANDOFF2_RETRY_OFF)
+        a("s_mov_b64 exec, %[mk]")
     a("s_add_u32 %[t1], %[t1], 1")
     a("s_cmp_lt_u32 %%[t1], 0x%x" % PARK_SPIN_CAP)
     a("s_cbranch_scc0 .Lpark_giveup_%s_%%=" % tag)

@@ -67,3 +67,35 @@ for q in range(3):
 A[:, 3] = Rw.ravel()
 coef = np.linalg.lstsq(A, t_all, rcond=None)[0]
 print("all waves: c0 %.1f c1 %.1f c2 %.1f cycles a step, r %.1f cycles a row; rms %.0f" % (coef[0], coef[1], coef[2], coef[3], np.sqrt(((t_all - A @ coef) ** 2).mean())))
+
+# ---- gathers by how hot their source row is (how often the graph gathers it: hot rows hit the vector L1 / L2) ----
+deg_src = np.bincount(data.edge_index[1].numpy(), minlength=N)
+rank = np.empty(N, dtype=np.int64)
+rank[np.argsort(-deg_src)] = np.arange(N)
+for cut in (300, 1000, 3000):
+    cold = np.zeros((nparts, 64))
+    for q in range(nparts):
+        for g in range(48):
+            first, n = int(sdesc[q, g, 0]), int(sdesc[q, g, 1])
+            seg = srec[first:first + n]
+            cols = seg[seg[:, 1] != R, 0]
+            cold[q, g] = (rank[cols] >= cut).sum()
+    Cw = cold[:, :48].reshape(nparts, 12, 4).max(axis=2)       # (the wave's slowest stream)
+    Csum = cold[:, :48].reshape(nparts, 12, 4).sum(axis=2)
+    A = np.zeros((nparts * 12, 7))
+    for q in range(3):
+        sel = np.zeros((nparts, 12), dtype=bool)
+        sel[:, 4 * q:4 * q + 4] = True
+        A[sel.ravel(), q] = S[sel]
+        A[sel.ravel(), 3 + q] = Csum[sel] / 4.0
+    A[:, 6] = Rw.ravel()
+    coef = np.linalg.lstsq(A, t_all, rcond=None)[0]
+    print("cold = source rank >= %d: steps c0 %.0f c1 %.0f c2 %.0f | extra per cold gather %.0f %.0f %.0f | row %.0f | rms %.0f"
+          % (cut, coef[0], coef[1], coef[2], coef[3], coef[4], coef[5], coef[6], np.sqrt(((t_all - A @ coef) ** 2).mean())))
+# per quartet: share of cold gathers and mean row length of its streams
+for q in range(3):
+    sl = slice(16 * q, 16 * q + 16)
+    print("quartet %d: steps a stream %.0f, rows a stream %.1f, cold share (rank >= 1000) %.3f" %
+          (q, steps[:, sl].mean(), rows[:, sl].mean(), 0.0 if steps[:, sl].sum() == 0 else
+           sum((rank[srec[int(sdesc[p_, g, 0]):int(sdesc[p_, g, 0]) + int(sdesc[p_, g, 1])][:, 0][srec[int(sdesc[p_, g, 0]):int(sdesc[p_, g, 0]) + int(sdesc[p_, g, 1])][:, 1] != R]] >= 1000).sum()
+               for p_ in range(nparts) for g in range(16 * q, 16 * q + 16)) / max(1.0, (steps[:, sl] - rows[:, sl]).sum())))

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 
 #ifndef ULTRA_DOL_ASM
@@ -71,25 +72,37 @@ __device__ __forceinline__ float byte_of(uint32_t w, int q) { return (float)((w 
 #else
 #define ULTRA_DOL_ATTR
 #endif
+// TILES: 16-row tiles of one workgroup (1 or 2).  Two tiles share every B operand of the chain -- the messages rel * x[column] are
+// the same for all rows; only the adjacency bytes and the accumulator differ -- so a wave runs two independent chains over one
+// stream of operands: half the workgroups (120 instead of 240 at 474 nodes x 8 samples), half the x traffic, and the second
+// chain's matrix instruction hides the byte -> float conversions and the product that one chain per SIMD leaves in the open.
+// Chosen where the launch does not own the chip (two batches in flight: the relation-graph layers of one batch run on the 64 CUs
+// the other batch's entity layers leave -- 240 workgroups need two rounds there, 120 one); same bits either way.
+template <int TILES>
 __global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(const DenseOrderParams p) {
-    __shared__ __attribute__((aligned(16))) float x_lds[16 * DOL_ROW_STRIDE];     // this tile's own rows of x
-    __shared__ __attribute__((aligned(16))) float agg_lds[16 * DOL_ROW_STRIDE];
-    __shared__ float ln_mom[16][8][2];
-    __shared__ float ln_stat[16][2];
+    __shared__ __attribute__((aligned(16))) float x_lds[TILES * 16 * DOL_ROW_STRIDE];     // the tiles' own rows of x
+    __shared__ __attribute__((aligned(16))) float agg_lds[TILES * 16 * DOL_ROW_STRIDE];
+    __shared__ float ln_mom[TILES * 16][8][2];
+    __shared__ float ln_stat[TILES * 16][2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kk = lane >> 4;
-    const int rt = blockIdx.x % p.n_rt16, outer = blockIdx.x / p.n_rt16;
+    const int n_wt = (p.n_rt16 + TILES - 1) / TILES;       // workgroups per sample
+    const int rt = blockIdx.x % n_wt, outer = blockIdx.x / n_wt;
     const float *xo = p.x + (long long)outer * p.x_so;
-    const int row0 = rt * 16;
+    const int row0 = rt * 16 * TILES;
     const int c0 = 16 * wave;
+    // (a second tile past the graph: reads the last tile's adjacency, its rows are never stored)
+    const bool tile1 = TILES > 1 && TILES * rt + 1 < p.n_rt16;
 
     // ---- phase 1 operands: all requested before anything waits ----
     // One wave per SIMD: whatever the wave does between two matrix instructions of the chain stalls the chain.  The fetch
     // of a stage is therefore pure load issue: a uniform (scalar) base per stage + per-lane byte offsets computed once
     // (global_load v, v_off, s[base]) -- no multiplies, no clamps in the loop.  Only the last stage can touch columns past
     // n_in (their adjacency bytes are 0); it has its own, clamped offsets.
-    const uint4 *ap = p.a_ex + (size_t)rt * p.n_jc * 64;
+    const uint4 *ap[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) ap[t] = p.a_ex + (size_t)min(TILES * rt + t, p.n_rt16 - 1) * p.n_jc * 64;
     const char *xbase = reinterpret_cast<const char *>(xo);
     const uint32_t x_row_bytes = (uint32_t)p.x_sr * 4u;
     const uint32_t lane_bytes = (uint32_t)(c0 + i16) * 4u;       // B operand: lane (kk, n) reads x[j][c0 + n]
@@ -101,13 +114,14 @@ __global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(c
         voff_last[q] = (uint32_t)min(16 * (p.n_jc - 1) + q, p.n_in - 1) * x_row_bytes + lane_bytes;
     }
     struct Stage {
-        uint4 a;
+        uint4 a[TILES];
         float x[16];
     };
     const auto fetch = [&](const int jc, Stage &st) {
         const bool last = jc >= p.n_jc - 1;                                   // uniform
         const int jcc = last ? p.n_jc - 1 : jc;
-        st.a = ap[(size_t)jcc * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) st.a[t] = ap[t][(size_t)jcc * 64 + lane];
         const char *sbase = xbase + (last ? 0u : (uint32_t)jcc * 16u * x_row_bytes);
 #pragma unroll
         for (int q = 0; q < 16; ++q) st.x[q] = *reinterpret_cast<const float *>(sbase + (last ? voff_last[q] : voff[q]));
@@ -121,12 +135,13 @@ __global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(c
 #endif
     const float relv = kk < p.n_rel ? p.rel[(long long)outer * p.rel_so + (long long)kk * p.rel_sr + c0 + i16] : 0.f;
 
-    // the tile's own x rows (update input and residual), the update weights of this wave's feature tile and the small
+    // the tiles' own x rows (update input and residual), the update weights of this wave's feature tile and the small
     // vectors of phases 2 / 3: requested now, consumed after the chain
-    float4 xtile;
-    {
-        const int row = min(row0 + (tid >> 4), p.n_out - 1);
-        xtile = *reinterpret_cast<const float4 *>(xo + (long long)row * p.x_sr + 4 * (tid & 15));
+    float4 xtile[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        const int row = min(row0 + 16 * t + (tid >> 4), p.n_out - 1);
+        xtile[t] = *reinterpret_cast<const float4 *>(xo + (long long)row * p.x_sr + 4 * (tid & 15));
     }
     float wfrag[32];   // A operand of phase 3: lane (i, kk) holds W[16 ft + i][4 s + kk], ft = wave
 #pragma unroll
@@ -139,34 +154,48 @@ __global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(c
         lnw[r] = (p.flags & DOL_LN) ? p.ln_w[f0 + r] : 1.f;
         lnb[r] = (p.flags & DOL_LN) ? p.ln_b[f0 + r] : 0.f;
     }
-    float bndv[4] = {0.f, 0.f, 0.f, 0.f};   // boundary addends of the accumulator elements (row 4 kk + r, column c0 + i16)
+    float bndv[TILES][4];   // boundary addends of the accumulator elements (row 4 kk + r of a tile, column c0 + i16)
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bndv[t][r] = 0.f;
     if (p.has_bnd) {
         const long long bnd_row = p.bnd_rows ? p.bnd_rows[outer] : -1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + 4 * kk + r;
-            if (row < p.n_out && (bnd_row < 0 || bnd_row == row))
-                bndv[r] = p.bnd[(long long)outer * p.bnd_so + (long long)row * p.bnd_sr + c0 + i16];   // (bnd_sr == 0 for a point)
-        }
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 16 * t + 4 * kk + r;
+                if (row < p.n_out && (bnd_row < 0 || bnd_row == row))
+                    bndv[t][r] = p.bnd[(long long)outer * p.bnd_so + (long long)row * p.bnd_sr + c0 + i16];   // (bnd_sr == 0 for a point)
+            }
     }
 
-    // ---- phase 1: the chain ----
-    f32x4 acc;
+    // ---- phase 1: the chain(s) ----
+    f32x4 acc[TILES];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = 0.f;
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
 #if ULTRA_DOL_ASM
-    dense_order_chain_asm(acc, p.n_jc, p.n_in, (uint32_t)lane * 16u, ap, xbase, lane_bytes, x_row_bytes, relv, (uint32_t)tid * 128u);
+    static_assert(TILES == 1, "the assembly chain of the measurement build walks one tile");
+    dense_order_chain_asm(acc[0], p.n_jc, p.n_in, (uint32_t)lane * 16u, ap[0], xbase, lane_bytes, x_row_bytes, relv, (uint32_t)tid * 128u);
 #else
     const auto chain = [&](const Stage &cur, const int jc) {
         // (stages past the graph chain zeros: fma(0, b, acc) = acc exactly -- rounds have no conditional exit, which
         // would be a join where the compiler stops counting outstanding loads and drains the queue)
         const uint32_t m = jc < p.n_jc ? 0xffffffffu : 0u;
-        const uint32_t aw[4] = {cur.a.x & m, cur.a.y & m, cur.a.z & m, cur.a.w & m};
+        uint32_t aw[TILES][4];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            aw[t][0] = cur.a[t].x & m, aw[t][1] = cur.a[t].y & m, aw[t][2] = cur.a[t].z & m, aw[t][3] = cur.a[t].w & m;
+        }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const float a = byte_of(aw[q >> 2], q & 3);
             const float b = relv * cur.x[q];          // the message, rounded on its own like rspmm.cpp:67
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(byte_of(aw[t][q >> 2], q & 3), b, acc[t], 0, 0, 0);
         }
     };
     for (int jc = 0; jc < p.n_jc; jc += 3) {
@@ -179,39 +208,49 @@ __global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(c
     }
 #endif
 
-    // ---- phase 2: + boundary (layers.py:199-200), aggregate tile and x tile to LDS ----
+    // ---- phase 2: + boundary (layers.py:199-200), aggregate tiles and x tiles to LDS ----
     // D layout: lane l, reg r -> tile row 4 (l >> 4) + r, column l & 15
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float v = acc[r];
-        if (p.has_bnd) v += bndv[r];   // (exactly 0 where there is no boundary value: same bits as not adding)
-        agg_lds[(4 * kk + r) * DOL_ROW_STRIDE + c0 + i16] = v;
+    for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[t][r];
+            if (p.has_bnd) v += bndv[t][r];   // (exactly 0 where there is no boundary value: same bits as not adding)
+            agg_lds[(16 * t + 4 * kk + r) * DOL_ROW_STRIDE + c0 + i16] = v;
+        }
+        *reinterpret_cast<float4 *>(x_lds + (16 * t + (tid >> 4)) * DOL_ROW_STRIDE + 4 * (tid & 15)) = xtile[t];
     }
-    *reinterpret_cast<float4 *>(x_lds + (tid >> 4) * DOL_ROW_STRIDE + 4 * (tid & 15)) = xtile;
     __syncthreads();
 
     // ---- phase 3: update (feature tile ft = wave): B operand lane (kk, j) holds data[row j][4 s + kk], data = cat[x, agg] ----
-    f32x4 d;
+    f32x4 d[TILES];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) d[r] = 0.f;
+    for (int t = 0; t < TILES; ++t) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[s], x_lds[i16 * DOL_ROW_STRIDE + 4 * s + kk], d, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) d[t][r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[16 + s], agg_lds[i16 * DOL_ROW_STRIDE + 4 * s + kk], d, 0, 0, 0);
+        for (int s = 0; s < 16; ++s)
+            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[s], x_lds[(16 * t + i16) * DOL_ROW_STRIDE + 4 * s + kk], d[t], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[16 + s], agg_lds[(16 * t + i16) * DOL_ROW_STRIDE + 4 * s + kk], d[t], 0, 0, 0);
+    }
     // D: lane l, reg r -> feature 16 ft + 4 (l >> 4) + r of tile row l & 15
-    float y[4];
+    float y[TILES][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) y[r] = d[r] + biasv[r];
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[t][r] = d[t][r] + biasv[r];
     if (p.flags & DOL_LN) {
-        // LayerNorm in the reference's operation order (torch_math.hpp): the pre-norm tile goes through LDS (agg_lds is
+        // LayerNorm in the reference's operation order (torch_math.hpp): the pre-norm tiles go through LDS (agg_lds is
         // free again), 8 threads per row run the Welford accumulators i = 0..7 over features 8 j + i, one merges them.
         __syncthreads();   // every wave is done reading agg_lds as its B operand
 #pragma unroll
-        for (int r = 0; r < 4; ++r) agg_lds[i16 * DOL_ROW_STRIDE + f0 + r] = y[r];
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) agg_lds[(16 * t + i16) * DOL_ROW_STRIDE + f0 + r] = y[t][r];
         __syncthreads();
-        if (tid < 128) {
+        if (tid < 128 * TILES) {
             const int row = tid >> 3, i = tid & 7;
             float xv[8];
 #pragma unroll
@@ -221,7 +260,7 @@ __global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(c
             ln_mom[row][i][1] = w.m2;
         }
         __syncthreads();
-        if (tid < 16) {
+        if (tid < 16 * TILES) {
             Moments all[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) all[i] = Moments{ln_mom[tid][i][0], ln_mom[tid][i][1]};
@@ -231,22 +270,28 @@ __global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(c
             ln_stat[tid][1] = rstd;
         }
         __syncthreads();
-        const float mean = ln_stat[i16][0], rstd = ln_stat[i16][1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[r] = ln_apply(y[r], mean, rstd, lnw[r], lnb[r]);
-    }
-    if (p.flags & DOL_RELU) {
+        for (int t = 0; t < TILES; ++t) {
+            const float mean = ln_stat[16 * t + i16][0], rstd = ln_stat[16 * t + i16][1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.f);
+            for (int r = 0; r < 4; ++r) y[t][r] = ln_apply(y[t][r], mean, rstd, lnw[r], lnb[r]);
+        }
     }
-    if (p.flags & DOL_RESIDUAL) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[r] += x_lds[i16 * DOL_ROW_STRIDE + f0 + r];
+    for (int t = 0; t < TILES; ++t) {
+        if (p.flags & DOL_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[t][r] = fmaxf(y[t][r], 0.f);
+        }
+        if (p.flags & DOL_RESIDUAL) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[t][r] += x_lds[(16 * t + i16) * DOL_ROW_STRIDE + f0 + r];
+        }
+        const int row = row0 + 16 * t + i16;
+        if (row < p.n_out && (t == 0 || tile1))
+            *reinterpret_cast<float4 *>(p.out + (long long)outer * p.out_so + (long long)row * p.out_sr + f0) =
+                make_float4(y[t][0], y[t][1], y[t][2], y[t][3]);
     }
-    const int row = row0 + i16;
-    if (row < p.n_out)
-        *reinterpret_cast<float4 *>(p.out + (long long)outer * p.out_so + (long long)row * p.out_sr + f0) =
-            make_float4(y[0], y[1], y[2], y[3]);
 }
 
 static bool dol_ok16(const ultra_mat *m) {
@@ -256,7 +301,7 @@ static bool dol_ok16(const ultra_mat *m) {
 // Called by ultra_nbf_dense_layer (rspmm_api.hip) with the plan uploaded, when the caller asks for the reference order.
 int launch_dense_order_layer(ultra_plan *p, const ultra_mat *rel, const ultra_mat *x, const ultra_mat *bnd, const int64_t *bnd_rows,
                              const void *weight, const void *bias, const void *ln_w, const void *ln_b, float eps, int flags,
-                             const ultra_mat *out, hipStream_t stream) {
+                             const ultra_mat *out, hipStream_t stream, bool shared_chip) {
     if (!(p->flags & ULTRA_PLAN_DENSE) || p->a_ex.empty() || !p->d.a_ex) {
         set_error("ultra_nbf_dense_layer (reference order) needs a ULTRA_PLAN_DENSE plan of a graph with at most 4 relation types "
                   "whose parallel edges are sorted by type and never repeated");
@@ -294,8 +339,22 @@ int launch_dense_order_layer(ultra_plan *p, const ultra_mat *rel, const ultra_ma
     dp.has_bnd = bnd ? 1 : 0;
     dp.flags = flags;
     dp.eps = eps;
-    const long long blocks = (long long)dp.n_rt16 * out->n_outer;
-    hipLaunchKernelGGL(dense_order_layer_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dp);
+    const char *tiles_str = std::getenv("ULTRA_DOL_TILES");      // (read per launch: the test toggles it)
+    const int tiles_env = tiles_str ? std::atoi(tiles_str) : 0;
+    // Measured (round 5, tools/dense_order_probe.py and tools/step_probe.py on one box): the two-tile form runs 32.2 us per layer
+    // against 23.7 stand-alone -- its two chains share one matrix pipe, 64 cycles a column -- and the step with two batches in
+    // flight 0.603 ms against 0.581: the relation-graph layers on the 64 free CUs are not what bounds that step.  So one tile
+    // per workgroup stays the choice everywhere; ULTRA_DOL_TILES=2 selects the other form (same bits: tests/test_order_gpu.py).
+    (void)shared_chip;
+    const int tiles = (ULTRA_DOL_ASM || dp.n_rt16 < 2) ? 1 : (tiles_env == 2 ? 2 : 1);
+    const long long blocks = (long long)((dp.n_rt16 + tiles - 1) / tiles) * out->n_outer;
+    if (tiles == 2) {
+#if !ULTRA_DOL_ASM
+        hipLaunchKernelGGL(dense_order_layer_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, dp);
+#endif
+    } else {
+        hipLaunchKernelGGL(dense_order_layer_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, dp);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error(std::string("dense_order_layer_kernel launch: ") + hipGetErrorString(e));

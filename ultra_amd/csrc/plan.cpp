@@ -259,6 +259,8 @@ static double WAVE_SHARE[4] = {1.7, 1.3, 0.7, 0.3};
 // ... and when the youngest quartet does not walk at all (its waves apply the layer update beside the walk:
 // rspmm_order_kernel, UPDATE == 2): the same age effect among the three walking quartets
 static double WAVE_SHARE_12[4] = {1.5, 1.2, 0.7, 0.0};
+// ... or per walker wave (calibration runs: ULTRA_STREAM_SHARES_WAVES_12="w0,...,w11"; negative = unset: the quartet's share)
+static double WAVE_SHARE_12_WAVES[12] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 // A row the plan lists as a chain row (> chain_min = 256 edges) is still better off as ONE group stream's row when the streams
 // of the launch are long enough to take it: the chain sums an edge in 11 workgroup-cycles, a stream in 6-8.  In the schedules of
 // the update-beside-the-walk launches (twelve walkers; nothing else reads them) chain rows of up to CHAIN_LIMIT_FACTOR x the mean
@@ -288,6 +290,13 @@ static void read_cost_override() {   // calibration runs only: ULTRA_SCHED_COSTS
     if (env && std::sscanf(env, "%lf,%lf,%lf", &v[0], &v[1], &v[2]) == 3) {
         for (int k = 0; k < 3; ++k) WAVE_SHARE_12[k] = v[k];
         WAVE_SHARE_12[3] = 0.0;
+    }
+    env = std::getenv("ULTRA_STREAM_SHARES_WAVES_12");
+    if (env) {
+        double w[12];
+        if (std::sscanf(env, "%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf", &w[0], &w[1], &w[2], &w[3], &w[4], &w[5], &w[6], &w[7], &w[8],
+                        &w[9], &w[10], &w[11]) == 12)
+            for (int k = 0; k < 12; ++k) WAVE_SHARE_12_WAVES[k] = w[k];
     }
     env = std::getenv("ULTRA_STREAM_ROW_COST_12");
     if (env && std::sscanf(env, "%lf,%lf,%lf", &v[0], &v[1], &v[2]) == 3) {
@@ -390,7 +399,11 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
         const double T = total / nparts;
         for (int32_t q = 0; q < nparts; ++q) {
             const double budget = std::max(T - chain_cost[(size_t)q], 0.02 * T);   // (never zero: every row needs a home)
-            for (int g = 0; g < ORDER_GROUPS; ++g) weight[(size_t)q * ORDER_GROUPS + g] = budget * wave_share[g / 16];
+            for (int g = 0; g < ORDER_GROUPS; ++g) {
+                double share = wave_share[g / 16];
+                if (walkers == 12 && g / 4 < 12 && WAVE_SHARE_12_WAVES[g / 4] >= 0.0) share = WAVE_SHARE_12_WAVES[g / 4];
+                weight[(size_t)q * ORDER_GROUPS + g] = budget * share;
+            }
         }
         typedef std::pair<double, int64_t> Slot;   // ((load + 1) / weight, stream): the heap's top is the relatively emptiest
         std::priority_queue<Slot, std::vector<Slot>, std::greater<Slot>> sheap;

@@ -48,7 +48,7 @@ int launch_dense_forward(ultra_plan *p, int sum, int mul, int dtype, const void 
 
 int launch_dense_order_layer(ultra_plan *p, const ultra_mat *rel, const ultra_mat *x, const ultra_mat *bnd, const int64_t *bnd_rows,
                              const void *weight, const void *bias, const void *ln_w, const void *ln_b, float eps, int flags,
-                             const ultra_mat *out, hipStream_t stream);   // dense_order_layer.hip
+                             const ultra_mat *out, hipStream_t stream, bool shared_chip);   // dense_order_layer.hip
 
 int launch_dense_layer(ultra_plan *p, const ultra_mat *rel, const ultra_mat *x, const ultra_mat *bnd, const int64_t *bnd_rows,
                        const void *weight, const void *bias, const void *ln_w, const void *ln_b, float eps, int flags,
@@ -1040,9 +1040,14 @@ int32_t ultra_nbf_dense_layer(ultra_plan *plan, const ultra_mat *relation, const
     if (boundary && (rc = check_mat(boundary, "boundary", point_rows_dev ? 1 : plan->num_out, n_outer, output->row_len))) return rc;
     if (n_outer == 0 || plan->num_out == 0) return ULTRA_OK;
     if ((rc = upload_plan(plan))) return rc;
-    if (flags & ULTRA_LAYER_REFERENCE_ORDER)
+    if (flags & ULTRA_LAYER_REFERENCE_ORDER) {
+        // (a launch-grid tuning below the CU count = this forward shares the chip with another batch in flight)
+        DevInfo di;
+        if ((rc = device_info(&di))) return rc;
+        const bool shared_chip = g_tuning.grid > 0 && g_tuning.grid < di.cu;
         return launch_dense_order_layer(plan, relation, input, boundary, point_rows_dev, weight, bias, ln_weight, ln_bias, eps,
-                                        flags & 7, output, reinterpret_cast<hipStream_t>(stream));
+                                        flags & 7, output, reinterpret_cast<hipStream_t>(stream), shared_chip);
+    }
     return launch_dense_layer(plan, relation, input, boundary, point_rows_dev, weight, bias, ln_weight, ln_bias, eps, flags,
                               output, reinterpret_cast<hipStream_t>(stream));
 }

@@ -391,6 +391,18 @@ __device__ __forceinline__ T chain_add_partial(T acc, const V (&v)[N], const int
 #else
 #define ULTRA_ORDER_VGPR_CAP
 #endif
+#ifndef ULTRA_UPD_SIMDS
+#define ULTRA_UPD_SIMDS 4
+#endif
+__device__ __forceinline__ int order_role(const int pw) {   // physical wave -> logical wave (a bijection that keeps wave 0)
+#if ULTRA_UPD_SIMDS == 2 && ULTRA_ORDER_WAVES == 16
+    return pw < 10 ? pw : (pw == 12 ? 10 : pw == 13 ? 11 : pw == 10 ? 12 : pw == 11 ? 13 : pw);
+#elif ULTRA_UPD_SIMDS == 1 && ULTRA_ORDER_WAVES == 16
+    return (pw & 3) == 3 ? 12 + (pw >> 2) : 3 * (pw >> 2) + (pw & 3);
+#else
+    return pw;
+#endif
+}
 template <typename T, int SUM, int MUL, bool REL_LDS, bool WEIGHTED, bool STREAMS, int UPDATE = 0>
 __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_order_kernel(const OrderParams p) {
     static_assert(!STREAMS || OrderAsm<T, MUL, REL_LDS, WEIGHTED>::value, "group streams exist for the assembly configurations only");
@@ -405,7 +417,12 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = rfl(tid >> 6);
+    // Roles by wave.  The hardware deals a workgroup's waves round-robin onto the CU's four SIMDs (wave w on SIMD w % 4), and the
+    // code below speaks of LOGICAL waves: 0 the chain consumer, 0 .. ORDER_WALKERS - 1 the walkers, the last ORDER_UPDATERS the
+    // update waves of form 3.  ULTRA_UPD_SIMDS (measurement builds): 4 = one update wave per SIMD (logical = physical), 2 = the
+    // four update waves on SIMDs 2 and 3 (physical 10, 11, 14, 15), 1 = all on SIMD 3 (physical 3, 7, 11, 15) -- a SIMD that
+    // executes matrix instructions issues little else, so where the update waves sit decides which walkers they hold up.
+    const int wave = order_role(rfl(tid >> 6));
     constexpr int nwave = ORDER_THREADS / 64;
     const int part = blockIdx.x / p.smod;
     if (part >= p.nparts) return;
@@ -951,6 +968,16 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
 #define UPD_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
 #define UPD_OP(expr) (expr)
 #endif
+#if ULTRA_UPD_SKIP == 4   /* measurement build (wrong results): the same matrix-pipe time as HALF as many, twice as long instructions */
+#define UPD_CHAIN16(W0, Q, D)                                                                                          \
+    _Pragma("unroll") for (int s = 0; s < 8; ++s) big = __builtin_amdgcn_mfma_f32_32x32x2f32(wfrag[(W0) + 2 * s], Q[2 * s], big, 0, 0, 0); \
+    D[0] += big[0];
+                        f32x16 big;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) big[r] = 0.f;
+#else
+#define UPD_CHAIN16(W0, Q, D) _Pragma("unroll") for (int s = 0; s < 16; ++s) D = UPD_MFMA(wfrag[(W0) + s], Q[s], D);
+#endif
                         {
                             // four quarters of operands (x and aggregate of half 0, of half 1), each requested while the quarter
                             // before it is multiplied: one LDS round trip in the open instead of two, 32 operand registers.  (One
@@ -963,21 +990,17 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
                             for (int s = 0; s < 16; ++s) q1[s] = UPD_OP(pa0[ri * UPD2_ROW_FLOATS + 4 * s + kk]);
                             x0 = *reinterpret_cast<const lds_f4 *>(px0 + rf * UPD2_ROW_FLOATS + 4 * i16);
                             asm volatile("" ::: "memory");
-#pragma unroll
-                            for (int s = 0; s < 16; ++s) d0 = UPD_MFMA(wfrag[s], q0[s], d0);
+                            UPD_CHAIN16(0, q0, d0)
 #pragma unroll
                             for (int s = 0; s < 16; ++s) q0[s] = UPD_OP(px1[ri * UPD2_ROW_FLOATS + 4 * s + kk]);
                             x1 = *reinterpret_cast<const lds_f4 *>(px1 + rf * UPD2_ROW_FLOATS + 4 * i16);
                             arrive();       // (this wave's reads of the x rows are served before its arrival shows)
-#pragma unroll
-                            for (int s = 0; s < 16; ++s) d0 = UPD_MFMA(wfrag[16 + s], q1[s], d0);
+                            UPD_CHAIN16(16, q1, d0)
 #pragma unroll
                             for (int s = 0; s < 16; ++s) q1[s] = UPD_OP(pa1[ri * UPD2_ROW_FLOATS + 4 * s + kk]);
                             asm volatile("" ::: "memory");
-#pragma unroll
-                            for (int s = 0; s < 16; ++s) d1 = UPD_MFMA(wfrag[s], q0[s], d1);
-#pragma unroll
-                            for (int s = 0; s < 16; ++s) d1 = UPD_MFMA(wfrag[16 + s], q1[s], d1);
+                            UPD_CHAIN16(0, q0, d1)
+                            UPD_CHAIN16(16, q1, d1)
                         }
 #else
                         x0 = x1 = f32x4m{0.f, 0.f, 0.f, 0.f};
@@ -1144,6 +1167,9 @@ __global__ void __launch_bounds__(ORDER_THREADS) ULTRA_ORDER_VGPR_CAP rspmm_orde
     if (p.trace) {
         __syncthreads();
         if (tid == 0) p.trace[3 * blockIdx.x + 2] = clock64();
+        if constexpr (UPDATE == 3) {   // (of the LAST span: how often this workgroup's walkers found the hand-off ring full)
+            if (tid == 0) p.trace[24 * gridDim.x + blockIdx.x] = ctl[UPD2_CTL_RETRIES];
+        }
     }
 }
 

@@ -85,7 +85,8 @@ constexpr int UPD2_MAX_CHAIN_ROWS = 64;          // chain rows of a workgroup th
 constexpr int UPD2_OVERLAY_BYTES = (UPD2_NT + 4) * UPD2_TILE_FLOATS * 4;
 // control block (behind ring / overlay; bytes): 0 tail, 4 walkers done, 8 update-wave barrier (arrivals), 12 chain done, 16
 // generations consumed, 20 chain rows listed, 32 posted[NT], 64 rowid[16 NT], 320 chain row offsets[64], 576 chain tile
-constexpr int UPD2_CTL_CONSUMED = 4, UPD2_CTL_NCHAIN = 5, UPD2_CTL_ERR = 7 /* a park wait of the generated walk gave up (HANDOFF2_ERR_OFF) */,
+constexpr int UPD2_CTL_CONSUMED = 4, UPD2_CTL_NCHAIN = 5, UPD2_CTL_RETRIES = 6 /* park waits that found the ring full (diagnostic) */,
+              UPD2_CTL_ERR = 7 /* a park wait of the generated walk gave up (HANDOFF2_ERR_OFF) */,
               UPD2_CTL_POSTED = 8, UPD2_CTL_ROWID = 16,
               UPD2_CTL_CROW = 80;   // (word offsets)
 constexpr int UPD2_CTL_CTILE_BYTES = 576, UPD2_CTL_BYTES = UPD2_CTL_CTILE_BYTES + UPD2_TILE_FLOATS * 4;
