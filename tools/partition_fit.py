@@ -22,7 +22,7 @@ want_grid = "grid %d" % grid
 take = False
 for line in open(path):
     if " form " in line and "grid" in line:
-        take = want_grid in line
+        take = want_grid in line and (shape + " bs") in line and (len(sys.argv) <= 5 or (" " + sys.argv[5] + " ") in line)
     if line.startswith("PARTS ") and take:
         name, vals = line.split()[1], np.array([float(v) for v in line.split()[2:]])
         if len(vals) == nparts:

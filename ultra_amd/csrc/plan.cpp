@@ -258,7 +258,7 @@ static double COST_S_CHUNK = 675.0, COST_S_ROW = 1380.0, COST_S_STEP = 6.0;
 static double WAVE_SHARE[4] = {1.7, 1.3, 0.7, 0.3};
 // ... and when the youngest quartet does not walk at all (its waves apply the layer update beside the walk:
 // rspmm_order_kernel, UPDATE == 2): the same age effect among the three walking quartets
-static double WAVE_SHARE_12[4] = {1.5, 1.2, 0.7, 0.0};
+static double WAVE_SHARE_12[4] = {1.35, 1.15, 0.9, 0.0};
 // ... or per walker wave (calibration runs: ULTRA_STREAM_SHARES_WAVES_12="w0,...,w11"; negative = unset: the quartet's share)
 static double WAVE_SHARE_12_WAVES[12] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 // A row the plan lists as a chain row (> chain_min = 256 edges) is still better off as ONE group stream's row when the streams
@@ -273,7 +273,11 @@ static double CHAIN_LIMIT_FACTOR = 2.1;
 // and the stall holds up all four streams of the wave, whatever the wave's age; the steps themselves go faster the older the
 // wave is (WAVE_SHARE_12).  Fitted from a traced launch (tools/wave_fit.py: walk = c_q steps + r rows per wave; a stream's share
 // of its wave's row stalls is 4 r / c_q steps a row).  ULTRA_STREAM_ROW_COST_12="r0,r1,r2" overrides (calibration runs).
-static double ROW_COST_12[4] = {0.0, 0.0, 0.0, 0.0};
+static double ROW_COST_12[4] = {10.0, 5.0, 0.0, 0.0};
+// (Measured and dropped in round 5: dealing the rows to the PARTITIONS first -- by steps + a row cost against the partition's budget
+// -- and then to each partition's streams: a long row then lands in a partition whose streams are shorter than it is (one stream
+// of 687 steps beside 500: 86 -> 95 us per layer at the FB15k237 shape); the one-level deal below places the long rows first,
+// across all streams of the launch.  profiles/r5_experiments.txt.)
 
 static void read_cost_override() {   // calibration runs only: ULTRA_SCHED_COSTS="edge,chunk,row,step,unit", ULTRA_STREAM_COSTS="chunk,row,step"
     const char *env = std::getenv("ULTRA_SCHED_COSTS");
@@ -397,8 +401,22 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
         std::vector<double> weight((size_t)nstream);
         total += COST_S_STEP * steps;
         const double T = total / nparts;
+        // per-partition multipliers of the stream budget (calibration: ULTRA_PART_WEIGHTS_FILE names a text file with nparts numbers
+        // for the twelve-walker schedule of that many partitions; tools/form3_probe.py PROBE_CALIBRATE writes it from a traced launch)
+        std::vector<double> part_mult((size_t)nparts, 1.0);
+        if (walkers == 12) {
+            if (const char *pw = std::getenv("ULTRA_PART_WEIGHTS_FILE")) {
+                if (FILE *f = std::fopen(pw, "r")) {
+                    std::vector<double> m;
+                    double v;
+                    while (std::fscanf(f, "%lf", &v) == 1) m.push_back(v);
+                    std::fclose(f);
+                    if ((int64_t)m.size() == nparts) part_mult = m;
+                }
+            }
+        }
         for (int32_t q = 0; q < nparts; ++q) {
-            const double budget = std::max(T - chain_cost[(size_t)q], 0.02 * T);   // (never zero: every row needs a home)
+            const double budget = std::max(T - chain_cost[(size_t)q], 0.02 * T) * part_mult[(size_t)q];   // (never zero: every row needs a home)
             for (int g = 0; g < ORDER_GROUPS; ++g) {
                 double share = wave_share[g / 16];
                 if (walkers == 12 && g / 4 < 12 && WAVE_SHARE_12_WAVES[g / 4] >= 0.0) share = WAVE_SHARE_12_WAVES[g / 4];
@@ -410,16 +428,21 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
         std::vector<int64_t> sload((size_t)nstream, 0);
         std::vector<double> scost((size_t)nstream, 0.0);   // steps + what the rows cost beyond them (ROW_COST_12)
         std::vector<std::vector<int32_t>> srows((size_t)nstream);
+        const auto deal_into = [&](const int64_t stream, const int64_t g) {
+            srows[(size_t)stream].push_back((int32_t)g);
+            sload[(size_t)stream] += p->items[(size_t)g].len + 1;
+            scost[(size_t)stream] += p->items[(size_t)g].len + 1 + (walkers == 12 ? ROW_COST_12[(stream % ORDER_GROUPS) / 16] : 0.0);
+        };
+        {
         for (int64_t g = 0; g < nstream; ++g)
             if (weight[(size_t)g] > 0.0) sheap.push(Slot(1.0 / weight[(size_t)g], g));   // (a stream without a share takes no rows)
         for (int64_t g = 0; g < n_item; ++g) {   // (chain items that go to the streams first: longest first throughout)
             if (g < n_chain && !to_stream[(size_t)g]) continue;
             const Slot sl = sheap.top();
             sheap.pop();
-            srows[(size_t)sl.second].push_back((int32_t)g);
-            sload[(size_t)sl.second] += p->items[(size_t)g].len + 1;
-            scost[(size_t)sl.second] += p->items[(size_t)g].len + 1 + (walkers == 12 ? ROW_COST_12[(sl.second % ORDER_GROUPS) / 16] : 0.0);
+            deal_into(sl.second, g);
             sheap.push(Slot((scost[(size_t)sl.second] + 1.0) / weight[(size_t)sl.second], sl.second));
+        }
         }
         s->sdesc.assign((size_t)nstream * 2, 0);
         s->srec.reserve((size_t)(2 * (int64_t)steps) + 2 * ORDER_PAD);

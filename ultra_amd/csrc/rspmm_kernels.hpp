@@ -102,12 +102,36 @@ __device__ __forceinline__ T nary_zero() {
     return std::numeric_limits<T>::lowest();
 }
 
+// min / max as ONE instruction.  The reference's `result < x ? result : x` (operator.cuh:58,71) compiles to v_cmp + v_cndmask (+ a
+// wait state between them) -- three issue slots and twice the latency per link of a chain row's 9,000 dependent links: the chain
+// phase of the max-aggregate kernels ran 40 % longer than the sum's (50 k against 35 k cycles, round 5).  v_min / v_max return the
+// same value for every non-NaN pair but for the sign of a zero (max(-0, +0) = +0 where the ternary keeps its second operand), which
+// torch.equal and every later product ignore -- the generated stream walk has used them since round 3.
+__device__ __forceinline__ float hw_min(float a, float b) {
+    float r;
+    asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float hw_max(float a, float b) {
+    float r;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double hw_min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double hw_max(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <typename T, int SUM>
 __device__ __forceinline__ T nary(T result, T x) {  // operator.cuh:45,58,71
     if (SUM == ULTRA_SUM_ADD) return result + x;
-    // v_min / v_max: identical to the reference's `result < x ? result : x` for every non-NaN input
-    if (SUM == ULTRA_SUM_MIN) return result < x ? result : x;
-    return result > x ? result : x;
+    if (SUM == ULTRA_SUM_MIN) return hw_min(result, x);
+    return hw_max(result, x);
 }
 
 template <typename T, int MUL>
