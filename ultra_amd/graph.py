@@ -149,6 +149,9 @@ def pick_slot_streams(device, n, trial):
 def shared_launch_grid(device):
     """Workgroups of an aggregation launch that leaves a quarter of the chip to the other batch in flight (whole XCD-sized
     multiples: 192 of 256 -- 200 and 208 measured 4 % slower than either neighbour)."""
+    import os
+    if os.environ.get("ULTRA_SHARED_GRID"):      # (measurements: tools/step_probe.py sweeps it)
+        return int(os.environ["ULTRA_SHARED_GRID"])
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     return max((3 * cus // 4) // 64 * 64, 3 * cus // 4 if cus < 86 else 64)
 
