@@ -202,20 +202,19 @@ int32_t ultra_rspmm_forward_point(ultra_plan *plan, int32_t sum, int32_t mul, in
  *   aggregate = rspmm(sum, mul)(relation, input) [+ point boundary]        -- as ultra_rspmm_forward_point / _forward
  *   output    = [input +] relu( LayerNorm( W . [input ; aggregate] + b ) ) -- as ultra_conv_update (ultra_nbfnet.h), same `flags` / `eps`
  *
- * Every workgroup of the reference-order kernel applies the update to the rows it aggregates, in one of three forms
+ * Every workgroup of the reference-order kernel applies the update to the rows it aggregates, in one of two forms
  * (ultra_tuning.reserved[2]; 0 = the library chooses: form 3 where it fits and the graph has 10+ steps -- edges + rows --
  * a row, the tail form otherwise):
  *   1  in the kernel's tail, once its walks have ended;
- *   2  beside the walk, rows by reference: twelve of the sixteen waves walk the graph, four multiply, while the walk goes
- *      on, the rows the walkers stored and handed over through an LDS queue;
- *   3  beside the walk, rows through LDS: the walkers park every finished aggregate row and its input row in a ring in
- *      LDS, the four update waves (the weight matrix split over their registers) take them from there -- no aggregate
- *      ever travels through memory.
- * Results are bit-equal with the two separate calls in every form.  sum: ULTRA_SUM_ADD / _MIN / _MAX (min / max with a
- * point boundary: see ultra_rspmm_forward_point).  A form asked for explicitly (2, 3) that does not fit the call (LDS, rows
- * per workgroup) is ULTRA_ERR_UNSUPPORTED.
- * `aggregate` is scratch for the caller (forms 1 and 2 leave the aggregate there; form 3 writes only the rows of its
- * chains); `output` must not alias it or `input`.
+ *   3  beside the walk, rows through LDS: twelve of the sixteen waves walk the graph and park every finished aggregate row
+ *      and its input row in a ring in LDS, the four update waves (the weight matrix split over their registers) take them
+ *      from there -- no aggregate ever travels through memory.  Every wait of that hand-off is bounded (ultra_device_error).
+ *   (2 -- rows handed over by reference through memory -- existed in ABI 5 and was removed in ABI 6: ULTRA_ERR_UNSUPPORTED.)
+ * Results are bit-equal with the two separate calls in either form.  sum: ULTRA_SUM_ADD / _MIN / _MAX (min / max with a
+ * point boundary: see ultra_rspmm_forward_point).  Form 3 asked for explicitly where it does not fit the call (LDS, chain
+ * rows per workgroup, a row pitch other than 256 bytes) is ULTRA_ERR_UNSUPPORTED.
+ * `aggregate` is scratch for the caller (form 1 leaves the aggregate there; form 3 writes only the rows of its chains);
+ * `output` must not alias it or `input`.
  * point_rows_dev / point_values: both NULL = no boundary.  Served where the stream walk serves ultra_rspmm_forward_point
  * (ULTRA_PLAN_EXACT_ORDER plan in the sparse format, 64-element rows, every stride equal): ULTRA_ERR_UNSUPPORTED
  * otherwise, nothing launched -- the caller then makes the two calls.
