@@ -8,7 +8,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 part="${1:-A}"
-R="${2:-r4}"
+R="${2:-r5}"
 OUT=gpurun_out/$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
