@@ -142,8 +142,21 @@ def pick_slot_streams(device, n, trial):
     for name, streams in cands:
         trial(streams)                                   # (first use of a stream: queue creation, not timed)
         times[name] = min(trial(streams) for _ in range(2))
-    chosen = "high" if times["high"] < 0.99 * times["normal"] else "normal"
-    return dict(cands)[chosen], {"chosen": chosen, "forced": False, "trial_ms": {k: round(1e3 * v, 4) for k, v in times.items()}}
+    # a tie (within 1 %) goes to the normal-priority pair in a plain process -- and to the high-priority pair in a rank that holds a
+    # RCCL communicator: there the short trial has twice been unable to tell the pairs apart (0.6226 / 0.6205, 0.6245 / 0.6196 ms)
+    # while the run that followed was 5 % slower on the normal pair than the high one measures (profiles/r5_launcher_path.txt)
+    prefer_high = False
+    try:
+        import torch.distributed as dist
+        prefer_high = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+    except Exception:
+        prefer_high = False
+    if prefer_high:
+        chosen = "normal" if times["normal"] < 0.99 * times["high"] else "high"
+    else:
+        chosen = "high" if times["high"] < 0.99 * times["normal"] else "normal"
+    return dict(cands)[chosen], {"chosen": chosen, "forced": False, "tie_goes_to": "high" if prefer_high else "normal",
+                                 "trial_ms": {k: round(1e3 * v, 4) for k, v in times.items()}}
 
 
 def shared_launch_grid(device):
