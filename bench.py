@@ -9,7 +9,7 @@ One step = one Ultra.forward(data, t_batch) per GPU with t_batch = (bs=8, N, 3) 
 bs * N triples -- with the plans that sum in the REFERENCE'S ORDER (rspmm.cpp:61-72; ultra_amd's default).  Queries
 shard over ranks (each rank scores its own 8 queries, graph + weights replicated); with N > 1 GPUs every step ends
 with one RCCL all-gather of the per-rank score rows.  Weak scaling: per-GPU work is fixed.  Rank 0 prints ONE JSON line.
-The forward is a captured hipGraph; by default TWO captures (three in a launcher's rank) take the steps alternately on as many streams (--in-flight,
+The forward is a captured hipGraph; by default THREE captures take the steps alternately on as many streams (--in-flight 3,
 ultra_amd/graph.py PipelinedForward): steps are independent batches, and the launches of one that leave the chip idle run
 beside the entity layers of the next.  ms_per_step = elapsed / steps; `modes.one_batch_in_flight` has the one-stream figure.
 
@@ -590,12 +590,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-graph", action="store_true", help="launch the forward eagerly instead of replaying its hipGraph")
-    ap.add_argument("--in-flight", type=int, default=0,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="captured forwards replayed round-robin on as many streams (consecutive batches are independent); 1 = one "
-                         "stream; default: 2 in a plain process, 3 in a launcher's rank -- measured (profiles/r5_launcher_path.txt, one "
-                         "rank under torch.distributed.run): 0.650 / 0.619 - 0.643 ms first run / repeats with two, 0.575 / 0.559 - 0.568 "
-                         "with three (the step's all-gather leaves its slot's stream waiting); plain: 0.5825 steady with two, 0.583 / "
-                         "0.576 - 0.604 with three")
+                         "stream.  Three: measured with the slots' streams picked by trial (graph.pick_slot_streams), plain process "
+                         "0.568 / 0.558 - 0.573 ms first run / repeats against 0.583 - 0.593 / 0.584 - 0.589 with two; a launcher's rank "
+                         "0.565 - 0.588 / 0.555 - 0.572 against 0.600 - 0.650 / 0.585 - 0.643 (profiles/r5_experiments.txt)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes of the roofline block")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fine-tuning steps of the `secondary` block")
@@ -619,8 +618,6 @@ def main():
     ap.add_argument("--trace-target", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    if args.in_flight <= 0:
-        args.in_flight = 3 if ("RANK" in os.environ and "MASTER_PORT" in os.environ) else 2
     if args.pmc_target or args.trace_target:
         import __graft_entry__ as entry
         entry.build()

@@ -16,9 +16,9 @@ if [ "$part" = "A" ]; then
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$OUT/${R}_smoke.txt" 2>&1
     ULTRA_BENCH_PMC_KEEP="$PWD/$OUT/${R}_pmc" timeout 900 python bench.py > "$OUT/${R}_bench.json" 2> "$OUT/bench.err"
     # (bench.py's own --kernel-trace child pass: the forward as ONE captured graph on ONE stream -- the durations DESIGN.md section 4 quotes)
-    cp "$OUT/${R}_pmc/bench_kernel_stats_inflight1.csv" "$OUT/${R}_bench_kernel_stats_inflight1.csv" 2>/dev/null
-    # (... and the second child pass: two captures on two streams as the timed region runs them)
-    cp "$OUT/${R}_pmc/bench_kernel_stats_inflight2.csv" "$OUT/${R}_bench_kernel_stats_inflight2.csv" 2>/dev/null
+    # (bench.py's own --kernel-trace child passes: inflight1 = the forward as ONE captured graph on ONE stream -- the durations DESIGN.md
+    # section 4 quotes; inflight<k> = k captures on k streams as the timed region runs them)
+    for f in "$OUT/${R}_pmc"/bench_kernel_stats_inflight*.csv; do cp "$f" "$OUT/${R}_$(basename "$f")" 2>/dev/null; done
     (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o run -- \
         python "$OLDPWD/bench.py" --no-cpu-baseline --no-roofline --no-secondary > /dev/null 2>&1)
     find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} "$OUT/${R}_bench_kernel_stats.csv" \;

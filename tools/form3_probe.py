@@ -90,15 +90,17 @@ if os.environ.get("PROBE_DUMP_PARTS"):
     for wv in range(16):      # end of every wave's work, mean over the partition's samples
         print("PARTS wave%d " % wv + " ".join("%.0f" % v for v in wave_end[:, wv].view(nparts, bs).mean(dim=1).tolist()))
 
-# ---- PROBE_CALIBRATE=n: n rounds of "trace -> per-partition budget multipliers -> new schedule" (ULTRA_PART_WEIGHTS_FILE, plan.cpp) ----
+# ---- PROBE_CALIBRATE=n: n rounds of "traced launches -> per-partition step deltas -> incremental re-deal" (ULTRA_PART_ADJUST_FILE, plan.cpp) ----
 n_cal = int(os.environ.get("PROBE_CALIBRATE", "0"))
 if n_cal:
     import numpy as np
     nparts = grid // bs
-    alpha = float(os.environ.get("PROBE_CAL_ALPHA", "0.8"))
-    wfile = os.environ.get("ULTRA_PART_WEIGHTS_FILE") or "/tmp/ultra_part_weights_%d.txt" % os.getpid()
-    os.environ["ULTRA_PART_WEIGHTS_FILE"] = wfile
-    mult = np.ones(nparts)
+    alpha = float(os.environ.get("PROBE_CAL_ALPHA", "0.7"))
+    afile = os.environ.get("ULTRA_PART_ADJUST_FILE") or "/tmp/ultra_part_adjust_%d.txt" % os.getpid()
+    os.environ["ULTRA_PART_ADJUST_FILE"] = afile
+    if os.path.exists(afile):
+        os.remove(afile)
+    adjust = np.zeros(nparts)
 
     def traced(pl):
         def run():
@@ -108,20 +110,19 @@ if n_cal:
             return out
         ends, chains = [], []
         run()
-        for _ in range(3):
+        for _ in range(4):
             tr = torch.zeros(grid * 32, dtype=torch.int64, device=dev)
             torch.cuda.synchronize()
             _lib.check(_lib.lib.ultra_order_trace(tr.data_ptr()))
             out = run()
             torch.cuda.synchronize()
             _lib.check(_lib.lib.ultra_order_trace(None))
-            tt = tr.cpu()
-            mm = tt[:3 * grid].view(grid, 3).double()
+            mm = tr.cpu()[:3 * grid].view(grid, 3).double()
             ends.append((mm[:, 2] - mm[:, 0]).view(nparts, bs).mean(dim=1).numpy())
             chains.append((mm[:, 1] - mm[:, 0]).view(nparts, bs).mean(dim=1).numpy())
-            e_all = (mm[:, 2] - mm[:, 0])
-        # time of 20 launches in a graph
+            e_all = mm[:, 2] - mm[:, 0]
         s2 = torch.cuda.Stream()
+        ts = []
         with torch.cuda.stream(s2):
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2, stream=s2):
@@ -129,29 +130,29 @@ if n_cal:
                     run()
             g2.replay()
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(s2)
-            for _ in range(5):
-                g2.replay()
-            e1.record(s2)
-            torch.cuda.synchronize()
-        return np.mean(ends, axis=0), np.mean(chains, axis=0), float(e_all.mean()), float(e_all.max()), e0.elapsed_time(e1) / 100 * 1e3, torch.equal(out, want)
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(s2)
+                for _ in range(5):
+                    g2.replay()
+                e1.record(s2)
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / 100 * 1e3)
+        return np.mean(ends, axis=0), np.mean(chains, axis=0), float(e_all.mean()), float(e_all.max()), sorted(ts)[1], torch.equal(out, want)
 
     for it in range(n_cal + 1):
         pl = rspmm.Plan(data.edge_index, data.edge_type, N, R, exact_order=True)
         sdesc, _ = pl.streams(nparts, walkers=12)
         steps_q = sdesc.view(nparts, 64, 2)[:, :, 1].sum(dim=1).double().numpy()
         end_q, chain_q, e_mean, e_max, us, ok = traced(pl)
-        print("calibration round %d: %.2f us equal %s | end mean %.0f max %.0f | partitions: std %.0f max-mean %.0f" %
-              (it, us, ok, e_mean, e_max, end_q.std(), end_q.max() - end_q.mean()))
-        drain = 8000.0
-        walk_q = np.maximum(end_q - chain_q - drain, 1000.0)
-        k_q = walk_q / np.maximum(steps_q, 1.0)
-        fixed = chain_q + drain
-        t_star = (steps_q.sum() + (fixed / k_q).sum()) / (1.0 / k_q).sum()
-        new_steps = np.maximum((t_star - fixed) / k_q, 0.02 * steps_q.mean())
-        mult = mult * (new_steps / np.maximum(steps_q, 1.0)) ** alpha
-        with open(wfile, "w") as f:
-            f.write(" ".join("%.5f" % m for m in mult))
+        print("calibration round %d: %.2f us equal %s | end mean %.0f max %.0f | partitions: std %.0f max-mean %.0f | steps moved so far %.0f" %
+              (it, us, ok, e_mean, e_max, end_q.std(), end_q.max() - end_q.mean(), np.abs(adjust).sum() / 2))
+        walk_q = np.maximum(end_q - chain_q - 8000.0, 1000.0)
+        k_q = walk_q / np.maximum(steps_q, 1.0)                    # cycles a step of this partition's mix
+        delta = (end_q - end_q.mean()) / np.maximum(k_q, 1.0)      # steps to give away (> 0: the partition ends late)
+        delta -= delta.mean()
+        adjust = adjust + alpha * delta
+        with open(afile, "w") as f:
+            f.write(" ".join("%.1f" % a for a in adjust))
         del pl
-    print("weights file: " + wfile + " : " + " ".join("%.3f" % m for m in mult))
+    print("adjust file: " + afile + " : " + " ".join("%.0f" % a for a in adjust))

@@ -110,7 +110,7 @@ HANDOFF2_X_OFF = HANDOFF2_NT * 16 * HANDOFF2_ROW_BYTES     # the x rows' ring si
 
 
 def stream_park(a, ob_q, x_q, tag):
-    """Flush of form 2, for the lanes in %[mk] (the 16-lane groups at a marker): accumulator (boundary already applied) ->
+    """Flush of the hand-off (POST == 2), for the lanes in %[mk] (the 16-lane groups at a marker): accumulator (boundary already applied) ->
     a row of the current tile, and beside it the row's x (registers x_q..: a marker step gathers at its own row's offset).  One lane per group takes the slot and later writes the row's id and bumps the buffer's
     count; all 16 write their 16 bytes.  A slot of generation G may be written once generation G - NT has been consumed
     (the update waves never wait for a walker that waits for them: the slots of the NT generations they may be working on

@@ -3,7 +3,7 @@ import collections
 import csv
 import sys
 
-NAMES = (("true, 1>(ultra::OrderParams)", "entity layer, 1 launch"), ("true, 2>(ultra::OrderParams)", "entity layer, update beside the walk"), ("rspmm_order_kernel", "entity rspmm"), ("rspmm_fwd_kernel", "entity rspmm (r1)"), ("conv_update_kernel", "entity update"),
+NAMES = (("true, 3>(ultra::OrderParams)", "entity layer, 1 launch"), ("true, 1>(ultra::OrderParams)", "entity layer, tail form"), ("rspmm_order_kernel", "entity rspmm"), ("rspmm_fwd_kernel", "entity rspmm (r1)"), ("conv_update_kernel", "entity update"),
          ("dense_order_layer_kernel", "relation layer"), ("dense_layer_kernel", "relation layer (r1)"), ("readout_kernel", "readout"),
          ("rspmm_fixup_kernel", "fix-up"))
 out = []

@@ -66,7 +66,7 @@ __device__ __forceinline__ void row_moments_pair(const float (&v)[2][16], const 
 }
 
 // ---- the update on 16-row tiles held in LDS, the feature axis split over four waves (rspmm_order_kernel, UPDATE == 3) ----
-// Hand-off form 2 of the order kernel: walkers park finished aggregate rows in LDS tiles (16 rows x UPD2_ROW_FLOATS floats: 64 +
+// The hand-off of the order kernel's form 3 (UPD2_*: the generator's HANDOFF2_*): walkers park finished aggregate rows in LDS tiles (16 rows x UPD2_ROW_FLOATS floats: 64 +
 // 4 pad -- lane (row n, k-quarter q) reading element 4 s + q of row n hits 64 distinct banks); each of the four update waves
 // keeps ITS 16 features of W in 32 registers (A operand of v_mfma_f32_16x16x4_f32: lane (i, q) holds W[16 u + i][4 s + q]) and
 // multiplies every tile -- the products are k-ascending fmaf chains, the reference's nn.Linear order (the same arrangement as

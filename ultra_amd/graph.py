@@ -116,47 +116,55 @@ def slot_stream(device, priority=0):
         return torch.cuda.Stream(priority=priority)
 
 
+def _skip_streams(device, priority):
+    """(measurements: ULTRA_SLOT_STREAM_SKIP=n takes n streams of that priority from torch's pool first -- the runtime maps streams
+    onto hardware queues in creation order, so this shifts which queues the slots' streams land on)"""
+    import os
+    for _ in range(int(os.environ.get("ULTRA_SLOT_STREAM_SKIP", "0"))):
+        st = slot_stream(device, priority)
+        with torch.cuda.stream(st):
+            torch.zeros(1, device=device)
+        st.synchronize()
+
+
 def pick_slot_streams(device, n, trial):
     """The streams the pipeline slots run on, chosen by MEASUREMENT.  The HIP runtime maps a process's streams onto a small pool
-    of hardware queues per priority level (GPU_MAX_HW_QUEUES of them, in creation order), and how two slots' launches interleave
-    depends on which queues their streams land on -- i.e. on how many streams the process made before (torch's side streams, the
-    capture streams, RCCL's).  Measured on MI355X, ms per step with two captured forwards in flight (profiles/r5_slot_streams.txt):
+    of hardware queues (GPU_MAX_HW_QUEUES of them) as they are created, and how the slots' launches interleave depends on which
+    queues their streams land on -- i.e. on how many streams of which priority the process made before (torch's side streams, the
+    capture streams, RCCL's).  Measured on MI355X, bench.py --steps 20 --warmup 5, ms per step first run / repeats
+    (profiles/r5_slot_streams.txt, r5_experiments.txt):
 
-        process                         normal-priority pair      high-priority pair
-        plain bench.py                  0.573 / 0.562 - 0.567     0.573 / 0.567 - 0.573
-        one rank under torchrun (RCCL)  0.616 / 0.587 - 0.605     0.584 / 0.573 - 0.576     (round 4's remedy: GPU_MAX_HW_QUEUES=3)
-        tools/step_probe.py             0.566                     0.709
+        plain process, two slots:   normal-priority pair 0.573 / 0.562 - 0.567, high 0.573 / 0.567 - 0.573 in one call -- 0.577 / 0.679
+                                    (trial) in another; the pair made after THREE other streams of its level: normal 0.606 / 0.597 - 0.612,
+                                    high 0.764 / 0.757
+        plain process, three slots: 0.595 / 0.580 - 0.594 (normal, first streams), 0.568 / 0.566 - 0.570 (normal, after three others),
+                                    0.569 / 0.558 - 0.573 (high, first), 0.645 / 0.637 - 0.652 (high, after two others)
+        a launcher's rank (RCCL):   two slots 0.616 / 0.587 - 0.605 (normal), 0.584 / 0.573 - 0.576 (high); three slots on the high
+                                    pair 0.565 - 0.588 / 0.555 - 0.572
 
-    Neither level is right everywhere, and nothing the process can ask the runtime tells it which one is.  So the pipeline times a
-    few steps on each candidate pair when it is built (`trial(streams)` -> seconds; ~ 20 ms in all) and keeps the faster pair,
-    normal priority on a tie (within 1 %): the launcher's rank and the plain process both end up on a pair that interleaves, by
-    construction rather than by an environment variable.  ULTRA_SLOT_STREAM_PRIORITY=0 / -1 pins a level (measurements).
-    Returns (streams, report)."""
+    The same step runs between 0.557 and 0.764 ms depending on nothing but where its streams landed, no level or position is right
+    everywhere, and nothing the process can ask the runtime says which is.  So the pipeline tries a handful of candidate sets when
+    it is built -- alternately normal- and high-priority, each made of fresh streams (which also moves the next candidate to other
+    queues) -- times a few steps on each (`trial(streams)` -> seconds per step, the step's post-op included; ~ 25 ms a candidate) and
+    keeps the fastest.  ULTRA_SLOT_STREAM_CANDIDATES sets how many (12); ULTRA_SLOT_STREAM_PRIORITY=0 / -1 pins the first set of that
+    level (measurements).  Returns (streams, report)."""
     import os
     forced = os.environ.get("ULTRA_SLOT_STREAM_PRIORITY")
     if forced not in (None, "", "auto"):
         prio = int(forced)
+        _skip_streams(device, prio)
         return [slot_stream(device, prio) for _ in range(n)], {"chosen": "high" if prio < 0 else "normal", "forced": True}
-    cands = [("normal", [slot_stream(device, 0) for _ in range(n)]), ("high", [slot_stream(device, -1) for _ in range(n)])]
-    times = {}
-    for name, streams in cands:
+    n_cand = max(2, int(os.environ.get("ULTRA_SLOT_STREAM_CANDIDATES", "12")))
+    best, report = None, []
+    for k in range(n_cand):
+        prio = 0 if k % 2 == 0 else -1
+        streams = [slot_stream(device, prio) for _ in range(n)]
         trial(streams)                                   # (first use of a stream: queue creation, not timed)
-        times[name] = min(trial(streams) for _ in range(2))
-    # a tie (within 1 %) goes to the normal-priority pair in a plain process -- and to the high-priority pair in a rank that holds a
-    # RCCL communicator: there the short trial has twice been unable to tell the pairs apart (0.6226 / 0.6205, 0.6245 / 0.6196 ms)
-    # while the run that followed was 5 % slower on the normal pair than the high one measures (profiles/r5_launcher_path.txt)
-    prefer_high = False
-    try:
-        import torch.distributed as dist
-        prefer_high = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
-    except Exception:
-        prefer_high = False
-    if prefer_high:
-        chosen = "normal" if times["normal"] < 0.99 * times["high"] else "high"
-    else:
-        chosen = "high" if times["high"] < 0.99 * times["normal"] else "normal"
-    return dict(cands)[chosen], {"chosen": chosen, "forced": False, "tie_goes_to": "high" if prefer_high else "normal",
-                                 "trial_ms": {k: round(1e3 * v, 4) for k, v in times.items()}}
+        t = min(trial(streams) for _ in range(2))
+        report.append(["normal" if prio == 0 else "high", round(1e3 * t, 4)])
+        if best is None or t < best[0]:
+            best = (t, k, streams)
+    return best[2], {"chosen": report[best[1]][0], "candidate": best[1], "forced": False, "trial_ms": report}
 
 
 def shared_launch_grid(device):

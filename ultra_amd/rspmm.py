@@ -748,9 +748,9 @@ def set_tuning(threads=0, grid=0, rel_lds=-1, x_lds=-1, unroll=0, general_walk=0
     """Kernel-launch tuning knobs (measurement / tests).  set_tuning() restores the defaults.
     general_walk: reference-order plans on the general walk kernel; unit_walk: the reference-order kernels walk units of
     four rows (C++ loops) instead of group streams (assembly loops); update_form: where forward_update applies the layer
-    update -- 0 the library's choice (3 where it fits and the graph has 10+ steps a row, else 1), 1 in the kernel's tail, 2 beside
-    the walk (rows handed over by reference, read back from memory), 3 beside the walk with the rows passing through LDS (2 / 3:
-    None where the form does not fit)."""
+    update -- 0 the library's choice (3 where it fits and the graph has 10+ steps a row, else 1), 1 in the kernel's tail, 3 beside the
+    walk with the rows passing through LDS (forward_update returns None where it does not fit; 2 -- rows by reference -- was removed
+    in ABI 6 and always answers None)."""
     t = _lib.Tuning(int(threads), int(grid), int(rel_lds), int(x_lds), int(unroll),
                     (ctypes.c_int32 * 3)(int(general_walk), int(unit_walk), int(update_form)))
     check(lib.ultra_set_tuning(ctypes.byref(t)))
