@@ -3,6 +3,8 @@ schedule's environment knobs (each needs its own process: the knobs are read whe
 
     python tools/form3_probe.py [shape] [batch] [sum]     env: PROBE_GRID (256), PROBE_DUMP_PARTS=1 (per-partition cycle dump),
                                                                ULTRA_STREAM_SHARES_12, ULTRA_CHAIN_LIMIT_FACTOR, ULTRA_STREAM_ROW_ORDER ...
+(The PROBE_CALIBRATE loops of round 5 -- profile-guided partition budgets, then an incremental re-deal -- were removed with their
+plan.cpp knobs after they showed no gain: profiles/r5_experiments.txt.)
 Prints: us per layer inside a hipGraph of 20 (median of 5), bit-equality with the two launches, and from one traced launch the
 cycles since each workgroup's start: chains done, walkers' last end, update waves' end (means over the workgroups), workgroup end
 mean / max."""
@@ -89,70 +91,3 @@ if os.environ.get("PROBE_DUMP_PARTS"):
         print("PARTS walkq%d " % q + " ".join("%.0f" % v for v in wave_end[:, 4 * q:4 * q + 4].max(dim=1)[0].view(nparts, bs).mean(dim=1).tolist()))
     for wv in range(16):      # end of every wave's work, mean over the partition's samples
         print("PARTS wave%d " % wv + " ".join("%.0f" % v for v in wave_end[:, wv].view(nparts, bs).mean(dim=1).tolist()))
-
-# ---- PROBE_CALIBRATE=n: n rounds of "traced launches -> per-partition step deltas -> incremental re-deal" (ULTRA_PART_ADJUST_FILE, plan.cpp) ----
-n_cal = int(os.environ.get("PROBE_CALIBRATE", "0"))
-if n_cal:
-    import numpy as np
-    nparts = grid // bs
-    alpha = float(os.environ.get("PROBE_CAL_ALPHA", "0.7"))
-    afile = os.environ.get("ULTRA_PART_ADJUST_FILE") or "/tmp/ultra_part_adjust_%d.txt" % os.getpid()
-    os.environ["ULTRA_PART_ADJUST_FILE"] = afile
-    if os.path.exists(afile):
-        os.remove(afile)
-    adjust = np.zeros(nparts)
-
-    def traced(pl):
-        def run():
-            rspmm.set_tuning(update_form=form, grid=grid if grid != 256 else 0)
-            out = pl.forward_update(rel, x, w, b, lw, lb, 1e-5, flags, point=point, sum=agg_sum)
-            rspmm.set_tuning()
-            return out
-        ends, chains = [], []
-        run()
-        for _ in range(4):
-            tr = torch.zeros(grid * 32, dtype=torch.int64, device=dev)
-            torch.cuda.synchronize()
-            _lib.check(_lib.lib.ultra_order_trace(tr.data_ptr()))
-            out = run()
-            torch.cuda.synchronize()
-            _lib.check(_lib.lib.ultra_order_trace(None))
-            mm = tr.cpu()[:3 * grid].view(grid, 3).double()
-            ends.append((mm[:, 2] - mm[:, 0]).view(nparts, bs).mean(dim=1).numpy())
-            chains.append((mm[:, 1] - mm[:, 0]).view(nparts, bs).mean(dim=1).numpy())
-            e_all = mm[:, 2] - mm[:, 0]
-        s2 = torch.cuda.Stream()
-        ts = []
-        with torch.cuda.stream(s2):
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, stream=s2):
-                for _ in range(20):
-                    run()
-            g2.replay()
-            torch.cuda.synchronize()
-            for _ in range(3):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(s2)
-                for _ in range(5):
-                    g2.replay()
-                e1.record(s2)
-                torch.cuda.synchronize()
-                ts.append(e0.elapsed_time(e1) / 100 * 1e3)
-        return np.mean(ends, axis=0), np.mean(chains, axis=0), float(e_all.mean()), float(e_all.max()), sorted(ts)[1], torch.equal(out, want)
-
-    for it in range(n_cal + 1):
-        pl = rspmm.Plan(data.edge_index, data.edge_type, N, R, exact_order=True)
-        sdesc, _ = pl.streams(nparts, walkers=12)
-        steps_q = sdesc.view(nparts, 64, 2)[:, :, 1].sum(dim=1).double().numpy()
-        end_q, chain_q, e_mean, e_max, us, ok = traced(pl)
-        print("calibration round %d: %.2f us equal %s | end mean %.0f max %.0f | partitions: std %.0f max-mean %.0f | steps moved so far %.0f" %
-              (it, us, ok, e_mean, e_max, end_q.std(), end_q.max() - end_q.mean(), np.abs(adjust).sum() / 2))
-        walk_q = np.maximum(end_q - chain_q - 8000.0, 1000.0)
-        k_q = walk_q / np.maximum(steps_q, 1.0)                    # cycles a step of this partition's mix
-        delta = (end_q - end_q.mean()) / np.maximum(k_q, 1.0)      # steps to give away (> 0: the partition ends late)
-        delta -= delta.mean()
-        adjust = adjust + alpha * delta
-        with open(afile, "w") as f:
-            f.write(" ".join("%.1f" % a for a in adjust))
-        del pl
-    print("adjust file: " + afile + " : " + " ".join("%.0f" % a for a in adjust))

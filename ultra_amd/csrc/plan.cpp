@@ -401,22 +401,8 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
         std::vector<double> weight((size_t)nstream);
         total += COST_S_STEP * steps;
         const double T = total / nparts;
-        // per-partition multipliers of the stream budget (calibration: ULTRA_PART_WEIGHTS_FILE names a text file with nparts numbers
-        // for the twelve-walker schedule of that many partitions; tools/form3_probe.py PROBE_CALIBRATE writes it from a traced launch)
-        std::vector<double> part_mult((size_t)nparts, 1.0);
-        if (walkers == 12) {
-            if (const char *pw = std::getenv("ULTRA_PART_WEIGHTS_FILE")) {
-                if (FILE *f = std::fopen(pw, "r")) {
-                    std::vector<double> m;
-                    double v;
-                    while (std::fscanf(f, "%lf", &v) == 1) m.push_back(v);
-                    std::fclose(f);
-                    if ((int64_t)m.size() == nparts) part_mult = m;
-                }
-            }
-        }
         for (int32_t q = 0; q < nparts; ++q) {
-            const double budget = std::max(T - chain_cost[(size_t)q], 0.02 * T) * part_mult[(size_t)q];   // (never zero: every row needs a home)
+            const double budget = std::max(T - chain_cost[(size_t)q], 0.02 * T);   // (never zero: every row needs a home)
             for (int g = 0; g < ORDER_GROUPS; ++g) {
                 double share = wave_share[g / 16];
                 if (walkers == 12 && g / 4 < 12 && WAVE_SHARE_12_WAVES[g / 4] >= 0.0) share = WAVE_SHARE_12_WAVES[g / 4];
@@ -443,67 +429,6 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
             deal_into(sl.second, g);
             sheap.push(Slot((scost[(size_t)sl.second] + 1.0) / weight[(size_t)sl.second], sl.second));
         }
-        }
-        // ---- incremental re-deal (calibration: ULTRA_PART_ADJUST_FILE names a text file with nparts numbers, the STEPS each partition
-        // of the twelve-walker schedule is to give away (> 0) or to take (< 0); tools/form3_probe.py PROBE_CALIBRATE=... writes it from
-        // traced launches).  Everything stays where the deal above put it except a few typical rows: median-length rows leave the
-        // donors' streams one stream at a time and go, longest first, to the receiver that still needs most, onto its emptiest stream.
-        if (walkers == 12) {
-            std::vector<double> adjust;
-            if (const char *pa = std::getenv("ULTRA_PART_ADJUST_FILE")) {
-                if (FILE *f = std::fopen(pa, "r")) {
-                    double v;
-                    while (std::fscanf(f, "%lf", &v) == 1) adjust.push_back(v);
-                    std::fclose(f);
-                }
-            }
-            if ((int64_t)adjust.size() == nparts) {
-                std::vector<int32_t> moved;      // item indices taken from the donors
-                for (int32_t q = 0; q < nparts; ++q) {
-                    double need = adjust[(size_t)q];
-                    if (need <= 0.0) continue;
-                    for (int round = 0; round < 64 && need > 0.0; ++round) {
-                        bool any = false;
-                        for (int g = 0; g < 16 * (walkers / 4) && need > 0.0; ++g) {
-                            std::vector<int32_t> &mine = srows[(size_t)q * ORDER_GROUPS + g];
-                            if (mine.size() < 2) continue;
-                            std::vector<int32_t> by_len(mine);
-                            std::sort(by_len.begin(), by_len.end(), [&](int32_t a, int32_t b) {
-                                return p->items[(size_t)a].len != p->items[(size_t)b].len ? p->items[(size_t)a].len < p->items[(size_t)b].len : a < b;
-                            });
-                            const int32_t pick = by_len[by_len.size() / 2];       // a typical row of this stream
-                            const int32_t len = p->items[(size_t)pick].len;
-                            if ((double)(len + 1) > 1.5 * need + 8.0) continue;
-                            mine.erase(std::find(mine.begin(), mine.end(), pick));
-                            sload[(size_t)q * ORDER_GROUPS + g] -= len + 1;
-                            scost[(size_t)q * ORDER_GROUPS + g] -= len + 1 + ROW_COST_12[g / 16];
-                            moved.push_back(pick);
-                            need -= len + 1;
-                            any = true;
-                        }
-                        if (!any) break;
-                    }
-                }
-                std::stable_sort(moved.begin(), moved.end(), [&](int32_t a, int32_t b) { return p->items[(size_t)a].len > p->items[(size_t)b].len; });
-                std::vector<double> want((size_t)nparts, 0.0);
-                for (int32_t q = 0; q < nparts; ++q) want[(size_t)q] = adjust[(size_t)q] < 0.0 ? -adjust[(size_t)q] : 0.0;
-                for (const int32_t it : moved) {
-                    int32_t best = 0;
-                    for (int32_t q = 1; q < nparts; ++q)
-                        if (want[(size_t)q] > want[(size_t)best]) best = q;
-                    int64_t st = -1;
-                    double ratio = 0.0;
-                    for (int g = 0; g < 16 * (walkers / 4); ++g) {
-                        const int64_t cand = (int64_t)best * ORDER_GROUPS + g;
-                        if (weight[(size_t)cand] <= 0.0) continue;
-                        const double r = (scost[(size_t)cand] + 1.0) / weight[(size_t)cand];
-                        if (st < 0 || r < ratio) st = cand, ratio = r;
-                    }
-                    if (st < 0) st = (int64_t)best * ORDER_GROUPS;
-                    deal_into(st, it);
-                    want[(size_t)best] -= p->items[(size_t)it].len + 1;
-                }
-            }
         }
         s->sdesc.assign((size_t)nstream * 2, 0);
         s->srec.reserve((size_t)(2 * (int64_t)steps) + 2 * ORDER_PAD);
