@@ -273,6 +273,8 @@ int32_t ultra_rspmm_forward_onehot(ultra_plan *plan, int32_t dtype, const void *
  * NULL to skip), relation and input, given the forward output and its gradient.  min/max give the
  * full gradient to every tying edge (operator.cuh:62-64,75-77).
  * relation_grad / input_grad are overwritten (the reference returns fresh zeros_like + accumulation).
+ * input_grad may be NULL under sum == add: the input gradient is then left to the caller -- it is an rspmm forward over
+ * the transposed graph (rspmm.cpp:110-112), which a graph with a dense-format twin runs on the matrix cores instead.
  */
 int32_t ultra_rspmm_backward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype,
                              const void *edge_weight_dev, const ultra_mat *relation, const ultra_mat *input,

@@ -56,6 +56,20 @@ def test_negative_sampling_is_strict():
         assert h_mask[i, out[i, 1:, 0]].all() and (out[i, :, 1] == batch[i, 1]).all()
 
 
+def test_prefetched_negatives_are_the_plain_loops_draws():
+    """prefetch_negatives (the sampler one batch ahead of the step): the same batches, in the same order, as calling
+    negative_sampling in the loop -- on the CPU it IS that loop; an empty loader yields nothing."""
+    data = synthetic.make_kg(num_node=60, num_triple=400, num_relation_base=3, seed=5, relation_graph=False)
+    triples = torch.stack([data.edge_index[0], data.edge_index[1], data.edge_type], dim=-1)
+    batches = [triples[8 * i:8 * i + 8] for i in range(5)]
+    torch.manual_seed(3)
+    plain = [tasks.negative_sampling(data, b, 16, strict=True) for b in batches]
+    torch.manual_seed(3)
+    ahead = list(tasks.prefetch_negatives(iter(batches), data, 16, strict=True))
+    assert len(ahead) == 5 and all(torch.equal(a, b) for a, b in zip(ahead, plain))
+    assert list(tasks.prefetch_negatives(iter([]), data, 16)) == []
+
+
 def test_synthetic_shapes():
     s = synthetic.SHAPES["fb15k237"]
     assert (s["num_node"], 2 * s["num_triple"], 2 * s["num_relation_base"], s["num_test"]) == (14541, 544230, 474, 20466)

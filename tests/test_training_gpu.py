@@ -216,3 +216,22 @@ def test_training_forward_equals_the_filtered_graph(dev, aggr):
     with torch.no_grad():
         want = model(filtered, neg)
     assert torch.allclose(out.detach(), want, atol=(2e-4 if aggr == "pna" else 2e-5), rtol=1e-4)
+
+
+def test_prefetched_negatives_equal_the_plain_loop_and_overlap_a_busy_stream(dev):
+    """tasks.prefetch_negatives on the GPU: the draws of the plain loop (same generator order), handed over through the
+    stream dependency -- checked while the training stream is kept busy between the batches, as a step would."""
+    data = synthetic.make_kg(num_node=300, num_triple=2500, num_relation_base=5, num_test=16, seed=8).to(dev)
+    triples = torch.stack([data.edge_index[0], data.edge_index[1], data.edge_type], dim=-1)
+    batches = [triples[8 * i:8 * i + 8] for i in range(6)]
+    torch.manual_seed(11)
+    plain = [tasks.negative_sampling(data, b, 32, strict=True) for b in batches]
+    busy = torch.randn(2048, 2048, device=dev)
+    torch.manual_seed(11)
+    got = []
+    for neg in tasks.prefetch_negatives(iter(batches), data, 32, strict=True):
+        got.append(neg.clone())              # (read on the training stream: behind the side stream's event)
+        for _ in range(4):
+            busy = busy @ busy / 2048.0      # the "step": work queued on the training stream
+    torch.cuda.synchronize()
+    assert len(got) == len(plain) and all(torch.equal(a, b) for a, b in zip(got, plain))

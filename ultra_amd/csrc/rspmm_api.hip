@@ -632,13 +632,16 @@ static int backward_impl(ultra_plan *p, int sum, int mul, int dtype, const void 
     if ((rc = check_mat(outm, "output", p->num_out, n_outer, row_len))) return rc;
     if ((rc = check_mat(og, "output_grad", p->num_out, n_outer, row_len))) return rc;
     if ((rc = check_mat(rgrad, "relation_grad", p->num_rel, n_outer, row_len))) return rc;
-    if ((rc = check_mat(xgrad, "input_grad", p->num_in, n_outer, row_len))) return rc;
+    // input_grad == NULL (sum == add only): the caller takes the input gradient elsewhere -- the gather over the transposed
+    // graph is an rspmm forward, and a graph with a dense-format twin runs it on the matrix cores (rspmm.py Plan.backward)
+    if (!xgrad && sum != ULTRA_SUM_ADD) return invalid("input_grad may be NULL under sum == add only");
+    if (xgrad && (rc = check_mat(xgrad, "input_grad", p->num_in, n_outer, row_len))) return rc;
     if ((rc = upload_plan(p))) return rc;
 
     const size_t esz = dtype == ULTRA_F32 ? 4 : 8;
     const int64_t step = dtype == ULTRA_F32 ? 4 : 2;
     const bool vec4 = (row_len % 4 == 0) && mat_vec_ok(rel, step) && mat_vec_ok(x, step) && mat_vec_ok(outm, step) &&
-                      mat_vec_ok(og, step) && mat_vec_ok(rgrad, step) && mat_vec_ok(xgrad, step);
+                      mat_vec_ok(og, step) && mat_vec_ok(rgrad, step) && (!xgrad || mat_vec_ok(xgrad, step));
 
     EdgeParams ep;
     std::memset(&ep, 0, sizeof(ep));
@@ -656,9 +659,9 @@ static int backward_impl(ultra_plan *p, int sum, int mul, int dtype, const void 
     ep.rgrad = rgrad->ptr;
     ep.rgrad_so = rgrad->stride_outer;
     ep.rgrad_sr = rgrad->stride_row;
-    ep.xgrad = xgrad->ptr;
-    ep.xgrad_so = xgrad->stride_outer;
-    ep.xgrad_sr = xgrad->stride_row;
+    ep.xgrad = xgrad ? xgrad->ptr : nullptr;
+    ep.xgrad_so = xgrad ? xgrad->stride_outer : 0;
+    ep.xgrad_sr = xgrad ? xgrad->stride_row : 0;
     ep.wgrad = wgrad;
     ep.n_outer = (int32_t)n_outer;
     ep.row_len = (int32_t)row_len;
@@ -666,8 +669,8 @@ static int backward_impl(ultra_plan *p, int sum, int mul, int dtype, const void 
     if (sum == ULTRA_SUM_ADD) {
         if ((rc = ensure_backward_plans(p))) return rc;
         // input_grad[col] = sum_e w * d(rel (x) in)/d in * out_grad[row]   (rspmm.cpp:110-112)
-        if ((rc = forward_impl(p->tplan, ULTRA_SUM_ADD, mul == ULTRA_MUL_MUL ? BIN_MUL : BIN_RHS, dtype, w, rel, og,
-                               nullptr, xgrad, stream)))
+        if (xgrad && (rc = forward_impl(p->tplan, ULTRA_SUM_ADD, mul == ULTRA_MUL_MUL ? BIN_MUL : BIN_RHS, dtype, w, rel, og,
+                                        nullptr, xgrad, stream)))
             return rc;
         // relation_grad[type] = sum_e w * d(rel (x) in)/d rel * out_grad[row]   (rspmm.cpp:106-108)
         if ((rc = forward_impl(p->rplan, ULTRA_SUM_ADD, mul == ULTRA_MUL_MUL ? BIN_MUL : BIN_LHS, dtype, w, og, x,

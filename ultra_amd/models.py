@@ -393,13 +393,13 @@ class EntityNBFNet(BaseNBFNet):
             score = dense.readout(self, hiddens[-1], query, t_index).view(shape)
             self._check_valid(valid)
             return score
-        node_query = query.unsqueeze(1).expand(-1, data.num_nodes, -1)
-        if self.concat_hidden:
-            feature = torch.cat(hiddens + [node_query], dim=-1)
-        else:
-            feature = torch.cat([hiddens[-1], node_query], dim=-1)
-        index = t_index.unsqueeze(-1).expand(-1, -1, feature.shape[-1])
-        feature = feature.gather(1, index)   # (batch, 1 + num_negative, feature_dim)
+        # models.py:202-207 builds cat[hidden, query] for EVERY node and then gathers the candidates' rows; gathering first
+        # gives the same (batch, 1 + num_negative, feature_dim) rows without the (batch, N, 128) tensor -- and, under
+        # autograd, without its backward: a (batch, N, 128) scatter target and the reduction over N of the expanded query
+        # (90 us of a 7 ms fine-tuning step at FB15k237's size, 0.9 ms of 23 at YAGO3-10's)
+        picked = [h.gather(1, t_index.unsqueeze(-1).expand(-1, -1, h.shape[-1]))
+                  for h in (hiddens if self.concat_hidden else hiddens[-1:])]
+        feature = torch.cat(picked + [query.unsqueeze(1).expand(-1, t_index.shape[1], -1)], dim=-1)
         score = self.mlp(feature).squeeze(-1)
         self._check_valid(valid)
         return score.view(shape)

@@ -99,6 +99,8 @@ class Plan(object):
         # (row, type) run) get a twin plan whose items hold one relation each; add_mul forwards use it.
         self.typed = None
         self.dense = None
+        self._edges = None
+        self._dense_t = None
         if dense == "only" or type_runs == "only":
             return
         # (Nearly) complete graphs -- again ULTRA's relation graph -- also get a dense-format twin: fp32 add_mul with unit
@@ -108,6 +110,7 @@ class Plan(object):
                 and cells <= (1 << 26) and (dense is True or self.num_edge >= self.DENSE_MIN_FILL * cells):
             try:
                 self.dense = Plan(ei, et, num_node, num_relation, num_in=num_in, type_runs=False, dense="only")
+                self._edges = (ei, et)      # (a few hundred nodes: kept for the transposed twin of the backward)
             except _lib.UltraError:     # an edge repeated more than 255 times: the edge walk serves it
                 if dense is True:
                     raise
@@ -132,6 +135,15 @@ class Plan(object):
             return self.dense
         return self.typed
 
+    def dense_transposed(self):
+        """The dense-format plan of the TRANSPOSED graph (built on first use): the input gradient of add_mul,
+        input_grad[col] = sum_e rel[type] * output_grad[row] (rspmm.cpp:110-112), is an rspmm forward over it."""
+        if self._dense_t is None and self.dense is not None and self._edges is not None:
+            ei, et = self._edges
+            self._dense_t = Plan(ei.flip(0).contiguous(), et, self.num_in, self.num_relation, num_in=self.num_node,
+                                 type_runs=False, dense="only")
+        return self._dense_t
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h and lib is not None:   # (module globals are gone at interpreter shutdown)
@@ -145,7 +157,7 @@ class Plan(object):
 
     def pin(self, delta=1):
         """A captured hipGraph starts (+1) / stops (-1) referencing this plan's device arrays (twins included)."""
-        for p in (self, self.typed, self.dense):
+        for p in (self, self.typed, self.dense, self._dense_t):
             if p is not None and getattr(p, "_h", None):
                 check(lib.ultra_plan_pin(p._h, int(delta)))
 
@@ -427,9 +439,19 @@ class Plan(object):
         output, mo = as_mat(output)
         output_grad, mog = as_mat(output_grad)
         rgrad = torch.empty(relation.shape, dtype=relation.dtype, device=relation.device)
-        xgrad = torch.empty(input.shape, dtype=input.dtype, device=input.device)
         _, mrg = as_mat(rgrad)
-        _, mxg = as_mat(xgrad)
+        # A graph with a dense-format twin (ULTRA's relation graph) takes its input gradient as that twin's forward over
+        # the transposed graph -- the matrix-core kernel of the forward pass, 15 us where the edge walk over the
+        # transposed plan takes 70 -- and asks ultra_rspmm_backward for the relation gradient alone.
+        xgrad, mxg = None, None
+        if self._twin_for(sum, mul, edge_weight, output_grad, relation) is self.dense and self.dense is not None \
+                and input.dtype == torch.float32:
+            twin = self.dense_transposed()
+            if twin is not None:
+                xgrad = twin.forward(relation, output_grad)
+        if xgrad is None:
+            xgrad = torch.empty(input.shape, dtype=input.dtype, device=input.device)
+            _, mxg = as_mat(xgrad)
         w = None
         if edge_weight is not None:
             edge_weight = edge_weight.contiguous()
@@ -441,7 +463,7 @@ class Plan(object):
             wg = wgrad.data_ptr()
         check(lib.ultra_rspmm_backward(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
                                        ctypes.byref(mx), ctypes.byref(mo), ctypes.byref(mog), wg, ctypes.byref(mrg),
-                                       ctypes.byref(mxg), _stream(input)))
+                                       ctypes.byref(mxg) if mxg is not None else None, _stream(input)))
         return wgrad, rgrad, xgrad
 
     def forward_timed(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", warmup=3, iters=20,

@@ -3,6 +3,7 @@ whatever device the graph lives on.  Same names, arguments and results as the re
 
   edge_match             tasks.py:7-39     all graph edges matching each query key, via mixed-radix keys + searchsorted
   negative_sampling      tasks.py:42-76
+  prefetch_negatives     (the same, one batch ahead of the training step on a side stream; script/run.py:53-55)
   all_negative           tasks.py:79-91    (bs, 3) positives -> (bs, N, 3) tail- and head-candidate batches
   strict_negative_mask   tasks.py:94-130   filtered-ranking masks
   compute_ranking        tasks.py:133-141  rank = #(masked candidates scoring >= positive) + 1
@@ -113,6 +114,48 @@ def negative_sampling(data, batch, num_negative, strict=True):
     t_index[:half, 1:] = neg_t
     h_index[half:, 1:] = neg_h
     return torch.stack([h_index, t_index, r_index], dim=-1)
+
+
+def prefetch_negatives(batches, data, num_negative, strict=True):
+    """negative_sampling() over an iterable of positive batches, one batch AHEAD of the training step and on a side stream:
+
+        for batch in prefetch_negatives(loader, train_data, num_negative, strict):      # script/run.py:53-55
+            pred = model(train_data, batch) ...
+
+    The strict sampler is ~ 60 small launches and three host synchronisations (nonzero, the match counts).  Issued on
+    the training stream it waits for the previous step's backward and optimiser to drain, then the GPU idles while the
+    host reads the counts back; issued here -- after the previous step's launches are enqueued, on its own stream --
+    its kernels run beside that step's backward and the host synchronises with the side stream alone.  The draws come
+    from the default generator in the same order as the plain loop makes them.  `batches` yields CPU tensors or GPU
+    tensors that are complete when they are yielded (a loader's, a slice of the triple list): the side stream does not
+    wait for the training stream.  A graph on the CPU: the plain loop, unchanged."""
+    it = iter(batches)
+    dev = data.edge_index.device
+    if dev.type != "cuda":
+        for batch in it:
+            yield negative_sampling(data, batch, num_negative, strict=strict)
+        return
+    with torch.cuda.device(dev):
+        side = torch.cuda.Stream()
+
+    def sample(batch):
+        with torch.cuda.stream(side):
+            return negative_sampling(data, batch.to(dev, non_blocking=True), num_negative, strict=strict)
+
+    try:
+        ahead = sample(next(it))
+    except StopIteration:
+        return
+    while ahead is not None:
+        main = torch.cuda.current_stream(dev)
+        main.wait_stream(side)
+        ahead.record_stream(main)        # (allocated on the side stream, read by the step on the training stream)
+        current, ahead = ahead, None
+        yield current                    # the caller enqueues its step ...
+        try:
+            ahead = sample(next(it))     # ... and the next batch's negatives are drawn while the GPU works through it
+        except StopIteration:
+            ahead = None
 
 
 def all_negative(data, batch):
