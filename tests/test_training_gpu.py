@@ -235,3 +235,68 @@ def test_prefetched_negatives_equal_the_plain_loop_and_overlap_a_busy_stream(dev
             busy = busy @ busy / 2048.0      # the "step": work queued on the training stream
     torch.cuda.synchronize()
     assert len(got) == len(plain) and all(torch.equal(a, b) for a, b in zip(got, plain))
+
+
+def _index_add_rspmm(ei, et, rel, x, keep, n):
+    msg = rel[:, et] * x[:, ei[1]]
+    if keep is not None:
+        msg = msg * keep.view(1, -1, 1)
+    return torch.zeros(x.shape[0], n, x.shape[2], dtype=x.dtype, device=x.device).index_add(1, ei[0], msg)
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_first_layer_rspmm_on_the_boundary_condition_matches_autograd(dev, masked):
+    """rspmm.onehot_rspmm: layer 0's add_mul on its one-hot input (values[b] at row rows[b]) + that boundary -- output,
+    relation gradient and values gradient against fp64 autograd of the dense formulation; one source is a hub, one has no
+    out-edge, a keep mask drops a fifth of the edges."""
+    gen = torch.Generator().manual_seed(21)
+    n, e, bs, num_rel = 500, 6000, 4, 11
+    ei = torch.randint(1, n, (2, e), generator=gen)          # (node 0 has no edge at all)
+    ei[1, :1500] = 7                                         # hub source
+    et = torch.randint(0, num_rel, (e,), generator=gen)
+    rows = torch.tensor([7, 0, 123, 7])
+    values = torch.randn(bs, 64, generator=gen)
+    rel = torch.randn(bs, num_rel, 64, generator=gen)
+    og = torch.randn(bs, n, 64, generator=gen)
+    keep = (torch.rand(e, generator=gen) > 0.2).float() if masked else None
+
+    v64, r64 = (t.double().to(dev).requires_grad_() for t in (values, rel))
+    x0 = torch.zeros(bs, n, 64, dtype=torch.float64, device=dev).index_put((torch.arange(bs, device=dev), rows.to(dev)), v64)
+    want = _index_add_rspmm(ei.to(dev), et.to(dev), r64, x0, keep.double().to(dev) if masked else None, n) + x0
+    want.backward(og.double().to(dev))
+
+    dei, det = ei.to(dev), et.to(dev)
+    plan = rspmm.get_plan(dei, det, n, num_rel, exact_order=False)
+    dv, dr = (t.to(dev).requires_grad_() for t in (values, rel))
+    boundary = layers.PointBoundary(rows.to(dev), dv, n)
+    out = rspmm.onehot_rspmm(plan, dei, det, dr, boundary.rows, dv, boundary.dense().detach(), keep.to(dev) if masked else None)
+    torch.testing.assert_close(out.detach().double(), want.detach(), rtol=1e-5, atol=1e-5)
+    out.backward(og.to(dev))
+    torch.testing.assert_close(dr.grad.double(), r64.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dv.grad.double(), v64.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_closed_form_boundary_gradient_of_the_differentiable_rspmm(dev):
+    """plan_rspmm(point=(rows, values)): same output and gradients as the boundary passed as a tensor built from
+    `values`; the values' gradient is bs rows of the output gradient."""
+    gen = torch.Generator().manual_seed(22)
+    n, e, bs, num_rel = 400, 5000, 3, 9
+    ei = torch.randint(0, n, (2, e), generator=gen).to(dev)
+    et = torch.randint(0, num_rel, (e,), generator=gen).to(dev)
+    rows = torch.tensor([5, 5, 399], device=dev)
+    og = torch.randn(bs, n, 64, generator=gen).to(dev)
+    plan = rspmm.get_plan(ei, et, n, num_rel, exact_order=False)
+    grads = []
+    for closed in (False, True):
+        g2 = torch.Generator().manual_seed(23)
+        values, rel, x = (t.to(dev).requires_grad_() for t in (torch.randn(bs, 64, generator=g2), torch.randn(bs, num_rel, 64, generator=g2),
+                                                               torch.randn(bs, n, 64, generator=g2)))
+        if closed:
+            out = rspmm.plan_rspmm(plan, rel, x, point=(rows, values))
+        else:
+            dense_b = torch.zeros(bs, n, 64, device=dev).index_put((torch.arange(bs, device=dev), rows), values)
+            out = rspmm.plan_rspmm(plan, rel, x, boundary=dense_b)
+        out.backward(og)
+        grads.append((out.detach(), values.grad, rel.grad, x.grad))
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)

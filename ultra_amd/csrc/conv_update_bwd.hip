@@ -344,18 +344,26 @@ __global__ void __launch_bounds__(512) conv_update_bwd_weights_kernel(const Conv
     for (int idx = tid; idx < 64 * 128 + 64; idx += blockDim.x) dst[idx] = lds_dw[idx];
 }
 
-// 64 consecutive entries per workgroup; the partials are split over four thread groups (q, q + 4, q + 8, ... in
-// ascending order each), folded 0 + 1 + 2 + 3 through LDS: a fixed order, reproducible run to run.
-__global__ void __launch_bounds__(256) conv_update_bwd_reduce_kernel(const ConvBwdParams p) {
-    __shared__ float lds_q[4][64];
+// 64 consecutive entries per workgroup; the partials are split over sixteen thread groups (q, q + 16, q + 32, ... in
+// ascending order each, four loads in flight), folded 0 + 1 + ... + 15 through LDS: a fixed order, reproducible run to run.
+__global__ void __launch_bounds__(1024) conv_update_bwd_reduce_kernel(const ConvBwdParams p) {
+    __shared__ float lds_q[16][64];
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + e;        // CB_PART is a multiple of 64
     float s = 0.f;
-    for (int k = q; k < p.n_part; k += 4) s += p.part[(long long)k * CB_PART + idx];
+    int k = q;
+    for (; k + 48 < p.n_part; k += 64) {
+        const float a = p.part[(long long)k * CB_PART + idx], b = p.part[(long long)(k + 16) * CB_PART + idx];
+        const float c = p.part[(long long)(k + 32) * CB_PART + idx], d = p.part[(long long)(k + 48) * CB_PART + idx];
+        s = (((s + a) + b) + c) + d;
+    }
+    for (; k < p.n_part; k += 16) s += p.part[(long long)k * CB_PART + idx];
     lds_q[q][e] = s;
     __syncthreads();
     if (q != 0) return;
-    s = ((lds_q[0][e] + lds_q[1][e]) + lds_q[2][e]) + lds_q[3][e];
+    s = lds_q[0][e];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) s += lds_q[g][e];
     if (idx < 64 * 128)
         p.gweight[idx] = s;
     else if (idx < 64 * 128 + 64) {
@@ -376,7 +384,10 @@ static int bwd_grid(long long rows) {
             cu = v;
     }
     const long long ntile = (rows + 31) / 32;
-    long long blocks = (ntile + 7) / 8;      // 8 waves per workgroup, one workgroup per CU, persistent over tiles
+    // 8 waves per workgroup, one workgroup per CU, persistent over tiles.  (Two per CU need the kernels in 128 VGPRs: they
+    // hold 232 / 218 -- the 128 accumulators of dW, the three row operands of a tile -- and built that way they spill:
+    // the FB15k237-shape step 6.1 -> 9.3 ms, profiles/r5_experiments.txt.)
+    long long blocks = (ntile + 7) / 8;
     if (blocks > cu) blocks = cu;
     return (int)(blocks < 1 ? 1 : blocks);
 }
@@ -435,7 +446,7 @@ int32_t ultra_conv_update_backward(const void *x, const void *agg, const void *g
     (void)hipGetLastError();
     hipLaunchKernelGGL(conv_update_bwd_rows_kernel, dim3(p.n_part), dim3(512), 0, s, p);
     hipLaunchKernelGGL(conv_update_bwd_weights_kernel, dim3(p.n_part), dim3(512), 0, s, p);
-    hipLaunchKernelGGL(conv_update_bwd_reduce_kernel, dim3(CB_PART / 64), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(conv_update_bwd_reduce_kernel, dim3(CB_PART / 64), dim3(1024), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error(std::string("conv_update backward launch: ") + hipGetErrorString(e));

@@ -23,6 +23,8 @@ ONEHOT_FAST_PATH = True
 # the boundary condition kept as (row, value) per sample instead of a (batch, N, d) tensor; layer 0 computed on its
 # special rows only (A/B switch for tests)
 POINT_BOUNDARY_FAST_PATH = True
+# ... and under autograd (fine-tuning): the sum aggregate's differentiable rspmm reads the closed form too (A/B switch for tests)
+POINT_BOUNDARY_TRAINING = True
 # aggregate + update of a layer in one launch on dense-format plans (A/B switch for tests)
 FUSED_DENSE_LAYER = True
 # aggregate + update of a layer in one launch on the reference-order plan of a sparse graph: the update runs in the tail of
@@ -191,8 +193,9 @@ class GeneralizedRelationalConv(nn.Module):
                 (edge_weight is not None and edge_weight.requires_grad) or self.message_func == "rotate"
                 or self.aggregate_func not in ("sum", "max") or not kwargs["input"].is_cuda
                 or (self.aggregate_func == "max" and (torch.is_grad_enabled() or edge_keep))
-                or (torch.is_grad_enabled() and (kwargs["input"].requires_grad or kwargs["relation"].requires_grad
-                                                 or kwargs["boundary"].requires_grad))):
+                or (torch.is_grad_enabled() and not self.point_boundary_trains()
+                    and (kwargs["input"].requires_grad or kwargs["relation"].requires_grad
+                         or kwargs["boundary"].requires_grad))):
             kwargs["boundary"] = kwargs["boundary"].dense()     # paths that need the boundary as a tensor
         if (edge_weight is not None and edge_weight.requires_grad) or self.message_func == "rotate":
             # layers.py:91-94: the fused kernel covers TransE / DistMult with constant edge weights only
@@ -209,6 +212,11 @@ class GeneralizedRelationalConv(nn.Module):
                                          kwargs["edge_type"], edge_weight, edge_index[1], num_node,
                                          onehot_rows=onehot_rows, edge_keep=edge_keep)
         return self.update(out, kwargs["input"], residual=residual)
+
+    def point_boundary_trains(self):
+        """The differentiable rspmm takes the boundary condition in closed form for the sum aggregate (rspmm._PlanRSPMM,
+        rspmm._OnehotRSPMM): no (batch, N, d) boundary gradient is formed, layer 0 walks the sources' edges only."""
+        return POINT_BOUNDARY_TRAINING and self.aggregate_func == "sum" and self.message_func in self.message2mul
 
     def _fused_dense_layer(self, edge_index, kwargs, num_node, residual, onehot_rows):
         """Aggregate + update in one launch where the graph has a dense-format plan (ULTRA's relation graph)."""
@@ -322,6 +330,9 @@ class GeneralizedRelationalConv(nn.Module):
             point, point_boundary, boundary = (boundary.rows, boundary.values), boundary, None
 
         def agg(sum, rel=relation, x=input, fuse_boundary=None):
+            if point is not None and needs_grad:
+                # (propagate() lets the closed form through under autograd for the sum aggregate only)
+                return rspmm.plan_rspmm(plan, rel, x, edge_weight, sum=sum, mul=mul, keep=edge_keep, point=point)
             if point is not None:
                 out = plan.forward(rel, x, edge_weight=edge_weight, sum=sum, mul=mul, point=point)
                 if out is not None:
@@ -348,7 +359,13 @@ class GeneralizedRelationalConv(nn.Module):
                 degree_out = torch.bincount(index, minlength=dim_size).to(input.dtype)
             degree_out = (degree_out + 1).view(1, -1, 1)
 
-        if (ONEHOT_FAST_PATH and onehot_rows is not None and not needs_grad and self.aggregate_func == "sum"
+        if (ONEHOT_FAST_PATH and onehot_rows is not None and needs_grad and point is not None and self.aggregate_func == "sum"
+                and mul == "mul" and input.is_cuda and input.dtype == torch.float32 and dim_size == input.shape[1]
+                and (edge_weight is None or not edge_weight.requires_grad)):
+            # layer 0 of a training step: `input` IS the boundary condition as a tensor (the caller's contract for
+            # onehot_rows beside a PointBoundary) -- forward and backward visit the sources' out-edges only
+            update = rspmm.onehot_rspmm(plan, edge_index, edge_type, relation, point[0], point[1], input, edge_weight)
+        elif (ONEHOT_FAST_PATH and onehot_rows is not None and not needs_grad and self.aggregate_func == "sum"
                 and mul == "mul" and input.is_cuda and point is None):
             # row-sparse input (layer 0): only the edges leaving the source rows contribute to a sum of products
             update = plan.forward_onehot(relation, input, onehot_rows, edge_weight=edge_weight, boundary=boundary)

@@ -128,7 +128,9 @@ class BaseNBFNet(nn.Module):
                 # (the layers still get the closed form: those that can use it -- the sum and max aggregates of the
                 # inference path -- do, the others ask it for the tensor, which is built once)
                 layer_input = boundary.dense()
-                if separate_grad or torch.is_grad_enabled():
+                # (a training step of the sum aggregate keeps the closed form: its gradient is bs rows of each layer's
+                # output gradient, not a (batch, N, d) tensor per layer for autograd to sum -- layers.point_boundary_trains)
+                if separate_grad or (torch.is_grad_enabled() and not all(l.point_boundary_trains() for l in self.layers)):
                     boundary = layer_input
         for i, layer in enumerate(self.layers):
             if i < first:
@@ -182,7 +184,8 @@ class RelNBFNet(BaseNBFNet):
         index = h_index.unsqueeze(-1).expand_as(query)
         # boundary: ones at the query relation's node, zeros elsewhere (models.py:59-66) -- in closed form
         boundary = layers.PointBoundary(h_index, query, data.num_nodes)
-        if not (layers.POINT_BOUNDARY_FAST_PATH and h_index.is_cuda and not torch.is_grad_enabled()):
+        if not (layers.POINT_BOUNDARY_FAST_PATH and h_index.is_cuda
+                and (not torch.is_grad_enabled() or all(l.point_boundary_trains() for l in self.layers))):
             boundary = boundary.dense()
         # layer 0 reads the one-hot boundary itself: tell the layer which row of each sample is non-zero
         hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad=False,
@@ -260,6 +263,12 @@ class EntityNBFNet(BaseNBFNet):
         if fused and layers.POINT_BOUNDARY_FAST_PATH and not torch.is_grad_enabled():
             # gather the query rows; the boundary stays in closed form
             _, query, _ = dense.query_boundary(h_index, self.query, r_index, data.num_nodes, materialize=False)
+            boundary = layers.PointBoundary(h_index, query, data.num_nodes)
+        elif (layers.POINT_BOUNDARY_FAST_PATH and h_index.is_cuda and torch.is_grad_enabled() and self.query.dim() == 3
+              and all(l.point_boundary_trains() for l in self.layers)):
+            # training step: the query rows through autograd's gather, the boundary in closed form (its dense form, which
+            # layer 0's update reads, is built from it once: PointBoundary.dense)
+            query = self.query[torch.arange(batch_size, device=r_index.device), r_index]
             boundary = layers.PointBoundary(h_index, query, data.num_nodes)
         elif fused:
             # gather + scatter, one kernel
