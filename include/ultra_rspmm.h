@@ -269,6 +269,23 @@ int32_t ultra_rspmm_forward_onehot(ultra_plan *plan, int32_t dtype, const void *
                                    const ultra_mat *boundary, const ultra_mat *output, void *stream);
 
 /*
+ * Backward of ultra_rspmm_forward_onehot in its layer-0 use (fine-tuning): the input is the boundary condition -- values[o]
+ * at row src_rows[o] of outer slice o, zero elsewhere -- and the same tensor is the boundary added to the sum.  Only the
+ * edges leaving the source rows matter (rspmm.cpp:106-112 restricted to them):
+ *   S[o, t]             = sum over edges e with source src_rows[o] and type t of  w_e * output_grad[o, target_e]
+ *   relation_grad[o, t] = values[o] * S[o, t]                                   ((n_outer, num_relation, row_len) contiguous)
+ *   values_grad[o]      = sum_t relation[o, t] * S[o, t] + output_grad[o, src_rows[o]]         ((n_outer, row_len) contiguous)
+ * The graph arrives as the caller's CSR over SOURCE nodes with every node's edges sorted by type: out_ptr (num_node + 1),
+ * out_edge (edge ids in (source, type) order), and the edge list's target / type arrays (original order; edge_weight too,
+ * NULL = ones).  fp32, row_len a multiple of 64, 16-byte aligned rows, num_relation * 256 B + 34 KB <= 160 KB of LDS;
+ * anything else: ULTRA_ERR_UNSUPPORTED.  No atomics: the same bits run to run.  Either gradient pointer may be NULL.
+ */
+int32_t ultra_rspmm_onehot_backward(const int64_t *out_ptr_dev, const int64_t *out_edge_dev, const int64_t *edge_target_dev,
+                                    const int64_t *edge_type_dev, const void *edge_weight_dev, const ultra_mat *relation,
+                                    const void *values_dev, const int64_t *src_rows_dev, const ultra_mat *output_grad,
+                                    void *relation_grad_dev, void *values_grad_dev, void *stream);
+
+/*
  * Backward (rspmm.cpp:77-119 / 164-219): gradients w.r.t. edge_weight (original edge order, may be
  * NULL to skip), relation and input, given the forward output and its gradient.  min/max give the
  * full gradient to every tying edge (operator.cuh:62-64,75-77).

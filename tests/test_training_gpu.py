@@ -300,3 +300,36 @@ def test_closed_form_boundary_gradient_of_the_differentiable_rspmm(dev):
         grads.append((out.detach(), values.grad, rel.grad, x.grad))
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("num_rel,n_edge", [(4, 40000), (37, 6000), (474, 6000), (600, 3000)])
+def test_first_layer_backward_kernel_against_its_torch_restatement(dev, num_rel, n_edge):
+    """csrc/onehot_bwd.hip (type-sorted runs per 16-lane group, boundary partials folded in order) against the padded-table
+    torch formulation: hubs whose edges of one type span many groups, sources without edges, a relation table that fills
+    the LDS (474) or exceeds it (600: declined, the torch route runs); the same bits run to run."""
+    gen = torch.Generator().manual_seed(num_rel)
+    n, bs = 600, 5
+    ei = torch.randint(1, n, (2, n_edge), generator=gen)
+    ei[1, : n_edge // 2] = 3                                 # hub: half of all edges leave node 3
+    et = torch.randint(0, num_rel, (n_edge,), generator=gen)
+    et[: n_edge // 4] = num_rel - 1                          # ... a quarter of them with one type (a run across many chunks)
+    ei, et = ei.to(dev), et.to(dev)
+    rows = torch.tensor([3, 0, 17, 3, 599], device=dev)
+    values = torch.randn(bs, 64, generator=gen).to(dev)
+    rel = torch.randn(bs, num_rel, 64, generator=gen).to(dev)
+    og = torch.randn(bs, n, 64, generator=gen).to(dev)
+    keep = (torch.rand(n_edge, generator=gen) > 0.3).float().to(dev)
+    ptr, order, max_deg = rspmm.out_edge_csr(ei, et, n)
+    for weight in (None, keep):
+        want = rspmm._onehot_backward_torch(ptr, order, max_deg, ei, et, weight, rel.double(), rows, values.double(), og.double(),
+                                            True, True)
+        got = rspmm._onehot_backward_kernel(ptr, order, ei, et, weight, rel, rows, values, og, True, True)
+        if num_rel * 256 + 64 * 2 * 68 * 4 > 160 * 1024:
+            assert got is None
+            continue
+        torch.testing.assert_close(got[0].double(), want[0], rtol=1e-4, atol=2e-3)
+        torch.testing.assert_close(got[1].double(), want[1], rtol=1e-4, atol=2e-3)
+        again = rspmm._onehot_backward_kernel(ptr, order, ei, et, weight, rel, rows, values, og, True, True)
+        assert torch.equal(got[0], again[0]) and torch.equal(got[1], again[1])
+        only_rel = rspmm._onehot_backward_kernel(ptr, order, ei, et, weight, rel, rows, values, og, True, False)
+        assert only_rel[1] is None and torch.equal(only_rel[0], got[0])

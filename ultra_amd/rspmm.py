@@ -620,18 +620,20 @@ class _PlanRSPMM(autograd.Function):
 _OUT_CSR_CACHE = OrderedDict()
 
 
-def out_edge_csr(edge_index, num_node):
-    """Edges grouped by their SOURCE node (edge_index[1], the gathered side): (ptr (num_node + 1), edge ids in source
-    order, largest out-degree); built once per edge list and kept with it."""
-    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_node))
+def out_edge_csr(edge_index, edge_type, num_node):
+    """Edges grouped by their SOURCE node (edge_index[1], the gathered side), every node's edges sorted by type:
+    (ptr (num_node + 1), edge ids in (source, type) order, largest out-degree); built once per edge list and kept with it."""
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), edge_type.data_ptr(), edge_type._version,
+           int(num_node))
     hit = _OUT_CSR_CACHE.get(key)
     if hit is None:
         src = edge_index[1]
         count = torch.bincount(src, minlength=int(num_node))
         ptr = torch.zeros(int(num_node) + 1, dtype=torch.int64, device=src.device)
         ptr[1:] = count.cumsum(0)
-        order = torch.sort(src, stable=True)[1]
-        hit = (ptr, order, int(count.max()) if count.numel() else 0, edge_index)      # (the tensor is kept with its entry)
+        num_type = int(edge_type.max()) + 1 if edge_type.numel() else 1
+        order = torch.sort(src * num_type + edge_type, stable=True)[1].contiguous()
+        hit = (ptr, order, int(count.max()) if count.numel() else 0, edge_index, edge_type)      # (the tensors stay with their entry)
         _OUT_CSR_CACHE[key] = hit
         while len(_OUT_CSR_CACHE) > _PLAN_CACHE_SIZE:
             _OUT_CSR_CACHE.popitem(last=False)
@@ -664,30 +666,64 @@ class _OnehotRSPMM(autograd.Function):
         edge_weight, relation, rows, values = ctx.saved_tensors
         edge_index, edge_type = ctx.edge_index, ctx.edge_type
         og = output_grad.contiguous()
-        bs, _, dim = og.shape
-        num_rel = relation.shape[1]
-        ptr, order, max_deg = out_edge_csr(edge_index, ctx.plan.num_in)
-        dev = og.device
-        batch_ids = torch.arange(bs, device=dev)
-        own = og[batch_ids, rows]                                            # (bs, dim): the boundary's share
         need_rel, need_val = ctx.needs_input_grad[4], ctx.needs_input_grad[6]
-        if max_deg == 0 or edge_index.shape[1] == 0:
-            return (None, None, None, None, torch.zeros_like(relation) if need_rel else None, None,
-                    own if need_val else None, None)
-        start = ptr[rows]
-        deg = ptr[rows + 1] - start
-        slot = torch.arange(max_deg, device=dev).unsqueeze(0)                # (1, max_deg)
-        valid = slot < deg.unsqueeze(1)                                      # (bs, max_deg)
-        edge = order[(start.unsqueeze(1) + slot).clamp_(max=edge_index.shape[1] - 1)]
-        weight = valid.to(og.dtype)
-        if edge_weight is not None:
-            weight = weight * edge_weight[edge].to(og.dtype)
-        picked = og.gather(1, edge_index[0][edge].unsqueeze(-1).expand(-1, -1, dim)) * weight.unsqueeze(-1)
-        cell = (edge_type[edge] + num_rel * batch_ids.unsqueeze(1)).flatten()
-        s = og.new_zeros(bs * num_rel, dim).index_add_(0, cell, picked.flatten(0, 1)).view(bs, num_rel, dim)
-        relation_grad = values.unsqueeze(1) * s if need_rel else None
-        values_grad = (relation * s).sum(dim=1) + own if need_val else None
-        return None, None, None, None, relation_grad, None, values_grad, None
+        ptr, order, max_deg = out_edge_csr(edge_index, edge_type, ctx.plan.num_in)
+        grads = _onehot_backward_kernel(ptr, order, edge_index, edge_type, edge_weight, relation, rows, values, og,
+                                        need_rel, need_val)
+        if grads is None:       # (shapes the kernel does not serve)
+            grads = _onehot_backward_torch(ptr, order, max_deg, edge_index, edge_type, edge_weight, relation, rows, values, og,
+                                           need_rel, need_val)
+        return None, None, None, None, grads[0], None, grads[1], None
+
+
+def _onehot_backward_kernel(ptr, order, edge_index, edge_type, edge_weight, relation, rows, values, og, need_rel, need_val):
+    """(relation_grad, values_grad) of _OnehotRSPMM in one launch (csrc/onehot_bwd.hip); None where it does not apply."""
+    if not (og.is_cuda and og.dtype == torch.float32 and relation.dtype == torch.float32 and values.dtype == torch.float32
+            and og.dim() == 3 and edge_index.dtype == torch.int64 and edge_type.dtype == torch.int64
+            and (edge_weight is None or edge_weight.dtype == torch.float32)):
+        return None
+    relation, mrel = as_mat(relation)
+    og, mog = as_mat(og)
+    values = values.contiguous()
+    rows = rows.to(torch.int64).contiguous()
+    target = edge_index[0].contiguous()
+    weight = edge_weight.contiguous() if edge_weight is not None else None
+    bs, dim = og.shape[0], og.shape[2]
+    rel_grad = torch.empty(bs, relation.shape[1], dim, dtype=torch.float32, device=og.device) if need_rel else None
+    val_grad = torch.empty(bs, dim, dtype=torch.float32, device=og.device) if need_val else None
+    rc = lib.ultra_rspmm_onehot_backward(ptr.data_ptr(), order.data_ptr(), target.data_ptr(), edge_type.data_ptr(),
+                                         weight.data_ptr() if weight is not None else None, ctypes.byref(mrel),
+                                         values.data_ptr(), rows.data_ptr(), ctypes.byref(mog),
+                                         rel_grad.data_ptr() if need_rel else None, val_grad.data_ptr() if need_val else None,
+                                         _stream(og))
+    if rc == _lib.ULTRA_ERR_UNSUPPORTED:
+        return None
+    check(rc)
+    return rel_grad, val_grad
+
+
+def _onehot_backward_torch(ptr, order, max_deg, edge_index, edge_type, edge_weight, relation, rows, values, og, need_rel, need_val):
+    """The same gradients as a handful of torch kernels over a (batch, largest out-degree) padded edge table: the
+    restatement the kernel is tested against, and the route for shapes it does not serve."""
+    bs, _, dim = og.shape
+    num_rel = relation.shape[1]
+    dev = og.device
+    batch_ids = torch.arange(bs, device=dev)
+    own = og[batch_ids, rows]                                            # (bs, dim): the boundary's share
+    if max_deg == 0 or edge_index.shape[1] == 0:
+        return (torch.zeros(bs, num_rel, dim, dtype=og.dtype, device=dev) if need_rel else None), (own if need_val else None)
+    start = ptr[rows]
+    deg = ptr[rows + 1] - start
+    slot = torch.arange(max_deg, device=dev).unsqueeze(0)                # (1, max_deg)
+    valid = slot < deg.unsqueeze(1)                                      # (bs, max_deg)
+    edge = order[(start.unsqueeze(1) + slot).clamp_(max=edge_index.shape[1] - 1)]
+    weight = valid.to(og.dtype)
+    if edge_weight is not None:
+        weight = weight * edge_weight[edge].to(og.dtype)
+    picked = og.gather(1, edge_index[0][edge].unsqueeze(-1).expand(-1, -1, dim)) * weight.unsqueeze(-1)
+    cell = (edge_type[edge] + num_rel * batch_ids.unsqueeze(1)).flatten()
+    s = og.new_zeros(bs * num_rel, dim).index_add_(0, cell, picked.flatten(0, 1)).view(bs, num_rel, dim)
+    return (values.unsqueeze(1) * s if need_rel else None), ((relation * s).sum(dim=1) + own if need_val else None)
 
 
 def onehot_rspmm(plan, edge_index, edge_type, relation, rows, values, dense_input, edge_weight=None):
