@@ -269,6 +269,15 @@ int32_t ultra_rspmm_forward_onehot(ultra_plan *plan, int32_t dtype, const void *
                                    const ultra_mat *boundary, const ultra_mat *output, void *stream);
 
 /*
+ * Tag of the edge-weight vector passed to the NEXT weighted call of this thread (ultra_rspmm_forward / _masked / _point /
+ * _backward); 0 = none.  Plans bring per-call weights (original edge order) into their own order with one small kernel per
+ * call; a caller that hands the SAME vector to many calls -- a training step's 0/1 keep mask goes to every layer's forward and
+ * backward walks -- tags it, and a plan that already holds the permutation of (this tag, this address, this stream) reuses it.
+ * The caller promises: equal tag + equal address = equal contents.  Never used while the stream is capturing.
+ */
+int32_t ultra_rspmm_weight_epoch(int64_t epoch);
+
+/*
  * Backward of ultra_rspmm_forward_onehot in its layer-0 use (fine-tuning): the input is the boundary condition -- values[o]
  * at row src_rows[o] of outer slice o, zero elsewhere -- and the same tensor is the boundary added to the sum.  Only the
  * edges leaving the source rows matter (rspmm.cpp:106-112 restricted to them):

@@ -333,3 +333,39 @@ def test_first_layer_backward_kernel_against_its_torch_restatement(dev, num_rel,
         assert torch.equal(got[0], again[0]) and torch.equal(got[1], again[1])
         only_rel = rspmm._onehot_backward_kernel(ptr, order, ei, et, weight, rel, rows, values, og, True, False)
         assert only_rel[1] is None and torch.equal(only_rel[0], got[0])
+
+
+def test_tagged_edge_weights_are_permuted_once_and_never_stale(dev):
+    """rspmm.tag_edge_weight: calls that carry the same tagged vector reuse the plan's permuted copy; an in-place write voids
+    the tag, an untagged vector (even at the same address) is always permuted -- every result equals the untagged call's."""
+    gen = torch.Generator().manual_seed(31)
+    n, e, bs, num_rel = 300, 4000, 2, 6
+    ei = torch.randint(0, n, (2, e), generator=gen).to(dev)
+    et = torch.randint(0, num_rel, (e,), generator=gen).to(dev)
+    rel = torch.randn(bs, num_rel, 64, generator=gen).to(dev)
+    x = torch.randn(bs, n, 64, generator=gen).to(dev)
+    plan = rspmm.Plan(ei, et, n, num_rel, exact_order=False, type_runs=False, dense=False)
+    w = torch.rand(e, generator=gen).to(dev)
+    want = plan.forward(rel, x, edge_weight=w.clone())
+    rspmm.tag_edge_weight(w)
+    assert rspmm._weight_epoch(w) > 0
+    assert torch.equal(plan.forward(rel, x, edge_weight=w), want)
+    assert torch.equal(plan.forward(rel, x, edge_weight=w), want)          # (the copy of the call before)
+    w.mul_(2.0)                                                            # in place: the tag no longer applies
+    assert rspmm._weight_epoch(w) == 0
+    want2 = plan.forward(rel, x, edge_weight=w.clone())
+    assert torch.equal(plan.forward(rel, x, edge_weight=w), want2) and not torch.equal(want2, want)
+    rspmm.tag_edge_weight(w)
+    assert torch.equal(plan.forward(rel, x, edge_weight=w), want2)
+    w.copy_(torch.rand(e, generator=gen))                                  # same address, new contents, tag void
+    assert torch.equal(plan.forward(rel, x, edge_weight=w), plan.forward(rel, x, edge_weight=w.clone()))
+    # through autograd: forward and both backward walks with one tagged keep vector
+    keep = rspmm.tag_edge_weight((torch.rand(e, generator=gen) > 0.3).float().to(dev))
+    grads = []
+    for tagged in (True, False):
+        drel, dx = rel.clone().requires_grad_(), x.clone().requires_grad_()
+        out = rspmm.plan_rspmm(plan, drel, dx, keep if tagged else keep.clone(), keep=True)
+        out.sum().backward()
+        grads.append((out.detach(), drel.grad, dx.grad))
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)

@@ -113,6 +113,11 @@ struct ultra_plan {
     int32_t seg_len = 256, g_max = 64, flags = 0;
     int32_t type_bits = 0;
     bool packed_ok = false;
+    // the weight vector whose permutation d.w_sorted holds (ultra_rspmm_weight_epoch): its tag, address, dtype, stream
+    int64_t w_epoch = 0;
+    const void *w_src = nullptr;
+    int32_t w_dtype = -1;
+    void *w_stream = nullptr;
     int32_t max_row_len = -1;     // longest row (edges); computed on first use (the layer-0 launch sizes its grid with it)
 
     std::vector<int32_t> row_ptr, col, type, perm, erow;  // erow: output row of each sorted edge

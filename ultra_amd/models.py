@@ -12,7 +12,7 @@ from collections.abc import Sequence
 import torch
 from torch import nn
 
-from . import dense, layers, tasks
+from . import dense, layers, rspmm, tasks
 
 
 # inference fast path of EntityNBFNet.forward: fused batch prologue + readout from the raw batch (A/B switch for tests)
@@ -80,8 +80,10 @@ class BaseNBFNet(nn.Module):
         """easy_edge_mask as the 0/1 float vector the rspmm kernels read (dense.edge_keep_mask: one kernel on the GPU)."""
         easy = self._easy_edges(data, h_index, t_index, r_index)
         if data.edge_index.is_cuda and data.edge_index.dtype == torch.int64 and easy.shape[1] <= dense.EDGE_KEEP_MAX_EASY:
-            return dense.edge_keep_mask(data.edge_index, None if self.remove_one_hop else data.edge_type, easy,
+            keep = dense.edge_keep_mask(data.edge_index, None if self.remove_one_hop else data.edge_type, easy,
                                         data.num_nodes, data.num_relations, dtype)
+            # (one vector for every layer's forward and backward walks of this step: permuted into each plan's order once)
+            return rspmm.tag_edge_weight(keep)
         return self.easy_edge_mask(data, h_index, t_index, r_index).to(dtype)
 
     def remove_easy_edges(self, data, h_index, t_index, r_index=None):

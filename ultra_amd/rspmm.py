@@ -27,6 +27,29 @@ module = sys.modules[__name__]
 _DTYPES = {torch.float32: _lib.F32, torch.float64: _lib.F64}
 
 
+_WEIGHT_EPOCH = [0]
+
+
+def tag_edge_weight(edge_weight):
+    """Marks a per-step edge-weight vector (a training step's 0/1 keep mask) as unchanged from here on: the plans then bring
+    it into their edge order once per step instead of once per rspmm call (ultra_rspmm_weight_epoch).  An in-place write
+    to the tensor voids the tag."""
+    _WEIGHT_EPOCH[0] += 1
+    edge_weight._ultra_epoch = (_WEIGHT_EPOCH[0], edge_weight._version)
+    return edge_weight
+
+
+def _weight_epoch(edge_weight):
+    tag = getattr(edge_weight, "_ultra_epoch", None) if edge_weight is not None else None
+    return tag[0] if tag is not None and tag[1] == edge_weight._version else 0
+
+
+def _announce_weight(edge_weight, epoch=None):
+    """Tells the library which tagged vector the next weighted call carries (0: untagged)."""
+    if edge_weight is not None:
+        lib.ultra_rspmm_weight_epoch(int(_weight_epoch(edge_weight) if epoch is None else epoch))
+
+
 def _stream(t):
     """The current HIP stream of the operand's device (the C entry points make that device current for the launch)."""
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
@@ -216,7 +239,7 @@ class Plan(object):
 
     # ---- kernels ----
     def forward(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", out=None, point=None,
-                keep=False):
+                keep=False, weight_epoch=None):
         """point=(rows, values): a boundary that is zero except row rows[o] of outer slice o, where it is values[o]
         (the NBFNet boundary condition); excludes `boundary`.  sum="add": added to that row only.  sum="min" / "max":
         that row meets values[o], every other row meets 0 (max(update, boundary), layers.py:206-207) -- served by
@@ -233,7 +256,7 @@ class Plan(object):
             twin = self._twin_for(sum, mul, edge_weight, input, relation, boundary, out)
         if twin is not None:
             return twin.forward(relation, input, edge_weight=edge_weight, boundary=boundary, sum=sum, mul=mul, out=out,
-                                point=point, keep=keep)
+                                point=point, keep=keep, weight_epoch=weight_epoch)
         _require_gpu(relation, input, edge_weight, boundary)
         dt = _dtype_code(*([relation, input] + ([edge_weight] if edge_weight is not None else [])
                            + ([boundary] if boundary is not None else [])))
@@ -254,6 +277,8 @@ class Plan(object):
         if edge_weight is not None:
             if edge_weight.dim() != 1 or edge_weight.shape[0] != self.num_edge:
                 raise RuntimeError("Expected `edge_weight` of shape (num_edge,)")
+            if weight_epoch is None:
+                weight_epoch = _weight_epoch(edge_weight) if edge_weight.is_contiguous() else 0
             edge_weight = edge_weight.contiguous()
             w = edge_weight.data_ptr()
         if point is not None:
@@ -265,6 +290,7 @@ class Plan(object):
                 raise RuntimeError("Expected one boundary row per outer slice (%d), got %d" % (n_outer, rows.numel()))
             _require_gpu(rows, vals)
             vals, mv = as_mat(vals)
+            _announce_weight(edge_weight, weight_epoch)
             rc = lib.ultra_rspmm_forward_point(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
                                                ctypes.byref(mx), rows.data_ptr(), ctypes.byref(mv), ctypes.byref(mout), _stream(input))
             if rc == _lib.ULTRA_ERR_UNSUPPORTED and sum != "add":
@@ -272,6 +298,7 @@ class Plan(object):
             check(rc)
             return out
         entry = lib.ultra_rspmm_forward_masked if (keep and w is not None and sum != "add") else lib.ultra_rspmm_forward
+        _announce_weight(edge_weight, weight_epoch)
         check(entry(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
                     ctypes.byref(mx), mb, ctypes.byref(mout), _stream(input)))
         return out
@@ -431,7 +458,7 @@ class Plan(object):
         return out
 
     def backward(self, relation, input, output, output_grad, edge_weight=None, need_weight_grad=False, sum="add",
-                 mul="mul"):
+                 mul="mul", weight_epoch=None):
         _require_gpu(relation, input, output, output_grad, edge_weight)
         dt = _dtype_code(relation, input, output, output_grad)
         relation, mrel = as_mat(relation)
@@ -454,6 +481,8 @@ class Plan(object):
             _, mxg = as_mat(xgrad)
         w = None
         if edge_weight is not None:
+            if weight_epoch is None:
+                weight_epoch = _weight_epoch(edge_weight) if edge_weight.is_contiguous() else 0
             edge_weight = edge_weight.contiguous()
             w = edge_weight.data_ptr()
         wgrad = None
@@ -461,6 +490,7 @@ class Plan(object):
         if need_weight_grad:
             wgrad = torch.zeros(self.num_edge, dtype=input.dtype, device=input.device)
             wg = wgrad.data_ptr()
+        _announce_weight(edge_weight, weight_epoch)
         check(lib.ultra_rspmm_backward(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
                                        ctypes.byref(mx), ctypes.byref(mo), ctypes.byref(mog), wg, ctypes.byref(mrg),
                                        ctypes.byref(mxg) if mxg is not None else None, _stream(input)))
@@ -597,6 +627,7 @@ class _PlanRSPMM(autograd.Function):
                               point=point)
         ctx.plan, ctx.sum, ctx.mul = plan, sum, mul
         ctx.point_rows = point_rows
+        ctx.weight_epoch = _weight_epoch(edge_weight)       # (the tag rides on the Python object: read it while it is at hand)
         ctx.save_for_backward(edge_weight, relation, input, output)   # rspmm.py:25
         return output
 
@@ -607,7 +638,8 @@ class _PlanRSPMM(autograd.Function):
         output_grad = output_grad.contiguous()
         weight_grad, relation_grad, input_grad = ctx.plan.backward(
             relation, input, output, output_grad, edge_weight=edge_weight, need_weight_grad=need_w,
-            sum=ctx.sum, mul=ctx.mul)
+            sum=ctx.sum, mul=ctx.mul,
+            weight_epoch=ctx.weight_epoch if (edge_weight is not None and edge_weight.is_contiguous()) else 0)
         boundary_grad = output_grad if ctx.needs_input_grad[6] else None
         values_grad = None
         if ctx.point_rows is not None and ctx.needs_input_grad[9]:
