@@ -309,6 +309,17 @@ int32_t ultra_rspmm_backward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t
                              void *stream);
 
 /*
+ * ultra_rspmm_backward under sum == add with input_grad = input_grad_base + (the gathered input gradient): the input of an
+ * NBFNet layer feeds the rspmm AND the layer update, and the update's share of its gradient is added in the epilogue of the
+ * walk instead of by a pass of its own over three (batch, N, d) tensors.  input_grad_base may alias input_grad.
+ */
+int32_t ultra_rspmm_backward_add(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype,
+                                 const void *edge_weight_dev, const ultra_mat *relation, const ultra_mat *input,
+                                 const ultra_mat *output, const ultra_mat *output_grad,
+                                 void *weight_grad_dev, const ultra_mat *relation_grad,
+                                 const ultra_mat *input_grad_base, const ultra_mat *input_grad, void *stream);
+
+/*
  * Reference-shaped stateless entry points (one per export of rspmm.h:63-105).  Operands are the
  * reference's: SORTED edge_index (2, E) int64, edge_type (E) int64, edge_weight (E), relation (R, D),
  * input (N, D), all contiguous device arrays; output (N, D) is written.  Unsorted edge_index ->

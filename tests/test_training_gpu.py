@@ -369,3 +369,29 @@ def test_tagged_edge_weights_are_permuted_once_and_never_stale(dev):
         grads.append((out.detach(), drel.grad, dx.grad))
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+def test_training_layer_as_one_node_gives_the_two_nodes_gradients(dev):
+    """dense.TrainLayerFunction (aggregate + update of a layer as one autograd node; the update's share of the input
+    gradient is the base of the input-gradient walk) against the two nodes whose shares autograd adds: the same scores and
+    the same parameter gradients, bit for bit (a + b = b + a), on a whole training step with a keep mask."""
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    data = synthetic.make_kg(num_node=300, num_triple=2500, num_relation_base=5, num_test=16, seed=8).to(dev)
+    batch = torch.stack([data.edge_index[0, :4], data.edge_index[1, :4], data.edge_type[:4]], dim=-1)
+    torch.manual_seed(0)
+    neg = tasks.negative_sampling(data, batch, 16, strict=True)
+    results = []
+    for one_node in (True, False):
+        layers.TRAINING_LAYER_NODE = one_node
+        try:
+            model = models.Ultra(**cfg)
+            model.load_state_dict(state)
+            model = model.to(dev).train()
+            out = model(data, neg)
+            F.binary_cross_entropy_with_logits(out, torch.zeros_like(out)).backward()
+            results.append((out.detach(), {k: p.grad.clone() for k, p in model.named_parameters()}))
+        finally:
+            layers.TRAINING_LAYER_NODE = True
+    assert torch.equal(results[0][0], results[1][0])
+    for name, g in results[0][1].items():
+        assert torch.equal(g, results[1][1][name]), name

@@ -635,8 +635,11 @@ static int ensure_backward_plans(ultra_plan *p) {
 
 static int backward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *w, const ultra_mat *rel,
                          const ultra_mat *x, const ultra_mat *outm, const ultra_mat *og, void *wgrad,
-                         const ultra_mat *rgrad, const ultra_mat *xgrad, hipStream_t stream) {
+                         const ultra_mat *rgrad, const ultra_mat *xgrad, hipStream_t stream, const ultra_mat *xbase = nullptr) {
+    // xbase (sum == add): input_grad = xbase + the gathered sum -- the input's gradient from its OTHER consumer (the layer
+    // update, which reads the same input), added in the walk's epilogue instead of by a separate pass; may alias input_grad
     if (!p) return invalid("plan is NULL");
+    if (xbase && (sum != ULTRA_SUM_ADD || !xgrad)) return invalid("input_grad_base is served under sum == add, with an input_grad");
     (void)hipGetLastError();
     if (p->flags & ULTRA_PLAN_DENSE) return invalid("a ULTRA_PLAN_DENSE plan has no backward; use the (row, col) plan");
     if (sum < 0 || sum > 2 || mul < 0 || mul > 1) return invalid("unknown sum/mul code");
@@ -654,6 +657,7 @@ static int backward_impl(ultra_plan *p, int sum, int mul, int dtype, const void 
     // graph is an rspmm forward, and a graph with a dense-format twin runs it on the matrix cores (rspmm.py Plan.backward)
     if (!xgrad && sum != ULTRA_SUM_ADD) return invalid("input_grad may be NULL under sum == add only");
     if (xgrad && (rc = check_mat(xgrad, "input_grad", p->num_in, n_outer, row_len))) return rc;
+    if (xbase && (rc = check_mat(xbase, "input_grad_base", p->num_in, n_outer, row_len))) return rc;
     if ((rc = upload_plan(p))) return rc;
 
     const size_t esz = dtype == ULTRA_F32 ? 4 : 8;
@@ -688,7 +692,7 @@ static int backward_impl(ultra_plan *p, int sum, int mul, int dtype, const void 
         if ((rc = ensure_backward_plans(p))) return rc;
         // input_grad[col] = sum_e w * d(rel (x) in)/d in * out_grad[row]   (rspmm.cpp:110-112)
         if (xgrad && (rc = forward_impl(p->tplan, ULTRA_SUM_ADD, mul == ULTRA_MUL_MUL ? BIN_MUL : BIN_RHS, dtype, w, rel, og,
-                                        nullptr, xgrad, stream)))
+                                        xbase, xgrad, stream)))
             return rc;
         // relation_grad[type] = sum_e w * d(rel (x) in)/d rel * out_grad[row]   (rspmm.cpp:106-108)
         if ((rc = forward_impl(p->rplan, ULTRA_SUM_ADD, mul == ULTRA_MUL_MUL ? BIN_MUL : BIN_LHS, dtype, w, og, x,
@@ -1089,6 +1093,17 @@ int32_t ultra_rspmm_backward(ultra_plan *plan, int32_t sum, int32_t mul, int32_t
     WeightEpochScope weight_epoch_scope;
     return backward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, output, output_grad, weight_grad_dev,
                          relation_grad, input_grad, reinterpret_cast<hipStream_t>(stream));
+}
+
+int32_t ultra_rspmm_backward_add(ultra_plan *plan, int32_t sum, int32_t mul, int32_t dtype, const void *edge_weight_dev,
+                                 const ultra_mat *relation, const ultra_mat *input, const ultra_mat *output,
+                                 const ultra_mat *output_grad, void *weight_grad_dev, const ultra_mat *relation_grad,
+                                 const ultra_mat *input_grad_base, const ultra_mat *input_grad, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream, output ? output->ptr : nullptr);
+    WeightEpochScope weight_epoch_scope;
+    if (!input_grad_base) return invalid("ultra_rspmm_backward_add: input_grad_base is NULL");
+    return backward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, output, output_grad, weight_grad_dev,
+                         relation_grad, input_grad, reinterpret_cast<hipStream_t>(stream), input_grad_base);
 }
 
 // Times `once` (a launch sequence on stream s) with HIP events: the mean of `iters` back-to-back calls, and -- the figure

@@ -69,6 +69,58 @@ class ConvUpdateFunction(torch.autograd.Function):
         return gx, gagg, gw, gb, gln_w, gln_b, None, None
 
 
+class TrainLayerFunction(torch.autograd.Function):
+    """A whole NBFNet layer of a training step as ONE autograd node (sum aggregate):
+
+        agg = rspmm(relation, x, keep mask) + boundary;      out = [x +] relu(LayerNorm(W . cat[x, agg] + b))
+
+    x feeds the rspmm AND the update.  As two nodes (rspmm._PlanRSPMM, ConvUpdateFunction) each returns its share of x's
+    gradient and autograd adds them -- a pass over three (batch, N, 64) tensors per layer (13 us at FB15k237's size, 100 at
+    YAGO3-10's); here the update's share is the base the input-gradient walk starts from (ultra_rspmm_backward_add).  The
+    boundary is the closed form (rows, values) -- its gradient bs rows of the aggregate's -- or a tensor."""
+
+    @staticmethod
+    def forward(ctx, plan, mul, keep, eps, flags, edge_weight, relation, x, boundary, point_rows, point_values, weight, bias,
+                ln_w, ln_b):
+        from . import rspmm
+        x, weight = x.contiguous(), weight.contiguous()
+        point = (point_rows, point_values) if point_rows is not None else None
+        agg = plan.forward(relation, x, edge_weight=edge_weight, boundary=boundary, sum="add", mul=mul, keep=keep, point=point)
+        ctx.plan, ctx.mul, ctx.eps, ctx.flags, ctx.point_rows = plan, mul, eps, flags, point_rows
+        ctx.weight_epoch = rspmm._weight_epoch(edge_weight)
+        ctx.save_for_backward(edge_weight, relation, x, agg, weight, bias, ln_w, ln_b)
+        return _conv_update_forward(x, agg, weight, bias, ln_w, ln_b, eps, flags)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        edge_weight, relation, x, agg, weight, bias, ln_w, ln_b = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        rows = x.numel() // 64
+        gx, gagg, gw = torch.empty_like(x), torch.empty_like(agg), torch.empty_like(weight)
+        gb = torch.empty_like(bias) if bias is not None else None
+        gln_w = torch.empty_like(ln_w) if ln_w is not None else None
+        gln_b = torch.empty_like(ln_b) if ln_b is not None else None
+        nbytes = lib.ultra_conv_update_backward_workspace(rows)
+        work = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+        check(lib.ultra_conv_update_backward(x.data_ptr(), agg.data_ptr(), grad_out.data_ptr(), weight.data_ptr(), _ptr(bias),
+                                             _ptr(ln_w), _ptr(ln_b), gx.data_ptr(), gagg.data_ptr(), gw.data_ptr(), _ptr(gb),
+                                             _ptr(gln_w), _ptr(gln_b), work.data_ptr(), nbytes, rows, 64, 64, ctx.eps,
+                                             ctx.flags, _stream(x)))
+        need = ctx.needs_input_grad
+        relation_grad, x_grad = None, gx
+        if need[6] or need[7]:
+            epoch = ctx.weight_epoch if (edge_weight is not None and edge_weight.is_contiguous()) else 0
+            _, relation_grad, x_grad = ctx.plan.backward(relation, x, agg, gagg, edge_weight=edge_weight, sum="add", mul=ctx.mul,
+                                                         weight_epoch=epoch, input_grad_base=gx)
+        values_grad = None
+        if ctx.point_rows is not None and need[10]:
+            r = ctx.point_rows
+            values_grad = gagg[torch.arange(r.shape[0], device=r.device), r]
+        return (None, None, None, None, None, None, relation_grad if need[6] else None, x_grad if need[7] else None,
+                gagg if need[8] else None, None, values_grad, gw, gb, gln_w, gln_b)
+
+
 def conv_update(layer, input, update, residual):
     """out = [input +] relu(layer_norm(linear(cat[input, update]))) for (..., 64) fp32 GPU tensors."""
     flags = (CONV_LAYER_NORM if layer.layer_norm is not None else 0) | (CONV_RELU if layer.activation is not None else 0) \

@@ -25,6 +25,8 @@ ONEHOT_FAST_PATH = True
 POINT_BOUNDARY_FAST_PATH = True
 # ... and under autograd (fine-tuning): the sum aggregate's differentiable rspmm reads the closed form too (A/B switch for tests)
 POINT_BOUNDARY_TRAINING = True
+# aggregate + update of a training step's layer as one autograd node (A/B switch for tests)
+TRAINING_LAYER_NODE = True
 # aggregate + update of a layer in one launch on dense-format plans (A/B switch for tests)
 FUSED_DENSE_LAYER = True
 # aggregate + update of a layer in one launch on the reference-order plan of a sparse graph: the update runs in the tail of
@@ -208,6 +210,9 @@ class GeneralizedRelationalConv(nn.Module):
         fused = self._fused_sparse_layer(edge_index, kwargs, num_node, residual, onehot_rows, edge_keep)
         if fused is not None:
             return fused
+        fused = self._training_layer(edge_index, kwargs, num_node, residual, onehot_rows, edge_keep)
+        if fused is not None:
+            return fused
         out = self.message_and_aggregate(edge_index, kwargs["input"], kwargs["relation"], kwargs["boundary"],
                                          kwargs["edge_type"], edge_weight, edge_index[1], num_node,
                                          onehot_rows=onehot_rows, edge_keep=edge_keep)
@@ -257,6 +262,30 @@ class GeneralizedRelationalConv(nn.Module):
                                    ln.bias if ln is not None else None, float(ln.eps) if ln is not None else 1e-5, flags,
                                    mul=self.message2mul[self.message_func], point=(boundary.rows, boundary.values),
                                    sum="add" if self.aggregate_func == "sum" else "max")
+
+    def _training_layer(self, edge_index, kwargs, num_node, residual, onehot_rows, edge_keep):
+        """Aggregate + update of a training step's layer as one autograd node (dense.TrainLayerFunction): the layer input's two
+        gradient shares -- through the rspmm and through the update -- leave the backward already summed.  Sum aggregate,
+        TransE / DistMult, the ULTRA update shape; layer 0 (one-hot input) has its own route in message_and_aggregate."""
+        input, relation, boundary, edge_weight = kwargs["input"], kwargs["relation"], kwargs["boundary"], kwargs["edge_weight"]
+        point = boundary if isinstance(boundary, PointBoundary) else None
+        if not (TRAINING_LAYER_NODE and torch.is_grad_enabled() and onehot_rows is None and self.aggregate_func == "sum"
+                and self.message_func in self.message2mul and input.is_cuda and input.dim() == 3
+                and input.dtype == torch.float32 and relation.dtype == torch.float32
+                and (edge_weight is None or (not edge_weight.requires_grad and edge_weight.dtype == torch.float32))
+                and (input.requires_grad or relation.requires_grad or boundary.requires_grad)
+                and (point is not None or boundary.dtype == torch.float32)
+                and dense.conv_update_supported(self, input, input)):
+            return None
+        plan = rspmm.get_plan(edge_index, kwargs["edge_type"], num_node, relation.shape[1], exact_order=False)
+        ln = self.layer_norm
+        flags = (dense.CONV_LAYER_NORM if ln is not None else 0) | (dense.CONV_RELU if self.activation is not None else 0) \
+            | (dense.CONV_RESIDUAL if residual else 0)
+        return dense.TrainLayerFunction.apply(
+            plan, self.message2mul[self.message_func], bool(edge_keep), float(ln.eps) if ln is not None else 1e-5, flags,
+            edge_weight, relation, input, None if point is not None else boundary,
+            point.rows if point is not None else None, point.values if point is not None else None,
+            self.linear.weight, self.linear.bias, ln.weight if ln is not None else None, ln.bias if ln is not None else None)
 
     # ---- unfused path: gather edge_index[0], scatter to edge_index[1] -- PyG's direction (layers.py:135-181) ----
     def _propagate_unfused(self, edge_index, size, input, relation, boundary, edge_type, edge_weight):

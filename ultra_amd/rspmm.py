@@ -458,7 +458,9 @@ class Plan(object):
         return out
 
     def backward(self, relation, input, output, output_grad, edge_weight=None, need_weight_grad=False, sum="add",
-                 mul="mul", weight_epoch=None):
+                 mul="mul", weight_epoch=None, input_grad_base=None):
+        """input_grad_base (sum == "add"): a tensor of the input's shape that the returned input gradient starts from (the
+        input's gradient from another consumer); it is overwritten with the total and returned."""
         _require_gpu(relation, input, output, output_grad, edge_weight)
         dt = _dtype_code(relation, input, output, output_grad)
         relation, mrel = as_mat(relation)
@@ -475,9 +477,16 @@ class Plan(object):
                 and input.dtype == torch.float32:
             twin = self.dense_transposed()
             if twin is not None:
-                xgrad = twin.forward(relation, output_grad)
+                xgrad = twin.forward(relation, output_grad, boundary=input_grad_base)
+        base = None
         if xgrad is None:
-            xgrad = torch.empty(input.shape, dtype=input.dtype, device=input.device)
+            if input_grad_base is not None:
+                if sum != "add" or tuple(input_grad_base.shape) != tuple(input.shape) or input_grad_base.dtype != input.dtype:
+                    raise RuntimeError("input_grad_base: the input's shape and dtype, sum == 'add'")
+                xgrad = input_grad_base if input_grad_base.is_contiguous() else input_grad_base.contiguous()
+                base = xgrad
+            else:
+                xgrad = torch.empty(input.shape, dtype=input.dtype, device=input.device)
             _, mxg = as_mat(xgrad)
         w = None
         if edge_weight is not None:
@@ -491,9 +500,14 @@ class Plan(object):
             wgrad = torch.zeros(self.num_edge, dtype=input.dtype, device=input.device)
             wg = wgrad.data_ptr()
         _announce_weight(edge_weight, weight_epoch)
-        check(lib.ultra_rspmm_backward(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
-                                       ctypes.byref(mx), ctypes.byref(mo), ctypes.byref(mog), wg, ctypes.byref(mrg),
-                                       ctypes.byref(mxg) if mxg is not None else None, _stream(input)))
+        if base is not None:      # (in place: every row's base is read by the thread that writes its total)
+            check(lib.ultra_rspmm_backward_add(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
+                                               ctypes.byref(mx), ctypes.byref(mo), ctypes.byref(mog), wg, ctypes.byref(mrg),
+                                               ctypes.byref(mxg), ctypes.byref(mxg), _stream(input)))
+        else:
+            check(lib.ultra_rspmm_backward(self._h, _lib.SUM_CODES[sum], _lib.MUL_CODES[mul], dt, w, ctypes.byref(mrel),
+                                           ctypes.byref(mx), ctypes.byref(mo), ctypes.byref(mog), wg, ctypes.byref(mrg),
+                                           ctypes.byref(mxg) if mxg is not None else None, _stream(input)))
         return wgrad, rgrad, xgrad
 
     def forward_timed(self, relation, input, edge_weight=None, boundary=None, sum="add", mul="mul", warmup=3, iters=20,
