@@ -463,7 +463,10 @@ Schedule *build_schedule(const ultra_plan *p, int32_t nparts, int32_t walkers) {
                 s->srec.push_back((int32_t)((uint32_t)p->num_rel << shift));
             }
         }
-        s->srec.resize(s->srec.size() + 2 * ORDER_PAD, 0);   // (records are requested two rounds ahead without a bounds test)
+        // (records are requested two rounds ahead without a bounds test, and the four streams of a wave are walked for as many
+        // rounds as the longest of them: the last wave's shorter streams request up to that many records past their own end)
+        s->srec_pad = 2 * ((int64_t)ORDER_PAD + (int64_t)s->max_stream_steps);
+        s->srec.resize(s->srec.size() + (size_t)s->srec_pad, 0);
         // rows per workgroup: chain rows + stream rows, ascending, whole 32-row tiles
         s->prow_ptr.assign((size_t)nparts + 1, 0);
         for (int32_t q = 0; q < nparts; ++q) {

@@ -81,6 +81,7 @@ struct Schedule {
     int32_t max_chain_rows = 0;                         // most chain rows any one workgroup walks
     int32_t max_stream_steps = 0;                       // longest group stream in steps (edges + markers)
     int32_t rec_shift = 0;                              // srec holds (col << rec_shift, type << rec_shift): ULTRA_STREAM_PRESHIFT
+    int64_t srec_pad = 2 * ORDER_PAD;                   // readable zeros (int32 words) behind the last stream's records
 };
 
 struct DevicePlan {

@@ -147,10 +147,16 @@ static int upload_plan(ultra_plan *p) {
     if ((rc = upload_array(&p->d.col, p->col))) return rc;
     if ((rc = upload_array(&p->d.type, p->type))) return rc;
     if (p->flags & ULTRA_PLAN_EXACT_ORDER) {
-        // the order kernels prefetch records unconditionally: both streams are padded with readable zeros
+        // the order kernels prefetch records unconditionally: both streams are padded with readable zeros.  The four groups
+        // of a wave walk as many rounds as the LONGEST of their rows: a short row at the end of the list requests up to that
+        // many records past its own end (the assembly walks; the C++ walk stops advancing, rspmm_order_kernels.hpp), so the
+        // padding covers the longest row a lane group walks (rows above chain_min are chain rows: items[0, n_chain)).
+        int64_t longest = 0;
+        for (size_t i = (size_t)p->n_chain; i < p->items.size(); ++i) longest = std::max<int64_t>(longest, p->items[i].len);
+        const size_t pad = (size_t)ORDER_PAD + (size_t)std::min<int64_t>(longest, 1 << 20);
         std::vector<int32_t> perm_pad(p->perm), rec_pad(p->rec);
-        perm_pad.resize(p->perm.size() + ORDER_PAD, 0);
-        rec_pad.resize(p->rec.size() + 2 * ORDER_PAD, 0);
+        perm_pad.resize(p->perm.size() + pad, 0);
+        rec_pad.resize(p->rec.size() + 2 * pad, 0);
         if ((rc = upload_array(&p->d.perm, perm_pad))) return rc;
         if ((rc = upload_array(&p->d.rec, rec_pad))) return rc;
     } else if ((rc = upload_array(&p->d.perm, p->perm))) {
@@ -1223,7 +1229,7 @@ int32_t ultra_plan_schedule_export(ultra_plan *plan, int32_t nparts, int32_t whi
         case 2: src = s->units.data(), n = (int64_t)s->units.size(); break;
         case 3: src = reinterpret_cast<const int32_t *>(s->chunks.data()), n = (int64_t)s->chunk_ptr.back() * 4; break;
         case 4: src = s->sdesc.data(), n = (int64_t)s->sdesc.size(); break;
-        case 5: src = s->srec.data(), n = (int64_t)s->srec.size() - 2 * ORDER_PAD; break;
+        case 5: src = s->srec.data(), n = (int64_t)s->srec.size() - s->srec_pad; break;
         case 6: src = s->prow.data(), n = (int64_t)s->prow.size(); break;
         case 7: src = s->prow_ptr.data(), n = (int64_t)s->prow_ptr.size(); break;
         default: delete s; return invalid("ultra_plan_schedule_export: unknown array id");

@@ -159,6 +159,12 @@ __device__ __forceinline__ Pack<T, 4> walk_row_in_order(const OrderParams &p, co
     const char *rec_base = reinterpret_cast<const char *>(p.rec);
     const char *perm_base = reinterpret_cast<const char *>(p.perm);
     const uint32_t first = (uint32_t)(begin + l8);
+    // The loop below runs nsteps rounds for ALL four groups of the wave (nsteps = the longest of their rows).  A group whose
+    // own row is short keeps requesting records past its end -- masked by promote() / the PRED computes, but REQUESTED: beside
+    // a 4,000-step sibling a row at the end of the edge list asked for records (and, weighted, for w[perm[.]] of whatever
+    // lay there) kilobytes past the ORDER_PAD entries that are readable.  The requests stop advancing a little past the
+    // row's own end.
+    const uint32_t last = (uint32_t)(begin + cnt) + 16u;
 
     struct Records {   // this lane holds the record of step (round base + l8) of its group's row
         int c, t;
@@ -167,11 +173,11 @@ __device__ __forceinline__ Pack<T, 4> walk_row_in_order(const OrderParams &p, co
     // raw = as loaded (a step past the row's end holds a neighbouring row's record); promote() masks those to node 0
     const auto load_records = [&](const int k0, int &pm) {
         Records r;
-        const int2 ct = *reinterpret_cast<const int2 *>(rec_base + (first + (uint32_t)k0) * 8u);
+        const int2 ct = *reinterpret_cast<const int2 *>(rec_base + min(first + (uint32_t)k0, last) * 8u);
         r.c = ct.x, r.t = ct.y, r.w = T(1);
         if (WEIGHTED) {
             r.w = wt[pm];           // pm: original edge id, requested one round earlier (w[perm[.]] is a dependent load)
-            pm = *reinterpret_cast<const int32_t *>(perm_base + (first + (uint32_t)k0 + 8u) * 4u);
+            pm = *reinterpret_cast<const int32_t *>(perm_base + min(first + (uint32_t)k0 + 8u, last) * 4u);
         }
         return r;
     };
