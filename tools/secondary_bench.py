@@ -24,14 +24,25 @@ def load_model(aggr, ckpt):
 
 
 def timeit(fn, warmup, iters):
+    """Mean wall time of fn() over `iters` calls after `warmup`; the cyclic garbage collector is off inside the timed region (as
+    in the standard library's timeit): host-bound steps otherwise depend on how many objects the PROCESS holds -- the same
+    fine-tuning step ran 5.5 ms in a fresh process and 6.2 ms at the end of bench.py's."""
+    import gc
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / iters
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters
+    finally:
+        if was:
+            gc.enable()
 
 
 def forward_case(shape, aggr, ckpt, bs=8):

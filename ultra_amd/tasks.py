@@ -136,7 +136,10 @@ def prefetch_negatives(batches, data, num_negative, strict=True):
             yield negative_sampling(data, batch, num_negative, strict=strict)
         return
     with torch.cuda.device(dev):
-        side = torch.cuda.Stream()
+        # (high priority: its own class of hardware queue whatever streams the process has made before -- a side stream that
+        # lands on the training stream's queue runs BEHIND the backward, not beside it -- and the sampler's small kernels, which
+        # the host waits for, are scheduled ahead of the backward's long ones)
+        side = torch.cuda.Stream(priority=-1)
 
     def sample(batch):
         with torch.cuda.stream(side):
