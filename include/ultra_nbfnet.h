@@ -149,6 +149,21 @@ int32_t ultra_filtered_rank(const void *score, const int64_t *pos_index, const i
                             int64_t *num_negative_out, void *stream);
 
 /*
+ * Strict negative sampling (/root/reference/ultra/tasks.py:42-76, strict = True) for n_query positives, n_draw negatives each,
+ * without the (batch, N) masks of tasks.py:94-130 and without the host round trip of nonzero():
+ *     out[q, d] = the floor(rand[q, d] * count[q])-th entity id, ascending, that is neither a known answer of query q nor its
+ *                 positive;   count[q] = num_node - |known(q) u {positive[q]}|            (= candidate[index] of tasks.py:57-61)
+ * known(q) is the slice of sorted_keys with (anchor[q] * num_relation + relation[q]) * num_node <= key < ... + num_node, where
+ * sorted_keys holds the graph's DISTINCT (anchor, relation, answer) triples as ascending int64 keys
+ * (anchor * num_relation + relation) * num_node + answer -- built once per graph by the caller (tails of (head, relation) for the
+ * tail half of a batch, heads of (tail, relation) for the head half).  rand: fp32 uniform draws in [0, 1), the caller's
+ * (torch.rand in the reference's order, so the sampled ids are the reference's).  All device pointers; ids int64.
+ */
+int32_t ultra_strict_negatives(const int64_t *sorted_keys_dev, int64_t n_key, const int64_t *anchor_dev, const int64_t *relation_dev,
+                               const int64_t *positive_dev, const void *rand_dev, int64_t n_query, int64_t n_draw, int64_t num_node,
+                               int64_t num_relation, int64_t *out_dev, void *stream);
+
+/*
  * Relation graph of a knowledge graph (/root/reference/ultra/tasks.py:144-199) on the GPU, as bit matrices.
  *   edge_index (2, num_edge) int64 [head; tail], edge_type (num_edge) int64 -- inverse edges already included;
  *   W = (num_relation + 31) / 32 words per bit row.

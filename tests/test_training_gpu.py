@@ -395,3 +395,33 @@ def test_training_layer_as_one_node_gives_the_two_nodes_gradients(dev):
     assert torch.equal(results[0][0], results[1][0])
     for name, g in results[0][1].items():
         assert torch.equal(g, results[1][1][name]), name
+
+
+@pytest.mark.parametrize("bs,num_negative", [(8, 256), (5, 33), (2, 1)])
+def test_strict_sampler_kernel_draws_the_reference_negatives(dev, bs, num_negative):
+    """csrc/sampling.hip (the idx-th entity that is not a known answer, by bisection over the sorted answer keys) against
+    the masks + nonzero() formulation of tasks.py:42-76 under the same generator state: the same (bs, 1 + k, 3) batch --
+    repeated edges, a hub anchor with thousands of known answers, positives that are not edges of the graph."""
+    data = synthetic.make_kg(num_node=400, num_triple=6000, num_relation_base=3, num_test=16, seed=12)
+    ei, et = data.edge_index.clone(), data.edge_type.clone()
+    ei[0, :2500] = 9                                       # node 9: ~ 2,500 edges as head, few relations -> hundreds of known tails
+    data.edge_index, data.edge_type = ei, et
+    data = data.to(dev)
+    batch = torch.stack([data.edge_index[0, :bs], data.edge_index[1, :bs], data.edge_type[:bs]], dim=-1).clone()
+    batch[-1, 1] = (batch[-1, 1] + 7) % 400                # a positive that (most likely) is no edge of the graph
+    results = []
+    for kernel in (True, False):
+        tasks.STRICT_SAMPLER_KERNEL = kernel
+        try:
+            torch.manual_seed(77)
+            results.append(tasks.negative_sampling(data, batch, num_negative, strict=True))
+            results.append(tasks.negative_sampling(data, batch.flip(0), num_negative, strict=True))      # (generator carried on)
+        finally:
+            tasks.STRICT_SAMPLER_KERNEL = True
+    assert torch.equal(results[0], results[2]) and torch.equal(results[1], results[3])
+    t_mask, h_mask = tasks.strict_negative_mask(data, batch)
+    out, half = results[0], bs // 2
+    for i in range(half):
+        assert t_mask[i, out[i, 1:, 1]].all()
+    for i in range(half, bs):
+        assert h_mask[i, out[i, 1:, 0]].all()

@@ -107,6 +107,7 @@ def _load():
     lib.ultra_readout.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, i32, i32, vp]
     lib.ultra_stream_copy.argtypes = [vp, vp, i64, vp]
     lib.ultra_filtered_rank.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
+    lib.ultra_strict_negatives.argtypes = [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp]
     lib.ultra_onehot_rows.argtypes = [vp, vp, vp, i64, i64, i64, vp]
     lib.ultra_batch_prologue.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     lib.ultra_readout_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, i32, i32, vp]

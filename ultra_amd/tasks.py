@@ -89,11 +89,47 @@ def strict_negative_mask(data, batch):
     return masks[0], masks[1]
 
 
+STRICT_SAMPLER_KERNEL = True      # (A/B switch for tests: the masks + nonzero() formulation below is the other side)
+
+
+def _answer_keys(data, known):
+    """The graph's distinct (anchor, relation, answer) triples as ascending int64 keys (anchor * R + relation) * N + answer --
+    known = 0: tails of every (head, relation); 1: heads of every (tail, relation).  Built once per graph."""
+    def build():
+        n, r = int(data.num_nodes), int(data.num_relations)
+        assert n * n * max(r, 1) < 2 ** 63, "edge key overflows int64"          # (tasks.py:19, same bound)
+        anchor, answer = data.edge_index[known], data.edge_index[1 - known]
+        return torch.unique((anchor * r + data.edge_type) * n + answer).contiguous()
+    return _key_index("answers%d" % known, (data.edge_index, data.edge_type), build)
+
+
+def _strict_negatives_gpu(data, anchor, relation, positive, num_negative, known):
+    """num_negative strict negatives per positive through csrc/sampling.hip: the reference's picks
+    candidate[floor(rand * count)] (tasks.py:57-61) for the same torch.rand draws, no mask, no host synchronisation."""
+    import ctypes
+    from ._lib import check, lib
+    keys = _answer_keys(data, known)
+    rows = len(anchor)
+    rand = torch.rand(rows, num_negative, device=anchor.device)
+    out = torch.empty(rows, num_negative, dtype=torch.long, device=anchor.device)
+    anchor, relation, positive = anchor.contiguous(), relation.contiguous(), positive.contiguous()
+    check(lib.ultra_strict_negatives(keys.data_ptr(), keys.numel(), anchor.data_ptr(), relation.data_ptr(), positive.data_ptr(),
+                                     rand.data_ptr(), rows, num_negative, int(data.num_nodes), int(data.num_relations),
+                                     out.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(anchor.device).cuda_stream)))
+    return out
+
+
 def negative_sampling(data, batch, num_negative, strict=True):
     batch_size = len(batch)
     pos_h, pos_t, pos_r = batch.t()
     half = batch_size // 2
-    if strict:
+    if strict and STRICT_SAMPLER_KERNEL and batch.is_cuda and batch.dtype == torch.long and data.edge_index.is_cuda \
+            and data.edge_index.dtype == torch.long and torch.get_default_dtype() == torch.float32:
+        # the same draws, in the same order, as the masks + nonzero() formulation below (tails of the first half, then heads of
+        # the second) -- two small kernels and no host synchronisation instead of ~ 60 launches and three
+        neg_t = _strict_negatives_gpu(data, pos_h[:half], pos_r[:half], pos_t[:half], num_negative, known=0)
+        neg_h = _strict_negatives_gpu(data, pos_t[half:], pos_r[half:], pos_h[half:], num_negative, known=1)
+    elif strict:
         t_mask, h_mask = strict_negative_mask(data, batch)
 
         def draw(mask):
