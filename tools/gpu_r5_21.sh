@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a call: PROBE_CALIBRATE and ULTRA_PART_ADJUST_FILE were removed from the tree after it -- no gain, profiles/r5_experiments.txt)
 # (one gpurun call, round 5) profile-guided schedule, INCREMENTAL: traced launches -> per-partition step deltas -> a few typical rows moved
 # from the late partitions' streams to the early ones' (ULTRA_PART_ADJUST_FILE, plan.cpp), everything else stays where it was dealt
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
