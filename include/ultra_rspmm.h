@@ -269,6 +269,24 @@ int32_t ultra_rspmm_forward_onehot(ultra_plan *plan, int32_t dtype, const void *
                                    const ultra_mat *boundary, const ultra_mat *output, void *stream);
 
 /*
+ * add-aggregate rspmm restricted to a LIST of output rows per outer slice (fine-tuning: a training step reads the last
+ * layer's output at its 1 + num_negative candidate rows only, /root/reference/ultra/models.py:202-207):
+ *   forward   aggregate[o, j] = sum_{e : row_e == rows[o, j]} w_e * BINARY(rel[o, type_e], input[o, col_e])
+ *                               + boundary[o, rows[o, j]]  (tensor, may be NULL)  + point_values[o] where rows[o, j] == point_rows[o]
+ *   backward  input_grad[o, col_e] += w_e * dBINARY/dinput * aggregate_grad[o, j];  relation_grad[o, type_e] += w_e * dBINARY/drel * ...
+ * rows: (n_outer, n_list) int64, repeats allowed; aggregate / aggregate_grad: (n_outer, n_list, row_len) fp32 contiguous.  The
+ * backward ADDS into relation_grad / input_grad (the caller zeroes or pre-fills them) with float atomics: like the reference's
+ * GPU backward (rspmm.cu:153-214) its last bits vary run to run.  fp32, row_len a multiple of 64, (row, col) plans;
+ * edge_weight in original edge order (NULL = ones).  Anything else: ULTRA_ERR_UNSUPPORTED.
+ */
+int32_t ultra_rspmm_rows_forward(ultra_plan *plan, int32_t mul, const void *edge_weight_dev, const ultra_mat *relation,
+                                 const ultra_mat *input, const int64_t *rows_dev, int64_t n_list, const ultra_mat *boundary,
+                                 const int64_t *point_rows_dev, const void *point_values_dev, void *aggregate_dev, void *stream);
+int32_t ultra_rspmm_rows_backward(ultra_plan *plan, int32_t mul, const void *edge_weight_dev, const ultra_mat *relation,
+                                  const ultra_mat *input, const int64_t *rows_dev, int64_t n_list, const void *aggregate_grad_dev,
+                                  const ultra_mat *relation_grad, const ultra_mat *input_grad, void *stream);
+
+/*
  * Tag of the edge-weight vector passed to the NEXT weighted call of this thread (ultra_rspmm_forward / _masked / _point /
  * _backward); 0 = none.  Plans bring per-call weights (original edge order) into their own order with one small kernel per
  * call; a caller that hands the SAME vector to many calls -- a training step's 0/1 keep mask goes to every layer's forward and

@@ -381,6 +381,7 @@ def test_training_layer_as_one_node_gives_the_two_nodes_gradients(dev):
     torch.manual_seed(0)
     neg = tasks.negative_sampling(data, batch, 16, strict=True)
     results = []
+    layers.LAST_LAYER_ON_ROWS = False         # (its scatter backward adds with float atomics: not a bit-for-bit matter)
     for one_node in (True, False):
         layers.TRAINING_LAYER_NODE = one_node
         try:
@@ -392,6 +393,8 @@ def test_training_layer_as_one_node_gives_the_two_nodes_gradients(dev):
             results.append((out.detach(), {k: p.grad.clone() for k, p in model.named_parameters()}))
         finally:
             layers.TRAINING_LAYER_NODE = True
+            if not one_node:
+                layers.LAST_LAYER_ON_ROWS = True
     assert torch.equal(results[0][0], results[1][0])
     for name, g in results[0][1].items():
         assert torch.equal(g, results[1][1][name]), name
@@ -425,3 +428,75 @@ def test_strict_sampler_kernel_draws_the_reference_negatives(dev, bs, num_negati
         assert t_mask[i, out[i, 1:, 1]].all()
     for i in range(half, bs):
         assert h_mask[i, out[i, 1:, 0]].all()
+
+
+@pytest.mark.parametrize("message,masked", [("distmult", True), ("transe", False)])
+def test_last_layer_on_listed_rows_matches_the_whole_layer(dev, message, masked):
+    """dense.TrainRowsLayerFunction (the layer at the rows the readout reads: in-edges of the listed rows only, scatter
+    backward) against the whole layer (dense.TrainLayerFunction) followed by a gather of the same rows: output and every
+    gradient -- repeated rows, a hub row, an isolated row, the query's own row (point boundary), a keep mask."""
+    gen = torch.Generator().manual_seed(41)
+    n, e, bs, num_rel = 500, 7000, 3, 7
+    ei = torch.randint(1, n, (2, e), generator=gen)
+    ei[0, :1800] = 4                                      # hub row on the aggregation side
+    et = torch.randint(0, num_rel, (e,), generator=gen)
+    ei, et = ei.to(dev), et.to(dev)
+    rows = torch.randint(1, n, (bs, 40), generator=gen)
+    rows[:, 0] = 4                                        # the hub
+    rows[:, 1] = rows[:, 2]                               # a repeated row
+    rows[:, 3] = 0                                        # a row without in-edges
+    point_rows = torch.tensor([4, 17, 0])
+    rows[1, 5] = 17                                       # a listed row that carries the boundary value
+    rows, point_rows = rows.to(dev), point_rows.to(dev)
+    keep = (torch.rand(e, generator=gen) > 0.25).float().to(dev) if masked else None
+    layer = layers.GeneralizedRelationalConv(64, 64, num_rel, 64, message_func=message, aggregate_func="sum", layer_norm=True,
+                                             activation="relu", dependent=False).to(dev)
+    plan = rspmm.get_plan(ei, et, n, num_rel, exact_order=False)
+    flags = dense.CONV_LAYER_NORM | dense.CONV_RELU | dense.CONV_RESIDUAL
+    og = torch.randn(bs, 40, 64, generator=gen).to(dev)
+    results = []
+    for on_rows in (True, False):
+        g2 = torch.Generator().manual_seed(42)
+        x, rel, values = (t.to(dev).requires_grad_() for t in (torch.randn(bs, n, 64, generator=g2), torch.randn(bs, num_rel, 64, generator=g2),
+                                                               torch.randn(bs, 64, generator=g2)))
+        layer.zero_grad()
+        args = (layer.linear.weight, layer.linear.bias, layer.layer_norm.weight, layer.layer_norm.bias)
+        mul = layer.message2mul[message]
+        if on_rows:
+            out = dense.TrainRowsLayerFunction.apply(plan, mul, 1e-5, flags, keep, rel, x, rows, None, point_rows, values, *args)
+        else:
+            whole = dense.TrainLayerFunction.apply(plan, mul, masked, 1e-5, flags, keep, rel, x, None, point_rows, values, *args)
+            out = whole.gather(1, rows.unsqueeze(-1).expand(-1, -1, 64))
+        out.backward(og)
+        results.append([out.detach(), x.grad, rel.grad, values.grad] + [p.grad.clone() for p in args])
+    for a, b in zip(*results):
+        scale = max(b.abs().max().item(), 1.0)
+        assert (a - b).abs().max().item() <= 2e-5 * scale, ((a - b).abs().max().item(), scale)
+
+
+def test_training_step_with_the_last_layer_on_the_candidates_rows(dev):
+    """A whole training step with layers.LAST_LAYER_ON_ROWS on / off: the same scores and parameter gradients up to fp32
+    summation order (the listed rows are summed edge by edge, the whole layer by the plan's work items)."""
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    data = synthetic.make_kg(num_node=300, num_triple=2500, num_relation_base=5, num_test=16, seed=8).to(dev)
+    batch = torch.stack([data.edge_index[0, :4], data.edge_index[1, :4], data.edge_type[:4]], dim=-1)
+    torch.manual_seed(0)
+    neg = tasks.negative_sampling(data, batch, 16, strict=True)
+    results = []
+    for on_rows in (True, False):
+        layers.LAST_LAYER_ON_ROWS = on_rows
+        try:
+            model = models.Ultra(**cfg)
+            model.load_state_dict(state)
+            model = model.to(dev).train()
+            out = model(data, neg)
+            assert model.entity_model._last_hidden_on_rows == on_rows
+            F.binary_cross_entropy_with_logits(out, torch.zeros_like(out)).backward()
+            results.append((out.detach(), {k: p.grad.clone() for k, p in model.named_parameters()}))
+        finally:
+            layers.LAST_LAYER_ON_ROWS = True
+    assert torch.allclose(results[0][0], results[1][0], rtol=1e-4, atol=1e-5)
+    for name, g in results[0][1].items():
+        other = results[1][1][name]
+        scale = max(other.abs().max().item(), 1e-6)
+        assert (g - other).abs().max().item() <= 1e-4 * scale + 1e-7, name

@@ -95,6 +95,8 @@ def _load():
     lib.ultra_nbf_layer0.argtypes = [vp, vp, matp, vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, matp, vp]
     lib.ultra_rspmm_backward.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp, matp, matp, vp]
     lib.ultra_rspmm_backward_add.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp, matp, matp, matp, vp]
+    lib.ultra_rspmm_rows_forward.argtypes = [vp, i32, vp, matp, matp, vp, i64, matp, vp, vp, vp, vp]
+    lib.ultra_rspmm_rows_backward.argtypes = [vp, i32, vp, matp, matp, vp, i64, vp, matp, matp, vp]
     lib.ultra_rspmm_weight_epoch.argtypes = [i64]
     lib.ultra_rspmm_onehot_backward.argtypes = [vp, vp, vp, vp, vp, matp, vp, vp, matp, vp, vp, vp]
     lib.ultra_rspmm_forward_timed.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, vp, matp, vp, i32, i32,

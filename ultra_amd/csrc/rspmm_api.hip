@@ -13,6 +13,7 @@
 #include "rspmm_bwd_kernels.hpp"
 #include "rspmm_kernels.hpp"
 #include "rspmm_order_kernels.hpp"
+#include "rspmm_rows_kernels.hpp"
 
 namespace ultra {
 
@@ -1110,6 +1111,79 @@ int32_t ultra_rspmm_backward_add(ultra_plan *plan, int32_t sum, int32_t mul, int
     if (!input_grad_base) return invalid("ultra_rspmm_backward_add: input_grad_base is NULL");
     return backward_impl(plan, sum, mul, dtype, edge_weight_dev, relation, input, output, output_grad, weight_grad_dev,
                          relation_grad, input_grad, reinterpret_cast<hipStream_t>(stream), input_grad_base);
+}
+
+// rspmm on a list of output rows (rspmm_rows_kernels.hpp): shared argument checks of the forward and the backward entry
+static int rows_params(ultra_plan *p, int mul, const void *w, const ultra_mat *rel, const ultra_mat *x, const int64_t *rows,
+                       int64_t n_list, RowsParams *rp, const char *who) {
+    if (!p) return invalid("plan is NULL");
+    (void)hipGetLastError();
+    if (p->flags & ULTRA_PLAN_DENSE) {
+        set_error(std::string(who) + ": served by (row, col) plans");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    if (mul < 0 || mul > 1) return invalid("unknown mul code");
+    if (!rows || n_list <= 0 || !x || !x->ptr || !rel || !rel->ptr) return invalid(std::string(who) + ": NULL operand or empty row list");
+    const int64_t n_outer = x->n_outer, row_len = x->row_len;
+    int rc;
+    if ((rc = check_mat(x, "input", p->num_in, n_outer, row_len))) return rc;
+    if ((rc = check_mat(rel, "relation", p->num_rel, n_outer, row_len))) return rc;
+    if (row_len % 64 != 0 || !mat_vec_ok(x, 4) || !mat_vec_ok(rel, 4) || n_outer * (row_len / 64) * n_list > (1ll << 31)) {
+        set_error(std::string(who) + ": fp32 rows of whole 64-element spans, 16-byte aligned");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    if ((rc = upload_plan(p))) return rc;
+    std::memset(rp, 0, sizeof(*rp));
+    rp->row_ptr = p->d.row_ptr, rp->col = p->d.col, rp->type = p->d.type, rp->perm = p->d.perm;
+    rp->w = static_cast<const float *>(w);
+    rp->rel = MatArg{rel->ptr, rel->stride_outer, rel->stride_row};
+    rp->x = MatArg{x->ptr, x->stride_outer, x->stride_row};
+    rp->rows = reinterpret_cast<const long long *>(rows);
+    rp->n_outer = (int32_t)n_outer, rp->n_list = (int32_t)n_list, rp->row_len = (int32_t)row_len, rp->spans = (int32_t)(row_len / 64);
+    rp->mul_add = mul == ULTRA_MUL_ADD ? 1 : 0;
+    return ULTRA_OK;
+}
+
+int32_t ultra_rspmm_rows_forward(ultra_plan *plan, int32_t mul, const void *edge_weight_dev, const ultra_mat *relation,
+                                 const ultra_mat *input, const int64_t *rows_dev, int64_t n_list, const ultra_mat *boundary,
+                                 const int64_t *point_rows_dev, const void *point_values_dev, void *aggregate_dev, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream, aggregate_dev);
+    RowsParams rp;
+    int rc;
+    if ((rc = rows_params(plan, mul, edge_weight_dev, relation, input, rows_dev, n_list, &rp, "ultra_rspmm_rows_forward"))) return rc;
+    if (!aggregate_dev) return invalid("ultra_rspmm_rows_forward: aggregate is NULL");
+    if (boundary) {
+        if ((rc = check_mat(boundary, "boundary", plan->num_out, rp.n_outer, rp.row_len))) return rc;
+        if (!mat_vec_ok(boundary, 4)) return invalid("boundary: rows must be 16-byte aligned");
+        rp.bnd = MatArg{boundary->ptr, boundary->stride_outer, boundary->stride_row};
+    }
+    if (point_rows_dev && !point_values_dev) return invalid("a point boundary needs its value rows");
+    rp.point_rows = reinterpret_cast<const long long *>(point_rows_dev);
+    rp.point_vals = static_cast<const float *>(point_values_dev);
+    rp.agg = static_cast<float *>(aggregate_dev);
+    const long long waves = (long long)rp.n_outer * rp.spans * rp.n_list;
+    hipLaunchKernelGGL(rspmm_rows_kernel<false>, dim3((unsigned)waves), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), rp);
+    HIP_TRY(hipGetLastError());
+    return ULTRA_OK;
+}
+
+int32_t ultra_rspmm_rows_backward(ultra_plan *plan, int32_t mul, const void *edge_weight_dev, const ultra_mat *relation,
+                                  const ultra_mat *input, const int64_t *rows_dev, int64_t n_list, const void *aggregate_grad_dev,
+                                  const ultra_mat *relation_grad, const ultra_mat *input_grad, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream, aggregate_grad_dev);
+    RowsParams rp;
+    int rc;
+    if ((rc = rows_params(plan, mul, edge_weight_dev, relation, input, rows_dev, n_list, &rp, "ultra_rspmm_rows_backward"))) return rc;
+    if (!aggregate_grad_dev) return invalid("ultra_rspmm_rows_backward: aggregate_grad is NULL");
+    if ((rc = check_mat(relation_grad, "relation_grad", plan->num_rel, rp.n_outer, rp.row_len))) return rc;
+    if ((rc = check_mat(input_grad, "input_grad", plan->num_in, rp.n_outer, rp.row_len))) return rc;
+    rp.agg = const_cast<float *>(static_cast<const float *>(aggregate_grad_dev));
+    rp.xgrad = static_cast<float *>(input_grad->ptr), rp.xgrad_so = input_grad->stride_outer, rp.xgrad_sr = input_grad->stride_row;
+    rp.rgrad = static_cast<float *>(relation_grad->ptr), rp.rgrad_so = relation_grad->stride_outer, rp.rgrad_sr = relation_grad->stride_row;
+    const long long waves = (long long)rp.n_outer * rp.spans * rp.n_list;
+    hipLaunchKernelGGL(rspmm_rows_kernel<true>, dim3((unsigned)waves), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), rp);
+    HIP_TRY(hipGetLastError());
+    return ULTRA_OK;
 }
 
 // Times `once` (a launch sequence on stream s) with HIP events: the mean of `iters` back-to-back calls, and -- the figure

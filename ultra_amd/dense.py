@@ -121,6 +121,80 @@ class TrainLayerFunction(torch.autograd.Function):
                 gagg if need[8] else None, None, values_grad, gw, gb, gln_w, gln_b)
 
 
+class TrainRowsLayerFunction(torch.autograd.Function):
+    """The LAST layer of a training step, evaluated at the rows the readout reads (models.py:202-207 gathers the candidates'
+    rows of the last hidden state: 1 + num_negative of N per sample):
+
+        out[b, j] = update(x[b, rows[b, j]], sum over the in-edges of rows[b, j] of w rel (x) x[col] + boundary[b, rows[b, j]])
+
+    -- the in-edges of ~ 2,000 listed rows instead of every edge of the graph, forward (ultra_rspmm_rows_forward) and
+    backward (ultra_rspmm_rows_backward: a scatter with float atomics into the zeroed input / relation gradients, as the
+    reference's GPU backward does), and the update and its backward on bs x (1 + num_negative) rows instead of bs x N.
+    Returns (batch, n_list, 64).  Boundary: the closed form (point_rows, point_values) or a tensor without gradient."""
+
+    @staticmethod
+    def forward(ctx, plan, mul, eps, flags, edge_weight, relation, x, rows, boundary, point_rows, point_values, weight, bias,
+                ln_w, ln_b):
+        from . import rspmm
+        x, weight = x.contiguous(), weight.contiguous()
+        rows = rows.to(torch.int64).contiguous()
+        bs, n_list = rows.shape
+        relation_c, mrel = rspmm.as_mat(relation)
+        _, mx = rspmm.as_mat(x)
+        mb = None
+        if boundary is not None:
+            boundary, mbv = rspmm.as_mat(boundary)
+            mb = ctypes.byref(mbv)
+        if point_values is not None:
+            point_values = point_values.contiguous()
+        agg = torch.empty(bs, n_list, 64, dtype=torch.float32, device=x.device)
+        w = edge_weight.contiguous() if edge_weight is not None else None
+        check(lib.ultra_rspmm_rows_forward(plan._h, rspmm._lib.MUL_CODES[mul], _ptr(w), ctypes.byref(mrel), ctypes.byref(mx),
+                                           rows.data_ptr(), n_list, mb, _ptr(point_rows), _ptr(point_values), agg.data_ptr(),
+                                           _stream(x)))
+        x_rows = x.gather(1, rows.unsqueeze(-1).expand(-1, -1, 64))
+        ctx.plan, ctx.mul, ctx.eps, ctx.flags = plan, mul, eps, flags
+        ctx.save_for_backward(w, relation_c, x, rows, x_rows, agg, point_rows, weight, bias, ln_w, ln_b)
+        return _conv_update_forward(x_rows, agg, weight, bias, ln_w, ln_b, eps, flags)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        from . import rspmm
+        w, relation, x, rows, x_rows, agg, point_rows, weight, bias, ln_w, ln_b = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        n = x_rows.numel() // 64
+        gx_rows, gagg, gw = torch.empty_like(x_rows), torch.empty_like(agg), torch.empty_like(weight)
+        gb = torch.empty_like(bias) if bias is not None else None
+        gln_w = torch.empty_like(ln_w) if ln_w is not None else None
+        gln_b = torch.empty_like(ln_b) if ln_b is not None else None
+        nbytes = lib.ultra_conv_update_backward_workspace(n)
+        work = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+        check(lib.ultra_conv_update_backward(x_rows.data_ptr(), agg.data_ptr(), grad_out.data_ptr(), weight.data_ptr(), _ptr(bias),
+                                             _ptr(ln_w), _ptr(ln_b), gx_rows.data_ptr(), gagg.data_ptr(), gw.data_ptr(), _ptr(gb),
+                                             _ptr(gln_w), _ptr(gln_b), work.data_ptr(), nbytes, n, 64, 64, ctx.eps,
+                                             ctx.flags, _stream(x)))
+        need = ctx.needs_input_grad
+        relation_grad = x_grad = None
+        if need[5] or need[6]:
+            # the update's share of the input gradient lands on the listed rows (repeats add up); the rspmm's is scattered on top
+            x_grad = torch.zeros_like(x).scatter_add_(1, rows.unsqueeze(-1).expand(-1, -1, 64), gx_rows)
+            relation_grad = torch.zeros(relation.shape, dtype=torch.float32, device=x.device)
+            _, mrel = rspmm.as_mat(relation)
+            _, mx = rspmm.as_mat(x)
+            _, mrg = rspmm.as_mat(relation_grad)
+            _, mxg = rspmm.as_mat(x_grad)
+            check(lib.ultra_rspmm_rows_backward(ctx.plan._h, rspmm._lib.MUL_CODES[ctx.mul], _ptr(w), ctypes.byref(mrel),
+                                                ctypes.byref(mx), rows.data_ptr(), rows.shape[1], gagg.data_ptr(),
+                                                ctypes.byref(mrg), ctypes.byref(mxg), _stream(x)))
+        values_grad = None
+        if point_rows is not None and need[10]:
+            hit = (rows == point_rows.unsqueeze(1)).to(gagg.dtype).unsqueeze(-1)
+            values_grad = (gagg * hit).sum(dim=1)
+        return (None, None, None, None, None, relation_grad if need[5] else None, x_grad if need[6] else None, None, None, None,
+                values_grad, gw, gb, gln_w, gln_b)
+
+
 def conv_update(layer, input, update, residual):
     """out = [input +] relu(layer_norm(linear(cat[input, update]))) for (..., 64) fp32 GPU tensors."""
     flags = (CONV_LAYER_NORM if layer.layer_norm is not None else 0) | (CONV_RELU if layer.activation is not None else 0) \

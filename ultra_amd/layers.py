@@ -27,6 +27,8 @@ POINT_BOUNDARY_FAST_PATH = True
 POINT_BOUNDARY_TRAINING = True
 # aggregate + update of a training step's layer as one autograd node (A/B switch for tests)
 TRAINING_LAYER_NODE = True
+# the last layer of a training step evaluated at the rows the readout reads (A/B switch for tests)
+LAST_LAYER_ON_ROWS = True
 # aggregate + update of a layer in one launch on dense-format plans (A/B switch for tests)
 FUSED_DENSE_LAYER = True
 # aggregate + update of a layer in one launch on the reference-order plan of a sparse graph: the update runs in the tail of
@@ -286,6 +288,33 @@ class GeneralizedRelationalConv(nn.Module):
             edge_weight, relation, input, None if point is not None else boundary,
             point.rows if point is not None else None, point.values if point is not None else None,
             self.linear.weight, self.linear.bias, ln.weight if ln is not None else None, ln.bias if ln is not None else None)
+
+    def training_rows_layer(self, input, query, boundary, edge_index, edge_type, num_node, rows, edge_weight=None, residual=False,
+                            relation=None):
+        """This layer's output at the listed rows only -- (batch, n_list, 64) for rows (batch, n_list) -- as one autograd node
+        (dense.TrainRowsLayerFunction): what the LAST layer of a training step needs, since the readout reads the candidates'
+        rows alone (models.py:202-207).  None where the route does not apply (the caller then runs the whole layer)."""
+        if relation is None:
+            relation = self._relation_for(query, len(query))
+        point = boundary if isinstance(boundary, PointBoundary) else None
+        if not (LAST_LAYER_ON_ROWS and torch.is_grad_enabled() and self.aggregate_func == "sum"
+                and self.message_func in self.message2mul and input.is_cuda and input.dim() == 3 and rows.dim() == 2
+                and input.dtype == torch.float32 and relation.dtype == torch.float32
+                and (edge_weight is None or (not edge_weight.requires_grad and edge_weight.dtype == torch.float32))
+                and (input.requires_grad or relation.requires_grad or boundary.requires_grad)
+                and (point is not None or (boundary.dtype == torch.float32 and not boundary.requires_grad))
+                and (point is None or point.values.dtype == torch.float32)
+                and dense.conv_update_supported(self, input, input)):
+            return None
+        plan = rspmm.get_plan(edge_index, edge_type, num_node, relation.shape[1], exact_order=False)
+        ln = self.layer_norm
+        flags = (dense.CONV_LAYER_NORM if ln is not None else 0) | (dense.CONV_RELU if self.activation is not None else 0) \
+            | (dense.CONV_RESIDUAL if residual else 0)
+        return dense.TrainRowsLayerFunction.apply(
+            plan, self.message2mul[self.message_func], float(ln.eps) if ln is not None else 1e-5, flags, edge_weight, relation, input,
+            rows, None if point is not None else boundary, point.rows if point is not None else None,
+            point.values if point is not None else None, self.linear.weight, self.linear.bias,
+            ln.weight if ln is not None else None, ln.bias if ln is not None else None)
 
     # ---- unfused path: gather edge_index[0], scatter to edge_index[1] -- PyG's direction (layers.py:135-181) ----
     def _propagate_unfused(self, edge_index, size, input, relation, boundary, edge_type, edge_weight):

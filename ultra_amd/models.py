@@ -103,12 +103,13 @@ class BaseNBFNet(nn.Module):
         return new_h_index, new_t_index, new_r_index
 
     def _propagate_layers(self, data, layer_input, query, boundary, separate_grad=False, relations=None,
-                          edge_weight=None, onehot_rows=None, edge_keep=False, prefilled=None):
+                          edge_weight=None, onehot_rows=None, edge_keep=False, prefilled=None, last_rows=None):
         """The Bellman-Ford loop shared by every model (models.py:72-80, 150-163, 233-246).
         `relations`: optional per-layer relation features computed up front (EntityNBFNet batches the six
         relation_projection MLPs, which all read the same relation representations).
         `boundary` may be a layers.PointBoundary (then `layer_input` is ignored: layer 0 reads the boundary condition)."""
         size = (data.num_nodes, data.num_nodes)
+        self._last_hidden_on_rows = False
         # edge_weight None = all ones (only materialised when its gradient is asked for); a 0/1 vector = edge dropout
         hiddens, edge_weights = [], []
         first = 0
@@ -141,6 +142,17 @@ class BaseNBFNet(nn.Module):
                 edge_weight = torch.ones(data.num_edges, device=layer_input.device).requires_grad_()
             # residual connection (models.py:158-160) is fused into the layer's update kernel
             residual = self.short_cut and layer.output_dim == layer_input.shape[-1]
+            if last_rows is not None and i == len(self.layers) - 1 and i > 0 and not separate_grad:
+                # the caller reads the last hidden state at `last_rows` only: that layer on those rows' in-edges alone.
+                # hiddens[-1] is then (batch, n_list, d), flagged by self._last_hidden_on_rows
+                rows_hidden = layer.training_rows_layer(layer_input, query, boundary, data.edge_index, data.edge_type,
+                                                        data.num_nodes, last_rows, edge_weight=edge_weight, residual=residual,
+                                                        relation=None if relations is None else relations[i])
+                if rows_hidden is not None:
+                    hiddens.append(rows_hidden)
+                    edge_weights.append(edge_weight)
+                    self._last_hidden_on_rows = True
+                    break
             hidden = layer._forward_impl(layer_input, query, boundary, data.edge_index, data.edge_type, size,
                                          edge_weight, residual=residual,
                                          relation=None if relations is None else relations[i],
@@ -257,7 +269,8 @@ class EntityNBFNet(BaseNBFNet):
             out = layer.layer0_fill(data.edge_index, data.edge_type, data.num_nodes, int(data.num_relations), batch_size)
         return out, side
 
-    def _bellmanford_hidden(self, data, h_index, r_index, separate_grad=False, edge_weight=None, edge_keep=False, prefilled=None):
+    def _bellmanford_hidden(self, data, h_index, r_index, separate_grad=False, edge_weight=None, edge_keep=False, prefilled=None,
+                            last_rows=None):
         batch_size = len(r_index)
         # query = representation of each sample's query relation, scattered to its head node
         fused = (dense.boundary_supported(h_index, self.query) and self.query.dim() == 3
@@ -283,7 +296,7 @@ class EntityNBFNet(BaseNBFNet):
         hiddens, edge_weights = self._propagate_layers(data, boundary, query, boundary, separate_grad,
                                                        relations=self._project_relations_batched(),
                                                        edge_weight=edge_weight, onehot_rows=h_index, edge_keep=edge_keep,
-                                                       prefilled=prefilled)
+                                                       prefilled=prefilled, last_rows=last_rows)
         return hiddens, edge_weights, query
 
     def _project_relations_batched(self):
@@ -397,8 +410,16 @@ class EntityNBFNet(BaseNBFNet):
                                      torch.where(is_t_neg, r_index, r_index + num_direct_rel))
         valid = ((same[:, 0] | same[:, 1]) & same[:, 2]).all()
 
+        # (under autograd only the candidates' rows of the last hidden state are read below: the last layer is evaluated on
+        # those rows' in-edges alone where the layer supports it -- layers.training_rows_layer)
+        rows_wanted = t_index if (torch.is_grad_enabled() and not self.concat_hidden and t_index.is_cuda) else None
         hiddens, _, query = self._bellmanford_hidden(data, h_index[:, 0], r_index[:, 0], edge_weight=edge_weight,
-                                                     edge_keep=edge_weight is not None)
+                                                     edge_keep=edge_weight is not None, last_rows=rows_wanted)
+        if self._last_hidden_on_rows:
+            feature = torch.cat([hiddens[-1], query.unsqueeze(1).expand(-1, t_index.shape[1], -1)], dim=-1)
+            score = self.mlp(feature).squeeze(-1)
+            self._check_valid(valid)
+            return score.view(shape)
         if dense.readout_supported(self, hiddens[-1]):
             # gather + cat[hidden, query] + MLP in one MFMA kernel (nothing of size (bs, N, 128) is materialised)
             score = dense.readout(self, hiddens[-1], query, t_index).view(shape)
