@@ -84,7 +84,10 @@ def test_bench_refuses_more_gpus_than_visible():
 DDP_STEP = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)
-from ultra_amd import models, synthetic, tasks
+from ultra_amd import layers, models, synthetic, tasks
+# (the plain step and the DDP step are compared bit for bit below: the one route of the training step whose backward adds with
+# float atomics -- the last layer on the candidates' rows -- is switched off for that; tests/test_training_gpu.py checks it)
+layers.LAST_LAYER_ON_ROWS = False
 rank, local = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
 dev = torch.device("cuda", local)
 dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm (ultra/util.py:121-122)

@@ -381,6 +381,7 @@ def test_training_layer_as_one_node_gives_the_two_nodes_gradients(dev):
     torch.manual_seed(0)
     neg = tasks.negative_sampling(data, batch, 16, strict=True)
     results = []
+    was = layers.LAST_LAYER_ON_ROWS
     layers.LAST_LAYER_ON_ROWS = False         # (its scatter backward adds with float atomics: not a bit-for-bit matter)
     for one_node in (True, False):
         layers.TRAINING_LAYER_NODE = one_node
@@ -394,7 +395,7 @@ def test_training_layer_as_one_node_gives_the_two_nodes_gradients(dev):
         finally:
             layers.TRAINING_LAYER_NODE = True
             if not one_node:
-                layers.LAST_LAYER_ON_ROWS = True
+                layers.LAST_LAYER_ON_ROWS = was
     assert torch.equal(results[0][0], results[1][0])
     for name, g in results[0][1].items():
         assert torch.equal(g, results[1][1][name]), name
@@ -483,6 +484,7 @@ def test_training_step_with_the_last_layer_on_the_candidates_rows(dev):
     torch.manual_seed(0)
     neg = tasks.negative_sampling(data, batch, 16, strict=True)
     results = []
+    was = layers.LAST_LAYER_ON_ROWS
     for on_rows in (True, False):
         layers.LAST_LAYER_ON_ROWS = on_rows
         try:
@@ -494,7 +496,7 @@ def test_training_step_with_the_last_layer_on_the_candidates_rows(dev):
             F.binary_cross_entropy_with_logits(out, torch.zeros_like(out)).backward()
             results.append((out.detach(), {k: p.grad.clone() for k, p in model.named_parameters()}))
         finally:
-            layers.LAST_LAYER_ON_ROWS = True
+            layers.LAST_LAYER_ON_ROWS = was
     assert torch.allclose(results[0][0], results[1][0], rtol=1e-4, atol=1e-5)
     for name, g in results[0][1].items():
         other = results[1][1][name]

@@ -27,8 +27,10 @@ POINT_BOUNDARY_FAST_PATH = True
 POINT_BOUNDARY_TRAINING = True
 # aggregate + update of a training step's layer as one autograd node (A/B switch for tests)
 TRAINING_LAYER_NODE = True
-# the last layer of a training step evaluated at the rows the readout reads (A/B switch for tests)
-LAST_LAYER_ON_ROWS = True
+# the last layer of a training step evaluated at the rows the readout reads.  Its backward is a scatter with float atomics (like
+# the reference's GPU backward): gradients then vary in their last bits run to run; ULTRA_LAST_LAYER_ON_ROWS=0 (or the
+# attribute) keeps every sum of the step in a fixed order at ~ 15 % of the step's time
+LAST_LAYER_ON_ROWS = os.environ.get("ULTRA_LAST_LAYER_ON_ROWS", "1") != "0"
 # aggregate + update of a layer in one launch on dense-format plans (A/B switch for tests)
 FUSED_DENSE_LAYER = True
 # aggregate + update of a layer in one launch on the reference-order plan of a sparse graph: the update runs in the tail of
