@@ -301,6 +301,7 @@ class GeneralizedRelationalConv(nn.Module):
         point = boundary if isinstance(boundary, PointBoundary) else None
         if not (LAST_LAYER_ON_ROWS and torch.is_grad_enabled() and self.aggregate_func == "sum"
                 and self.message_func in self.message2mul and input.is_cuda and input.dim() == 3 and rows.dim() == 2
+                and 4 * rows.shape[1] <= num_node         # (a list that covers most of the graph: the whole layer's walk is the better one)
                 and input.dtype == torch.float32 and relation.dtype == torch.float32
                 and (edge_weight is None or (not edge_weight.requires_grad and edge_weight.dtype == torch.float32))
                 and (input.requires_grad or relation.requires_grad or boundary.requires_grad)
