@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a call: the two-workgroup build of the update backward it measures was not kept: profiles/r5_experiments.txt)
 # Update backward with two workgroups per CU (compiler held to 128 VGPRs: spills) -- step times and the YAGO3-10 kernel table.
 OUT=gpurun_out/r5x
 mkdir -p $OUT

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a call: the kernel variant it probes -- relation_grad accumulated in LDS by the input-gradient walk, ULTRA_RG_PROBE -- was removed after it: profiles/r5_experiments.txt)
 # One-walk backward (input_grad + relation_grad): parity tests, step times, kernel table.
 OUT=gpurun_out/r5y
 mkdir -p $OUT

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a call: the kernel variant it probes -- relation_grad accumulated in LDS by the input-gradient walk, ULTRA_RG_PROBE -- was removed after it: profiles/r5_experiments.txt)
 # What the one-walk backward's LDS adds cost: ds_add_f32 against a plain store and a racy read-add-store (timing only).
 OUT=gpurun_out/r5z
 mkdir -p $OUT
