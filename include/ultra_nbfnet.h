@@ -164,6 +164,17 @@ int32_t ultra_strict_negatives(const int64_t *sorted_keys_dev, int64_t n_key, co
                                int64_t num_relation, int64_t *out_dev, void *stream);
 
 /*
+ * The fine-tuning step's loss and its gradient in one launch (/root/reference/script/run.py:66-77):
+ *     target = [1, 0, ..., 0];  l = binary_cross_entropy_with_logits(pred, target, reduction = none)
+ *     w[:, 0] = 1;  w[:, 1:] = softmax(pred[:, 1:] / temperature)  (temperature > 0; a constant, as under run.py's no_grad)
+ *                              or uniform_weight (= 1 / num_negative; temperature == 0)
+ *     loss = mean_b( sum_i l w / sum_i w );   grad = d loss / d pred
+ * pred, grad (rows, n) fp32 row-major; loss one fp32.  rows <= 4096, n >= 2.  Sums run in a fixed order (reproducible).
+ */
+int32_t ultra_ranking_loss(const void *pred, int64_t rows, int64_t n, float temperature, float uniform_weight, void *loss,
+                           void *grad, void *stream);
+
+/*
  * Relation graph of a knowledge graph (/root/reference/ultra/tasks.py:144-199) on the GPU, as bit matrices.
  *   edge_index (2, num_edge) int64 [head; tail], edge_type (num_edge) int64 -- inverse edges already included;
  *   W = (num_relation + 31) / 32 words per bit row.

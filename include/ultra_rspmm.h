@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_ABI_VERSION 6
+#define ULTRA_ABI_VERSION 7
 
 typedef enum {
     ULTRA_OK = 0,
@@ -269,6 +269,17 @@ int32_t ultra_rspmm_forward_onehot(ultra_plan *plan, int32_t dtype, const void *
                                    const ultra_mat *boundary, const ultra_mat *output, void *stream);
 
 /*
+ * relation_grad of add_mul with unit edge weights on a ULTRA_PLAN_DENSE plan (/root/reference/ultra/rspmm/source/rspmm.cpp:106-108):
+ *     relation_grad[o, t, :] = sum_{e : type_e == t} output_grad[o, row_e, :] * input[o, col_e, :]
+ * as the per-type products A_t . input of the dense forward, weighed with output_grad and summed over the rows -- the backward of
+ * ULTRA's relation graph (474 nodes, 4 types, 0.9 M edges) without a walk over its edge list.  fp32, row_len a multiple of 32,
+ * at most 32 relation types, 16-byte aligned operands; otherwise ULTRA_ERR_UNSUPPORTED (use ultra_rspmm_backward).
+ * Deterministic (fixed summation order, no atomics).
+ */
+int32_t ultra_rspmm_dense_relation_grad(ultra_plan *plan, const ultra_mat *input, const ultra_mat *output_grad,
+                                        const ultra_mat *relation_grad, void *stream);
+
+/*
  * add-aggregate rspmm restricted to a LIST of output rows per outer slice (fine-tuning: a training step reads the last
  * layer's output at its 1 + num_negative candidate rows only, /root/reference/ultra/models.py:202-207):
  *   forward   aggregate[o, j] = sum_{e : row_e == rows[o, j]} w_e * BINARY(rel[o, type_e], input[o, col_e])
@@ -285,6 +296,24 @@ int32_t ultra_rspmm_rows_forward(ultra_plan *plan, int32_t mul, const void *edge
 int32_t ultra_rspmm_rows_backward(ultra_plan *plan, int32_t mul, const void *edge_weight_dev, const ultra_mat *relation,
                                   const ultra_mat *input, const int64_t *rows_dev, int64_t n_list, const void *aggregate_grad_dev,
                                   const ultra_mat *relation_grad, const ultra_mat *input_grad, void *stream);
+
+/*
+ * The same backward as GATHERS -- no atomics, a fixed summation order, both gradients WRITTEN in full (no zeroing by the caller):
+ *     input_grad[o, c]    = sum_{j : rows[o, j] == c} update_grad[o, j]  +  sum_{e : col_e == c, row_e listed} w_e dBINARY/dinput * aggregate_grad[o, j(row_e)]
+ *     relation_grad[o, t] = sum_{e : type_e == t, row_e listed} w_e dBINARY/drel * aggregate_grad[o, j(row_e)]
+ * (repeated list entries count once each, as in the scatter).  update_grad (n_outer, n_list, row_len; may be NULL): the share of
+ * the input gradient that reaches the listed rows directly (the layer update reads input[o, rows[o, j]]).  point_values_grad
+ * (n_outer, row_len; may be NULL) receives sum_{j : rows[o, j] == point_rows[o]} aggregate_grad[o, j] -- the gradient of the point
+ * boundary's values.  Every destination row is summed by one owner that walks ITS edges (the edge list grouped by source / by type,
+ * built with the plan on first use) and looks every edge's aggregation row up in a per-step table of the listed rows.
+ * fp32, row_len == 64, n_list <= 1024, square graphs, plans that kept their edge list; otherwise ULTRA_ERR_UNSUPPORTED (use
+ * ultra_rspmm_rows_backward).  Uses plan-owned scratch: one call at a time per plan.
+ */
+int32_t ultra_rspmm_rows_backward_gather(ultra_plan *plan, int32_t mul, const void *edge_weight_dev, const ultra_mat *relation,
+                                         const ultra_mat *input, const int64_t *rows_dev, int64_t n_list,
+                                         const void *aggregate_grad_dev, const void *update_grad_dev, const int64_t *point_rows_dev,
+                                         void *point_values_grad_dev, const ultra_mat *relation_grad, const ultra_mat *input_grad,
+                                         void *stream);
 
 /*
  * Tag of the edge-weight vector passed to the NEXT weighted call of this thread (ultra_rspmm_forward / _masked / _point /

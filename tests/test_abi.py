@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
 def test_host_entry_points_without_gpu():
     from ultra_amd import _lib
     lib = _lib.lib
-    assert lib.ultra_abi_version() == 6
+    assert lib.ultra_abi_version() == 7
     assert lib.ultra_device_count() >= 0
     t = _lib.Tuning()
     assert lib.ultra_get_tuning(ctypes.byref(t)) == 0

@@ -221,3 +221,31 @@ def test_captured_evaluation_step_equals_the_eager_protocol(dev):
     # two captured steps in flight on two streams (the default from 128 batches on): same rankings, same metrics
     piped = ueval.evaluate(model, data, batch_size=8, metrics=names, in_flight=2)
     assert piped == eager
+    # ... and three (evaluate()'s default from 256 batches on; bench.py's secondary.evaluate), with the time table filled in
+    stats = {}
+    piped = ueval.evaluate(model, data, batch_size=8, metrics=names, in_flight=3, stats=stats)
+    assert piped == eager
+    assert stats["in_flight"] == 3 and stats["batches"] == 5 and stats["capture"] > 0 and stats["replay"] > 0
+
+
+def test_slot_stream_trial_of_evaluate_runs_on_real_batches_once_per_process(dev):
+    """With enough batches evaluate() picks the streams of its captured steps by timing REAL batches (their rows are kept: the
+    rankings equal the one-at-a-time protocol's) and keeps the choice for later calls of the process."""
+    from tests.test_oracle_model import load_golden
+    from ultra_amd import eval as ueval
+    from ultra_amd import models, synthetic
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    data = synthetic.make_kg(num_node=300, num_triple=2500, num_relation_base=4, num_test=200, seed=12).to(dev)
+    model = models.Ultra(**cfg)
+    model.load_state_dict(state)
+    model = model.to(dev).eval()
+    eager = ueval.evaluate(model, data, batch_size=2, use_graph=False)
+    ueval._SLOT_STREAMS.clear()
+    stats = {}
+    piped = ueval.evaluate(model, data, batch_size=2, in_flight=2, stats=stats)       # 100 batches: 4 candidates x 3 x 4 batches
+    assert piped == eager
+    assert stats["in_flight"] == 2 and 0 < stats["trial_batches"] <= 50 and len(stats["slot_streams"]["trial_ms"]) >= 2
+    assert len(ueval._SLOT_STREAMS) == 1
+    stats = {}
+    again = ueval.evaluate(model, data, batch_size=2, in_flight=2, stats=stats)
+    assert again == eager and "trial" not in stats                                    # the choice was kept

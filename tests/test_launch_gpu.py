@@ -85,9 +85,9 @@ DDP_STEP = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)
 from ultra_amd import layers, models, synthetic, tasks
-# (the plain step and the DDP step are compared bit for bit below: the one route of the training step whose backward adds with
-# float atomics -- the last layer on the candidates' rows -- is switched off for that; tests/test_training_gpu.py checks it)
-layers.LAST_LAYER_ON_ROWS = False
+# (the plain step and the DDP step are compared bit for bit below, on the DEFAULT route: since round 6 the last layer's backward
+# on the candidates' rows is a gather in a fixed order too -- ultra_rspmm_rows_backward_gather -- so every sum of the step is)
+assert layers.LAST_LAYER_ON_ROWS
 rank, local = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
 dev = torch.device("cuda", local)
 dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm (ultra/util.py:121-122)
@@ -195,3 +195,59 @@ def test_bench_with_two_ranks_sharing_the_gpu_over_gloo():
     per = cfg["per_rank"]
     assert per["probe_scores_identical"] is True and per["readout_order_identical"] is True and len(per["ms_per_step"]) == 2
     assert out["value"] == pytest.approx(2 * 8 * 14541 * 6 / (out["ms_per_step"] * 6e-3), rel=1e-6)      # whole-job aggregate
+
+
+GRAPHED_TWO_RANKS = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from ultra_amd import models, synthetic, tasks, train
+rank = int(os.environ["RANK"])
+dev = torch.device("cuda", 0)                            # both ranks on the one GPU of the box: gloo carries the all-reduce
+torch.cuda.set_device(dev)
+dist.init_process_group("gloo")
+data = synthetic.make_kg(num_node=800, num_triple=8000, num_relation_base=6, num_test=16, seed=5).to(dev)
+triples = torch.stack([data.edge_index[0], data.edge_index[1], data.edge_type], dim=-1)
+torch.manual_seed(3 + rank)
+batches = [tasks.negative_sampling(data, triples[(2 * i + rank) * 4:(2 * i + rank + 1) * 4], 16, strict=True) for i in range(3)]
+
+def fresh():
+    torch.manual_seed(0)
+    return models.Ultra(**synthetic.default_model_cfg()).to(dev).train()
+
+# the reference's way (script/run.py:44-45, 63-82): DistributedDataParallel around the model, AdamW, three steps
+model = fresh()
+net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+opt = train.make_adamw(model, lr=5e-3)
+want_loss = [train.train_step(net, data, b, opt, num_negative=16).item() for b in batches]
+want = [p.detach().clone() for p in model.parameters()]
+
+# the captured step: forward + backward as one graph, ONE all-reduce of the flat gradient bucket, AdamW as a second graph
+model = fresh()
+opt = train.make_adamw(model, lr=5e-3, capturable=True)
+step = train.GraphedTrainStep(model, data, opt, batches[0], num_negative=16)
+assert step.world == 2 and step.step_graph is not None
+got_loss = [step(b).item() for b in batches]
+for a, b in zip(got_loss, want_loss):
+    assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (got_loss, want_loss)
+worst = 0.0
+for p, q in zip(model.parameters(), want):
+    worst = max(worst, (p - q).abs().max().item() / max(1.0, q.abs().max().item()))
+assert worst <= 1e-5, worst                              # (DDP averages per bucket, the captured step one flat bucket: same mean to rounding)
+flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+ref = flat.clone()
+dist.broadcast(ref, 0)
+assert torch.equal(ref, flat), "parameters differ across ranks after three captured steps"
+print("GRAPHED2_OK rank %%d worst %%.3g" %% (rank, worst))
+dist.destroy_process_group()
+"""
+
+
+def test_captured_training_step_with_two_ranks_matches_ddp(tmp_path):
+    """train.GraphedTrainStep at world size 2 (gloo, both ranks on cuda:0): the same losses and parameters after three steps as
+    DistributedDataParallel + train_step on the same per-rank batches, and identical parameters on both ranks."""
+    script = tmp_path / "graphed_two.py"
+    script.write_text(GRAPHED_TWO_RANKS % ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.count("GRAPHED2_OK") == 2, (r.stdout + r.stderr)[-3000:]

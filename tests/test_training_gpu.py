@@ -237,6 +237,33 @@ def test_prefetched_negatives_equal_the_plain_loop_and_overlap_a_busy_stream(dev
     assert len(got) == len(plain) and all(torch.equal(a, b) for a, b in zip(got, plain))
 
 
+def test_prefetched_negatives_behind_a_loader_that_builds_its_batches_with_kernels(dev):
+    """script/run.py:32-34 keeps the triple list on the device: the DataLoader then stacks every batch with a KERNEL on the
+    current stream.  The sampler's side stream must see that kernel's result, not the memory before it ran -- with the
+    training stream kept busy for tens of milliseconds in front of every batch (the collate was queued behind the
+    previous step and the sampler read the batch first)."""
+    from torch.utils import data as torch_data
+    data = synthetic.make_kg(num_node=300, num_triple=2500, num_relation_base=5, num_test=16, seed=8).to(dev)
+    triples = torch.stack([data.edge_index[0], data.edge_index[1], data.edge_type], dim=-1)[:64].contiguous()
+    loader = torch_data.DataLoader(triples, 8)               # default collate: torch.stack of 8 GPU rows
+    busy = torch.randn(4096, 4096, device=dev)
+    for _ in range(6):
+        busy = busy @ busy / 4096.0                           # the queue the first batch would wait behind
+    torch.manual_seed(11)
+    plain = [tasks.negative_sampling(data, triples[8 * i:8 * i + 8], 32, strict=True) for i in range(8)]
+    torch.manual_seed(11)
+    got = []
+    for neg in tasks.prefetch_negatives(loader, data, 32, strict=True):
+        got.append(neg.clone())
+        for _ in range(6):
+            busy = busy @ busy / 4096.0                       # the "step"
+    torch.cuda.synchronize()
+    assert len(got) == 8
+    for i, (a, b) in enumerate(zip(got, plain)):
+        assert torch.equal(a[:, 0], triples[8 * i:8 * i + 8]), "batch %d: the sampler read the positives before they were written" % i
+        assert torch.equal(a, b)
+
+
 def _index_add_rspmm(ei, et, rel, x, keep, n):
     msg = rel[:, et] * x[:, ei[1]]
     if keep is not None:
@@ -382,7 +409,7 @@ def test_training_layer_as_one_node_gives_the_two_nodes_gradients(dev):
     neg = tasks.negative_sampling(data, batch, 16, strict=True)
     results = []
     was = layers.LAST_LAYER_ON_ROWS
-    layers.LAST_LAYER_ON_ROWS = False         # (its scatter backward adds with float atomics: not a bit-for-bit matter)
+    layers.LAST_LAYER_ON_ROWS = False         # (this test is about the whole-layer node: every layer takes it)
     for one_node in (True, False):
         layers.TRAINING_LAYER_NODE = one_node
         try:

@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 6, call 4: rows backward, second version (batch look-ups, eight-slice combine, prepare without scans)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 1200 python -m pytest tests/test_round6_gpu.py tests/test_train_gpu.py tests/test_training_gpu.py -x -q > gpurun_out/r6_04_tests.txt 2>&1; echo "tests rc $?" >> gpurun_out/r6_04_tests.txt
+tail -5 gpurun_out/r6_04_tests.txt
+timeout 600 python tools/train_graph_probe.py fb15k237 yago310 > gpurun_out/r6_04_probe.txt 2>&1
+grep -v amdgpu.ids gpurun_out/r6_04_probe.txt | cut -c1-420
+for shape in fb15k237 yago310; do
+  rm -rf /tmp/tl_$shape
+  PROBE_ONLY=eager timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$shape -- python tools/train_graph_probe.py $shape > /dev/null 2>&1
+  f=$(ls /tmp/tl_$shape/*/*_kernel_trace.csv | head -1)
+  python tools/train_timeline.py $f > gpurun_out/r6_04_timeline_$shape.txt 2>&1
+  grep "rows_\|launches" gpurun_out/r6_04_timeline_$shape.txt | grep -v conv_update | cut -c1-100
+done

@@ -95,8 +95,10 @@ def _load():
     lib.ultra_nbf_layer0.argtypes = [vp, vp, matp, vp, vp, vp, vp, vp, vp, ctypes.c_float, i32, matp, vp]
     lib.ultra_rspmm_backward.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp, matp, matp, vp]
     lib.ultra_rspmm_backward_add.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, matp, vp, matp, matp, matp, vp]
+    lib.ultra_rspmm_dense_relation_grad.argtypes = [vp, matp, matp, matp, vp]
     lib.ultra_rspmm_rows_forward.argtypes = [vp, i32, vp, matp, matp, vp, i64, matp, vp, vp, vp, vp]
     lib.ultra_rspmm_rows_backward.argtypes = [vp, i32, vp, matp, matp, vp, i64, vp, matp, matp, vp]
+    lib.ultra_rspmm_rows_backward_gather.argtypes = [vp, i32, vp, matp, matp, vp, i64, vp, vp, vp, vp, matp, matp, vp]
     lib.ultra_rspmm_weight_epoch.argtypes = [i64]
     lib.ultra_rspmm_onehot_backward.argtypes = [vp, vp, vp, vp, vp, matp, vp, vp, matp, vp, vp, vp]
     lib.ultra_rspmm_forward_timed.argtypes = [vp, i32, i32, i32, vp, matp, matp, matp, vp, matp, vp, i32, i32,
@@ -110,6 +112,7 @@ def _load():
     lib.ultra_stream_copy.argtypes = [vp, vp, i64, vp]
     lib.ultra_filtered_rank.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
     lib.ultra_strict_negatives.argtypes = [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp]
+    lib.ultra_ranking_loss.argtypes = [vp, i64, i64, ctypes.c_float, ctypes.c_float, vp, vp, vp]
     lib.ultra_onehot_rows.argtypes = [vp, vp, vp, i64, i64, i64, vp]
     lib.ultra_batch_prologue.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     lib.ultra_readout_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, i32, i32, vp]
@@ -133,7 +136,7 @@ def _load():
 
 
 lib = _load()
-if lib.ultra_abi_version() != 6:
+if lib.ultra_abi_version() != 7:
     raise ImportError("ultra_amd: libultra_amd.so ABI version mismatch")
 
 

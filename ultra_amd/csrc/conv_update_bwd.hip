@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/ultra_nbfnet.h"
@@ -81,7 +83,8 @@ __global__ void __launch_bounds__(512) conv_update_bwd_rows_kernel(const ConvBwd
 #pragma unroll
         for (int r = 0; r < 16; ++r) dgam[m][r] = 0.f, dbet[m][r] = 0.f;
 
-    for (long long tile = (long long)blockIdx.x * wpb + wave; tile < ntile; tile += tstride) {
+    // (wave-major: workgroup b takes tiles b, b + grid, ... -- with fewer tiles than waves every workgroup still gets its share)
+    for (long long tile = blockIdx.x + (long long)gridDim.x * wave; tile < ntile; tile += tstride) {
         const long long row = tile * 32 + j;
         const bool valid = row < p.rows;
         const long long rc = valid ? row : p.rows - 1;
@@ -294,7 +297,7 @@ __global__ void __launch_bounds__(512) conv_update_bwd_weights_kernel(const Conv
             g.b[u][3] = ar[32];
         }
     };
-    long long tile = (long long)blockIdx.x * wpb + wave;
+    long long tile = blockIdx.x + (long long)gridDim.x * wave;
     Group cur;
     if (tile < ntile) load_group(cur, tile, 0);
     for (; tile < ntile; tile += tstride) {
@@ -374,22 +377,41 @@ __global__ void __launch_bounds__(1024) conv_update_bwd_reduce_kernel(const Conv
         p.gln_b[idx - 64 * 128 - 128] = s;
 }
 
-static int bwd_grid(long long rows) {
-    static int cu = 0;   // queried once (kept out of hipGraph capture)
+// Launch shape of the two persistent kernels: `blocks` workgroups (= the number of partial-sum rows both write), wpb_rows /
+// wpb_weights waves in each.  One workgroup per CU at most (the kernels hold 232 / 218 VGPRs: built for 128 they spill -- the
+// FB15k237-shape step 6.1 -> 9.3 ms, profiles/r5_experiments.txt), and as many waves as it has 32-row tiles, up to 8.
+// Few rows (the relation model's 3,792, the last layer's 2,056 listed rows: one tile a wave at most) are latency, not
+// throughput: round 5 packed them into ceil(tiles / 8) workgroups of 8 waves -- 15 workgroups, 29 + 40 us a call whatever the
+// row count (profiles/r6_01_timeline_eager.txt), of which the weight kernel's eight-deep serial fold through LDS and the
+// rows kernel's staging by few workgroups are most.  Now: one tile per workgroup while the CUs last; the weight kernel runs ONE
+// wave there (no fold), the rows kernel keeps four (three of them only help staging the weight matrix into LDS).
+// ULTRA_CONV_BWD_SHAPE=blocks_cap,wpb_rows,wpb_weights overrides (0: the rule above; measurements).
+struct BwdShape {
+    int blocks, wpb_rows, wpb_weights;
+};
+static BwdShape bwd_shape(long long rows) {
+    static int cu = 0, env[3] = {0, 0, 0};   // queried once (kept out of hipGraph capture)
     if (cu == 0) {
         int dev = 0, v = 0;
         cu = 256;
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
             cu = v;
+        if (const char *e = getenv("ULTRA_CONV_BWD_SHAPE")) (void)sscanf(e, "%d,%d,%d", &env[0], &env[1], &env[2]);
     }
     const long long ntile = (rows + 31) / 32;
-    // 8 waves per workgroup, one workgroup per CU, persistent over tiles.  (Two per CU need the kernels in 128 VGPRs: they
-    // hold 232 / 218 -- the 128 accumulators of dW, the three row operands of a tile -- and built that way they spill:
-    // the FB15k237-shape step 6.1 -> 9.3 ms, profiles/r5_experiments.txt.)
-    long long blocks = (ntile + 7) / 8;
-    if (blocks > cu) blocks = cu;
-    return (int)(blocks < 1 ? 1 : blocks);
+    const long long cap = env[0] > 0 ? env[0] : cu;
+    long long blocks = ntile < cap ? ntile : cap;
+    if (blocks < 1) blocks = 1;
+    long long per = (ntile + blocks - 1) / blocks;      // tiles per workgroup
+    if (per < 1) per = 1;
+    BwdShape sh;
+    sh.blocks = (int)blocks;
+    // (measured, profiles/r6_experiments.txt: four waves of the weight kernel beside eight of the rows kernel -- 102.5 us per call at
+    // 116 k rows against 119.4 with eight and eight, 575 against 584 at 985 k: half the serial fold, the loads still covered)
+    sh.wpb_weights = env[2] > 0 ? env[2] : (int)(per > 4 ? 4 : per);
+    sh.wpb_rows = env[1] > 0 ? env[1] : (int)(per > 8 ? 8 : (per < 4 ? 4 : per));
+    return sh;
 }
 
 }  // namespace ultra
@@ -400,7 +422,7 @@ extern "C" {
 
 int64_t ultra_conv_update_backward_workspace(int64_t rows) {
     if (rows < 0) return 0;
-    return rows * 64 * (int64_t)sizeof(float) + (int64_t)bwd_grid(rows) * CB_PART * (int64_t)sizeof(float);
+    return rows * 64 * (int64_t)sizeof(float) + (int64_t)bwd_shape(rows).blocks * CB_PART * (int64_t)sizeof(float);
 }
 
 int32_t ultra_conv_update_backward(const void *x, const void *agg, const void *grad_out, const void *weight, const void *bias,
@@ -439,13 +461,14 @@ int32_t ultra_conv_update_backward(const void *x, const void *agg, const void *g
     p.gln_w = (flags & CB_LN) ? (float *)grad_ln_weight : nullptr;
     p.gln_b = (flags & CB_LN) ? (float *)grad_ln_bias : nullptr;
     p.rows = rows;
-    p.n_part = bwd_grid(rows);
+    const BwdShape shape = bwd_shape(rows);
+    p.n_part = shape.blocks;
     p.eps = eps;
     p.flags = flags;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(conv_update_bwd_rows_kernel, dim3(p.n_part), dim3(512), 0, s, p);
-    hipLaunchKernelGGL(conv_update_bwd_weights_kernel, dim3(p.n_part), dim3(512), 0, s, p);
+    hipLaunchKernelGGL(conv_update_bwd_rows_kernel, dim3(p.n_part), dim3(64 * shape.wpb_rows), 0, s, p);
+    hipLaunchKernelGGL(conv_update_bwd_weights_kernel, dim3(p.n_part), dim3(64 * shape.wpb_weights), 0, s, p);
     hipLaunchKernelGGL(conv_update_bwd_reduce_kernel, dim3(CB_PART / 64), dim3(1024), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

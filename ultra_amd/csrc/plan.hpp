@@ -96,8 +96,16 @@ struct DevicePlan {
     uint8_t *self_loop = nullptr;   // per node: bit 0 = has an edge onto itself, bit 1 = has an in-edge from another node (layer-0 path)
     void *w_sorted = nullptr;
     size_t w_sorted_bytes = 0;
+    void *w_sorted_cap = nullptr;     // the permuted weights of launches recorded into a hipGraph (replays never touch w_sorted)
+    size_t w_sorted_cap_bytes = 0;
     void *partial = nullptr;
     size_t partial_bytes = 0;
+    // backward of the rspmm on listed rows as gathers (rows_bwd_kernels.hpp): the edge list grouped by source / by type, cut into
+    // segments; built on first use
+    void *rb_rec_c = nullptr, *rb_seg_c = nullptr, *rb_multi_c = nullptr;
+    void *rb_rec_t = nullptr, *rb_seg_t = nullptr, *rb_multi_t = nullptr;
+    void *rb_work = nullptr;
+    size_t rb_work_bytes = 0;
     int device = -1;
 };
 
@@ -119,7 +127,16 @@ struct ultra_plan {
     const void *w_src = nullptr;
     int32_t w_dtype = -1;
     void *w_stream = nullptr;
+    // ... and the same for d.w_sorted_cap, valid inside the stream capture w_cap_id only
+    int64_t w_cap_epoch = 0;
+    const void *w_cap_src = nullptr;
+    int32_t w_cap_dtype = -1;
+    void *w_cap_stream = nullptr;
+    unsigned long long w_cap_id = 0;
     int32_t max_row_len = -1;     // longest row (edges); computed on first use (the layer-0 launch sizes its grid with it)
+    // rows-backward index (d.rb_*): segments / owners with several segments / partial rows, by source and by type
+    bool rb_built = false;
+    int64_t rb_n_seg_c = 0, rb_n_multi_c = 0, rb_n_part_c = 0, rb_n_seg_t = 0, rb_n_multi_t = 0, rb_n_part_t = 0;
 
     std::vector<int32_t> row_ptr, col, type, perm, erow;  // erow: output row of each sorted edge
     std::vector<uint32_t> packed;

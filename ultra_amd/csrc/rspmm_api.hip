@@ -14,6 +14,7 @@
 #include "rspmm_kernels.hpp"
 #include "rspmm_order_kernels.hpp"
 #include "rspmm_rows_kernels.hpp"
+#include "rows_bwd_kernels.hpp"
 
 namespace ultra {
 
@@ -43,6 +44,8 @@ ULTRA_EXTERN_ORDER_VARIANT(double, true, false)
 ULTRA_EXTERN_ORDER_VARIANT(double, false, true)
 ULTRA_EXTERN_ORDER_VARIANT(double, false, false)
 
+int launch_dense_relation_grad(ultra_plan *p, const ultra_mat *x, const ultra_mat *og, const ultra_mat *rgrad, float *scratch,
+                               hipStream_t stream);   // rspmm_dense.hip
 int launch_dense_forward(ultra_plan *p, int sum, int mul, int dtype, const void *w, const ultra_mat *rel, const ultra_mat *x,
                          const ultra_mat *bnd, const int64_t *bnd_rows, const ultra_mat *out,
                          hipStream_t stream);   // rspmm_dense.hip
@@ -233,7 +236,11 @@ static void free_device(ultra_plan *p) {
     if (p->d.a_ex) (void)hipFree(p->d.a_ex);
     if (p->d.self_loop) (void)hipFree(p->d.self_loop);
     if (p->d.w_sorted) (void)hipFree(p->d.w_sorted);
+    if (p->d.w_sorted_cap) (void)hipFree(p->d.w_sorted_cap);
     if (p->d.partial) (void)hipFree(p->d.partial);
+    for (void *q : {p->d.rb_rec_c, p->d.rb_seg_c, p->d.rb_multi_c, p->d.rb_rec_t, p->d.rb_seg_t, p->d.rb_multi_t, p->d.rb_work})
+        if (q) (void)hipFree(q);
+    p->rb_built = false;
     p->d = DevicePlan();
     p->on_device = false;
 }
@@ -520,26 +527,48 @@ static int forward_impl(ultra_plan *p, int sum, int mul, int dtype, const void *
     }
     // per-call edge weights -> sorted order
     if (w && p->num_edge > 0) {
-        // (a capture records every permutation: a hit taken from the warm-up runs would leave the replays without one)
+        // A launch that is being recorded into a hipGraph keeps its permuted copy in a buffer of its own (d.w_sorted_cap): replays
+        // then never overwrite the copy an eager caller may still hold a tag for, and inside ONE capture a tagged vector is
+        // permuted once (a hit taken from outside the capture -- the warm-up runs -- would leave the replays without the
+        // permutation: the capture id is part of the key).
         hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-        const bool tagged = g_w_epoch != 0 && hipStreamIsCapturing(stream, &capturing) == hipSuccess &&
-                            capturing == hipStreamCaptureStatusNone;
-        const bool hit = tagged && p->w_epoch == g_w_epoch && p->w_src == w && p->w_dtype == dtype && p->w_stream == stream &&
-                         p->d.w_sorted && p->d.w_sorted_bytes >= (size_t)p->num_edge * esz;
+        unsigned long long cap_id = 0;
+        if (hipStreamGetCaptureInfo(stream, &capturing, &cap_id) != hipSuccess) {
+            (void)hipGetLastError();
+            capturing = hipStreamCaptureStatusNone;
+        }
+        const bool in_cap = capturing != hipStreamCaptureStatusNone;
+        const bool tagged = g_w_epoch != 0;
+        const size_t w_bytes = (size_t)p->num_edge * esz;
+        if (!in_cap) {      // (both buffers exist before any capture begins: no allocation while a stream records)
+            if ((rc = ensure_scratch(&p->d.w_sorted, &p->d.w_sorted_bytes, w_bytes, p))) return rc;
+            if ((rc = ensure_scratch(&p->d.w_sorted_cap, &p->d.w_sorted_cap_bytes, w_bytes, p))) return rc;
+        } else if (p->d.w_sorted_cap_bytes < w_bytes) {
+            return invalid("a weighted rspmm call is being captured on a plan that has not served one eagerly (run the step once "
+                           "before capturing it: the plan's scratch buffers are allocated there)");
+        }
+        void *dst = in_cap ? p->d.w_sorted_cap : p->d.w_sorted;
+        const bool hit = tagged && (in_cap ? (p->w_cap_id == cap_id && p->w_cap_epoch == g_w_epoch && p->w_cap_src == w &&
+                                              p->w_cap_dtype == dtype && p->w_cap_stream == stream)
+                                           : (p->w_epoch == g_w_epoch && p->w_src == w && p->w_dtype == dtype && p->w_stream == stream));
         if (!hit) {
-            if ((rc = ensure_scratch(&p->d.w_sorted, &p->d.w_sorted_bytes, (size_t)p->num_edge * esz, p))) return rc;
             const int blocks = (int)std::min<int64_t>((p->num_edge + 255) / 256, 4096);
             if (dtype == ULTRA_F32)
                 hipLaunchKernelGGL(permute_weight_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float *)w,
-                                   p->d.perm, (float *)p->d.w_sorted, p->num_edge);
+                                   p->d.perm, (float *)dst, p->num_edge);
             else
                 hipLaunchKernelGGL(permute_weight_kernel<double>, dim3(blocks), dim3(256), 0, stream, (const double *)w,
-                                   p->d.perm, (double *)p->d.w_sorted, p->num_edge);
+                                   p->d.perm, (double *)dst, p->num_edge);
             HIP_TRY(hipGetLastError());
-            p->w_epoch = tagged ? g_w_epoch : 0;
-            p->w_src = w, p->w_dtype = dtype, p->w_stream = stream;
+            if (in_cap) {
+                p->w_cap_epoch = tagged ? g_w_epoch : 0;
+                p->w_cap_src = w, p->w_cap_dtype = dtype, p->w_cap_stream = stream, p->w_cap_id = cap_id;
+            } else {
+                p->w_epoch = tagged ? g_w_epoch : 0;
+                p->w_src = w, p->w_dtype = dtype, p->w_stream = stream;
+            }
         }
-        fp.w_sorted = p->d.w_sorted;
+        fp.w_sorted = dst;
     }
     if (p->n_slot > 0) {
         if ((rc = ensure_scratch(&p->d.partial, &p->d.partial_bytes, (size_t)p->n_slot * n_outer * row_len * esz, p)))
@@ -1113,6 +1142,31 @@ int32_t ultra_rspmm_backward_add(ultra_plan *plan, int32_t sum, int32_t mul, int
                          relation_grad, input_grad, reinterpret_cast<hipStream_t>(stream), input_grad_base);
 }
 
+int32_t ultra_rspmm_dense_relation_grad(ultra_plan *plan, const ultra_mat *input, const ultra_mat *output_grad,
+                                        const ultra_mat *relation_grad, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream, output_grad ? output_grad->ptr : nullptr);
+    if (!plan) return invalid("plan is NULL");
+    (void)hipGetLastError();
+    if (!(plan->flags & ULTRA_PLAN_DENSE)) {
+        set_error("ultra_rspmm_dense_relation_grad: served by ULTRA_PLAN_DENSE plans");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    if (!input || !input->ptr || !output_grad || !output_grad->ptr || !relation_grad || !relation_grad->ptr)
+        return invalid("ultra_rspmm_dense_relation_grad: NULL operand");
+    const int64_t n_outer = output_grad->n_outer, row_len = output_grad->row_len;
+    if (n_outer <= 0 || row_len <= 0) return invalid("output_grad: empty n_outer / row_len");
+    int rc;
+    if ((rc = check_mat(input, "input", plan->num_in, n_outer, row_len))) return rc;
+    if ((rc = check_mat(output_grad, "output_grad", plan->num_out, n_outer, row_len))) return rc;
+    if ((rc = check_mat(relation_grad, "relation_grad", plan->num_rel, n_outer, row_len))) return rc;
+    if ((rc = upload_plan(plan))) return rc;
+    if ((rc = ensure_scratch(&plan->d.partial, &plan->d.partial_bytes,
+                             (size_t)plan->dense_rt * plan->num_rel * n_outer * row_len * sizeof(float), plan)))
+        return rc;
+    return launch_dense_relation_grad(plan, input, output_grad, relation_grad, static_cast<float *>(plan->d.partial),
+                                      reinterpret_cast<hipStream_t>(stream));
+}
+
 // rspmm on a list of output rows (rspmm_rows_kernels.hpp): shared argument checks of the forward and the backward entry
 static int rows_params(ultra_plan *p, int mul, const void *w, const ultra_mat *rel, const ultra_mat *x, const int64_t *rows,
                        int64_t n_list, RowsParams *rp, const char *who) {
@@ -1163,6 +1217,159 @@ int32_t ultra_rspmm_rows_forward(ultra_plan *plan, int32_t mul, const void *edge
     rp.agg = static_cast<float *>(aggregate_dev);
     const long long waves = (long long)rp.n_outer * rp.spans * rp.n_list;
     hipLaunchKernelGGL(rspmm_rows_kernel<false>, dim3((unsigned)waves), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), rp);
+    HIP_TRY(hipGetLastError());
+    return ULTRA_OK;
+}
+
+// The edge list grouped by `key` (counting sort, original order inside a group) and cut into segments of ROWS_BWD_SEG edges:
+// rec = {aggregation row, other operand's row, original edge id, 0}; seg = {owner, first, end, partial row or -1}; multi = the
+// owners that need a combine = {owner, first partial row, partial rows, 0}.  every_owner_partial: every owner goes through the
+// partial rows (relation gradient: few owners, long lists), else owners with one segment are written by the gather itself.
+static int build_rows_bwd_group(const std::vector<int32_t> &key, const std::vector<int32_t> &other, const std::vector<int32_t> &row,
+                                int64_t n_owner, bool every_owner_partial, int64_t seg_len, void **d_rec, void **d_seg, void **d_multi,
+                                int64_t *n_seg, int64_t *n_multi, int64_t *n_part) {
+    const int64_t E = (int64_t)key.size();
+    std::vector<int64_t> ptr(n_owner + 1, 0);
+    for (int64_t e = 0; e < E; ++e) ptr[key[e] + 1]++;
+    for (int64_t o = 0; o < n_owner; ++o) ptr[o + 1] += ptr[o];
+    std::vector<int32_t> rec((size_t)std::max<int64_t>(E, 1) * 4, 0);
+    {
+        std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
+        for (int64_t e = 0; e < E; ++e) {
+            const int64_t k = fill[key[e]]++;
+            rec[4 * k + 0] = row[e], rec[4 * k + 1] = other[e], rec[4 * k + 2] = (int32_t)e;
+        }
+    }
+    std::vector<int32_t> seg, multi;
+    int64_t parts = 0;
+    for (int64_t o = 0; o < n_owner; ++o) {
+        const int64_t beg = ptr[o], end = ptr[o + 1];
+        int64_t pieces = (end - beg + seg_len - 1) / seg_len;
+        if (pieces < 1 && !every_owner_partial) pieces = 1;      // (an owner without edges still writes its row)
+        const bool through_partials = every_owner_partial || pieces > 1;
+        if (through_partials) {
+            multi.push_back((int32_t)o), multi.push_back((int32_t)parts), multi.push_back((int32_t)pieces), multi.push_back(0);
+        }
+        for (int64_t k = 0; k < pieces; ++k) {
+            seg.push_back((int32_t)o);
+            seg.push_back((int32_t)(beg + k * seg_len));
+            seg.push_back((int32_t)std::min<int64_t>(end, beg + (k + 1) * seg_len));
+            seg.push_back(through_partials ? (int32_t)parts++ : -1);
+        }
+    }
+    *n_seg = (int64_t)seg.size() / 4, *n_multi = (int64_t)multi.size() / 4, *n_part = parts;
+    if (seg.empty()) seg.assign(4, 0);
+    if (multi.empty()) multi.assign(4, 0);
+    int rc;
+    if ((rc = upload_array(reinterpret_cast<int32_t **>(d_rec), rec))) return rc;
+    if ((rc = upload_array(reinterpret_cast<int32_t **>(d_seg), seg))) return rc;
+    return upload_array(reinterpret_cast<int32_t **>(d_multi), multi);
+}
+
+static int ensure_rows_bwd_index(ultra_plan *p) {
+    if (p->rb_built) return ULTRA_OK;
+    if ((int64_t)p->h_row.size() != p->num_edge) return invalid("plan was built without its edge list; backward unavailable");
+    int rc;
+    if ((rc = build_rows_bwd_group(p->h_col, p->h_type, p->h_row, p->num_in, false, ROWS_BWD_SEG, &p->d.rb_rec_c, &p->d.rb_seg_c, &p->d.rb_multi_c,
+                                   &p->rb_n_seg_c, &p->rb_n_multi_c, &p->rb_n_part_c)))
+        return rc;
+    if ((rc = build_rows_bwd_group(p->h_type, p->h_col, p->h_row, p->num_rel, true, ROWS_BWD_SEG_TYPE, &p->d.rb_rec_t, &p->d.rb_seg_t, &p->d.rb_multi_t,
+                                   &p->rb_n_seg_t, &p->rb_n_multi_t, &p->rb_n_part_t)))
+        return rc;
+    p->rb_built = true;
+    return ULTRA_OK;
+}
+
+int32_t ultra_rspmm_rows_backward_gather(ultra_plan *plan, int32_t mul, const void *edge_weight_dev, const ultra_mat *relation,
+                                         const ultra_mat *input, const int64_t *rows_dev, int64_t n_list,
+                                         const void *aggregate_grad_dev, const void *update_grad_dev, const int64_t *point_rows_dev,
+                                         void *point_values_grad_dev, const ultra_mat *relation_grad, const ultra_mat *input_grad,
+                                         void *stream) {
+    ULTRA_DEVICE_SCOPE(stream, aggregate_grad_dev);
+    RowsParams rp;
+    int rc;
+    if ((rc = rows_params(plan, mul, edge_weight_dev, relation, input, rows_dev, n_list, &rp, "ultra_rspmm_rows_backward_gather"))) return rc;
+    if (!aggregate_grad_dev || !relation_grad || !input_grad || !relation_grad->ptr || !input_grad->ptr)
+        return invalid("ultra_rspmm_rows_backward_gather: NULL gradient operand");
+    if (point_values_grad_dev && !point_rows_dev) return invalid("point_values_grad needs point_rows");
+    if ((rc = check_mat(relation_grad, "relation_grad", plan->num_rel, rp.n_outer, rp.row_len))) return rc;
+    if ((rc = check_mat(input_grad, "input_grad", plan->num_in, rp.n_outer, rp.row_len))) return rc;
+    if (rp.row_len != 64 || n_list > ROWS_BWD_MAX_LIST || plan->num_out != plan->num_in || !mat_vec_ok(relation_grad, 4) ||
+        !mat_vec_ok(input_grad, 4)) {
+        set_error("ultra_rspmm_rows_backward_gather: 64-element rows, at most 1024 listed rows per sample, square graphs; otherwise "
+                  "ultra_rspmm_rows_backward");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    if ((rc = ensure_rows_bwd_index(plan))) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t n_outer = rp.n_outer, n_chunk = (n_outer + 7) / 8, N = plan->num_out;
+    // workspace: slot table | combined aggregate gradient | combined update share | partial rows (input grad) | partial rows (relation grad)
+    const size_t slot_bytes = (size_t)n_chunk * N * 16;
+    const size_t g_bytes = (size_t)n_outer * n_list * 64 * sizeof(float);
+    const size_t px_bytes = (size_t)std::max<int64_t>(plan->rb_n_part_c, 1) * 8 * 64 * sizeof(float);
+    const size_t pr_bytes = (size_t)std::max<int64_t>(plan->rb_n_part_t, 1) * 8 * 64 * sizeof(float);
+    if ((rc = ensure_scratch(&plan->d.rb_work, &plan->d.rb_work_bytes, slot_bytes + 2 * g_bytes + px_bytes + pr_bytes, plan))) return rc;
+    char *work = static_cast<char *>(plan->d.rb_work);
+    uint16_t *slot = reinterpret_cast<uint16_t *>(work);
+    float *gc = reinterpret_cast<float *>(work + slot_bytes), *uc = reinterpret_cast<float *>(work + slot_bytes + g_bytes);
+    float *px = reinterpret_cast<float *>(work + slot_bytes + 2 * g_bytes);
+    float *pr = reinterpret_cast<float *>(work + slot_bytes + 2 * g_bytes + px_bytes);
+    {
+        const long long n16 = (long long)(slot_bytes / 16);
+        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<long long>((n16 + 255) / 256, 2048)), dim3(256), 0, s,
+                           reinterpret_cast<uint4 *>(slot), n16);
+        RowsPrepParams pp;
+        pp.rows = rp.rows;
+        pp.agg_grad = static_cast<const float *>(aggregate_grad_dev);
+        pp.upd_grad = static_cast<const float *>(update_grad_dev);
+        pp.point_rows = reinterpret_cast<const long long *>(point_rows_dev);
+        pp.slot = slot, pp.gc = gc, pp.uc = uc;
+        pp.values_grad = static_cast<float *>(point_values_grad_dev);
+        pp.num_row = N, pp.n_list = (int)n_list;
+        hipLaunchKernelGGL(rows_prepare_kernel, dim3((unsigned)n_outer), dim3(1024), 0, s, pp);
+    }
+    for (int64_t chunk = 0; chunk < n_chunk; ++chunk) {
+        RowsGatherParams gp;
+        std::memset(&gp, 0, sizeof(gp));
+        gp.slot = slot + (size_t)chunk * N * 8;
+        gp.keep = rp.w;
+        gp.gc = gc;
+        gp.n_list = (int)n_list, gp.o0 = (int)(chunk * 8), gp.nb = (int)std::min<int64_t>(8, n_outer - chunk * 8);
+        gp.mul_add = rp.mul_add;
+        // ---- input gradient: owners = sources ----
+        gp.rec = static_cast<const int4 *>(plan->d.rb_rec_c), gp.seg = static_cast<const int4 *>(plan->d.rb_seg_c);
+        gp.n_seg = (int)plan->rb_n_seg_c;
+        gp.uc = update_grad_dev ? uc : nullptr;
+        gp.other = rp.rel;
+        gp.out = static_cast<float *>(input_grad->ptr), gp.out_so = input_grad->stride_outer, gp.out_sr = input_grad->stride_row;
+        gp.partial = px;
+        if (gp.n_seg > 0)
+            hipLaunchKernelGGL(rows_bwd_gather_kernel<true>, dim3((unsigned)((gp.n_seg + 15) / 16)), dim3(256), 0, s, gp);
+        RowsCombineParams cp;
+        std::memset(&cp, 0, sizeof(cp));
+        cp.slot = gp.slot, cp.n_list = gp.n_list, cp.o0 = gp.o0, cp.nb = gp.nb;
+        if (plan->rb_n_multi_c > 0) {
+            cp.multi = static_cast<const int4 *>(plan->d.rb_multi_c), cp.n_multi = (int)plan->rb_n_multi_c;
+            cp.partial = px, cp.uc = gp.uc;
+            cp.out = gp.out, cp.out_so = gp.out_so, cp.out_sr = gp.out_sr;
+            hipLaunchKernelGGL(rows_bwd_combine_kernel, dim3((unsigned)cp.n_multi), dim3(1024), 0, s, cp);
+        }
+        // ---- relation gradient: owners = types ----
+        gp.rec = static_cast<const int4 *>(plan->d.rb_rec_t), gp.seg = static_cast<const int4 *>(plan->d.rb_seg_t);
+        gp.n_seg = (int)plan->rb_n_seg_t;
+        gp.uc = nullptr;
+        gp.other = rp.x;
+        gp.out = static_cast<float *>(relation_grad->ptr), gp.out_so = relation_grad->stride_outer, gp.out_sr = relation_grad->stride_row;
+        gp.partial = pr;
+        if (gp.n_seg > 0)
+            hipLaunchKernelGGL(rows_bwd_gather_kernel<false>, dim3((unsigned)((gp.n_seg + 15) / 16)), dim3(256), 0, s, gp);
+        if (plan->rb_n_multi_t > 0) {
+            cp.multi = static_cast<const int4 *>(plan->d.rb_multi_t), cp.n_multi = (int)plan->rb_n_multi_t;
+            cp.partial = pr, cp.uc = nullptr;
+            cp.out = gp.out, cp.out_so = gp.out_so, cp.out_sr = gp.out_sr;
+            hipLaunchKernelGGL(rows_bwd_combine_kernel, dim3((unsigned)cp.n_multi), dim3(1024), 0, s, cp);
+        }
+    }
     HIP_TRY(hipGetLastError());
     return ULTRA_OK;
 }

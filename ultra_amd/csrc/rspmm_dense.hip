@@ -40,7 +40,13 @@ struct DenseStage {
     float x[4];
 };
 
-template <int TC>
+// RG: the relation gradient of the same product instead of the product (fine-tuning, the relation graph's backward):
+//     relation_grad[t][col] = sum_row og[row][col] * (A_t . x)[row][col]            (rspmm.cpp:106-108 for add_mul, unit weights)
+// -- the per-type tiles this kernel holds anyway, weighed with the output gradient (p.bnd) instead of rel[t] and summed over the
+// tile's rows instead of over the types.  Each workgroup leaves one partial row per type (p.out: [row tile][type][column]);
+// dense_rgrad_combine_kernel adds the row tiles in order.  The edge walk over the relation-major plan took 71 + 12 us per
+// relation-model layer for this (a 474-node graph with 0.9 M edges), five times a step.
+template <int TC, bool RG = false>
 __global__ void __launch_bounds__(256) rspmm_dense_kernel(const DenseParams p) {
     __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];   // [wave][accumulator register][lane]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -62,6 +68,14 @@ __global__ void __launch_bounds__(256) rspmm_dense_kernel(const DenseParams p) {
     f32x16 total;
 #pragma unroll
     for (int r = 0; r < 16; ++r) total[r] = 0.f;
+    float ogv[16];      // RG: og[rt * 32 + (r & 3) + 8 (r >> 2) + 4 h][d0 + j], zero past the last row
+    if constexpr (RG) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            ogv[r] = row < p.n_out ? p.bnd[(long long)outer * p.bnd_so + (long long)row * p.bnd_sr + d0 + j] : 0.f;
+        }
+    }
 
     for (int tc = 0; tc < p.n_tc; ++tc) {
         f32x16 acc[TC];
@@ -117,11 +131,27 @@ __global__ void __launch_bounds__(256) rspmm_dense_kernel(const DenseParams p) {
         for (int tl = 0; tl < TC; ++tl) {
             const int t = tc * TC + tl;
             if (t < p.n_rel) {
-                const float rv = relb[(long long)t * p.rel_sr];
+                if constexpr (RG) {
+                    float sacc = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) total[r] += rv * acc[tl][r];
+                    for (int r = 0; r < 16; ++r) sacc += ogv[r] * acc[tl][r];
+                    sacc += __shfl_xor(sacc, 32);
+                    if (h == 0) red[(wave * p.n_rel + t) * 32 + j] = sacc;
+                } else {
+                    const float rv = relb[(long long)t * p.rel_sr];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) total[r] += rv * acc[tl][r];
+                }
             }
         }
+    }
+    if constexpr (RG) {
+        __syncthreads();
+        for (int idx = tid; idx < p.n_rel * 32; idx += 256) {     // (type, column): the four source-row quarters in wave order
+            const float sum = ((red[idx] + red[p.n_rel * 32 + idx]) + red[2 * p.n_rel * 32 + idx]) + red[3 * p.n_rel * 32 + idx];
+            p.out[((long long)rt * p.n_rel + idx / 32) * ((long long)p.n_ct * 32) + g0 + (idx & 31)] = sum;
+        }
+        return;
     }
 
 #pragma unroll
@@ -152,6 +182,19 @@ __global__ void __launch_bounds__(256) rspmm_dense_kernel(const DenseParams p) {
         }
         *reinterpret_cast<float4 *>(p.out + (long long)outer * p.out_so + (long long)row * p.out_sr + d0 + c4 * 4) = sum;
     }
+}
+
+// relation_grad[outer][t][d] = sum over the row tiles of partial[tile][t][outer * row_len + d], tiles in ascending order
+__global__ void __launch_bounds__(256) dense_rgrad_combine_kernel(const float *__restrict__ partial, int n_rt, int n_rel, int row_len,
+                                                                  long long ncol, float *__restrict__ out, long long out_so,
+                                                                  long long out_sr) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)n_rel * ncol) return;
+    const int t = (int)(idx / ncol);
+    const long long col = idx % ncol;
+    float s = 0.f;
+    for (int rt = 0; rt < n_rt; ++rt) s += partial[((long long)rt * n_rel + t) * ncol + col];
+    out[(col / row_len) * out_so + (long long)t * out_sr + col % row_len] = s;
 }
 
 static bool ok16(const ultra_mat *m) {
@@ -199,6 +242,50 @@ int launch_dense_forward(ultra_plan *p, int sum, int mul, int dtype, const void 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error(std::string("rspmm_dense_kernel launch: ") + hipGetErrorString(e));
+        return ULTRA_ERR_HIP;
+    }
+    return ULTRA_OK;
+}
+
+// relation_grad of add_mul with unit edge weights on a ULTRA_PLAN_DENSE plan (operands shape-checked by the caller).
+// `scratch` holds dense_rt * num_rel * n_outer * row_len floats.
+int launch_dense_relation_grad(ultra_plan *p, const ultra_mat *x, const ultra_mat *og, const ultra_mat *rgrad, float *scratch,
+                               hipStream_t stream) {
+    if (p->num_rel > 32 || og->row_len % 32 != 0 || !ok16(x) || !ok16(og) || !ok16(rgrad) ||
+        (uint64_t)p->num_in * (uint64_t)x->stride_row * 4u >= (1ull << 32)) {
+        set_error("ULTRA_PLAN_DENSE relation gradient: at most 32 relation types, row_len a multiple of 32, 16-byte aligned operands");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    DenseParams dp;
+    dp.a_frag = reinterpret_cast<const uint32_t *>(p->d.a_frag);
+    dp.rel = nullptr;
+    dp.x = static_cast<const float *>(x->ptr);
+    dp.bnd = static_cast<const float *>(og->ptr);
+    dp.out = scratch;
+    dp.rel_so = dp.rel_sr = 0;
+    dp.x_so = x->stride_outer, dp.x_sr = x->stride_row;
+    dp.bnd_so = og->stride_outer, dp.bnd_sr = og->stride_row;
+    dp.bnd_rows = nullptr;
+    dp.out_so = dp.out_sr = 0;
+    dp.n_out = (int)p->num_out, dp.n_in = (int)p->num_in, dp.n_rel = (int)p->num_rel;
+    dp.kg = p->dense_kg, dp.n_rt = p->dense_rt, dp.n_tc = p->dense_ntc;
+    dp.n_ct = (int)(og->n_outer * og->row_len / 32);
+    dp.row_len = (int)og->row_len;
+    dp.has_bnd = 0;
+    const long long blocks = (long long)((p->dense_rt + 7) / 8) * 8 * dp.n_ct;
+    const dim3 grid((unsigned)blocks), block(256);
+    switch (p->dense_tc) {
+        case 1: hipLaunchKernelGGL((rspmm_dense_kernel<1, true>), grid, block, 0, stream, dp); break;
+        case 2: hipLaunchKernelGGL((rspmm_dense_kernel<2, true>), grid, block, 0, stream, dp); break;
+        default: hipLaunchKernelGGL((rspmm_dense_kernel<4, true>), grid, block, 0, stream, dp); break;
+    }
+    const long long ncol = (long long)dp.n_ct * 32, total = (long long)dp.n_rel * ncol;
+    hipLaunchKernelGGL(dense_rgrad_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, scratch, dp.n_rt,
+                       dp.n_rel, dp.row_len, ncol, static_cast<float *>(rgrad->ptr), (long long)rgrad->stride_outer,
+                       (long long)rgrad->stride_row);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error(std::string("rspmm_dense_kernel (relation gradient) launch: ") + hipGetErrorString(e));
         return ULTRA_ERR_HIP;
     }
     return ULTRA_OK;

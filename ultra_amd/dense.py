@@ -7,9 +7,12 @@ import torch
 from torch.autograd.function import once_differentiable
 from torch.nn import functional as F
 
+from . import _lib as _lib_codes
 from ._lib import check, lib
 
 CONV_LAYER_NORM, CONV_RELU, CONV_RESIDUAL = 1, 2, 4
+# the last layer's backward on the listed rows as gathers (A/B switch for tests: the scatter with float atomics is the other side)
+ROWS_BACKWARD_GATHER = True
 
 
 def _stream(t):
@@ -175,20 +178,38 @@ class TrainRowsLayerFunction(torch.autograd.Function):
                                              _ptr(gln_w), _ptr(gln_b), work.data_ptr(), nbytes, n, 64, 64, ctx.eps,
                                              ctx.flags, _stream(x)))
         need = ctx.needs_input_grad
-        relation_grad = x_grad = None
+        relation_grad = x_grad = values_grad = None
+        want_values = point_rows is not None and need[10]
         if need[5] or need[6]:
-            # the update's share of the input gradient lands on the listed rows (repeats add up); the rspmm's is scattered on top
-            x_grad = torch.zeros_like(x).scatter_add_(1, rows.unsqueeze(-1).expand(-1, -1, 64), gx_rows)
-            relation_grad = torch.zeros(relation.shape, dtype=torch.float32, device=x.device)
             _, mrel = rspmm.as_mat(relation)
             _, mx = rspmm.as_mat(x)
-            _, mrg = rspmm.as_mat(relation_grad)
-            _, mxg = rspmm.as_mat(x_grad)
-            check(lib.ultra_rspmm_rows_backward(ctx.plan._h, rspmm._lib.MUL_CODES[ctx.mul], _ptr(w), ctypes.byref(mrel),
-                                                ctypes.byref(mx), rows.data_ptr(), rows.shape[1], gagg.data_ptr(),
-                                                ctypes.byref(mrg), ctypes.byref(mxg), _stream(x)))
-        values_grad = None
-        if point_rows is not None and need[10]:
+            rc = _lib_codes.ULTRA_ERR_UNSUPPORTED
+            if ROWS_BACKWARD_GATHER:
+                # both gradients as gathers, written in full: no zero fill, no scatter of the update's share, no atomics
+                x_grad = torch.empty_like(x)
+                relation_grad = torch.empty(relation.shape, dtype=torch.float32, device=x.device)
+                _, mrg = rspmm.as_mat(relation_grad)
+                _, mxg = rspmm.as_mat(x_grad)
+                if want_values:
+                    values_grad = torch.empty(rows.shape[0], 64, dtype=torch.float32, device=x.device)
+                rc = lib.ultra_rspmm_rows_backward_gather(ctx.plan._h, rspmm._lib.MUL_CODES[ctx.mul], _ptr(w), ctypes.byref(mrel),
+                                                          ctypes.byref(mx), rows.data_ptr(), rows.shape[1], gagg.data_ptr(),
+                                                          gx_rows.data_ptr(), _ptr(point_rows) if want_values else None,
+                                                          _ptr(values_grad), ctypes.byref(mrg), ctypes.byref(mxg), _stream(x))
+                if rc != _lib_codes.ULTRA_ERR_UNSUPPORTED:
+                    check(rc)
+            if rc == _lib_codes.ULTRA_ERR_UNSUPPORTED:
+                # the scatter with float atomics (round 5): the update's share of the input gradient lands on the listed rows
+                # (repeats add up); the rspmm's is scattered on top
+                values_grad = None
+                x_grad = torch.zeros_like(x).scatter_add_(1, rows.unsqueeze(-1).expand(-1, -1, 64), gx_rows)
+                relation_grad = torch.zeros(relation.shape, dtype=torch.float32, device=x.device)
+                _, mrg = rspmm.as_mat(relation_grad)
+                _, mxg = rspmm.as_mat(x_grad)
+                check(lib.ultra_rspmm_rows_backward(ctx.plan._h, rspmm._lib.MUL_CODES[ctx.mul], _ptr(w), ctypes.byref(mrel),
+                                                    ctypes.byref(mx), rows.data_ptr(), rows.shape[1], gagg.data_ptr(),
+                                                    ctypes.byref(mrg), ctypes.byref(mxg), _stream(x)))
+        if want_values and values_grad is None:
             hit = (rows == point_rows.unsqueeze(1)).to(gagg.dtype).unsqueeze(-1)
             values_grad = (gagg * hit).sum(dim=1)
         return (None, None, None, None, None, relation_grad if need[5] else None, x_grad if need[6] else None, None, None, None,

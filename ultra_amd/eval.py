@@ -21,6 +21,12 @@ from . import distributed as udist
 from . import models, tasks
 
 
+RELATION_TABLE_MAX_BYTES = 1 << 30      # evaluate() builds the relation table by default only below this size
+MAX_IN_FLIGHT = 3                       # captured evaluation steps replayed round-robin (bench.py found three worth 3 - 4 % over two)
+# the streams the captured steps run on, chosen once per process and device by a short trial on REAL batches (graph.pick_slot_streams)
+_SLOT_STREAMS = {}
+
+
 def metrics_from_rankings(ranking, num_negative, metric_names):
     out = {}
     for metric in metric_names:
@@ -50,13 +56,15 @@ def metrics_from_rankings(ranking, num_negative, metric_names):
 
 @torch.no_grad()
 def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", "mrr", "hits@1", "hits@3", "hits@10"),
-             max_triples=None, use_graph=True, in_flight=None, cache_relations=None):
+             max_triples=None, use_graph=True, in_flight=None, cache_relations=None, stats=None):
     """Returns {metric: value} on every rank (the reference only fills it on rank 0).
-    in_flight: captured evaluation steps replayed round-robin on as many streams (1 or 2; None: 2 for shards of 128 full
-    batches or more, where the second capture pays for itself).
+    in_flight: captured evaluation steps replayed round-robin on as many streams (1 to 3; None: 3 for shards of 256 full
+    batches or more, 2 from 128, where the extra captures pay for themselves).
     cache_relations: compute the relation model's output for every relation once (Ultra.cache_relation_representations: it
     depends on the query relation only) instead of once per batch and direction; same bits, same metrics.  None: when the
-    shard has at least as many batches as the graph has relation chunks (then the table costs less than it saves)."""
+    shard has at least as many batches as the graph has relation chunks (then the table costs less than it saves).
+    stats: a dict that receives where the time went on this rank (seconds: "table", "capture", "trial", "replay"; "in_flight",
+    "batches", "slot_streams") -- measurements; the timers synchronise the device, so leave it None otherwise."""
     world, rank = udist.world_size(), udist.rank()
     triples = torch.cat([test_data.target_edge_index, test_data.target_edge_type.unsqueeze(0)]).t()
     if max_triples is not None:
@@ -74,17 +82,19 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
             and getattr(model, "_rel_table", None) is None:
         num_rel = int(test_data.relation_graph.num_nodes)
         if cache_relations is None:
-            cache_relations = 2 * len(mine) // max(batch_size, 1) >= (num_rel + batch_size - 1) // batch_size
-            # (by default only where the (num_rel, num_rel, 64) fp32 table is small next to what is free: it grows with the SQUARE of
-            # the relation count -- 2.6 GB at 3,200 relations -- and a second captured step may hold its activations beside it)
-            if cache_relations and mine.is_cuda:
-                free_bytes = torch.cuda.mem_get_info(mine.device)[0]
-                cache_relations = num_rel * num_rel * 256 <= free_bytes // 8
+            # decided from quantities every rank agrees on (the shard size of the smallest rank, the relation count) -- never from
+            # a rank's own free memory, or ranks could take different paths -- and only where the
+            # (num_rel, num_rel, 64) fp32 table is small: it grows with the SQUARE of the relation count, 2.6 GB at 3,200 relations
+            per_rank = len(triples) // max(world, 1)
+            cache_relations = (2 * per_rank // max(batch_size, 1) >= (num_rel + batch_size - 1) // batch_size
+                               and num_rel * num_rel * 256 <= RELATION_TABLE_MAX_BYTES)
         if cache_relations:
+            t0 = _tick(stats, mine.device)
             model.cache_relation_representations(test_data, chunk=batch_size)
             made_table = True
+            _tock(stats, "table", t0, mine.device)
     try:
-        local = _local_rows(model, test_data, filt, mine, batch_size, use_graph, in_flight, triples.device)
+        local = _local_rows(model, test_data, filt, mine, batch_size, use_graph, in_flight, triples.device, stats)
     finally:
         if made_table:
             model.drop_relation_cache()      # (also when an exception escapes: the table must not stay on the model)
@@ -104,7 +114,21 @@ def evaluate(model, test_data, batch_size=8, filtered_data=None, metrics=("mr", 
     return out
 
 
-def _local_rows(model, test_data, filt, mine, batch_size, use_graph, in_flight, device):
+def _tick(stats, device):
+    if stats is None:
+        return None
+    import time
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    return time.perf_counter()
+
+
+def _tock(stats, key, t0, device):
+    if stats is not None:
+        stats[key] = stats.get(key, 0.0) + _tick(stats, device) - t0
+
+
+def _local_rows(model, test_data, filt, mine, batch_size, use_graph, in_flight, device, stats=None):
     """(rank, #negatives, is_tail) rows of this rank's shard `mine`, tail and head direction, in shard order."""
     rows = []
     n_full = (len(mine) // batch_size) * batch_size
@@ -123,55 +147,97 @@ def _local_rows(model, test_data, filt, mine, batch_size, use_graph, in_flight, 
             # re-associating plans own scratch buffers that concurrent steps would share.
             from . import rspmm
             # (a second capture costs about what it saves on a hundred batches: 130 vs 125 M scores/s on 64 batches, 170 vs 160 on 512)
+            n_batch = n_full // batch_size
             if in_flight is None:
-                in_flight = 1 if os.environ.get("ULTRA_EVAL_IN_FLIGHT", "2") == "1" or n_full < 128 * batch_size else 2
-            # (two steps in flight share the chip like graph.PipelinedForward: the aggregation launches of each capture on three
+                env = os.environ.get("ULTRA_EVAL_IN_FLIGHT")
+                in_flight = int(env) if env else (1 if n_batch < 128 else (2 if n_batch < 256 else 3))
+            in_flight = max(1, min(int(in_flight), MAX_IN_FLIGHT, n_batch))
+            # (several steps in flight share the chip like graph.PipelinedForward: the aggregation launches of each capture on three
             # quarters of the CUs, where a layer's activations fit the last-level cache)
             from .graph import shared_launch_grid
-            want_two = int(in_flight) >= 2 and n_full >= 2 * batch_size and rspmm._plan_defaults["exact_order"]
-            share = want_two and 2 * batch_size * int(test_data.num_nodes) * 256 <= 128 << 20
+            want_more = in_flight >= 2 and rspmm._plan_defaults["exact_order"]
+            share = want_more and 2 * batch_size * int(test_data.num_nodes) * 256 <= 128 << 20
             scope = (lambda: rspmm.tuning_scope(grid=shared_launch_grid(mine.device))) if share else (lambda: rspmm.tuning_scope())
+            t_cap = _tick(stats, mine.device)
             with scope():
                 steps = [GraphedEvalStep(model, test_data, batch_size, t_index, h_index)]
                 # ... if the plans the captured step really uses are all of that kind (a max-aggregate model sends its relation
-                # graph to a re-associating plan), and if a second capture fits: it doubles the captured activation memory
-                if want_two and all(p.exact for p in steps[0]._pinned):
+                # graph to a re-associating plan), and while another capture fits: each holds its own activation memory
+                while want_more and len(steps) < in_flight and all(p.exact for p in steps[0]._pinned):
                     try:
                         steps.append(GraphedEvalStep(model, test_data, batch_size, t_index, h_index))
-                    except torch.cuda.OutOfMemoryError:      # one step at a time then (any other error is a real one: raised)
+                    except (torch.cuda.OutOfMemoryError, RuntimeError) as err:
+                        # fewer steps at a time then; on ROCm a capture that runs out of memory may surface as a plain
+                        # RuntimeError (hipErrorOutOfMemory from hipGraphInstantiate): anything else is a real error
+                        if not isinstance(err, torch.cuda.OutOfMemoryError) and "out of memory" not in str(err).lower():
+                            raise
                         torch.cuda.synchronize()
+                        break
             if share and len(steps) == 1:       # (alone after all: it gets the whole chip)
                 steps = [GraphedEvalStep(model, test_data, batch_size, t_index, h_index)]
             n_slot = len(steps)
+            _tock(stats, "capture", t_cap, mine.device)
+            if stats is not None:
+                stats.update(in_flight=n_slot, batches=n_batch)
             cur = torch.cuda.current_stream(mine.device)
-            streams = [cur]
-            if n_slot > 1:
-                # (which pair of streams interleaves is decided by a short trial: graph.pick_slot_streams)
-                from .graph import pick_slot_streams
+            out = torch.empty(n_batch, 2 * batch_size, 3, dtype=torch.long, device=mine.device)
 
-                def trial(cand, reps=6):
-                    import time
-                    torch.cuda.synchronize(mine.device)
-                    t0 = time.perf_counter()
-                    for i in range(reps):
-                        with torch.cuda.stream(cand[i % n_slot]):
-                            steps[i % n_slot](mine[:batch_size], t_ptr[:batch_size + 1], h_ptr[:batch_size + 1])
-                    torch.cuda.synchronize(mine.device)
-                    return (time.perf_counter() - t0) / reps
-                streams, _report = pick_slot_streams(mine.device, n_slot, trial)
-            out = torch.empty(n_full // batch_size, 2 * batch_size, 3, dtype=torch.long, device=mine.device)
+            def run(streams, b_lo, b_hi):
+                """Enqueue batches [b_lo, b_hi): step k always on streams[k] (a step's buffers belong to one stream at a time)."""
+                for b in range(b_lo, b_hi):
+                    lo = b * batch_size
+                    k = b % n_slot
+                    with torch.cuda.stream(streams[k]):
+                        out[b].copy_(steps[k](mine[lo:lo + batch_size], t_ptr[lo:lo + batch_size + 1], h_ptr[lo:lo + batch_size + 1]),
+                                     non_blocking=True)
+
+            streams = [cur]
+            done = 0
+            if n_slot > 1:
+                # Which set of streams interleaves well is decided by a short trial (graph.pick_slot_streams) -- on REAL batches,
+                # whose rows are kept, so the trial discards no work (ADVICE r5: 216 replays of a dummy batch per evaluate() call
+                # cost more than the second capture saved on shards of a few hundred batches) -- once per process and device;
+                # shards too small to spare the trial's batches take the first candidate.
+                key = (str(mine.device), n_slot)
+                streams = _SLOT_STREAMS.get(key)
+                if streams is None:
+                    from .graph import pick_slot_streams, slot_stream
+                    reps = 2 * n_slot
+                    n_cand = min(int(os.environ.get("ULTRA_SLOT_STREAM_CANDIDATES", "12")), n_batch // (6 * reps))
+                    if n_cand >= 2:
+                        cursor = [0]
+
+                        def trial(cand):
+                            import time
+                            cur.synchronize()
+                            for s in cand:
+                                s.wait_stream(cur)
+                            t0 = time.perf_counter()
+                            run(cand, cursor[0], cursor[0] + reps)
+                            for s in cand:
+                                s.synchronize()
+                            cursor[0] += reps
+                            return (time.perf_counter() - t0) / reps
+                        t_trial = _tick(stats, mine.device)
+                        try:
+                            streams, _report = pick_slot_streams(mine.device, n_slot, trial, n_cand=n_cand)
+                        finally:
+                            done = cursor[0]
+                        _tock(stats, "trial", t_trial, mine.device)
+                        if stats is not None:
+                            stats.update(slot_streams=_report, trial_batches=done)
+                    else:
+                        streams = [slot_stream(mine.device) for _ in range(n_slot)]
+                    _SLOT_STREAMS[key] = streams
             for s in streams:
                 if s is not cur:
                     s.wait_stream(cur)          # the known-answer lists, `mine`, `out` were produced on the caller's stream
-            for b in range(n_full // batch_size):
-                lo = b * batch_size
-                k = b % n_slot
-                with torch.cuda.stream(streams[k]):
-                    out[b].copy_(steps[k](mine[lo:lo + batch_size], t_ptr[lo:lo + batch_size + 1], h_ptr[lo:lo + batch_size + 1]),
-                                 non_blocking=True)
+            t_run = _tick(stats, mine.device)
+            run(streams, done, n_batch)
             for s in streams:
                 if s is not cur:
                     cur.wait_stream(s)
+            _tock(stats, "replay", t_run, mine.device)
             rows.append(out.view(-1, 3))
             start = n_full
             for s in streams:

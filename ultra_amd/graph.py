@@ -127,7 +127,7 @@ def _skip_streams(device, priority):
         st.synchronize()
 
 
-def pick_slot_streams(device, n, trial):
+def pick_slot_streams(device, n, trial, n_cand=None):
     """The streams the pipeline slots run on, chosen by MEASUREMENT.  The HIP runtime maps a process's streams onto a small pool
     of hardware queues (GPU_MAX_HW_QUEUES of them) as they are created, and how the slots' launches interleave depends on which
     queues their streams land on -- i.e. on how many streams of which priority the process made before (torch's side streams, the
@@ -154,7 +154,7 @@ def pick_slot_streams(device, n, trial):
         prio = int(forced)
         _skip_streams(device, prio)
         return [slot_stream(device, prio) for _ in range(n)], {"chosen": "high" if prio < 0 else "normal", "forced": True}
-    n_cand = max(2, int(os.environ.get("ULTRA_SLOT_STREAM_CANDIDATES", "12")))
+    n_cand = max(2, int(os.environ.get("ULTRA_SLOT_STREAM_CANDIDATES", "12")) if n_cand is None else int(n_cand))
     best, report = None, []
     for k in range(n_cand):
         prio = 0 if k % 2 == 0 else -1

@@ -21,6 +21,8 @@ PROLOGUE_FAST_PATH = True
 # (measured on MI355X, tools/step_probe.py: the fork / join of the side stream inside the captured graph costs more than the
 # 11 us of fill it hides -- 0.717 vs 0.687 ms per step one batch at a time, 0.631 vs 0.621 two in flight -- so: off)
 PREFILL_LAYER0 = False
+# set by train.GraphedTrainStep around its capture: the generic (training) path of EntityNBFNet.forward may be recorded
+CAPTURE_GENERIC_PATH = False
 
 
 class NotOnFusedPath(RuntimeError):
@@ -394,9 +396,11 @@ class EntityNBFNet(BaseNBFNet):
                 self._check_valid(valid)
                 return score
             # (shape not covered by the fused readout: fall through to the generic path below)
-        if batch.is_cuda and torch.cuda.is_current_stream_capturing():
+        if batch.is_cuda and torch.cuda.is_current_stream_capturing() and not CAPTURE_GENERIC_PATH:
             # the generic path goes through torch reductions / memsets whose captured nodes were seen to go stale
-            # when replays interleave with eager work (ROCm 7.2); only the fused inference path is graph-captured
+            # when replays interleave with eager work (ROCm 7.2); of the inference paths only the fused one is
+            # graph-captured.  train.GraphedTrainStep captures the training step (this path, under autograd) and sets the
+            # switch for the length of its capture.
             raise NotOnFusedPath("hipGraph capture is supported for the fused inference path only "
                                  "(64-d hidden, no concat_hidden, eval mode, no_grad)")
         # One reduction tells, per row, whether heads / tails / relations are constant along the candidates:

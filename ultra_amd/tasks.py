@@ -162,9 +162,14 @@ def prefetch_negatives(batches, data, num_negative, strict=True):
     the training stream it waits for the previous step's backward and optimiser to drain, then the GPU idles while the
     host reads the counts back; issued here -- after the previous step's launches are enqueued, on its own stream --
     its kernels run beside that step's backward and the host synchronises with the side stream alone.  The draws come
-    from the default generator in the same order as the plain loop makes them.  `batches` yields CPU tensors or GPU
-    tensors that are complete when they are yielded (a loader's, a slice of the triple list): the side stream does not
-    wait for the training stream.  A graph on the CPU: the plain loop, unchanged."""
+    from the default generator in the same order as the plain loop makes them.
+
+    The positives are PRODUCED on the side stream too: `next(batches)` runs under it, so whatever kernels the iterable
+    launches to build a batch -- a DataLoader over a GPU tensor stacks its rows with a kernel on the current stream
+    (script/run.py:32-34 keeps train_triplets on the device) -- are ordered in front of the sampler that reads the batch,
+    instead of behind the previous step's backward on the training stream (where the sampler would read the batch before it
+    is written: ADVICE r5).  What the iterable READS must be complete when the loop starts (the triple list is static).
+    A graph on the CPU: the plain loop, unchanged."""
     it = iter(batches)
     dev = data.edge_index.device
     if dev.type != "cuda":
@@ -176,13 +181,16 @@ def prefetch_negatives(batches, data, num_negative, strict=True):
         # lands on the training stream's queue runs BEHIND the backward, not beside it -- and the sampler's small kernels, which
         # the host waits for, are scheduled ahead of the backward's long ones)
         side = torch.cuda.Stream(priority=-1)
+        # the triple list and the graph were written on the caller's stream before this loop began
+        side.wait_stream(torch.cuda.current_stream(dev))
 
-    def sample(batch):
+    def sample():
         with torch.cuda.stream(side):
+            batch = next(it)            # (StopIteration passes through)
             return negative_sampling(data, batch.to(dev, non_blocking=True), num_negative, strict=strict)
 
     try:
-        ahead = sample(next(it))
+        ahead = sample()
     except StopIteration:
         return
     while ahead is not None:
@@ -192,7 +200,7 @@ def prefetch_negatives(batches, data, num_negative, strict=True):
         current, ahead = ahead, None
         yield current                    # the caller enqueues its step ...
         try:
-            ahead = sample(next(it))     # ... and the next batch's negatives are drawn while the GPU works through it
+            ahead = sample()             # ... and the next batch's negatives are drawn while the GPU works through it
         except StopIteration:
             ahead = None
 
