@@ -137,6 +137,27 @@ int32_t ultra_relation_projection(const void *x, const void *w0, const void *b0,
                                   int64_t rows, int32_t n_layer, int32_t dim, void *stream);
 
 /*
+ * The same products with every layer's parameters where they live (n_layer host arrays of device pointers: w0[l], w2[l] (64, 64)
+ * row-major [out][in]; b0[l], b2[l] (64)) -- the training step, whose parameters change every step, needs no stacked copies.
+ */
+int32_t ultra_relation_projection_layers(const void *x, const void *const *w0, const void *const *b0, const void *const *w2,
+                                         const void *const *b2, void *out, int64_t rows, int32_t n_layer, int32_t dim, void *stream);
+
+/*
+ * Backward of ultra_relation_projection_layers for all layers in three launches (csrc/relproj_bwd.hip):
+ *     grad_x (rows, 64) = sum_l ((grad_out[l] W2_l) * [h_l > 0]) W0_l,      h_l = relu(x W0_l^T + b0_l) recomputed
+ *     grad_w2[l] = grad_out[l]^T h_l,  grad_b2[l] = column sums of grad_out[l],  grad_w0[l] = gh_l^T x,  grad_b0[l] = column sums of gh_l
+ * grad_out: n_layer device pointers to (rows, 64) fp32; grad_w0 / grad_w2 stacked (n_layer, 64, 64), grad_b0 / grad_b2 (n_layer, 64),
+ * all written in full.  workspace: ultra_relation_projection_backward_workspace(rows, n_layer) bytes.  dim == 64, n_layer <= 8.
+ * Fixed summation order (no atomics).
+ */
+int64_t ultra_relation_projection_backward_workspace(int64_t rows, int32_t n_layer);
+int32_t ultra_relation_projection_backward(const void *x, const void *const *w0, const void *const *b0, const void *const *w2,
+                                           const void *const *grad_out, void *grad_x, void *grad_w0, void *grad_b0, void *grad_w2,
+                                           void *grad_b2, void *workspace, int64_t workspace_bytes, int64_t rows, int32_t n_layer,
+                                           int32_t dim, void *stream);
+
+/*
  * Filtered ranking without the (batch, N) mask (/root/reference/ultra/tasks.py:94-141):
  *     rank[q] = 1 + #{t : t not in known(q) and score[q, pos[q]] <= score[q, t]}
  *     num_negative[q] = n_cand - |known(q)|

@@ -14,6 +14,10 @@ the shipped checkpoints.  Outputs (small, committed):
                             scores for tail and head batches, filter masks and rankings
   query_nbfnet_ultra_3g.pt  QueryNBFNet (models.py:212-275) on dense initial node features
   relation_projection_ultra_3g.pt   RelationProjection (ultraquery.py:245-277) with and without its threshold
+  negative_sampling.pt      tasks.negative_sampling (tasks.py:42-76) on a seeded KG with a hub node: for several (batch,
+                            num_negative, strict) cases the global generator's state right before the call and the batch the
+                            reference returned -- the tests replay the state through ultra_amd.tasks.negative_sampling (CPU: the
+                            mask formulation; GPU: csrc/sampling.hip fed the same uniform draws)
 """
 import os
 import sys
@@ -165,13 +169,51 @@ def gen_relation_projection():
     print("relation_projection", tuple(out[0.0].shape), float((out[0.0] - out[0.3]).abs().max()))
 
 
+def gen_negative_sampling():
+    """The reference's sampler on a KG whose node 3 is a hub (a tenth of all triples start there: hundreds of known tails per
+    (hub, relation) query, most candidates of its row filtered), strict and not, odd and even batch sizes."""
+    from torch_geometric.data import Data
+    from ultra import tasks as ref_tasks
+    from ultra_amd import synthetic
+    kg = synthetic.make_kg(num_node=400, num_triple=6000, num_relation_base=5, num_test=16, seed=31, relation_graph=False)
+    ei, et = kg.edge_index.clone(), kg.edge_type.clone()
+    half = ei.shape[1] // 2
+    hub = torch.arange(0, half, 10)
+    ei[0, hub] = 3                                    # heads of the forward edges ...
+    ei[1, hub + half] = 3                             # ... and tails of their inverses
+    data = Data(edge_index=ei, edge_type=et, num_nodes=kg.num_nodes, num_relations=kg.num_relations)
+    triples = torch.stack([ei[0, :half], ei[1, :half], et[:half]], dim=-1)
+    hub_rows = triples[triples[:, 0] == 3][:3]
+    inverse = torch.stack([ei[0, half:], ei[1, half:], et[half:]], dim=-1)
+    hub_as_tail = inverse[inverse[:, 1] == 3][:3]    # (head, 3, inverse relation): hundreds of known heads of (tail = 3, relation)
+    cases = []
+    for bs, num_negative, strict, seed in ((8, 32, True, 101), (6, 7, True, 102), (5, 16, True, 103), (8, 32, False, 104),
+                                           (2, 256, True, 105)):
+        g = torch.Generator().manual_seed(seed)
+        pick = torch.randint(0, half, (bs,), generator=g)
+        batch = triples[pick].clone()
+        batch[0] = hub_rows[seed % 3]                 # a hub anchor in the tail half (first half of the batch: tasks.py:50-52) ...
+        batch[-1] = hub_as_tail[seed % 3]             # ... and one in the head half
+        torch.manual_seed(seed)
+        state = torch.get_rng_state()
+        out = ref_tasks.negative_sampling(data, batch, num_negative, strict=strict)
+        cases.append(dict(batch=batch, num_negative=num_negative, strict=strict, rng_state=state, out=out))
+        print("negative_sampling", bs, num_negative, strict, tuple(out.shape))
+    torch.save(dict(edge_index=ei, edge_type=et, num_nodes=kg.num_nodes, num_relations=kg.num_relations, cases=cases),
+               os.path.join(HERE, "negative_sampling.pt"))
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden generation needs the reference checkout at /root/reference"
     torch.manual_seed(0)     # negative_sampling draws from the global generator
     if "--only-relation-projection" in sys.argv:
         gen_relation_projection()
         sys.exit(0)
+    if "--only-negative-sampling" in sys.argv:
+        gen_negative_sampling()
+        sys.exit(0)
     gen_rspmm()
     gen_models()
     gen_query_nbfnet()
     gen_relation_projection()
+    gen_negative_sampling()

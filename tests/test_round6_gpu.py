@@ -236,3 +236,77 @@ def test_first_layer_backward_kernel_against_the_oracle(dev, masked):
     assert got is not None
     assert (got[0].cpu() - want_rg).abs().max().item() <= 3e-5 * max(1.0, want_rg.abs().max().item())
     assert (got[1].cpu() - want_vg).abs().max().item() <= 3e-5 * max(1.0, want_vg.abs().max().item())
+
+
+# ---- the entity model's relation_projection MLPs as one autograd node (csrc/relproj_bwd.hip) ----
+@pytest.mark.parametrize("rows_shape,n_layer", [((8, 474), 6), ((3, 37), 2), ((1, 5), 1), ((2, 64), 8)])
+def test_relation_projection_node_matches_autograd_of_the_reference_chain(dev, rows_shape, n_layer):
+    """dense.RelationProjectionFunction vs torch autograd of nn.Sequential(Linear(64, 64), ReLU, Linear(64, 64)) per layer
+    (layers.py:43-47, 80) in fp64 -- outputs, the input gradient and all four parameter gradients of every layer; the fused fp32
+    result may not be further from fp64 than a few times torch's own fp32 chain.  One layer's output is left unused (its gradient
+    arrives as None)."""
+    from ultra_amd import dense
+    gen = torch.Generator().manual_seed(n_layer * 100 + rows_shape[1])
+    x = torch.randn(*rows_shape, 64, generator=gen)
+    params = []
+    for _ in range(n_layer):
+        params.append([torch.randn(64, 64, generator=gen) / 8, torch.randn(64, generator=gen) / 4,
+                       torch.randn(64, 64, generator=gen) / 8, torch.randn(64, generator=gen) / 4])
+    gouts = [torch.randn(*rows_shape, 64, generator=gen) for _ in range(n_layer)]
+    unused = n_layer - 1 if n_layer > 1 else None
+
+    def chain(dtype, device, fused):
+        xs = x.clone().to(device=device, dtype=dtype).requires_grad_()
+        ps = [[t.clone().to(device=device, dtype=dtype).requires_grad_() for t in group] for group in params]
+        if fused:
+            outs = dense.relation_projection_train(xs, [tuple(g) for g in ps])
+        else:
+            outs = [torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(xs, w0, b0)), w2, b2) for w0, b0, w2, b2 in ps]
+        loss = sum((o * g.to(device=device, dtype=dtype)).sum() for l, (o, g) in enumerate(zip(outs, gouts)) if l != unused)
+        loss.backward()
+        grads = [xs.grad] + [t.grad if t.grad is not None else torch.zeros_like(t) for group in ps for t in group]
+        return [o.detach().cpu().double() for o in outs], [g.cpu().double() for g in grads]
+
+    out64, g64 = chain(torch.float64, "cpu", False)
+    out32, g32 = chain(torch.float32, dev, False)
+    outf, gf = chain(torch.float32, dev, True)
+    for a, b in zip(outf, out64):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+    for k, (a, r32, r64) in enumerate(zip(gf, g32, g64)):
+        scale = max(r64.abs().max().item(), 1e-6)
+        err, err_torch = (a - r64).abs().max().item(), (r32 - r64).abs().max().item()
+        assert err <= 4 * err_torch + 2e-5 * scale, "gradient %d: |fused - fp64| = %g, |torch fp32 - fp64| = %g (scale %g)" % (
+            k, err, err_torch, scale)
+    # deterministic
+    _, again = chain(torch.float32, dev, True)
+    assert all(torch.equal(a, b) for a, b in zip(gf, again))
+
+
+# ---- the strict sampler kernel (csrc/sampling.hip) against batches recorded from the REFERENCE ----
+def test_strict_sampler_kernel_replays_the_reference_batches(dev):
+    """tests/golden/negative_sampling.pt: generator state before, and batch returned by, the reference's tasks.negative_sampling
+    (strict, a KG with a hub node).  The uniform draws are replayed from that state on the CPU -- torch.rand in the reference's
+    order and shapes (tasks.py:57, 65: tails of the first half, then heads of the second) -- and fed to ultra_strict_negatives:
+    the kernel returns the reference's ids, id for id."""
+    import os
+    from ultra_amd import tasks
+    from ultra_amd.data import Data
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "negative_sampling.pt"))
+    data = Data(edge_index=g["edge_index"], edge_type=g["edge_type"], num_nodes=g["num_nodes"], num_relations=g["num_relations"]).to(dev)
+    checked = 0
+    for case in g["cases"]:
+        if not case["strict"]:
+            continue
+        batch, n_neg = case["batch"], case["num_negative"]
+        half = len(batch) // 2
+        torch.set_rng_state(case["rng_state"])
+        rand_t = torch.rand(half, n_neg)
+        rand_h = torch.rand(len(batch) - half, n_neg)
+        pos_h, pos_t, pos_r = batch.to(dev).t()
+        neg_t = tasks._strict_negatives_gpu(data, pos_h[:half], pos_r[:half], pos_t[:half], n_neg, known=0, rand=rand_t)
+        neg_h = tasks._strict_negatives_gpu(data, pos_t[half:], pos_r[half:], pos_h[half:], n_neg, known=1, rand=rand_h)
+        want = case["out"]
+        assert torch.equal(neg_t.cpu(), want[:half, 1:, 1]), "tails, %d negatives" % n_neg
+        assert torch.equal(neg_h.cpu(), want[half:, 1:, 0]), "heads, %d negatives" % n_neg
+        checked += 1
+    assert checked == 4

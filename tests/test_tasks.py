@@ -79,3 +79,27 @@ def test_synthetic_shapes():
     assert torch.equal(d.edge_type[500:], d.edge_type[:500] + 4)
     d2 = synthetic.make_kg(num_node=100, num_triple=500, num_relation_base=4, seed=1)
     assert torch.equal(d.edge_index, d2.edge_index)                            # seeded
+
+
+def _negative_sampling_golden():
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "negative_sampling.pt"))
+    data = Data(edge_index=g["edge_index"], edge_type=g["edge_type"], num_nodes=g["num_nodes"], num_relations=g["num_relations"])
+    return data, g["cases"]
+
+
+def test_negative_sampling_replays_the_reference_draws():
+    """tests/golden/negative_sampling.pt holds, for five (batch, num_negative, strict) cases on a KG with a hub node, the global
+    generator's state right before the REFERENCE's tasks.negative_sampling (tasks.py:42-76) and the batch it returned
+    (tests/golden/gen_golden.py: gen_negative_sampling).  From the same state ultra_amd.tasks.negative_sampling returns the same
+    batch, id for id (CPU: the masks + nonzero() formulation)."""
+    data, cases = _negative_sampling_golden()
+    assert len(cases) == 5 and any(not c["strict"] for c in cases)
+    for case in cases:
+        torch.set_rng_state(case["rng_state"])
+        got = tasks.negative_sampling(data, case["batch"], case["num_negative"], strict=case["strict"])
+        assert torch.equal(got, case["out"]), (case["num_negative"], case["strict"])
+        if case["strict"]:      # (the hub rows are really filtered: no sampled tail is a known answer)
+            t_mask, h_mask = tasks.strict_negative_mask(data, case["batch"])
+            half = len(case["batch"]) // 2
+            assert all(t_mask[i, got[i, 1:, 1]].all() for i in range(half))
+            assert all(h_mask[i, got[i, 1:, 0]].all() for i in range(half, len(case["batch"])))

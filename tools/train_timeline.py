@@ -11,8 +11,8 @@ import sys
 
 
 def short(name):
-    name = re.sub(r"\(.*", "", name)
     name = re.sub(r"at::native::|\(anonymous namespace\)::|void |ultra::|rocprim::ROCPRIM_\d+_NS::detail::", "", name)
+    name = re.sub(r"\(.*", "", name)
     m = re.search(r"(vectorized_elementwise_kernel|elementwise_kernel_manual_unroll|elementwise_kernel)<.*?(\w+Functor\w*|\w+_kernel_cuda|direct_copy|FillFunctor)", name)
     if m:
         return "elementwise:" + m.group(2)

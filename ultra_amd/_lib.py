@@ -118,6 +118,11 @@ def _load():
     lib.ultra_readout_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, i32, i32, vp]
     lib.ultra_query_boundary.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp]
     lib.ultra_relation_projection.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]
+    pp = ctypes.POINTER(vp)
+    lib.ultra_relation_projection_layers.argtypes = [vp, pp, pp, pp, pp, vp, i64, i32, i32, vp]
+    lib.ultra_relation_projection_backward_workspace.argtypes = [i64, i32]
+    lib.ultra_relation_projection_backward_workspace.restype = i64
+    lib.ultra_relation_projection_backward.argtypes = [vp, pp, pp, pp, pp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]
     lib.ultra_plan_schedule_info.argtypes = [vp, i32, ctypes.POINTER(ScheduleInfo)]
     lib.ultra_order_trace.argtypes = [vp]
     lib.ultra_plan_schedule_export.argtypes = [vp, i32, i32, vp, i64, ctypes.POINTER(i64)]

@@ -408,11 +408,12 @@ __global__ void __launch_bounds__(512) readout_kernel(const ReadoutParams p) {
 // relation representations, models.py:184-185) in ONE launch: workgroup = (16 rows, layer), wave = 16 output features.
 // Both products run on v_mfma_f32_16x16x4_f32 with k ascending -- the reference's nn.Linear chain (torch_math.hpp),
 // bias added after the chain -- the hidden activation passes through LDS between them.
+constexpr int RELPROJ_MAX_LAYERS = 8;
 struct RelProjParams {
-    const float *x;        // (rows, 64)
-    const float *w0, *b0;  // (n_layer, 64, 64) row-major [out][in], (n_layer, 64)
-    const float *w2, *b2;
-    float *out;            // (n_layer, rows, 64)
+    const float *x;                                         // (rows, 64)
+    const float *w0[RELPROJ_MAX_LAYERS], *b0[RELPROJ_MAX_LAYERS];   // per layer: (64, 64) row-major [out][in], (64)
+    const float *w2[RELPROJ_MAX_LAYERS], *b2[RELPROJ_MAX_LAYERS];
+    float *out;                                             // (n_layer, rows, 64)
     long long rows;
     int n_layer;
 };
@@ -428,7 +429,7 @@ __global__ void __launch_bounds__(256) relation_projection_kernel(const RelProjP
     const int i16 = lane & 15, kk = lane >> 4;
     const int layer = blockIdx.y;
     const long long row_base = (long long)blockIdx.x * (16 * RELPROJ_TILES);
-    const float *w0 = p.w0 + (size_t)layer * 64 * 64, *w2 = p.w2 + (size_t)layer * 64 * 64;
+    const float *w0 = p.w0[layer], *w2 = p.w2[layer];
 #pragma unroll
     for (int t = 0; t < RELPROJ_TILES; ++t) {
         const long long row = min(row_base + 16 * t + (tid >> 4), p.rows - 1);
@@ -452,8 +453,8 @@ __global__ void __launch_bounds__(256) relation_projection_kernel(const RelProjP
     float b0v[4], b2v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        b0v[r] = p.b0[layer * 64 + f0 + r];
-        b2v[r] = p.b2[layer * 64 + f0 + r];
+        b0v[r] = p.b0[layer][f0 + r];
+        b2v[r] = p.b2[layer][f0 + r];
     }
     __syncthreads();
     // the RELPROJ_TILES chains are independent: interleaved, they fill the 40-cycle latency of a dependent 16x16x4
@@ -629,11 +630,23 @@ int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const in
                           feature_dim, stream, "ultra_readout_batch");
 }
 
+static int32_t launch_relation_projection(RelProjParams &p, void *stream) {
+    const dim3 grid((unsigned)((p.rows + 16 * RELPROJ_TILES - 1) / (16 * RELPROJ_TILES)), (unsigned)p.n_layer);
+    (void)hipGetLastError();   // drop any stale error left by other users of the runtime
+    hipLaunchKernelGGL(relation_projection_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error(std::string("relation_projection_kernel launch: ") + hipGetErrorString(e));
+        return ULTRA_ERR_HIP;
+    }
+    return ULTRA_OK;
+}
+
 int32_t ultra_relation_projection(const void *x, const void *w0, const void *b0, const void *w2, const void *b2, void *out,
                                   int64_t rows, int32_t n_layer, int32_t dim, void *stream) {
     ULTRA_DEVICE_SCOPE(stream, x);
-    if (dim != 64) {
-        set_error("ultra_relation_projection: only dim = 64 is built (the ULTRA checkpoints' shape)");
+    if (dim != 64 || n_layer > RELPROJ_MAX_LAYERS) {
+        set_error("ultra_relation_projection: only dim = 64 and at most 8 layers are built (the ULTRA checkpoints' shape)");
         return ULTRA_ERR_UNSUPPORTED;
     }
     if (!x || !w0 || !b0 || !w2 || !b2 || !out || rows < 0 || n_layer < 0) {
@@ -643,22 +656,42 @@ int32_t ultra_relation_projection(const void *x, const void *w0, const void *b0,
     if (rows == 0 || n_layer == 0) return ULTRA_OK;
     RelProjParams p;
     p.x = (const float *)x;
-    p.w0 = (const float *)w0;
-    p.b0 = (const float *)b0;
-    p.w2 = (const float *)w2;
-    p.b2 = (const float *)b2;
+    for (int l = 0; l < n_layer; ++l) {
+        p.w0[l] = (const float *)w0 + (size_t)l * 64 * 64, p.b0[l] = (const float *)b0 + (size_t)l * 64;
+        p.w2[l] = (const float *)w2 + (size_t)l * 64 * 64, p.b2[l] = (const float *)b2 + (size_t)l * 64;
+    }
     p.out = (float *)out;
     p.rows = rows;
     p.n_layer = n_layer;
-    const dim3 grid((unsigned)((rows + 16 * RELPROJ_TILES - 1) / (16 * RELPROJ_TILES)), (unsigned)n_layer);
-    (void)hipGetLastError();   // drop any stale error left by other users of the runtime
-    hipLaunchKernelGGL(relation_projection_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        set_error(std::string("relation_projection_kernel launch: ") + hipGetErrorString(e));
-        return ULTRA_ERR_HIP;
+    return launch_relation_projection(p, stream);
+}
+
+int32_t ultra_relation_projection_layers(const void *x, const void *const *w0, const void *const *b0, const void *const *w2,
+                                         const void *const *b2, void *out, int64_t rows, int32_t n_layer, int32_t dim,
+                                         void *stream) {
+    ULTRA_DEVICE_SCOPE(stream, x);
+    if (dim != 64 || n_layer > RELPROJ_MAX_LAYERS) {
+        set_error("ultra_relation_projection_layers: only dim = 64 and at most 8 layers are built (the ULTRA checkpoints' shape)");
+        return ULTRA_ERR_UNSUPPORTED;
     }
-    return ULTRA_OK;
+    if (!x || !w0 || !b0 || !w2 || !b2 || !out || rows < 0 || n_layer < 0) {
+        set_error("ultra_relation_projection_layers: NULL operand");
+        return ULTRA_ERR_INVALID;
+    }
+    if (rows == 0 || n_layer == 0) return ULTRA_OK;
+    RelProjParams p;
+    p.x = (const float *)x;
+    for (int l = 0; l < n_layer; ++l) {
+        if (!w0[l] || !b0[l] || !w2[l] || !b2[l]) {
+            set_error("ultra_relation_projection_layers: NULL layer parameter");
+            return ULTRA_ERR_INVALID;
+        }
+        p.w0[l] = (const float *)w0[l], p.b0[l] = (const float *)b0[l], p.w2[l] = (const float *)w2[l], p.b2[l] = (const float *)b2[l];
+    }
+    p.out = (float *)out;
+    p.rows = rows;
+    p.n_layer = n_layer;
+    return launch_relation_projection(p, stream);
 }
 
 }  // extern "C"

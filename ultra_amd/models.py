@@ -23,6 +23,8 @@ PROLOGUE_FAST_PATH = True
 PREFILL_LAYER0 = False
 # set by train.GraphedTrainStep around its capture: the generic (training) path of EntityNBFNet.forward may be recorded
 CAPTURE_GENERIC_PATH = False
+# the six relation_projection MLPs of a training step as one autograd node (A/B switch for tests: two batched torch products are the other side)
+RELATION_PROJECTION_NODE = True
 
 
 class NotOnFusedPath(RuntimeError):
@@ -310,7 +312,15 @@ class EntityNBFNet(BaseNBFNet):
                 getattr(l, "project_relations", False) and not l.dependent for l in self.layers):
             return None
         if torch.is_grad_enabled():
-            # Training: the same twelve products as two batched ones that autograd differentiates -- torch.stack hands every
+            if (RELATION_PROJECTION_NODE and rel.dtype == torch.float32 and rel.shape[-1] == 64 and len(self.layers) <= 8 and all(
+                    tuple(l.relation_projection[i].weight.shape) == (64, 64) and l.relation_projection[i].bias is not None
+                    for l in self.layers for i in (0, 2))):
+                # Training: every layer's MLP as ONE autograd node over the layers' own parameters -- one launch forward, three
+                # backward (dense.RelationProjectionFunction)
+                return dense.relation_projection_train(
+                    rel, [(l.relation_projection[0].weight, l.relation_projection[0].bias, l.relation_projection[2].weight,
+                           l.relation_projection[2].bias) for l in self.layers])
+            # (other shapes) the same twelve products as two batched ones that autograd differentiates -- torch.stack hands every
             # layer's parameters their own gradient slice.  Per layer the step otherwise spends two 39-us GEMM launches forward
             # (3,792 x 64 x 64: launch-bound) and four backward.  Same formula as nn.Sequential(Linear, ReLU, Linear).
             n = len(self.layers)

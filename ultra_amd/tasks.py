@@ -103,14 +103,18 @@ def _answer_keys(data, known):
     return _key_index("answers%d" % known, (data.edge_index, data.edge_type), build)
 
 
-def _strict_negatives_gpu(data, anchor, relation, positive, num_negative, known):
+def _strict_negatives_gpu(data, anchor, relation, positive, num_negative, known, rand=None):
     """num_negative strict negatives per positive through csrc/sampling.hip: the reference's picks
-    candidate[floor(rand * count)] (tasks.py:57-61) for the same torch.rand draws, no mask, no host synchronisation."""
+    candidate[floor(rand * count)] (tasks.py:57-61) for the same torch.rand draws, no mask, no host synchronisation.
+    rand: the (rows, num_negative) uniform draws to use instead of torch.rand on the device (tests feed the CPU generator's, to
+    replay batches recorded from the reference)."""
     import ctypes
     from ._lib import check, lib
     keys = _answer_keys(data, known)
     rows = len(anchor)
-    rand = torch.rand(rows, num_negative, device=anchor.device)
+    if rand is None:
+        rand = torch.rand(rows, num_negative, device=anchor.device)
+    rand = rand.to(device=anchor.device, dtype=torch.float32).contiguous()
     out = torch.empty(rows, num_negative, dtype=torch.long, device=anchor.device)
     anchor, relation, positive = anchor.contiguous(), relation.contiguous(), positive.contiguous()
     check(lib.ultra_strict_negatives(keys.data_ptr(), keys.numel(), anchor.data_ptr(), relation.data_ptr(), positive.data_ptr(),
