@@ -557,6 +557,7 @@ def stub_main(args):
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64)
     per_rank = None
+    slot_report = getattr(piped, "stream_report", None) or {}      # (CPU slots have no streams to choose: None per rank)
     if gather:
         probe = score(tasks.all_negative(data, triples[:bs])[0]).double()
         order_word = float(int(host_order.order_id(host_order.readout_stages(128)[0]).split("-")[1], 16))
@@ -574,6 +575,14 @@ def stub_main(args):
                     "readout_order_id": ["order-%08x" % int(v) for v in g[:, 4].tolist()],
                     "readout_order_identical": bool((g[:, 4] == g[0, 4]).all()),
                     "gathered_rows_per_step": seen[-1][0], "gathered_blocks_in_rank_order": bool(blocks_ok)}
+        # every rank's choice of slot streams (candidate, priority class, trial and settled figures)
+        mine = {k: slot_report.get(k) for k in ("chosen", "candidate", "forced", "settle")} if slot_report else None
+        if mine and slot_report.get("trial_ms"):
+            ms = [m for _, m in slot_report["trial_ms"]]
+            mine.update(chosen_ms=min(ms), spread_ms=[min(ms), max(ms)])
+        choices = [None] * dist.get_world_size()
+        dist.all_gather_object(choices, mine)
+        per_rank["slot_streams"] = choices
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
     out = {"metric": "triples scored/sec (all-tail ranking) on FB15k237", "value": world * bs * N * args.steps / elapsed,
@@ -727,6 +736,7 @@ def main():
         return post(score) if post is not None else score
 
     slot_report = {}      # which streams the pipeline slots of the timed forward run on (graph.pick_slot_streams)
+    pipelines = []        # the PipelinedForward behind `forward` (its settle() watches the pre-warm steps)
 
     def make_forward():
         if args.no_graph:
@@ -743,6 +753,7 @@ def main():
                                          trial_post=udist.all_gather_scores if (world > 1 or launched) else None)
                 if not slot_report:
                     slot_report.update(piped.stream_report or {})
+                pipelines.append(piped)
                 return lambda data_, batch_, post=None: piped(batch_, post=post)
             graphed = GraphedForward(model, data, example)
 
@@ -773,8 +784,16 @@ def main():
             # 5 warm-up steps run 3 - 4 % slower than the same 20 steps repeated; after 50 warm-up steps they do not) -- so the
             # FIRST timed run of the process is preceded by `--pre-warm` untimed steps (reported as `pre_warmup_steps`), then
             # the W warm-up steps and the K timed steps as asked for
-            for i in range(pre_warm.pop() if pre_warm else 0):
-                one_step(i)
+            n_pre = pre_warm.pop() if pre_warm else 0
+            if n_pre and pipelines:
+                # the pre-warm steps double as the check of the slot streams' choice against the steady state: slower than the
+                # trial promised by more than 3 % -> one more choice (graph.PipelinedForward.settle)
+                settled = pipelines[0].settle(one_step, steps=n_pre, collective=gather)
+                if settled is not None:
+                    slot_report["settle"] = settled
+            else:
+                for i in range(n_pre):
+                    one_step(i)
             for i in range(args.warmup):
                 one_step(i)
             torch.cuda.synchronize()
@@ -817,6 +836,14 @@ def main():
                     "probe_scores_identical": bool((g[:, :3] == g[0, :3]).all()),
                     "readout_order_id": ["order-%08x" % int(v) for v in g[:, 4].tolist()],
                     "readout_order_identical": bool((g[:, 4] == g[0, 4]).all())}
+        # every rank's choice of slot streams (candidate, priority class, trial and settled figures)
+        mine = {k: slot_report.get(k) for k in ("chosen", "candidate", "forced", "settle")} if slot_report else None
+        if mine and slot_report.get("trial_ms"):
+            ms = [m for _, m in slot_report["trial_ms"]]
+            mine.update(chosen_ms=min(ms), spread_ms=[min(ms), max(ms)])
+        choices = [None] * dist.get_world_size()
+        dist.all_gather_object(choices, mine)
+        per_rank["slot_streams"] = choices
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
     triples_per_s = world * bs * N * args.steps / elapsed

@@ -340,7 +340,7 @@ def test_dense_order_layer_matches_rspmm_plus_update(dev, residual, layer_norm, 
     assert (got - want).abs().max().item() <= 2e-5 * max(scale, 1.0)
 
 
-@pytest.mark.parametrize("N", [474, 40, 17, 33])
+@pytest.mark.parametrize("N", [474, 40, 17, 33, 100])
 def test_dense_order_layer_with_two_row_tiles_per_workgroup_keeps_its_bits(dev, N, monkeypatch):
     """The relation-graph layer with TWO 16-row tiles per workgroup over one stream of B operands (dense_order_layer_kernel<2>,
     ULTRA_DOL_TILES=2 -- VERDICT r4 item 3a: built, measured slower in the step, not the default): the same bits as one tile per
@@ -365,6 +365,17 @@ def test_dense_order_layer_with_two_row_tiles_per_workgroup_keeps_its_bits(dev, 
                        plan.fused_layer(rel, x, lin, layer_norm=None, relu=False, residual=False, boundary=tensor_bnd))
     assert all(o is not None for pair in outs.values() for o in pair)
     assert torch.equal(outs["1"][0], outs["2"][0]) and torch.equal(outs["1"][1], outs["2"][1])
+    # the four-workgroups-a-CU form (round 6: <= 128 registers, late operands of phases 2 / 3; the default where the launch shares
+    # the chip): the same bits again
+    # ... and as ONE 1024-thread workgroup of four such quartets (the default there: packs the chains onto few CUs) -- graphs whose
+    # tile count is not a multiple of four leave quartets without a tile
+    monkeypatch.setenv("ULTRA_DOL_TILES", "1")
+    for form in ("1", "2"):
+        monkeypatch.setenv("ULTRA_DOL_LEAN", form)
+        lean = (plan.fused_layer(rel, x, lin, layer_norm=ln, relu=True, residual=True, point=point),
+                plan.fused_layer(rel, x, lin, layer_norm=None, relu=False, residual=False, boundary=tensor_bnd))
+        assert torch.equal(lean[0], outs["1"][0]) and torch.equal(lean[1], outs["1"][1]), form
+    monkeypatch.setenv("ULTRA_DOL_LEAN", "0")
 
 
 @pytest.mark.parametrize("sum,mul", list(itertools.product(SUMS, MULS)))

@@ -78,17 +78,37 @@ __device__ __forceinline__ float byte_of(uint32_t w, int q) { return (float)((w 
 // chain's matrix instruction hides the byte -> float conversions and the product that one chain per SIMD leaves in the open.
 // Chosen where the launch does not own the chip (two batches in flight: the relation-graph layers of one batch run on the 64 CUs
 // the other batch's entity layers leave -- 240 workgroups need two rounds there, 120 one); same bits either way.
-template <int TILES>
-__global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(const DenseOrderParams p) {
-    __shared__ __attribute__((aligned(16))) float x_lds[TILES * 16 * DOL_ROW_STRIDE];     // the tiles' own rows of x
-    __shared__ __attribute__((aligned(16))) float agg_lds[TILES * 16 * DOL_ROW_STRIDE];
-    __shared__ float ln_mom[TILES * 16][8][2];
-    __shared__ float ln_stat[TILES * 16][2];
-    const int tid = threadIdx.x, lane = tid & 63;
+// LEAN: the same body in at most 128 registers a lane, so that FOUR of its workgroups share a CU (four waves per SIMD, their
+// chains interleaved on the matrix pipe: 4 x 32 cycles per column where one wave alone takes 67).  With batches in flight the
+// relation-graph layers of one batch run on the 64 CUs the other batches' entity layers leave: 240 workgroups at three a CU
+// (162 registers) need two rounds there -- 58 us a layer as timed against 22.5 alone -- at four a CU one.  What is
+// given up: the operands of phases 2 / 3 (update weights, own x rows, boundary, small vectors) are requested AFTER the chain
+// instead of before it (their latency shows once per workgroup), and the offsets of the last, clamped stage are computed where
+// they are used instead of being held in registers.  Same instruction sequence on the data: the same bits.
+// SUBS: quartets of waves per workgroup (1 or 4), each quartet a row tile of its own.  The hardware spreads the workgroups of a
+// launch over whatever CUs have room; a CU that holds ONE 256-thread workgroup of this kernel no longer has the LDS (and, at four a
+// SIMD, the registers) for a workgroup of the entity layer, which wants the whole CU -- so 240 small workgroups can block up to 240
+// CUs for the length of a chain that keeps one wave a SIMD busy.  Sixteen waves in ONE workgroup pack four chains onto every SIMD
+// of one CU by construction: 60 workgroups a layer instead of 240, the matrix pipe of the CUs they do take busy 128 of 128 cycles a
+// column.  (With batches in flight the step is bound by CU-time: profiles/r5_experiments.txt.)
+template <int TILES, bool LEAN, int SUBS = 1>
+__device__ __forceinline__ void dense_order_layer_impl(const DenseOrderParams &p) {
+    __shared__ __attribute__((aligned(16))) float x_lds_all[SUBS * TILES * 16 * DOL_ROW_STRIDE];     // the tiles' own rows of x
+    __shared__ __attribute__((aligned(16))) float agg_lds_all[SUBS * TILES * 16 * DOL_ROW_STRIDE];
+    __shared__ float ln_mom_all[SUBS][TILES * 16][8][2];
+    __shared__ float ln_stat_all[SUBS][TILES * 16][2];
+    const int sub = SUBS > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+    float *x_lds = x_lds_all + sub * (TILES * 16 * DOL_ROW_STRIDE), *agg_lds = agg_lds_all + sub * (TILES * 16 * DOL_ROW_STRIDE);
+    float(&ln_mom)[TILES * 16][8][2] = ln_mom_all[sub];
+    float(&ln_stat)[TILES * 16][2] = ln_stat_all[sub];
+    const int tid = threadIdx.x & 255, lane = tid & 63;      // (tid: within the quartet)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kk = lane >> 4;
-    const int n_wt = (p.n_rt16 + TILES - 1) / TILES;       // workgroups per sample
-    const int rt = blockIdx.x % n_wt, outer = blockIdx.x / n_wt;
+    const int n_wt = (p.n_rt16 + TILES * SUBS - 1) / (TILES * SUBS);       // workgroups per sample
+    const int rt_raw = (blockIdx.x % n_wt) * SUBS + sub, outer = blockIdx.x / n_wt;
+    // (a quartet past the graph walks the last tile again -- every wave takes part in the workgroup's barriers -- and stores nothing)
+    const bool quartet_live = rt_raw * TILES < p.n_rt16;
+    const int rt = quartet_live ? rt_raw : (p.n_rt16 - 1) / TILES;
     const float *xo = p.x + (long long)outer * p.x_so;
     const int row0 = rt * 16 * TILES;
     const int c0 = 16 * wave;
@@ -107,12 +127,14 @@ __global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(c
     const uint32_t x_row_bytes = (uint32_t)p.x_sr * 4u;
     const uint32_t lane_bytes = (uint32_t)(c0 + i16) * 4u;       // B operand: lane (kk, n) reads x[j][c0 + n]
 #if !ULTRA_DOL_ASM
-    uint32_t voff[16], voff_last[16];
+    uint32_t voff[16], voff_last[LEAN ? 1 : 16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         voff[q] = (uint32_t)q * x_row_bytes + lane_bytes;
-        voff_last[q] = (uint32_t)min(16 * (p.n_jc - 1) + q, p.n_in - 1) * x_row_bytes + lane_bytes;
+        if (!LEAN) voff_last[q] = (uint32_t)min(16 * (p.n_jc - 1) + q, p.n_in - 1) * x_row_bytes + lane_bytes;
     }
+    // (LEAN: the last stage's offsets relative to ITS base, clamped to the graph's last row, from one register)
+    const uint32_t off_max = (uint32_t)(p.n_in - 1 - 16 * (p.n_jc - 1)) * x_row_bytes + lane_bytes;
     struct Stage {
         uint4 a[TILES];
         float x[16];
@@ -122,9 +144,16 @@ __global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(c
         const int jcc = last ? p.n_jc - 1 : jc;
 #pragma unroll
         for (int t = 0; t < TILES; ++t) st.a[t] = ap[t][(size_t)jcc * 64 + lane];
-        const char *sbase = xbase + (last ? 0u : (uint32_t)jcc * 16u * x_row_bytes);
+        if (LEAN) {
+            const char *sbase = xbase + (uint32_t)jcc * 16u * x_row_bytes;
+            const uint32_t cap = last ? off_max : 0xffffffffu;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) st.x[q] = *reinterpret_cast<const float *>(sbase + (last ? voff_last[q] : voff[q]));
+            for (int q = 0; q < 16; ++q) st.x[q] = *reinterpret_cast<const float *>(sbase + min(voff[q], cap));
+        } else {
+            const char *sbase = xbase + (last ? 0u : (uint32_t)jcc * 16u * x_row_bytes);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) st.x[q] = *reinterpret_cast<const float *>(sbase + (last ? voff_last[q] : voff[q]));
+        }
     };
     // three stages (48 source columns, ~1,900 cycles of chain) in flight: one wave per SIMD has nothing else to hide an
     // L2 round trip behind
@@ -136,40 +165,43 @@ __global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(c
     const float relv = kk < p.n_rel ? p.rel[(long long)outer * p.rel_so + (long long)kk * p.rel_sr + c0 + i16] : 0.f;
 
     // the tiles' own x rows (update input and residual), the update weights of this wave's feature tile and the small
-    // vectors of phases 2 / 3: requested now, consumed after the chain
+    // vectors of phases 2 / 3: requested now, consumed after the chain (LEAN: requested after the chain)
     float4 xtile[TILES];
-#pragma unroll
-    for (int t = 0; t < TILES; ++t) {
-        const int row = min(row0 + 16 * t + (tid >> 4), p.n_out - 1);
-        xtile[t] = *reinterpret_cast<const float4 *>(xo + (long long)row * p.x_sr + 4 * (tid & 15));
-    }
     float wfrag[32];   // A operand of phase 3: lane (i, kk) holds W[16 ft + i][4 s + kk], ft = wave
-#pragma unroll
-    for (int s = 0; s < 32; ++s) wfrag[s] = p.weight[(16 * wave + i16) * 128 + 4 * s + kk];
     const int f0 = 16 * wave + 4 * kk;   // first of this lane's 4 features in phase 3
     float biasv[4], lnw[4], lnb[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        biasv[r] = p.bias ? p.bias[f0 + r] : 0.f;
-        lnw[r] = (p.flags & DOL_LN) ? p.ln_w[f0 + r] : 1.f;
-        lnb[r] = (p.flags & DOL_LN) ? p.ln_b[f0 + r] : 0.f;
-    }
     float bndv[TILES][4];   // boundary addends of the accumulator elements (row 4 kk + r of a tile, column c0 + i16)
+    const auto fetch_late_operands = [&]() {
 #pragma unroll
-    for (int t = 0; t < TILES; ++t)
+        for (int t = 0; t < TILES; ++t) {
+            const int row = min(row0 + 16 * t + (tid >> 4), p.n_out - 1);
+            xtile[t] = *reinterpret_cast<const float4 *>(xo + (long long)row * p.x_sr + 4 * (tid & 15));
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bndv[t][r] = 0.f;
-    if (p.has_bnd) {
-        const long long bnd_row = p.bnd_rows ? p.bnd_rows[outer] : -1;
+        for (int s = 0; s < 32; ++s) wfrag[s] = p.weight[(16 * wave + i16) * 128 + 4 * s + kk];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            biasv[r] = p.bias ? p.bias[f0 + r] : 0.f;
+            lnw[r] = (p.flags & DOL_LN) ? p.ln_w[f0 + r] : 1.f;
+            lnb[r] = (p.flags & DOL_LN) ? p.ln_b[f0 + r] : 0.f;
+        }
 #pragma unroll
         for (int t = 0; t < TILES; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 16 * t + 4 * kk + r;
-                if (row < p.n_out && (bnd_row < 0 || bnd_row == row))
-                    bndv[t][r] = p.bnd[(long long)outer * p.bnd_so + (long long)row * p.bnd_sr + c0 + i16];   // (bnd_sr == 0 for a point)
-            }
-    }
+            for (int r = 0; r < 4; ++r) bndv[t][r] = 0.f;
+        if (p.has_bnd) {
+            const long long bnd_row = p.bnd_rows ? p.bnd_rows[outer] : -1;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + 16 * t + 4 * kk + r;
+                    if (row < p.n_out && (bnd_row < 0 || bnd_row == row))
+                        bndv[t][r] = p.bnd[(long long)outer * p.bnd_so + (long long)row * p.bnd_sr + c0 + i16];   // (bnd_sr == 0 for a point)
+                }
+        }
+    };
+    if (!LEAN) fetch_late_operands();
 
     // ---- phase 1: the chain(s) ----
     f32x4 acc[TILES];
@@ -207,6 +239,8 @@ __global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(c
         fetch(jc + 5, st2);
     }
 #endif
+
+    if (LEAN) fetch_late_operands();
 
     // ---- phase 2: + boundary (layers.py:199-200), aggregate tiles and x tiles to LDS ----
     // D layout: lane l, reg r -> tile row 4 (l >> 4) + r, column l & 15
@@ -288,10 +322,23 @@ __global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(c
             for (int r = 0; r < 4; ++r) y[t][r] += x_lds[(16 * t + i16) * DOL_ROW_STRIDE + f0 + r];
         }
         const int row = row0 + 16 * t + i16;
-        if (row < p.n_out && (t == 0 || tile1))
+        if (row < p.n_out && (t == 0 || tile1) && quartet_live)
             *reinterpret_cast<float4 *>(p.out + (long long)outer * p.out_so + (long long)row * p.out_sr + f0) =
                 make_float4(y[t][0], y[t][1], y[t][2], y[t][3]);
     }
+}
+
+template <int TILES>
+__global__ void __launch_bounds__(256) ULTRA_DOL_ATTR dense_order_layer_kernel(const DenseOrderParams p) {
+    dense_order_layer_impl<TILES, false>(p);
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) dense_order_layer_lean_kernel(const DenseOrderParams p) {
+    dense_order_layer_impl<1, true>(p);
+}
+
+__global__ void __launch_bounds__(1024) dense_order_layer_packed_kernel(const DenseOrderParams p) {
+    dense_order_layer_impl<1, true, 4>(p);
 }
 
 static bool dol_ok16(const ultra_mat *m) {
@@ -345,12 +392,25 @@ int launch_dense_order_layer(ultra_plan *p, const ultra_mat *rel, const ultra_ma
     // against 23.7 stand-alone -- its two chains share one matrix pipe, 64 cycles a column -- and the step with two batches in
     // flight 0.603 ms against 0.581: the relation-graph layers on the 64 free CUs are not what bounds that step.  So one tile
     // per workgroup stays the choice everywhere; ULTRA_DOL_TILES=2 selects the other form (same bits: tests/test_order_gpu.py).
-    (void)shared_chip;
+    // ULTRA_DOL_LEAN=0 / 1 overrides the choice of the four-workgroups-a-CU form (default: where the launch shares the chip).
+    const char *lean_str = std::getenv("ULTRA_DOL_LEAN");
+    // 0: the 160-register form; 1: four 256-thread workgroups a CU; 2 (default where the launch shares the chip): ONE 1024-thread
+    // workgroup of four quartets -- the packing by construction
+    const int lean = (ULTRA_DOL_ASM || tiles_env == 2) ? 0 : (lean_str ? std::atoi(lean_str) : (shared_chip ? 2 : 0));
     const int tiles = (ULTRA_DOL_ASM || dp.n_rt16 < 2) ? 1 : (tiles_env == 2 ? 2 : 1);
     const long long blocks = (long long)((dp.n_rt16 + tiles - 1) / tiles) * out->n_outer;
     if (tiles == 2) {
 #if !ULTRA_DOL_ASM
         hipLaunchKernelGGL(dense_order_layer_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, dp);
+#endif
+    } else if (lean == 2 && dp.n_rt16 >= 4) {
+#if !ULTRA_DOL_ASM
+        const long long packed = (long long)((dp.n_rt16 + 3) / 4) * out->n_outer;
+        hipLaunchKernelGGL(dense_order_layer_packed_kernel, dim3((unsigned)packed), dim3(1024), 0, stream, dp);
+#endif
+    } else if (lean) {
+#if !ULTRA_DOL_ASM
+        hipLaunchKernelGGL(dense_order_layer_lean_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dp);
 #endif
     } else {
         hipLaunchKernelGGL(dense_order_layer_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, dp);

@@ -236,6 +236,7 @@ class PipelinedForward(object):
                 self.join()
                 torch.cuda.synchronize(dev)
                 return (time.perf_counter() - t0) / steps
+            self._trial = trial
             self.streams, self.stream_report = pick_slot_streams(dev, len(self.slots), trial)
             self.calls = 0
         elif dev.type == "cuda":
@@ -267,6 +268,57 @@ class PipelinedForward(object):
         cur = torch.cuda.current_stream(self.device)
         for s in self.streams:
             cur.wait_stream(s)
+
+    def settle(self, step_fn, steps=48, tolerance=0.03, collective=False):
+        """The pipeline's warm-up, watched: run step_fn(0 .. steps - 1) (each enqueues one step through this pipeline), and if they
+        took more than `tolerance` over the trial's winning figure per step -- the ~ 25 ms trial that chose the slots' streams can
+        be wrong about the steady state: the same streams were seen at 0.57 and 0.97 ms per step within one process
+        (profiles/r5_slot_streams.txt) -- choose the streams ONCE more (replays onto another stream set cost nothing), time
+        `steps` steps on the new set and keep whichever set was faster.  collective: the steps contain a collective (a multi-GPU
+        step's all-gather) -- every rank then takes the same decision (any rank slow -> all re-pick: their trial steps pair up).
+        Returns the report (also merged into self.stream_report); a pipeline without a choice to make just runs the steps."""
+        import time
+
+        def timed():
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step_fn(i)
+            self.join()
+            torch.cuda.synchronize(self.device)
+            return (time.perf_counter() - t0) / max(steps, 1)
+        report = self.stream_report
+        if (self.device.type != "cuda" or len(self.slots) < 2 or not report or report.get("forced") or not report.get("trial_ms")
+                or steps < 8):
+            for i in range(steps):
+                step_fn(i)
+            return None
+        first = timed()
+        best_trial = min(ms for _, ms in report["trial_ms"]) * 1e-3
+        slow = first > (1.0 + tolerance) * best_trial
+        if collective and torch.distributed.is_available() and torch.distributed.is_initialized():
+            flag = torch.tensor([1.0 if slow else 0.0], device=self.device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            slow = bool(flag.item() > 0)
+        out = {"settle_steps": steps, "settled_ms": round(1e3 * first, 4), "trial_best_ms": round(1e3 * best_trial, 4), "repicked": False}
+        if slow:
+            old = self.streams
+            self.streams, again = pick_slot_streams(self.device, len(self.slots), self._trial)
+            self.calls = 0
+            second = timed()
+            out.update(repicked=True, repick_trial_ms=again.get("trial_ms"), repick_settled_ms=round(1e3 * second, 4))
+            keep_old = second > first
+            if collective and torch.distributed.is_available() and torch.distributed.is_initialized():
+                # (one decision for the job: the sets are kept or swapped back on every rank alike -- a rank's streams only matter
+                # to its own clock, but the ranks' steps must stay paired)
+                flag = torch.tensor([1.0 if keep_old else 0.0], device=self.device)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                keep_old = bool(flag.item() > 0)
+            if keep_old:
+                self.streams = old
+            out["kept"] = "first choice" if keep_old else "second choice"
+        self.stream_report = dict(report, settle=out)
+        return out
 
 
 class GraphedEvalStep(object):
