@@ -115,3 +115,21 @@ def test_captured_step_refuses_another_batch_shape_and_an_uncapturable_optimizer
     step = train.GraphedTrainStep(model, data, train.make_adamw(model, capturable=True), batches[0], num_negative=32)
     with pytest.raises(ValueError):
         step(batches[0][:4])
+
+
+@pytest.mark.parametrize("num_node,expect_rows", [(4 * 33, True), (4 * 33 - 1, False)])
+def test_rows_route_threshold_is_a_quarter_of_the_graph(dev, num_node, expect_rows):
+    """layers.training_rows_layer takes the last layer on the candidates' rows iff 4 * (1 + num_negative) <= num_node (a list that
+    covers most of the graph takes the whole layer's walk): pinned on both sides of the threshold."""
+    _, state, _, cfg = load_golden("ultra_3g", "sum")
+    data = synthetic.make_kg(num_node=num_node, num_triple=1500, num_relation_base=4, num_test=16, seed=3).to(dev)
+    batch = torch.stack([data.edge_index[0, :4], data.edge_index[1, :4], data.edge_type[:4]], dim=-1)
+    torch.manual_seed(0)
+    neg = tasks.negative_sampling(data, batch, 32, strict=False)          # 33 candidates per row
+    model = models.Ultra(**cfg)
+    model.load_state_dict(state)
+    model = model.to(dev).train()
+    out = model(data, neg)
+    assert model.entity_model._last_hidden_on_rows == expect_rows
+    out.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())

@@ -8,7 +8,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 part="${1:-A}"
-R="${2:-r5}"
+R="${2:-r6}"
 OUT=gpurun_out/$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -45,5 +45,13 @@ else
     find /tmp/prof_c3 -name "*kernel_stats.csv" -exec cp {} "$OUT/${R}_config3_kernel_stats.csv" \;
     { timeout 120 python tools/conv_probe.py; timeout 120 python tools/readout_probe.py; } > "$OUT/${R}_kernel_probes.txt" 2>&1
     timeout 600 python tools/eval_speed.py 512 > "$OUT/${R}_eval_speed.txt" 2>&1
+    # the fine-tuning step launched kernel by kernel and as one hipGraph replay: ms per step and host issue time of both forms
+    timeout 600 python tools/train_graph_probe.py fb15k237 yago310 2>&1 | grep -v amdgpu.ids > "$OUT/${R}_finetune_phases.txt"
+    for shape in fb15k237 yago310; do
+        rm -rf /tmp/tl_$shape
+        (cd /tmp && PROBE_ONLY=eager timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$shape -- \
+            python "$OLDPWD/tools/train_graph_probe.py" $shape > /dev/null 2>&1)
+        python tools/train_timeline.py $(ls /tmp/tl_$shape/*/*_kernel_trace.csv | head -1) > "$OUT/${R}_finetune_timeline_$shape.txt" 2>&1
+    done
 fi
 ls -la "$OUT"

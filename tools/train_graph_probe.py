@@ -45,6 +45,15 @@ def eager(data, positives, num_negative, aggr, steps):
         losses.append(train.train_step(model, data, next(negatives), opt, num_negative=num_negative))
     out["eager_ms"] = 1e3 * sb.timeit(eager_step, 3, steps)
     out["eager_loss"] = [round(l.item(), 6) for l in losses[:6]]
+    import time
+    torch.cuda.synchronize()
+    issue = 0.0
+    for _ in range(steps):
+        t = time.perf_counter()
+        eager_step()
+        issue += time.perf_counter() - t
+    torch.cuda.synchronize()
+    out["eager_host_issue_ms"] = 1e3 * issue / steps
     return out
 
 
@@ -62,6 +71,19 @@ def captured(data, positives, num_negative, aggr, steps):
         losses.append(step(next(negatives)).clone())
     out["captured_ms"] = 1e3 * sb.timeit(graph_step, 2, steps)
     out["captured_loss"] = [round(l.item(), 6) for l in losses[:6]]
+    # host time to ISSUE a step (sampler's launches for the next batch + input copy + replay; nothing synchronised but the
+    # sampler's own stream) against the step's time: who sets the pace
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    issue = 0.0
+    for _ in range(steps):
+        t = time.perf_counter()
+        step(next(negatives))
+        issue += time.perf_counter() - t
+    torch.cuda.synchronize()
+    out["captured_host_issue_ms"] = 1e3 * issue / steps
+    out["captured_ms_second_loop"] = 1e3 * (time.perf_counter() - t0) / steps
     step.check()
     return out
 

@@ -78,22 +78,35 @@ struct WeightEpochScope {
 // ---- the device-side error word (OrderParams::err) ----
 // One word of pinned, mapped host memory per process: a kernel whose bounded spin gave up stores (code << 24 | workgroup) there
 // with a system-scope store; the host reads it without any HIP call -- at the next forward entry and in ultra_device_error().
-static uint32_t *g_dev_err = nullptr;
+// (one word PER DEVICE: a give-up on device k is reported by the next forward on device k -- or by ultra_device_error() called with
+// device k current -- not by whatever launch of another device's thread happens to come first)
+static constexpr int MAX_ERR_DEVICES = 64;
+static uint32_t *g_dev_err[MAX_ERR_DEVICES] = {nullptr};
+static int current_device_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return dev >= 0 && dev < MAX_ERR_DEVICES ? dev : 0;
+}
 static uint32_t *device_error_word() {
-    if (!g_dev_err) {
+    const int slot = current_device_slot();
+    if (!g_dev_err[slot]) {
         void *ptr = nullptr;
         if (hipHostMalloc(&ptr, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
             (void)hipGetLastError();
             return nullptr;      // (no word: the kernels then only keep their spins bounded)
         }
         std::memset(ptr, 0, 64);
-        g_dev_err = static_cast<uint32_t *>(ptr);
+        g_dev_err[slot] = static_cast<uint32_t *>(ptr);
     }
-    return g_dev_err;
+    return g_dev_err[slot];
 }
 static int take_device_error() {
-    if (!g_dev_err) return ULTRA_OK;
-    const uint32_t word = __atomic_exchange_n(g_dev_err, 0u, __ATOMIC_RELAXED);
+    uint32_t *cell = g_dev_err[current_device_slot()];
+    if (!cell) return ULTRA_OK;
+    const uint32_t word = __atomic_exchange_n(cell, 0u, __ATOMIC_RELAXED);
     if (!word) return ULTRA_OK;
     static const char *const what[] = {"?", "an update wave waiting for rows from the walkers", "an update wave waiting for the other update waves",
                                        "a walker waiting for the chain consumer", "an update wave waiting for the chain consumer",
