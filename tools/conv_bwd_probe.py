@@ -26,7 +26,7 @@ def run(rows, iters=20):
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(lib.ultra_conv_update_backward(x.data_ptr(), agg.data_ptr(), gout.data_ptr(), w.data_ptr(), b.data_ptr(), lw.data_ptr(),
                                              lb.data_ptr(), gx.data_ptr(), gagg.data_ptr(), gw.data_ptr(), gb.data_ptr(), glw.data_ptr(),
-                                             glb.data_ptr(), work.data_ptr(), nbytes, rows, 64, 64, 1e-5, 7, st))
+                                             glb.data_ptr(), work.data_ptr(), nbytes, rows, 64, 64, 1e-5, 7 | int(os.environ.get("PROBE_FLAGS", "0")), st))
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         for _ in range(3):

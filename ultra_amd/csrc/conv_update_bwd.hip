@@ -33,7 +33,9 @@ namespace ultra {
 
 using f32x16 = float __attribute__((ext_vector_type(16)));
 
-enum { CB_LN = 1, CB_RELU = 2, CB_RESIDUAL = 4 };
+enum { CB_LN = 1, CB_RELU = 2, CB_RESIDUAL = 4,
+       // measurement switches of the fused kernel (results are wrong with any of them): tools/conv_bwd_probe.py PROBE_FLAGS
+       CB_DBG_NO_W_MFMA = 256, CB_DBG_NO_DX_MFMA = 512, CB_DBG_NO_Z_MFMA = 1024 };
 constexpr int CB_WR_STRIDE = 136;                 // row stride (floats) of the row-major weight copy: 4 rows apart = 32 banks apart
 constexpr int CB_PART = 64 * 128 + 3 * 64;        // floats per workgroup partial: dW, db, d gamma, d beta
 
@@ -347,6 +349,342 @@ __global__ void __launch_bounds__(512) conv_update_bwd_weights_kernel(const Conv
     for (int idx = tid; idx < 64 * 128 + 64; idx += blockDim.x) dst[idx] = lds_dw[idx];
 }
 
+// ---- rows + weights in ONE launch (round 6): dz never goes through memory ----
+// Waves 0 - 3 of a workgroup run the rows kernel's tile loop, waves 4 - 7 the weight kernel's; wave r and wave r + 4 share a SIMD and
+// a tile sequence.  The rows wave parks each tile's dz (32 x 64 floats) in one of its pair's two LDS buffers instead of storing it;
+// its partner reads the A operands of dW = dz^T [x ; agg] from there and the B operands ([x ; agg] as 128-byte row segments) from
+// L2, where the rows wave's own loads have just put them.  HBM traffic per call: x, agg, grad_out in, gx, gagg out -- 1.26 GB at
+// 985 k rows where the two launches moved 2.27 GB (dz out and in again, x and agg in again); the SIMD's matrix pipe sees the same
+// 384 instructions a tile, now from two waves that fill each other's gaps.  Hand-off: one flag per buffer (0 = free, 1 = full),
+// release / acquire at workgroup scope; strictly alternating, so neither side can run ahead by more than two tiles.
+// LDS layout of a parked tile: row-major [32][64] with the two 32-column halves of ODD rows swapped (column ^ 32): the weight wave's
+// A-operand reads -- lane (n, hh) takes dz[2 q + hh][n] and [32 + n] -- then touch 64 different banks.
+constexpr int CBF_TILE = 32 * 64;                  // floats per parked dz tile
+
+__global__ void __launch_bounds__(512) conv_update_bwd_fused_kernel(const ConvBwdParams p) {
+    __shared__ __attribute__((aligned(16))) float lds_wf[2 * 16 * 64 * 4];
+    __shared__ float lds_wr[64 * CB_WR_STRIDE];
+    __shared__ float lds_vec[3 * 64];
+    __shared__ __attribute__((aligned(16))) float lds_dz[4 * 2 * CBF_TILE];      // [pair][buffer][tile]; the weight waves' fold afterwards
+    __shared__ int lds_flag[4 * 2];
+    const int tid = threadIdx.x;
+    for (int idx4 = tid; idx4 < 2 * 16 * 64; idx4 += blockDim.x) {
+        const int l = idx4 & 63, c = (idx4 >> 6) & 15, m = idx4 >> 10;
+        reinterpret_cast<float4 *>(lds_wf)[idx4] =
+            *reinterpret_cast<const float4 *>(p.weight + (32 * m + (l & 31)) * 128 + 8 * c + 4 * (l >> 5));
+    }
+    for (int idx = tid; idx < 64 * 128; idx += blockDim.x) lds_wr[(idx >> 7) * CB_WR_STRIDE + (idx & 127)] = p.weight[idx];
+    if (tid < 64) {
+        lds_vec[tid] = p.bias ? p.bias[tid] : 0.f;
+        lds_vec[64 + tid] = (p.flags & CB_LN) ? p.ln_w[tid] : 1.f;
+        lds_vec[128 + tid] = (p.flags & CB_LN) ? p.ln_b[tid] : 0.f;
+    }
+    if (tid < 8) lds_flag[tid] = 0;
+    __syncthreads();
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool rows_role = wave < 4;
+    const int pair = wave & 3;
+    const long long ntile = (p.rows + 31) / 32;
+    const long long tstride = (long long)gridDim.x * 4;
+    float *const my_dz = lds_dz + pair * 2 * CBF_TILE;
+    int *const my_flag = lds_flag + pair * 2;
+    // (each role's persistent registers -- d gamma / d beta partials here, the 128 accumulators of dW there -- live in its own branch
+    // only; both branches pass the same five workgroup barriers)
+    float *const lds_dw = lds_dz;
+    if (rows_role) {
+        float dgam[2][16], dbet[2][16];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dgam[m][r] = 0.f, dbet[m][r] = 0.f;
+        const int j = lane & 31, h = lane >> 5;
+        const float4 *w4 = reinterpret_cast<const float4 *>(lds_wf);
+        int buf = 0;
+        // One rows wave per SIMD has nobody to hide its loads behind (the two-launch form ran two): the NEXT tile's x and agg rows are
+        // requested once this tile's LayerNorm backward is through (their registers are free after the recompute, and the
+        // LayerNorm phase is the register peak) and arrive under the 128 matrix instructions of d[x ; agg]; this tile's grad_out
+        // rows are requested at the top and arrive under the recompute's 128.
+        float4 bx[8], ba[8], g4[8];
+        const auto row_of = [&](const long long tile) {
+            const long long row = tile * 32 + j;
+            return row < p.rows ? row : p.rows - 1;
+        };
+        const auto load_xa = [&](const long long tile, float4 (&tx)[8], float4 (&ta)[8]) {
+            const float4 *xr = reinterpret_cast<const float4 *>(p.x + row_of(tile) * 64);
+            const float4 *ar = reinterpret_cast<const float4 *>(p.agg + row_of(tile) * 64);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tx[i] = xr[2 * i + h];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ta[i] = ar[2 * i + h];
+        };
+        const auto load_g = [&](const long long tile, float4 (&tg)[8]) {
+            // the incoming gradient in the accumulator layout: features 32 m + 8 g + 4 h .. + 3
+            const float4 *gr = reinterpret_cast<const float4 *>(p.gout + row_of(tile) * 64);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tg[i] = gr[8 * (i >> 2) + 2 * (i & 3) + h];
+        };
+        long long tile = blockIdx.x + (long long)gridDim.x * pair;
+        if (tile < ntile) load_xa(tile, bx, ba);
+        for (; tile < ntile; tile += tstride, buf ^= 1) {
+            const long long row = tile * 32 + j;
+            const bool valid = row < p.rows;
+            const long long tnext = tile + tstride < ntile ? tile + tstride : tile;      // (past the end: a harmless reload)
+            load_g(tile, g4);      // (needed after the recompute: arrives under its 128 matrix instructions)
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
+            if (p.flags & CB_DBG_NO_Z_MFMA) {      // (timing-only build switch: wrong results)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc0[c] = bx[c].x + ba[c].y, acc1[c] = bx[c].z + ba[c].w;
+            } else
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const float4 b = c < 8 ? bx[c] : ba[c - 8];
+                const float4 a0 = w4[(0 * 16 + c) * 64 + lane];
+                const float4 a1 = w4[(1 * 16 + c) * 64 + lane];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float v[2][16], d[2][16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v[0][r] = acc0[r] + lds_vec[cb_feat(0, r, h)];
+                v[1][r] = acc1[r] + lds_vec[cb_feat(1, r, h)];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                d[i >> 2][4 * (i & 3) + 0] = g4[i].x;
+                d[i >> 2][4 * (i & 3) + 1] = g4[i].y;
+                d[i >> 2][4 * (i & 3) + 2] = g4[i].z;
+                d[i >> 2][4 * (i & 3) + 3] = g4[i].w;
+            }
+            float rstd = 1.f;
+            if (p.flags & CB_LN) {
+                float s1 = 0.f;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s1 += v[m][r];
+                s1 += __shfl_xor(s1, 32);
+                const float mean = s1 * (1.f / 64.f);
+                float s2 = 0.f;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        v[m][r] -= mean;
+                        s2 += v[m][r] * v[m][r];
+                    }
+                s2 += __shfl_xor(s2, 32);
+                rstd = 1.f / sqrtf(s2 * (1.f / 64.f) + p.eps);
+            }
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = cb_feat(m, r, h);
+                    const float gam = lds_vec[64 + f], bet = lds_vec[128 + f];
+                    const float zh = (p.flags & CB_LN) ? v[m][r] * rstd : v[m][r];
+                    const float y = (p.flags & CB_LN) ? zh * gam + bet : zh;
+                    float dy = d[m][r];
+                    if ((p.flags & CB_RELU) && !(y > 0.f)) dy = 0.f;
+                    if (!valid) dy = 0.f;
+                    if (p.flags & CB_LN) {
+                        dgam[m][r] += dy * zh;
+                        dbet[m][r] += dy;
+                        dy *= gam;
+                        m1 += dy;
+                        m2 += dy * zh;
+                    }
+                    v[m][r] = zh;
+                    d[m][r] = dy;
+                }
+            if (p.flags & CB_LN) {
+                m1 += __shfl_xor(m1, 32);
+                m2 += __shfl_xor(m2, 32);
+                m1 *= (1.f / 64.f);
+                m2 *= (1.f / 64.f);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) d[m][r] = rstd * (d[m][r] - m1 - v[m][r] * m2);
+            }
+            // (this tile's x and agg rows were consumed by the recompute: their registers take the next tile's, which arrive under the
+            // 128 matrix instructions of d[x ; agg] below)
+            __builtin_amdgcn_sched_barrier(0);
+            load_xa(tnext, bx, ba);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- dz to the pair's buffer (an invalid row parks zeros: dy was zeroed above) ----
+            while (__hip_atomic_load(my_flag + buf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) __builtin_amdgcn_s_sleep(1);
+            {
+                float *dst = my_dz + buf * CBF_TILE + j * 64;
+                const int swap = 32 * (j & 1);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4 *>(dst + ((32 * m + 8 * g + 4 * h) ^ swap)) =
+                            make_float4(d[m][4 * g + 0], d[m][4 * g + 1], d[m][4 * g + 2], d[m][4 * g + 3]);
+            }
+            if (lane == 0) __hip_atomic_store(my_flag + buf, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // ---- d[x ; agg] = dz . W ----
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                // (the residual's share of gx -- grad_out itself -- is the chain's starting value: accumulator element 4 g + c of
+                // tile kt is feature 32 kt + 8 g + 4 h + c of this lane's row, the layout grad_out was loaded in; its registers are
+                // then free for the whole product)
+                f32x16 o0, o1;
+                const bool res = half == 0 && (p.flags & CB_RESIDUAL);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    o0[4 * g + 0] = res ? g4[g].x : 0.f, o0[4 * g + 1] = res ? g4[g].y : 0.f;
+                    o0[4 * g + 2] = res ? g4[g].z : 0.f, o0[4 * g + 3] = res ? g4[g].w : 0.f;
+                    o1[4 * g + 0] = res ? g4[4 + g].x : 0.f, o1[4 * g + 1] = res ? g4[4 + g].y : 0.f;
+                    o1[4 * g + 2] = res ? g4[4 + g].z : 0.f, o1[4 * g + 3] = res ? g4[4 + g].w : 0.f;
+                }
+                if (!(p.flags & CB_DBG_NO_DX_MFMA))      // (timing-only build switch: wrong results)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float *wrow = lds_wr + cb_feat(m, r, h) * CB_WR_STRIDE + 64 * half + j;
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[0], d[m][r], o0, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[32], d[m][r], o1, 0, 0, 0);
+                        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    }
+                float *dst = (half == 0 ? p.gx : p.gagg) + row * 64;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x16 &o = kt == 0 ? o0 : o1;
+                        if (valid)
+                            *reinterpret_cast<float4 *>(dst + 32 * kt + 8 * g + 4 * h) =
+                                make_float4(o[4 * g + 0], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
+                    }
+            }
+        }
+        __syncthreads();      // (1) every tile done: the weight copies and the dz buffers are free
+        // ---- d gamma / d beta: each rows wave through its 8 KB of lds_wf, then over the waves ----
+        {
+            float *mine = lds_wf + pair * 32 * 64;
+            for (int which = 0; which < 2; ++which) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mine[(16 * m + r) * 64 + lane] = which == 0 ? dgam[m][r] : dbet[m][r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                const int reg = lane & 31, hq = lane >> 5;
+                float sum = 0.f;
+                for (int q = 0; q < 32; ++q) sum += mine[reg * 64 + hq * 32 + ((q + lane) & 31)];
+                lds_wr[(pair * 2 + which) * 64 + cb_feat(reg >> 4, reg & 15, hq)] = sum;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        for (int w = 0; w < 4; ++w) __syncthreads();      // (2 - 5) the weight waves' fold
+    } else {
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][kt][r] = 0.f;
+        float dbias[2] = {0.f, 0.f};
+        const int n = lane & 31, hh = lane >> 5;
+        // B operands ([x ; agg] as 128-byte row segments) of four contraction steps (8 rows) at a time; the next group -- across
+        // tile boundaries too -- is requested before the 32 matrix instructions of the current one
+        struct Group {
+            float b[4][4];
+        };
+        const auto load_group = [&](Group &g, const long long tile, const int s4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long row = tile * 32 + 2 * (4 * s4 + u) + hh;
+                const long long rc = row < p.rows ? row : p.rows - 1;      // (past the end: dz there is zero)
+                const float *xr = p.x + rc * 64 + n, *ar = p.agg + rc * 64 + n;
+                g.b[u][0] = xr[0], g.b[u][1] = xr[32], g.b[u][2] = ar[0], g.b[u][3] = ar[32];
+            }
+        };
+        long long tile = blockIdx.x + (long long)gridDim.x * pair;
+        Group cur;
+        if (tile < ntile) load_group(cur, tile, 0);
+        int buf = 0;
+        for (; tile < ntile; tile += tstride, buf ^= 1) {
+            const float *dzt = my_dz + buf * CBF_TILE;
+            while (__hip_atomic_load(my_flag + buf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 1) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                Group nxt;
+                {
+                    const bool last = s4 == 3;
+                    const long long tn = last ? tile + tstride : tile;
+                    load_group(nxt, tn < ntile ? tn : tile, last ? 0 : s4 + 1);      // (past the end: a harmless reload)
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rt = 2 * (4 * s4 + u) + hh;          // row inside the tile; odd rows hold their halves swapped
+                    const float a0 = dzt[rt * 64 + (n ^ (32 * hh))], a1 = dzt[rt * 64 + ((32 + n) ^ (32 * hh))];
+                    dbias[0] += a0;
+                    dbias[1] += a1;
+                    if (p.flags & CB_DBG_NO_W_MFMA) {      // (timing-only build switch: wrong results)
+                        acc[0][0][0] += a0 * cur.b[u][0] + a1 * cur.b[u][1] + cur.b[u][2] + cur.b[u][3];
+                        continue;
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) {
+                        acc[0][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, cur.b[u][kt], acc[0][kt], 0, 0, 0);
+                        acc[1][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, cur.b[u][kt], acc[1][kt], 0, 0, 0);
+                    }
+                }
+                cur = nxt;
+            }
+            // (LDS operations of a wave execute in order: the reads above are done when this store is)
+            if (lane == 0) __hip_atomic_store(my_flag + buf, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        dbias[0] += __shfl_xor(dbias[0], 32);
+        dbias[1] += __shfl_xor(dbias[1], 32);
+        __syncthreads();      // (1)
+        // the weight waves fold their accumulators into the (now free) dz buffers one after the other: a fixed order
+        for (int w = 0; w < 4; ++w) {
+            if (pair == w) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int idx = cb_feat(m, r, hh) * 128 + 32 * kt + n;
+                            lds_dw[idx] = w == 0 ? acc[m][kt][r] : lds_dw[idx] + acc[m][kt][r];
+                        }
+                if (hh == 0) {
+                    lds_dw[64 * 128 + n] = w == 0 ? dbias[0] : lds_dw[64 * 128 + n] + dbias[0];
+                    lds_dw[64 * 128 + 32 + n] = w == 0 ? dbias[1] : lds_dw[64 * 128 + 32 + n] + dbias[1];
+                }
+            }
+            __syncthreads();      // (2 - 5)
+        }
+    }
+    float *dst = p.part + (long long)blockIdx.x * CB_PART;
+    for (int idx = tid; idx < 64 * 128 + 64; idx += blockDim.x) dst[idx] = lds_dw[idx];
+    if (tid < 128) {
+        const int which = tid >> 6, f = tid & 63;
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += lds_wr[(w * 2 + which) * 64 + f];
+        dst[64 * 128 + 64 + tid] = s;
+    }
+}
+
 // 64 consecutive entries per workgroup; the partials are split over sixteen thread groups (q, q + 16, q + 32, ... in
 // ascending order each, four loads in flight), folded 0 + 1 + ... + 15 through LDS: a fixed order, reproducible run to run.
 __global__ void __launch_bounds__(1024) conv_update_bwd_reduce_kernel(const ConvBwdParams p) {
@@ -467,8 +805,17 @@ int32_t ultra_conv_update_backward(const void *x, const void *agg, const void *g
     p.flags = flags;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(conv_update_bwd_rows_kernel, dim3(p.n_part), dim3(64 * shape.wpb_rows), 0, s, p);
-    hipLaunchKernelGGL(conv_update_bwd_weights_kernel, dim3(p.n_part), dim3(64 * shape.wpb_weights), 0, s, p);
+    // ULTRA_CONV_BWD_FUSED=0: rows kernel and weights kernel as two launches (round 5's form, dz through memory)
+    static const bool fused = [] {
+        const char *e = getenv("ULTRA_CONV_BWD_FUSED");
+        return !(e && e[0] == '0');
+    }();
+    if (fused) {
+        hipLaunchKernelGGL(conv_update_bwd_fused_kernel, dim3(p.n_part), dim3(512), 0, s, p);
+    } else {
+        hipLaunchKernelGGL(conv_update_bwd_rows_kernel, dim3(p.n_part), dim3(64 * shape.wpb_rows), 0, s, p);
+        hipLaunchKernelGGL(conv_update_bwd_weights_kernel, dim3(p.n_part), dim3(64 * shape.wpb_weights), 0, s, p);
+    }
     hipLaunchKernelGGL(conv_update_bwd_reduce_kernel, dim3(CB_PART / 64), dim3(1024), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
