@@ -86,6 +86,11 @@ int32_t ultra_readout(const void *hidden, const int64_t *t_index, const void *w1
  */
 int32_t ultra_batch_prologue(const int64_t *triples, int64_t batch, int64_t n_cand, int64_t num_direct_rel, int64_t *h0,
                              int64_t *r0, int32_t *side, int32_t *valid, int64_t *rel_first, void *stream);
+/* ultra_batch_prologue with one more output for the training step (rows of a few hundred candidates): cand (batch, n_cand)
+ * int64 = the candidate nodes of the converted rows, new_t_index of /root/reference/ultra/base_nbfnet.py:84 (the tail where
+ * side[b] = 1, the head otherwise).  cand may be NULL. */
+int32_t ultra_batch_prologue_rows(const int64_t *triples, int64_t batch, int64_t n_cand, int64_t num_direct_rel, int64_t *h0,
+                                  int64_t *r0, int32_t *side, int32_t *valid, int64_t *rel_first, int64_t *cand, void *stream);
 int32_t ultra_readout_batch(const void *hidden, const int64_t *triples, const int32_t *side, const void *w1, const void *query,
                             const void *b1, const void *w2, const void *b2, const int32_t *order_dev, int64_t order_len,
                             void *score, int64_t batch, int64_t num_node, int64_t n_cand, int32_t hidden_dim,
@@ -109,6 +114,16 @@ int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void *values, in
 int32_t ultra_edge_keep_mask(const int64_t *head, const int64_t *tail, const int64_t *type, int64_t num_edge,
                              const int64_t *easy_key_sorted, int64_t n_easy, int64_t num_node, int64_t num_rel, void *keep,
                              void *stream);
+/*
+ * The same vector straight from the batch's triples (base_nbfnet.py:57-59 builds the list: every (h, t, r) of the batch and
+ * its inverse (t, h, r + inverse_offset), inverse_offset = num_relations / 2): h, t, r point at the first of n_triple <= 4096
+ * int64 ids each, `stride` elements apart (3 for the columns of a contiguous (batch, n, 3) tensor, 1 for separate vectors).
+ * Every workgroup hashes the 2 n_triple keys into a table in LDS and looks each of its edges up: no list, no sort.
+ * type == NULL / r == NULL (`remove_one_hop`): keys of (head, tail) alone.  Same keys, same result as ultra_edge_keep_mask.
+ */
+int32_t ultra_easy_edge_keep(const int64_t *head, const int64_t *tail, const int64_t *type, int64_t num_edge, const int64_t *h,
+                             const int64_t *t, const int64_t *r, int64_t n_triple, int64_t stride, int64_t num_node,
+                             int64_t num_rel, int64_t inverse_offset, void *keep, void *stream);
 
 /*
  * Boundary condition of EntityNBFNet (/root/reference/ultra/models.py:131-141) with the query gather fused:

@@ -203,6 +203,48 @@ def gen_negative_sampling():
                os.path.join(HERE, "negative_sampling.pt"))
 
 
+def gen_easy_edges():
+    """BaseNBFNet.remove_easy_edges (base_nbfnet.py:54-77) of the unchanged reference: the filtered edge list for batches of
+    positives that ARE graph edges plus their strict negatives (tail and head halves), with and without remove_one_hop."""
+    import types
+    from torch_geometric.data import Data
+    from ultra import tasks as ref_tasks
+    from ultra.base_nbfnet import BaseNBFNet
+    from ultra_amd import synthetic
+    kg = synthetic.make_kg(num_node=300, num_triple=5000, num_relation_base=6, num_test=16, seed=41, relation_graph=False)
+    ei, et = kg.edge_index.clone(), kg.edge_type.clone()
+    half = ei.shape[1] // 2
+    ei[:, 7] = ei[:, 5]                                # a duplicate edge (both copies go) ...
+    et[7] = et[5]
+    ei[:, 9] = ei[:, 5]                                # ... and the same pair under another relation (goes with remove_one_hop only)
+    et[9] = (et[5] + 1) % (kg.num_relations // 2)
+    data = Data(edge_index=ei, edge_type=et, num_nodes=kg.num_nodes, num_relations=kg.num_relations)
+    triples = torch.stack([ei[0, :half], ei[1, :half], et[:half]], dim=-1)
+    cases = []
+    for bs, num_negative, one_hop, seed in ((8, 32, False, 201), (8, 32, True, 202), (5, 256, False, 203), (2, 3, True, 204),
+                                            (1, 1, False, 205)):
+        g = torch.Generator().manual_seed(seed)
+        pick = torch.randint(0, half, (bs,), generator=g)
+        pick[0] = 5
+        torch.manual_seed(seed)
+        batch = ref_tasks.negative_sampling(data, triples[pick], num_negative, strict=True)
+        h, t, r = batch.unbind(-1)
+        out = BaseNBFNet.remove_easy_edges(types.SimpleNamespace(remove_one_hop=one_hop), data, h, t, r)
+        # (the filter keeps the order and identical edges go or stay together: the kept list read back as a mask over the edges)
+        full = torch.cat([ei, et.unsqueeze(0)]).t().tolist()
+        kept = torch.cat([out.edge_index, out.edge_type.unsqueeze(0)]).t().tolist()
+        keep, j = [], 0
+        for row in full:
+            hit = j < len(kept) and kept[j] == row
+            keep.append(hit)
+            j += hit
+        assert j == len(kept)
+        cases.append(dict(batch=batch, remove_one_hop=one_hop, keep=torch.tensor(keep)))
+        print("remove_easy_edges", bs, num_negative, one_hop, ei.shape[1], "->", out.edge_index.shape[1])
+    torch.save(dict(edge_index=ei, edge_type=et, num_nodes=kg.num_nodes, num_relations=kg.num_relations, cases=cases),
+               os.path.join(HERE, "easy_edges.pt"))
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden generation needs the reference checkout at /root/reference"
     torch.manual_seed(0)     # negative_sampling draws from the global generator
@@ -212,8 +254,12 @@ if __name__ == "__main__":
     if "--only-negative-sampling" in sys.argv:
         gen_negative_sampling()
         sys.exit(0)
+    if "--only-easy-edges" in sys.argv:
+        gen_easy_edges()
+        sys.exit(0)
     gen_rspmm()
     gen_models()
     gen_query_nbfnet()
     gen_relation_projection()
     gen_negative_sampling()
+    gen_easy_edges()

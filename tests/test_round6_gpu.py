@@ -310,3 +310,60 @@ def test_strict_sampler_kernel_replays_the_reference_batches(dev):
         assert torch.equal(neg_h.cpu(), want[half:, 1:, 0]), "heads, %d negatives" % n_neg
         checked += 1
     assert checked == 4
+
+
+@pytest.mark.parametrize("route", ["hash", "sorted"])
+def test_edge_keep_vector_marks_the_edges_the_reference_removes(dev, route):
+    """The training step's 0/1 edge vector (ultra_easy_edge_keep: the batch's triples hashed in LDS; ultra_edge_keep_mask: the
+    sorted key list) against which edges the REFERENCE's remove_easy_edges left in the graph (tests/golden/easy_edges.pt,
+    recorded by gen_golden.py from base_nbfnet.py:54-77)."""
+    from tests.test_tasks import easy_edges_golden
+    from ultra_amd import dense, models
+    data, cases = easy_edges_golden()
+    data = data.to(dev)
+    models.EASY_EDGE_KEEP_KERNEL = route == "hash"
+    try:
+        for case in cases:
+            model = models.EntityNBFNet(64, [64] * 2, remove_one_hop=case["remove_one_hop"])
+            batch = case["batch"].to(dev)
+            h, t, r = batch.unbind(-1)                       # (columns of the contiguous batch: stride 3)
+            got = model.easy_edge_keep(data, h, t, r)
+            assert got.dtype == torch.float32 and torch.equal(got.bool().cpu(), case["keep"])
+            got = model.easy_edge_keep(data, h.contiguous(), t.contiguous(), r.contiguous())      # (stride 1)
+            assert torch.equal(got.bool().cpu(), case["keep"])
+    finally:
+        models.EASY_EDGE_KEEP_KERNEL = True
+    if route == "hash":
+        # the entry itself took the batch (not the fallback), and a list beyond its table is declined, not truncated
+        case = cases[0]
+        h, t, r = case["batch"].to(dev).unbind(-1)
+        assert dense.easy_edge_keep(data.edge_index, data.edge_type, h, t, r, data.num_nodes, data.num_relations) is not None
+        big = case["batch"].to(dev).repeat(1, 20, 1)
+        h, t, r = big.unbind(-1)
+        assert 2 * h.numel() > dense.EDGE_KEEP_MAX_EASY
+        assert dense.easy_edge_keep(data.edge_index, data.edge_type, h, t, r, data.num_nodes, data.num_relations) is None
+
+
+def test_batch_prologue_converts_the_rows_as_the_reference_does(dev):
+    """ultra_batch_prologue_rows (h0, r0, the converted rows' candidates, the validity flag) against negative_sample_to_tail as
+    restated in the oracle (oracle/ultra_oracle_model.py, base_nbfnet.py:79-86), on the reference-recorded batches of
+    tests/golden/negative_sampling.pt (tail rows in the first half, head rows in the second)."""
+    from oracle import ultra_oracle_model
+    from tests.test_tasks import _negative_sampling_golden
+    from ultra_amd import dense
+    data, cases = _negative_sampling_golden()
+    num_direct = data.num_relations // 2
+    for case in cases:
+        batch = case["out"]
+        h, t, r = ultra_oracle_model.negative_sample_to_tail(*batch.unbind(-1), num_direct)
+        pro = dense.batch_prologue(batch.to(dev), num_direct, candidates=True)
+        assert torch.equal(pro[1].cpu(), h[:, 0]) and torch.equal(pro[2].cpu(), r[:, 0])
+        assert torch.equal(pro.cand.cpu(), t)
+        assert bool(pro[4].all())
+        assert (h == h[:, :1]).all() and (r == r[:, :1]).all()
+    # a row with neither a shared head nor a shared tail is reported, not converted silently
+    bad = cases[0]["out"].clone()
+    bad[1, 3, 0] += 1
+    bad[1, 4, 1] += 1
+    pro = dense.batch_prologue(bad.to(dev), num_direct, candidates=True)
+    assert pro[4].cpu().tolist() == [1] + [0] + [1] * (len(bad) - 2)

@@ -103,3 +103,26 @@ def test_negative_sampling_replays_the_reference_draws():
             half = len(case["batch"]) // 2
             assert all(t_mask[i, got[i, 1:, 1]].all() for i in range(half))
             assert all(h_mask[i, got[i, 1:, 0]].all() for i in range(half, len(case["batch"])))
+
+
+def easy_edges_golden():
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "easy_edges.pt"))
+    data = Data(edge_index=g["edge_index"], edge_type=g["edge_type"], num_nodes=g["num_nodes"], num_relations=g["num_relations"])
+    return data, g["cases"]
+
+
+def test_easy_edge_mask_keeps_the_edges_the_reference_keeps():
+    """tests/golden/easy_edges.pt: five batches (positives that are graph edges + strict negatives, both halves; a duplicated
+    edge; the same pair under another relation) and, per batch, which edges the REFERENCE's BaseNBFNet.remove_easy_edges
+    (base_nbfnet.py:54-77) left in the graph (gen_golden.py: gen_easy_edges).  models.BaseNBFNet.easy_edge_mask marks the same."""
+    from ultra_amd import models
+    data, cases = easy_edges_golden()
+    assert {c["remove_one_hop"] for c in cases} == {False, True}
+    for case in cases:
+        model = models.EntityNBFNet(64, [64] * 2, remove_one_hop=case["remove_one_hop"])
+        h, t, r = case["batch"].unbind(-1)
+        assert torch.equal(model.easy_edge_mask(data, h, t, r), case["keep"])
+        assert 0 < int((~case["keep"]).sum()) < 100
+        kept = model.remove_easy_edges(data, h, t, r)
+        assert torch.equal(kept.edge_index, data.edge_index[:, case["keep"]])
+        assert torch.equal(kept.edge_type, data.edge_type[case["keep"]])

@@ -108,6 +108,7 @@ def _load():
     lib.ultra_conv_update_backward_workspace.restype = i64
     lib.ultra_conv_update_backward.argtypes = [vp] * 14 + [i64, i64, i32, i32, ctypes.c_float, i32, vp]
     lib.ultra_edge_keep_mask.argtypes = [vp, vp, vp, i64, vp, i64, i64, i64, vp, vp]
+    lib.ultra_easy_edge_keep.argtypes = [vp, vp, vp, i64, vp, vp, vp, i64, i64, i64, i64, i64, vp, vp]
     lib.ultra_readout.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, i32, i32, vp]
     lib.ultra_stream_copy.argtypes = [vp, vp, i64, vp]
     lib.ultra_filtered_rank.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
@@ -115,6 +116,7 @@ def _load():
     lib.ultra_ranking_loss.argtypes = [vp, i64, i64, ctypes.c_float, ctypes.c_float, vp, vp, vp]
     lib.ultra_onehot_rows.argtypes = [vp, vp, vp, i64, i64, i64, vp]
     lib.ultra_batch_prologue.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
+    lib.ultra_batch_prologue_rows.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]
     lib.ultra_readout_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, i32, i32, vp]
     lib.ultra_query_boundary.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp]
     lib.ultra_relation_projection.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]

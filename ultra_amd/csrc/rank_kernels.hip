@@ -58,10 +58,14 @@ __global__ void __launch_bounds__(256) filtered_rank_kernel(const float *__restr
 // through device-scope atomics -- 15.6 us; 64 workgroups per row with coalesced loads -- 38.7 us: the 64 arrival tickets of
 // a row are atomics on ONE address issued from eight XCDs, which the memory side serialises at ~0.5 us apiece.
 // rel_first[b] (optional) = the row's relation as given, triples[b, 0, 2]: the relation model's query (models.py:20).
+// cand[b][i] (optional; the training step, where a row is a few hundred candidates) = candidate node i of the converted row:
+// its tail in a tail-prediction row, its head otherwise (new_t_index of base_nbfnet.py:84) -- a second pass over the row the
+// workgroup has just read.
 constexpr int PROLOGUE_THREADS = 1024;
 __global__ void __launch_bounds__(PROLOGUE_THREADS) batch_prologue_kernel(const int64_t *__restrict__ batch, long long n_cand,
                                                                          long long num_direct_rel, int64_t *h0, int64_t *r0,
-                                                                         int32_t *side, int32_t *valid, int64_t *rel_first) {
+                                                                         int32_t *side, int32_t *valid, int64_t *rel_first,
+                                                                         int64_t *cand) {
     __shared__ int lds_bad[3];
     const int b = blockIdx.x;
     const long long L = 3 * n_cand;
@@ -117,13 +121,17 @@ __global__ void __launch_bounds__(PROLOGUE_THREADS) batch_prologue_kernel(const 
         valid[b] = ((any_h == 0 || any_t == 0) && any_r == 0) ? 1 : 0;
         if (rel_first) rel_first[b] = fr;
     }
+    if (cand) {
+        const int col = lds_bad[0] == 0 ? 1 : 0;
+        for (long long c2 = threadIdx.x; c2 < n_cand; c2 += PROLOGUE_THREADS) cand[(long long)b * n_cand + c2] = row[3 * c2 + col];
+    }
 }
 
 }  // namespace ultra
 
-extern "C" int32_t ultra_batch_prologue(const int64_t *batch, int64_t batch_size, int64_t n_cand, int64_t num_direct_rel,
-                                        int64_t *h0, int64_t *r0, int32_t *side, int32_t *valid, int64_t *rel_first,
-                                        void *stream) {
+extern "C" int32_t ultra_batch_prologue_rows(const int64_t *batch, int64_t batch_size, int64_t n_cand, int64_t num_direct_rel,
+                                             int64_t *h0, int64_t *r0, int32_t *side, int32_t *valid, int64_t *rel_first,
+                                             int64_t *cand, void *stream) {
     ULTRA_DEVICE_SCOPE(stream, batch);
     if (!batch || !h0 || !r0 || !side || !valid || batch_size < 0 || n_cand <= 0) {
         ultra::set_error("ultra_batch_prologue: NULL operand or empty candidate set");
@@ -133,12 +141,18 @@ extern "C" int32_t ultra_batch_prologue(const int64_t *batch, int64_t batch_size
     if (batch_size == 0) return ULTRA_OK;
     (void)hipGetLastError();   // drop any stale error left by other users of the runtime
     hipLaunchKernelGGL(ultra::batch_prologue_kernel, dim3((unsigned)batch_size), dim3(ultra::PROLOGUE_THREADS), 0, s, batch, (long long)n_cand,
-                       (long long)num_direct_rel, h0, r0, side, valid, rel_first);
+                       (long long)num_direct_rel, h0, r0, side, valid, rel_first, cand);
     if (hipGetLastError() != hipSuccess) {
         ultra::set_error("batch_prologue_kernel launch failed");
         return ULTRA_ERR_HIP;
     }
     return ULTRA_OK;
+}
+
+extern "C" int32_t ultra_batch_prologue(const int64_t *batch, int64_t batch_size, int64_t n_cand, int64_t num_direct_rel,
+                                        int64_t *h0, int64_t *r0, int32_t *side, int32_t *valid, int64_t *rel_first,
+                                        void *stream) {
+    return ultra_batch_prologue_rows(batch, batch_size, n_cand, num_direct_rel, h0, r0, side, valid, rel_first, nullptr, stream);
 }
 
 extern "C" int32_t ultra_filtered_rank(const void *score, const int64_t *pos_index, const int64_t *known_ptr,

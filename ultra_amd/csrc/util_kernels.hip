@@ -141,7 +141,90 @@ __global__ void __launch_bounds__(256) edge_keep_mask_kernel(const long long *he
     }
 }
 
+// edge_keep_mask_kernel with the list built in place: every workgroup hashes the batch's 2 n_triple keys ((h, t, r) and
+// (t, h, r + inverse_offset), base_nbfnet.py:57-59) into an open-addressing table in LDS (16,384 slots for <= 8,192 keys) and
+// probes it once per edge -- no concatenations, no key arithmetic in torch, no sort: one launch instead of ~ 20.
+constexpr int EASY_SLOTS = 16384;
+constexpr int EASY_THREADS = 1024;
+__device__ __forceinline__ unsigned easy_slot(const unsigned long long key) {
+    return (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 50);      // top 14 bits
+}
+__global__ void __launch_bounds__(EASY_THREADS) easy_edge_keep_kernel(const long long *head, const long long *tail, const long long *type,
+                                                                     long long num_edge, const long long *qh, const long long *qt,
+                                                                     const long long *qr, int n_triple, long long stride,
+                                                                     long long num_node, long long num_rel, long long inverse_offset,
+                                                                     float *keep) {
+    __shared__ unsigned long long table[EASY_SLOTS];
+    constexpr unsigned long long EMPTY = ~0ull;
+    for (int i = threadIdx.x; i < EASY_SLOTS; i += EASY_THREADS) table[i] = EMPTY;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * n_triple; i += EASY_THREADS) {
+        const int j = i < n_triple ? i : i - n_triple;
+        long long a = qh[j * stride], b = qt[j * stride];
+        long long key;
+        if (i >= n_triple) {
+            const long long s = a;
+            a = b;
+            b = s;
+        }
+        key = a * num_node + b;
+        if (type) key = key * num_rel + qr[j * stride] + (i >= n_triple ? inverse_offset : 0);
+        if (key < 0) continue;               // (no edge of a valid graph has a negative key)
+        unsigned slot = easy_slot((unsigned long long)key);
+        while (true) {
+            const unsigned long long old = atomicCAS(&table[slot], EMPTY, (unsigned long long)key);
+            if (old == EMPTY || old == (unsigned long long)key) break;
+            slot = (slot + 1) & (EASY_SLOTS - 1);
+        }
+    }
+    __syncthreads();
+    for (long long e = blockIdx.x * (long long)EASY_THREADS + threadIdx.x; e < num_edge; e += (long long)gridDim.x * EASY_THREADS) {
+        long long key = head[e] * num_node + tail[e];
+        if (type) key = key * num_rel + type[e];
+        unsigned slot = easy_slot((unsigned long long)key);
+        float k = 1.f;
+        while (true) {
+            const unsigned long long seen = table[slot];
+            if (seen == EMPTY) break;
+            if (seen == (unsigned long long)key) {
+                k = 0.f;
+                break;
+            }
+            slot = (slot + 1) & (EASY_SLOTS - 1);
+        }
+        keep[e] = k;
+    }
+}
+
 }  // namespace ultra
+
+extern "C" int32_t ultra_easy_edge_keep(const int64_t *head, const int64_t *tail, const int64_t *type, int64_t num_edge,
+                                        const int64_t *h, const int64_t *t, const int64_t *r, int64_t n_triple, int64_t stride,
+                                        int64_t num_node, int64_t num_rel, int64_t inverse_offset, void *keep, void *stream) {
+    ULTRA_DEVICE_SCOPE(stream, keep);
+    if (!head || !tail || !keep || num_edge < 0 || n_triple < 0 || (n_triple > 0 && (!h || !t)) || stride <= 0 || num_node <= 0 ||
+        (type && (num_rel <= 0 || !r))) {
+        ultra::set_error("ultra_easy_edge_keep: NULL operand or empty key space");
+        return ULTRA_ERR_INVALID;
+    }
+    if (2 * n_triple > ultra::EASY_MAX) {
+        ultra::set_error("ultra_easy_edge_keep: more than 8192 edges to match");
+        return ULTRA_ERR_UNSUPPORTED;
+    }
+    if (num_edge == 0) return ULTRA_OK;
+    (void)hipGetLastError();   // drop any stale error left by other users of the runtime
+    const long long want = (num_edge + ultra::EASY_THREADS - 1) / ultra::EASY_THREADS;
+    const unsigned blocks = (unsigned)(want < 256 ? want : 256);
+    hipLaunchKernelGGL(ultra::easy_edge_keep_kernel, dim3(blocks), dim3(ultra::EASY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const long long *)head, (const long long *)tail, (const long long *)type, (long long)num_edge,
+                       (const long long *)h, (const long long *)t, (const long long *)r, (int)n_triple, (long long)stride,
+                       (long long)num_node, (long long)num_rel, (long long)inverse_offset, (float *)keep);
+    if (hipGetLastError() != hipSuccess) {
+        ultra::set_error("easy_edge_keep_kernel launch failed");
+        return ULTRA_ERR_HIP;
+    }
+    return ULTRA_OK;
+}
 
 extern "C" int32_t ultra_onehot_rows(void *out, const int64_t *rows, const void *values, int64_t batch, int64_t num_node,
                                      int64_t dim, void *stream) {

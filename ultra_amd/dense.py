@@ -34,6 +34,12 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+def pick_rows(table, rows):
+    """table[b, rows[b], :] for every b -- table[arange(batch), rows] as ONE gather launch (no arange; under autograd its backward
+    is a zero fill + scatter_add of distinct rows, where advanced indexing's index_put_ sorts its indices first)."""
+    return table.gather(1, rows.view(-1, 1, 1).expand(-1, 1, table.shape[-1])).squeeze(1)
+
+
 def _conv_update_forward(x, agg, weight, bias, ln_w, ln_b, eps, flags):
     out = torch.empty_like(x)
     check(lib.ultra_conv_update(x.data_ptr(), agg.data_ptr(), weight.data_ptr(), _ptr(bias), _ptr(ln_w), _ptr(ln_b),
@@ -119,7 +125,7 @@ class TrainLayerFunction(torch.autograd.Function):
         values_grad = None
         if ctx.point_rows is not None and need[10]:
             r = ctx.point_rows
-            values_grad = gagg[torch.arange(r.shape[0], device=r.device), r]
+            values_grad = pick_rows(gagg, r)
         return (None, None, None, None, None, None, relation_grad if need[6] else None, x_grad if need[7] else None,
                 gagg if need[8] else None, None, values_grad, gw, gb, gln_w, gln_b)
 
@@ -253,6 +259,34 @@ def edge_keep_mask(edge_index, edge_type, easy_edge, num_node, num_relation, dty
     return keep if dtype == torch.float32 else keep.to(dtype)
 
 
+def easy_edge_keep(edge_index, edge_type, h_index, t_index, r_index, num_node, num_relation, dtype=torch.float32):
+    """edge_keep_mask straight from the batch's (h, t, r) -- the list of base_nbfnet.py:57-59 (every triple and its inverse) is
+    never built: one launch (ultra_easy_edge_keep).  h / t / r: equally shaped int64 GPU tensors that are either contiguous
+    or the columns of one contiguous (..., 3) tensor; None where that does not hold (the caller builds the list)."""
+    n = h_index.numel()
+    if not (edge_index.is_cuda and edge_index.dtype == torch.int64 and h_index.dtype == torch.int64 and h_index.is_cuda
+            and 0 < 2 * n <= EDGE_KEEP_MAX_EASY and h_index.shape == t_index.shape == r_index.shape
+            and int(num_node) ** 2 * max(int(num_relation), 1) < 2 ** 62):
+        return None
+    if h_index.is_contiguous() and t_index.is_contiguous() and r_index.is_contiguous():
+        stride = 1
+    else:
+        # columns of a contiguous (..., 3) tensor: element i of each sits 3 i elements behind its first
+        want = tuple(3 * s for s in torch.empty(h_index.shape, device="meta").stride())
+        if not (h_index.stride() == t_index.stride() == r_index.stride() == want):
+            return None
+        stride = 3
+    edge_index = edge_index.contiguous()
+    if edge_type is not None:
+        edge_type = edge_type.contiguous()
+    keep = torch.empty(edge_index.shape[1], dtype=torch.float32, device=edge_index.device)
+    check(lib.ultra_easy_edge_keep(edge_index[0].data_ptr(), edge_index[1].data_ptr(), _ptr(edge_type), edge_index.shape[1],
+                                   h_index.data_ptr(), t_index.data_ptr(), r_index.data_ptr() if edge_type is not None else None,
+                                   n, stride, int(num_node), int(num_relation), int(num_relation) // 2, keep.data_ptr(),
+                                   _stream(keep)))
+    return keep if dtype == torch.float32 else keep.to(dtype)
+
+
 def readout_supported(model, hidden):
     mlp = model.mlp
     return (hidden.is_cuda and hidden.dtype == torch.float32 and hidden.shape[-1] == 64 and not model.concat_hidden
@@ -301,19 +335,22 @@ class Prologue(tuple):
     rel_first = None
 
 
-def batch_prologue(batch, num_direct_rel):
-    """(batch, h0, r0, side, valid) of a (bs, n_cand, 3) GPU batch in one kernel (models.py:190-197, base_nbfnet.py:79-86)."""
+def batch_prologue(batch, num_direct_rel, candidates=False):
+    """(batch, h0, r0, side, valid) of a (bs, n_cand, 3) GPU batch in one kernel (models.py:190-197, base_nbfnet.py:79-86);
+    candidates=True: also `.cand`, the (bs, n_cand) candidate nodes of the converted rows (new_t_index, base_nbfnet.py:84)."""
     batch = batch.contiguous()
     bs, n_cand = batch.shape[:2]
+    cand = torch.empty(bs, n_cand, dtype=torch.long, device=batch.device) if candidates else None
     h0 = torch.empty(bs, dtype=torch.long, device=batch.device)
     r0 = torch.empty_like(h0)
     rel_first = torch.empty_like(h0)
     side = torch.empty(bs, dtype=torch.int32, device=batch.device)
     valid = torch.empty(bs, dtype=torch.int32, device=batch.device)
-    check(lib.ultra_batch_prologue(batch.data_ptr(), bs, n_cand, int(num_direct_rel), h0.data_ptr(), r0.data_ptr(),
-                                   side.data_ptr(), valid.data_ptr(), rel_first.data_ptr(), _stream(batch)))
+    check(lib.ultra_batch_prologue_rows(batch.data_ptr(), bs, n_cand, int(num_direct_rel), h0.data_ptr(), r0.data_ptr(),
+                                        side.data_ptr(), valid.data_ptr(), rel_first.data_ptr(), _ptr(cand), _stream(batch)))
     out = Prologue((batch, h0, r0, side, valid))
     out.rel_first = rel_first
+    out.cand = cand
     return out
 
 

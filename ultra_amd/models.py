@@ -25,6 +25,9 @@ PREFILL_LAYER0 = False
 CAPTURE_GENERIC_PATH = False
 # the six relation_projection MLPs of a training step as one autograd node (A/B switch for tests: two batched torch products are the other side)
 RELATION_PROJECTION_NODE = True
+# the training step's 0/1 edge vector straight from the batch's triples (dense.easy_edge_keep; A/B switch for tests: off = the
+# list of easy edges, its sorted keys and dense.edge_keep_mask)
+EASY_EDGE_KEEP_KERNEL = True
 
 
 class NotOnFusedPath(RuntimeError):
@@ -81,7 +84,13 @@ class BaseNBFNet(nn.Module):
         return ~index_to_mask(dropped, data.num_edges)
 
     def easy_edge_keep(self, data, h_index, t_index, r_index, dtype=torch.float32):
-        """easy_edge_mask as the 0/1 float vector the rspmm kernels read (dense.edge_keep_mask: one kernel on the GPU)."""
+        """easy_edge_mask as the 0/1 float vector the rspmm kernels read (dense.easy_edge_keep: one kernel on the GPU, the
+        batch's triples hashed in LDS; dense.edge_keep_mask -- a sorted list of keys -- for batches it does not take)."""
+        if EASY_EDGE_KEEP_KERNEL and data.edge_index.is_cuda:
+            keep = dense.easy_edge_keep(data.edge_index, None if self.remove_one_hop else data.edge_type, h_index, t_index,
+                                        r_index, data.num_nodes, data.num_relations, dtype)
+            if keep is not None:
+                return rspmm.tag_edge_weight(keep)
         easy = self._easy_edges(data, h_index, t_index, r_index)
         if data.edge_index.is_cuda and data.edge_index.dtype == torch.int64 and easy.shape[1] <= dense.EDGE_KEEP_MAX_EASY:
             keep = dense.edge_keep_mask(data.edge_index, None if self.remove_one_hop else data.edge_type, easy,
@@ -287,7 +296,8 @@ class EntityNBFNet(BaseNBFNet):
               and all(l.point_boundary_trains() for l in self.layers)):
             # training step: the query rows through autograd's gather, the boundary in closed form (its dense form, which
             # layer 0's update reads, is built from it once: PointBoundary.dense)
-            query = self.query[torch.arange(batch_size, device=r_index.device), r_index]
+            # (gather, not advanced indexing: its backward is one scatter_add instead of index_put_'s sort + ~ 10 launches)
+            query = dense.pick_rows(self.query, r_index)
             boundary = layers.PointBoundary(h_index, query, data.num_nodes)
         elif fused:
             # gather + scatter, one kernel
@@ -417,17 +427,23 @@ class EntityNBFNet(BaseNBFNet):
         # it drives the head->tail conversion (base_nbfnet.py:82) AND replaces the two asserts of models.py:196-197
         # (two host syncs in the middle of the forward there; here the flag is checked after the whole forward has
         # been enqueued): a converted row has a uniform head iff its heads or its tails were uniform.
-        same = (batch == batch[:, :1]).all(dim=1)                      # (bs, 3): h, t, r uniform?
-        is_t_neg = same[:, :1]
         num_direct_rel = data.num_relations // 2
-        h_index, t_index, r_index = (torch.where(is_t_neg, h_index, t_index), torch.where(is_t_neg, t_index, h_index),
-                                     torch.where(is_t_neg, r_index, r_index + num_direct_rel))
-        valid = ((same[:, 0] | same[:, 1]) & same[:, 2]).all()
+        if PROLOGUE_FAST_PATH and batch.is_cuda and batch.dtype == torch.long and batch.dim() == 3 and batch.shape[1] <= 65536:
+            # the same in ONE launch (dense.batch_prologue: uniformity per row, conversion, the converted rows' candidates)
+            pro = dense.batch_prologue(batch, num_direct_rel, candidates=True)
+            h0, r0, valid, t_index = pro[1], pro[2], pro[4], pro.cand
+        else:
+            same = (batch == batch[:, :1]).all(dim=1)                      # (bs, 3): h, t, r uniform?
+            is_t_neg = same[:, :1]
+            h_index, t_index, r_index = (torch.where(is_t_neg, h_index, t_index), torch.where(is_t_neg, t_index, h_index),
+                                         torch.where(is_t_neg, r_index, r_index + num_direct_rel))
+            h0, r0 = h_index[:, 0], r_index[:, 0]
+            valid = ((same[:, 0] | same[:, 1]) & same[:, 2]).all()
 
         # (under autograd only the candidates' rows of the last hidden state are read below: the last layer is evaluated on
         # those rows' in-edges alone where the layer supports it -- layers.training_rows_layer)
         rows_wanted = t_index if (torch.is_grad_enabled() and not self.concat_hidden and t_index.is_cuda) else None
-        hiddens, _, query = self._bellmanford_hidden(data, h_index[:, 0], r_index[:, 0], edge_weight=edge_weight,
+        hiddens, _, query = self._bellmanford_hidden(data, h0, r0, edge_weight=edge_weight,
                                                      edge_keep=edge_weight is not None, last_rows=rows_wanted)
         if self._last_hidden_on_rows:
             feature = torch.cat([hiddens[-1], query.unsqueeze(1).expand(-1, t_index.shape[1], -1)], dim=-1)

@@ -669,7 +669,7 @@ class _PlanRSPMM(autograd.Function):
         values_grad = None
         if ctx.point_rows is not None and ctx.needs_input_grad[9]:
             rows = ctx.point_rows
-            values_grad = (output_grad[torch.arange(rows.shape[0], device=rows.device), rows] if output_grad.dim() == 3
+            values_grad = (output_grad.gather(1, rows.view(-1, 1, 1).expand(-1, 1, output_grad.shape[-1])).squeeze(1) if output_grad.dim() == 3
                            else output_grad[rows[0]].unsqueeze(0))
         return None, None, None, weight_grad, relation_grad, input_grad, boundary_grad, None, None, values_grad   # rspmm.py:35
 
