@@ -211,6 +211,22 @@ int32_t ultra_ranking_loss(const void *pred, int64_t rows, int64_t n, float temp
                            void *grad, void *stream);
 
 /*
+ * The readout of a training step on the candidates' rows (/root/reference/ultra/models.py:202-207: score = mlp(cat[hidden,
+ * query]), mlp = Linear(128, 128), ReLU, Linear(128, 1)) and its backward -- one launch forward, two backward:
+ *     h = relu([hid[b, j] ; query[b]] w1^T + b1)          score[b, j] = h . w2 + b2
+ * hid (batch, n, 64), query (batch, 64), w1 (128, 128) = mlp.0.weight, b1 (128), w2 (128) = mlp.2.weight, b2 (1); all fp32.
+ * forward writes h (batch * n, 128) for the backward and score (batch, n).  backward takes grad_score (batch, n) and writes
+ * grad_hid (batch, n, 64), grad_query (batch, 64), grad_w1 (128, 128), grad_b1 (128), grad_w2 (128), grad_b2 (1); work: scratch of
+ * ultra_readout_train_backward_workspace(batch, n) bytes.  Every sum has a fixed order (reproducible run to run).
+ */
+int32_t ultra_readout_train_forward(const void *hid, const void *query, const void *w1, const void *b1, const void *w2,
+                                    const void *b2, void *h, void *score, int64_t batch, int64_t n, void *stream);
+int64_t ultra_readout_train_backward_workspace(int64_t batch, int64_t n);
+int32_t ultra_readout_train_backward(const void *grad_score, const void *h, const void *hid, const void *query, const void *w1,
+                                     const void *w2, void *grad_hid, void *grad_query, void *grad_w1, void *grad_b1, void *grad_w2,
+                                     void *grad_b2, void *work, int64_t work_bytes, int64_t batch, int64_t n, void *stream);
+
+/*
  * Relation graph of a knowledge graph (/root/reference/ultra/tasks.py:144-199) on the GPU, as bit matrices.
  *   edge_index (2, num_edge) int64 [head; tail], edge_type (num_edge) int64 -- inverse edges already included;
  *   W = (num_relation + 31) / 32 words per bit row.

@@ -367,3 +367,74 @@ def test_batch_prologue_converts_the_rows_as_the_reference_does(dev):
     bad[1, 4, 1] += 1
     pro = dense.batch_prologue(bad.to(dev), num_direct, candidates=True)
     assert pro[4].cpu().tolist() == [1] + [0] + [1] * (len(bad) - 2)
+
+
+# ---- the training step's readout as one autograd node (csrc/readout_train.hip) ----
+@pytest.mark.parametrize("bs,n", [(8, 257), (3, 33), (1, 1), (2, 64), (5, 31)])
+def test_readout_node_matches_autograd_of_the_reference_chain(dev, bs, n):
+    """dense.ReadoutTrainFunction vs the reference's readout on the candidates' rows -- mlp(cat[hidden, query]) with
+    mlp = nn.Sequential(Linear(128, 128), ReLU, Linear(128, 1)) (models.py:120-127, 202-207) -- under torch autograd in fp64: the
+    scores (also against the oracle's fp32 restatement of torch's Linear, oracle/torch_math_oracle.py), the gradients of the hidden
+    rows, the query and the four parameters.  The fused fp32 result may not be further from fp64 than a few times torch's own fp32
+    chain; two runs give the same bits."""
+    from oracle import torch_math_oracle
+    from ultra_amd import dense
+    gen = torch.Generator().manual_seed(bs * 1000 + n)
+    hid = torch.randn(bs, n, 64, generator=gen)
+    query = torch.randn(bs, 64, generator=gen)
+    params = [torch.randn(128, 128, generator=gen) / 11, torch.randn(128, generator=gen) / 4,
+              torch.randn(1, 128, generator=gen) / 11, torch.randn(1, generator=gen)]
+    gout = torch.randn(bs, n, generator=gen)
+
+    def chain(dtype, device, fused):
+        leaves = [t.clone().to(device=device, dtype=dtype).requires_grad_() for t in (hid, query, *params)]
+        h, q, w1, b1, w2, b2 = leaves
+        if fused:
+            score = dense.ReadoutTrainFunction.apply(h, q, w1, b1, w2, b2)
+        else:
+            feature = torch.cat([h, q.unsqueeze(1).expand(-1, n, -1)], dim=-1)
+            score = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(feature, w1, b1)), w2, b2).squeeze(-1)
+        (score * gout.to(device=device, dtype=dtype)).sum().backward()
+        return score.detach().cpu().double(), [t.grad.cpu().double() for t in leaves]
+
+    s64, g64 = chain(torch.float64, "cpu", False)
+    s32, g32 = chain(torch.float32, dev, False)
+    sf, gf = chain(torch.float32, dev, True)
+    assert sf.shape == (bs, n)
+    assert (sf - s64).abs().max().item() <= 2e-5 * max(1.0, s64.abs().max().item())
+    feature = torch.cat([hid, query.unsqueeze(1).expand(-1, n, -1)], dim=-1).reshape(-1, 128)
+    want = torch_math_oracle.linear(torch.relu(torch_math_oracle.linear(feature, params[0], params[1])), params[2], params[3])
+    assert (sf.float() - want.view(bs, n)).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    for k, (a, r32, r64) in enumerate(zip(gf, g32, g64)):
+        assert a.shape == r64.shape
+        scale = max(r64.abs().max().item(), 1e-6)
+        err, err_torch = (a - r64).abs().max().item(), (r32 - r64).abs().max().item()
+        assert err <= 4 * err_torch + 2e-5 * scale, "gradient %d: |fused - fp64| = %g, |torch fp32 - fp64| = %g (scale %g)" % (
+            k, err, err_torch, scale)
+    s_again, g_again = chain(torch.float32, dev, True)
+    assert torch.equal(sf, s_again) and all(torch.equal(a, b) for a, b in zip(gf, g_again))
+
+
+def test_training_forward_takes_the_readout_node(dev):
+    """EntityNBFNet.forward under autograd with the ULTRA readout goes through ReadoutTrainFunction; the switch selects torch's chain,
+    same scores to rounding."""
+    from ultra_amd import dense, models, synthetic
+    data = synthetic.make_kg(num_node=300, num_triple=3000, num_relation_base=5, num_test=16, seed=5).to(dev)
+    torch.manual_seed(0)
+    model = models.Ultra(**synthetic.default_model_cfg()).to(dev).train()
+    batch = torch.stack([data.edge_index[0, :4], data.edge_index[1, :4], data.edge_type[:4]], dim=-1)
+    from ultra_amd import tasks
+    batch = tasks.negative_sampling(data, batch, 16, strict=True)
+    score = model(data, batch)
+    node = score.grad_fn
+    for _ in range(3):                      # (the score comes back through .view(shape))
+        if type(node).__name__ == "ReadoutTrainFunctionBackward":
+            break
+        node = node.next_functions[0][0]
+    assert type(node).__name__ == "ReadoutTrainFunctionBackward"
+    dense.READOUT_TRAIN_NODE = False
+    try:
+        other = model(data, batch)
+    finally:
+        dense.READOUT_TRAIN_NODE = True
+    assert torch.allclose(score, other, rtol=1e-5, atol=1e-5)

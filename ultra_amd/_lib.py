@@ -114,6 +114,10 @@ def _load():
     lib.ultra_filtered_rank.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
     lib.ultra_strict_negatives.argtypes = [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp]
     lib.ultra_ranking_loss.argtypes = [vp, i64, i64, ctypes.c_float, ctypes.c_float, vp, vp, vp]
+    lib.ultra_readout_train_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]
+    lib.ultra_readout_train_backward_workspace.argtypes = [i64, i64]
+    lib.ultra_readout_train_backward_workspace.restype = i64
+    lib.ultra_readout_train_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, vp]
     lib.ultra_onehot_rows.argtypes = [vp, vp, vp, i64, i64, i64, vp]
     lib.ultra_batch_prologue.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     lib.ultra_batch_prologue_rows.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]

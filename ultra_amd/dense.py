@@ -297,6 +297,63 @@ def readout_supported(model, hidden):
             and not (torch.is_grad_enabled() and (hidden.requires_grad or mlp[0].weight.requires_grad)))
 
 
+READOUT_TRAIN_NODE = True
+
+
+def readout_train_supported(model, hidden_rows, query):
+    """The training step's readout as one autograd node (ReadoutTrainFunction): the ULTRA shape -- 64-d hidden rows of the
+    candidates, mlp = Linear(128, 128), ReLU, Linear(128, 1) -- in fp32 on the GPU."""
+    mlp = model.mlp
+    return (READOUT_TRAIN_NODE and hidden_rows.is_cuda and hidden_rows.dtype == torch.float32 and hidden_rows.dim() == 3
+            and hidden_rows.shape[-1] == 64 and query.shape == (hidden_rows.shape[0], 64) and query.dtype == torch.float32
+            and hidden_rows.shape[0] <= 4096 and not model.concat_hidden
+            and len(mlp) == 3 and isinstance(mlp[0], torch.nn.Linear) and isinstance(mlp[1], torch.nn.ReLU)
+            and isinstance(mlp[2], torch.nn.Linear) and tuple(mlp[0].weight.shape) == (128, 128)
+            and tuple(mlp[2].weight.shape) == (1, 128) and mlp[0].bias is not None and mlp[2].bias is not None
+            and mlp[0].weight.dtype == torch.float32)
+
+
+class ReadoutTrainFunction(torch.autograd.Function):
+    """score = mlp(cat[hidden_rows, query]) (models.py:202-207 on the candidates' rows) with the ULTRA readout MLP: one launch
+    forward (ultra_readout_train_forward), two backward (ultra_readout_train_backward) instead of torch's cat + two products +
+    relu + copies and their dozen backward launches.  Sums in a fixed order: reproducible run to run."""
+
+    @staticmethod
+    def forward(ctx, hidden_rows, query, w1, b1, w2, b2):
+        hidden_rows, query = hidden_rows.contiguous(), query.contiguous()
+        w1, b1, w2, b2 = w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous()
+        bs, n = hidden_rows.shape[:2]
+        h = torch.empty(bs * n, 128, dtype=torch.float32, device=hidden_rows.device)
+        score = torch.empty(bs, n, dtype=torch.float32, device=hidden_rows.device)
+        check(lib.ultra_readout_train_forward(hidden_rows.data_ptr(), query.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                              b2.data_ptr(), h.data_ptr(), score.data_ptr(), bs, n, _stream(score)))
+        ctx.save_for_backward(hidden_rows, query, w1, w2, h)
+        return score
+
+    @staticmethod
+    def backward(ctx, grad_score):
+        hidden_rows, query, w1, w2, h = ctx.saved_tensors
+        grad_score = grad_score.contiguous()
+        bs, n = hidden_rows.shape[:2]
+        dev = hidden_rows.device
+        g_hid, g_query = torch.empty_like(hidden_rows), torch.empty_like(query)
+        g_w1, g_w2 = torch.empty_like(w1), torch.empty_like(w2)
+        g_b1 = torch.empty(128, dtype=torch.float32, device=dev)
+        g_b2 = torch.empty(1, dtype=torch.float32, device=dev)
+        nbytes = lib.ultra_readout_train_backward_workspace(bs, n)
+        work = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        check(lib.ultra_readout_train_backward(grad_score.data_ptr(), h.data_ptr(), hidden_rows.data_ptr(), query.data_ptr(),
+                                               w1.data_ptr(), w2.data_ptr(), g_hid.data_ptr(), g_query.data_ptr(), g_w1.data_ptr(),
+                                               g_b1.data_ptr(), g_w2.data_ptr(), g_b2.data_ptr(), work.data_ptr(), nbytes, bs, n,
+                                               _stream(g_hid)))
+        return g_hid, g_query, g_w1, g_b1, g_w2, g_b2
+
+
+def readout_train(model, hidden_rows, query):
+    mlp = model.mlp
+    return ReadoutTrainFunction.apply(hidden_rows, query, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)
+
+
 _ORDER_CACHE = {}
 _ORDER_RETIRED = []      # programs replaced by host_order.adopt(): kept alive for captured graphs that still point at them
 

@@ -446,8 +446,11 @@ class EntityNBFNet(BaseNBFNet):
         hiddens, _, query = self._bellmanford_hidden(data, h0, r0, edge_weight=edge_weight,
                                                      edge_keep=edge_weight is not None, last_rows=rows_wanted)
         if self._last_hidden_on_rows:
-            feature = torch.cat([hiddens[-1], query.unsqueeze(1).expand(-1, t_index.shape[1], -1)], dim=-1)
-            score = self.mlp(feature).squeeze(-1)
+            if torch.is_grad_enabled() and dense.readout_train_supported(self, hiddens[-1], query):
+                score = dense.readout_train(self, hiddens[-1], query)          # one autograd node: 1 + 2 launches
+            else:
+                feature = torch.cat([hiddens[-1], query.unsqueeze(1).expand(-1, t_index.shape[1], -1)], dim=-1)
+                score = self.mlp(feature).squeeze(-1)
             self._check_valid(valid)
             return score.view(shape)
         if dense.readout_supported(self, hiddens[-1]):
