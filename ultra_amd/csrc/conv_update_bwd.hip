@@ -616,21 +616,25 @@ __global__ void __launch_bounds__(512) conv_update_bwd_fused_kernel(const ConvBw
                 g.b[u][0] = xr[0], g.b[u][1] = xr[32], g.b[u][2] = ar[0], g.b[u][3] = ar[32];
             }
         };
+        // (two groups ahead: a group's 32 matrix instructions take ~ 2 k cycles, a load under the kernel's own traffic more)
+        const auto group_at = [&](Group &g, const long long tile, const int s4) {      // group s4 >= 4: of the workgroup's next tile
+            const long long tn = s4 < 4 ? tile : tile + tstride;
+            load_group(g, tn < ntile ? tn : tile, s4 & 3);                             // (past the end: a harmless reload)
+        };
         long long tile = blockIdx.x + (long long)gridDim.x * pair;
-        Group cur;
-        if (tile < ntile) load_group(cur, tile, 0);
+        Group cur, nx1;
+        if (tile < ntile) {
+            load_group(cur, tile, 0);
+            load_group(nx1, tile, 1);
+        }
         int buf = 0;
         for (; tile < ntile; tile += tstride, buf ^= 1) {
             const float *dzt = my_dz + buf * CBF_TILE;
             while (__hip_atomic_load(my_flag + buf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 1) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                Group nxt;
-                {
-                    const bool last = s4 == 3;
-                    const long long tn = last ? tile + tstride : tile;
-                    load_group(nxt, tn < ntile ? tn : tile, last ? 0 : s4 + 1);      // (past the end: a harmless reload)
-                }
+                Group nx2;
+                group_at(nx2, tile, s4 + 2);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int rt = 2 * (4 * s4 + u) + hh;          // row inside the tile; odd rows hold their halves swapped
@@ -647,7 +651,8 @@ __global__ void __launch_bounds__(512) conv_update_bwd_fused_kernel(const ConvBw
                         acc[1][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, cur.b[u][kt], acc[1][kt], 0, 0, 0);
                     }
                 }
-                cur = nxt;
+                cur = nx1;
+                nx1 = nx2;
             }
             // (LDS operations of a wave execute in order: the reads above are done when this store is)
             if (lane == 0) __hip_atomic_store(my_flag + buf, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
