@@ -44,6 +44,10 @@ def run(rows, iters=20):
         graph.replay()
     e1.record()
     torch.cuda.synchronize()
+    if int(os.environ.get("PROBE_FLAGS", "0")) & 2048:      # CB_DBG_CLOCK: workgroup 0's shader-clock and 100-MHz ticks of the last call
+        ticks = work[:4].view(torch.int64).tolist()
+        print("  %d rows: workgroup 0 ran %d shader cycles in %.1f us = %.0f MHz" % (rows, ticks[0], ticks[1] / 100.0,
+                                                                                 ticks[0] / (ticks[1] / 100.0)), flush=True)
     return e0.elapsed_time(e1) / (5 * iters) * 1e3, float(gw.abs().sum())
 
 

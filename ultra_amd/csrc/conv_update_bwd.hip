@@ -35,7 +35,9 @@ using f32x16 = float __attribute__((ext_vector_type(16)));
 
 enum { CB_LN = 1, CB_RELU = 2, CB_RESIDUAL = 4,
        // measurement switches of the fused kernel (results are wrong with any of them): tools/conv_bwd_probe.py PROBE_FLAGS
-       CB_DBG_NO_W_MFMA = 256, CB_DBG_NO_DX_MFMA = 512, CB_DBG_NO_Z_MFMA = 1024 };
+       CB_DBG_NO_W_MFMA = 256, CB_DBG_NO_DX_MFMA = 512, CB_DBG_NO_Z_MFMA = 1024,
+       // workgroup 0 leaves its shader-clock ticks (s_memtime) and its 100-MHz ticks (s_memrealtime) in the first 16 bytes of the workspace
+       CB_DBG_CLOCK = 2048 };
 constexpr int CB_WR_STRIDE = 136;                 // row stride (floats) of the row-major weight copy: 4 rows apart = 32 banks apart
 constexpr int CB_PART = 64 * 128 + 3 * 64;        // floats per workgroup partial: dW, db, d gamma, d beta
 
@@ -368,6 +370,7 @@ __global__ void __launch_bounds__(512) conv_update_bwd_fused_kernel(const ConvBw
     __shared__ __attribute__((aligned(16))) float lds_dz[4 * 2 * CBF_TILE];      // [pair][buffer][tile]; the weight waves' fold afterwards
     __shared__ int lds_flag[4 * 2];
     const int tid = threadIdx.x;
+    const unsigned long long clk0 = __builtin_readcyclecounter(), real0 = __builtin_amdgcn_s_memrealtime();
     for (int idx4 = tid; idx4 < 2 * 16 * 64; idx4 += blockDim.x) {
         const int l = idx4 & 63, c = (idx4 >> 6) & 15, m = idx4 >> 10;
         reinterpret_cast<float4 *>(lds_wf)[idx4] =
@@ -687,6 +690,11 @@ __global__ void __launch_bounds__(512) conv_update_bwd_fused_kernel(const ConvBw
         float s = 0.f;
         for (int w = 0; w < 4; ++w) s += lds_wr[(w * 2 + which) * 64 + f];
         dst[64 * 128 + 64 + tid] = s;
+    }
+    if ((p.flags & CB_DBG_CLOCK) && blockIdx.x == 0 && tid == 0) {
+        unsigned long long *out = reinterpret_cast<unsigned long long *>(p.dz);
+        out[0] = __builtin_readcyclecounter() - clk0;
+        out[1] = __builtin_amdgcn_s_memrealtime() - real0;
     }
 }
 
