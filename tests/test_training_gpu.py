@@ -529,3 +529,30 @@ def test_training_step_with_the_last_layer_on_the_candidates_rows(dev):
         other = results[1][1][name]
         scale = max(other.abs().max().item(), 1e-6)
         assert (g - other).abs().max().item() <= 1e-4 * scale + 1e-7, name
+
+
+def test_sampler_stream_runs_beside_the_training_stream(dev):
+    """tasks.overlapping_stream: whatever streams the process made before (here: sixteen of both priorities, used), the stream the
+    sampler gets runs a kernel to completion while the current stream is still busy."""
+    used = []
+    for i in range(16):
+        s = torch.cuda.Stream(priority=-1 if i % 2 else 0)
+        with torch.cuda.stream(s):
+            torch.zeros(8, device=dev).add_(1)
+        used.append(s)
+    torch.cuda.synchronize()
+    side = tasks.overlapping_stream(dev)
+    assert side != torch.cuda.current_stream(dev)
+    probe = torch.zeros(8, device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    torch.cuda.synchronize()
+    busy, tiny = torch.cuda.Event(), torch.cuda.Event()
+    torch.cuda._sleep(4_000_000)
+    busy.record()
+    with torch.cuda.stream(side):
+        probe.add_(1)
+        tiny.record(side)
+    tiny.synchronize()
+    assert not busy.query(), "the side stream's kernel waited for the current stream's"
+    torch.cuda.synchronize()
+    assert probe.tolist() == [1.0] * 8

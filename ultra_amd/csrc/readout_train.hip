@@ -236,7 +236,16 @@ __global__ void __launch_bounds__(256) readout_train_reduce_kernel(const float *
     const int shared = RT_F * RT_F + 2 * RT_F + 1;
     if (i < shared) {
         float s = 0.f;
-        for (int t = 0; t < batch * tiles; ++t) s += part[(long long)t * RT_PART + i];
+        const int total = batch * tiles;
+        int t = 0;
+        for (; t + 8 <= total; t += 8) {          // (eight loads in flight, added in tile order)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(long long)(t + u) * RT_PART + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; t < total; ++t) s += part[(long long)t * RT_PART + i];
         if (i < RT_F * RT_F)
             gw1[i] = s;
         else if (i < RT_F * RT_F + RT_F)

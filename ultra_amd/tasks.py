@@ -156,6 +156,39 @@ def negative_sampling(data, batch, num_negative, strict=True):
     return torch.stack([h_index, t_index, r_index], dim=-1)
 
 
+def overlapping_stream(dev, candidates=8, busy_cycles=2_000_000):
+    """A stream whose kernels run BESIDE those of the current stream of `dev`, found by trying: the runtime maps every stream onto
+    one of a handful of hardware queues when it is created, and a stream that shares the current stream's queue runs behind its
+    kernels, not beside them -- high priority does not prevent that.  (Measured: the captured fine-tuning step takes 2.9 ms with the
+    sampler on a high-priority stream made first in the process and 3.25 -- the step plus the sampler, end to end -- with the same
+    stream made after bench.py's pipelined forward had made its own; profiles/r6_experiments.txt.)  Each candidate (high and normal
+    priority in turn) gets one tiny kernel while the current stream spins for ~ 1 ms; the first whose kernel finishes before the
+    spin does is taken."""
+    main = torch.cuda.current_stream(dev)
+    probe = torch.zeros(64, device=dev)
+    best = None
+    with torch.cuda.device(dev):
+        for i in range(int(candidates)):
+            cand = torch.cuda.Stream(priority=-1 if i % 2 == 0 else 0)
+            best = best or cand
+            if not hasattr(torch.cuda, "_sleep"):
+                break
+            cand.wait_stream(main)
+            torch.cuda.synchronize(dev)
+            done_main, done_cand = torch.cuda.Event(), torch.cuda.Event()
+            torch.cuda._sleep(int(busy_cycles))
+            done_main.record(main)
+            with torch.cuda.stream(cand):
+                probe.add_(1.0)
+                done_cand.record(cand)
+            done_cand.synchronize()
+            beside = not done_main.query()
+            torch.cuda.synchronize(dev)
+            if beside:
+                return cand
+    return best
+
+
 def prefetch_negatives(batches, data, num_negative, strict=True):
     """negative_sampling() over an iterable of positive batches, one batch AHEAD of the training step and on a side stream:
 
@@ -181,10 +214,7 @@ def prefetch_negatives(batches, data, num_negative, strict=True):
             yield negative_sampling(data, batch, num_negative, strict=strict)
         return
     with torch.cuda.device(dev):
-        # (high priority: its own class of hardware queue whatever streams the process has made before -- a side stream that
-        # lands on the training stream's queue runs BEHIND the backward, not beside it -- and the sampler's small kernels, which
-        # the host waits for, are scheduled ahead of the backward's long ones)
-        side = torch.cuda.Stream(priority=-1)
+        side = overlapping_stream(dev)
         # the triple list and the graph were written on the caller's stream before this loop began
         side.wait_stream(torch.cuda.current_stream(dev))
 
