@@ -227,16 +227,39 @@ def prefetch_negatives(batches, data, num_negative, strict=True):
         ahead = sample()
     except StopIteration:
         return
+    # The stream is re-checked while the loop runs: what the caller launches between two draws may use hardware queues of its own
+    # (a hipGraph replay does), so the one-off trial above cannot see every collision.  For the first steps an event behind the
+    # caller's step and one behind the draw issued right after it are compared: a draw that ends AFTER the step it was issued beside
+    # ran behind it.  Twice in a row -> the next candidate stream (at most six times; a loop whose steps are shorter than a draw
+    # ends up on the last one, which costs nothing).
+    checks_left, late_in_a_row, switches_left, pending = 24, 0, 6, []
     while ahead is not None:
         main = torch.cuda.current_stream(dev)
         main.wait_stream(side)
         ahead.record_stream(main)        # (allocated on the side stream, read by the step on the training stream)
         current, ahead = ahead, None
         yield current                    # the caller enqueues its step ...
+        behind_step = None
+        if checks_left > 0 and switches_left > 0:
+            behind_step = torch.cuda.Event(enable_timing=True)
+            behind_step.record(main)
         try:
             ahead = sample()             # ... and the next batch's negatives are drawn while the GPU works through it
         except StopIteration:
             ahead = None
+        if behind_step is not None:
+            behind_draw = torch.cuda.Event(enable_timing=True)
+            behind_draw.record(side)
+            pending.append((behind_step, behind_draw))
+            checks_left -= 1
+        while pending and pending[0][0].query() and pending[0][1].query():
+            step_end, draw_end = pending.pop(0)
+            late_in_a_row = late_in_a_row + 1 if step_end.elapsed_time(draw_end) > 0.0 else 0
+            if late_in_a_row >= 2 and switches_left > 0:
+                with torch.cuda.device(dev):
+                    fresh = torch.cuda.Stream(priority=0 if switches_left % 2 else -1)
+                fresh.wait_stream(side)
+                side, late_in_a_row, switches_left, checks_left, pending = fresh, 0, switches_left - 1, 24, []
 
 
 def all_negative(data, batch):
