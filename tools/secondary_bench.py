@@ -168,6 +168,7 @@ def train_case(shape, bs=8, num_negative=256, aggr="sum", prefetch=True, fused=T
         del model, opt
         model = load_model(aggr, "ultra_50g").train()
         opt = train.make_adamw(model, capturable=True)
+        tasks.PREFETCH_REPORT.append({"open": True})
         negatives = batches()
         t0 = time.perf_counter()
         try:
@@ -185,7 +186,8 @@ def train_case(shape, bs=8, num_negative=256, aggr="sum", prefetch=True, fused=T
         graphed.check()
         out.update({"ms_per_step": 1e3 * dt, "samples_per_s": bs / dt, "launch": "hipGraph replay (forward + loss + backward + AdamW)",
                     "ms_per_step_eager": 1e3 * dt_eager, "capture_s": capture_s,
-                    "optimizer": "AdamW(fused=True, capturable=True)"})
+                    "optimizer": "AdamW(fused=True, capturable=True)",
+                    "sampler_stream_check": {k: v for k, v in tasks.PREFETCH_REPORT[-1].items() if k != "open"}})
     return out
 
 

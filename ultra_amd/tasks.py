@@ -156,6 +156,10 @@ def negative_sampling(data, batch, num_negative, strict=True):
     return torch.stack([h_index, t_index, r_index], dim=-1)
 
 
+# measurements: append {"open": True} before creating a prefetch_negatives generator and it fills in what its stream check saw
+PREFETCH_REPORT = []
+
+
 def overlapping_stream(dev, candidates=8, busy_cycles=2_000_000):
     """A stream whose kernels run BESIDE those of the current stream of `dev`, found by trying: the runtime maps every stream onto
     one of a handful of hardware queues when it is created, and a stream that shares the current stream's queue runs behind its
@@ -228,11 +232,15 @@ def prefetch_negatives(batches, data, num_negative, strict=True):
     except StopIteration:
         return
     # The stream is re-checked while the loop runs: what the caller launches between two draws may use hardware queues of its own
-    # (a hipGraph replay does), so the one-off trial above cannot see every collision.  For the first steps an event behind the
-    # caller's step and one behind the draw issued right after it are compared: a draw that ends AFTER the step it was issued beside
-    # ran behind it.  Twice in a row -> the next candidate stream (at most six times; a loop whose steps are shorter than a draw
-    # ends up on the last one, which costs nothing).
-    checks_left, late_in_a_row, switches_left, pending = 24, 0, 6, []
+    # (a hipGraph replay does), so the one-off trial above cannot see every collision.  An event behind the caller's step and one
+    # behind the draw issued right after it are compared: a draw that ends AFTER the step it was issued beside ran behind it.  Twice
+    # in a row -> the next candidate stream (at most six times; a loop whose steps are shorter than a draw ends up on the last one,
+    # which costs nothing).  The first observations are WAITED for (the host would otherwise be dozens of replays ahead before an
+    # event completes: a few steps of a warm-up run in lock-step with the GPU, until two draws in a row end in time); later ones are
+    # looked at when they happen to be complete.
+    waited_left, checks_left, late_in_a_row, fine_in_a_row, switches_left, pending = 12, 24, 0, 0, 6, []
+    report = PREFETCH_REPORT[-1] if PREFETCH_REPORT and PREFETCH_REPORT[-1].get("open") else {}
+    report.update({"observed": 0, "late": 0, "switches": 0, "waited": 0})
     while ahead is not None:
         main = torch.cuda.current_stream(dev)
         main.wait_stream(side)
@@ -240,7 +248,7 @@ def prefetch_negatives(batches, data, num_negative, strict=True):
         current, ahead = ahead, None
         yield current                    # the caller enqueues its step ...
         behind_step = None
-        if checks_left > 0 and switches_left > 0:
+        if checks_left > 0 and switches_left > 0 and not torch.cuda.is_current_stream_capturing():
             behind_step = torch.cuda.Event(enable_timing=True)
             behind_step.record(main)
         try:
@@ -252,14 +260,24 @@ def prefetch_negatives(batches, data, num_negative, strict=True):
             behind_draw.record(side)
             pending.append((behind_step, behind_draw))
             checks_left -= 1
+            if waited_left > 0 and fine_in_a_row < 2:
+                waited_left -= 1
+                report["waited"] += 1
+                behind_step.synchronize()
+                behind_draw.synchronize()
         while pending and pending[0][0].query() and pending[0][1].query():
             step_end, draw_end = pending.pop(0)
-            late_in_a_row = late_in_a_row + 1 if step_end.elapsed_time(draw_end) > 0.0 else 0
+            late = step_end.elapsed_time(draw_end) > 0.0
+            report["observed"] += 1
+            report["late"] += int(late)
+            late_in_a_row, fine_in_a_row = (late_in_a_row + 1, 0) if late else (0, fine_in_a_row + 1)
             if late_in_a_row >= 2 and switches_left > 0:
                 with torch.cuda.device(dev):
                     fresh = torch.cuda.Stream(priority=0 if switches_left % 2 else -1)
                 fresh.wait_stream(side)
-                side, late_in_a_row, switches_left, checks_left, pending = fresh, 0, switches_left - 1, 24, []
+                side, late_in_a_row, fine_in_a_row, switches_left, pending = fresh, 0, 0, switches_left - 1, []
+                report["switches"] += 1
+                waited_left, checks_left = max(waited_left, 4), 24
 
 
 def all_negative(data, batch):
