@@ -35,8 +35,8 @@ struct RowsParams {
     int32_t n_outer, n_list, row_len, spans, mul_add;   // mul_add: 0 = rel * x (DistMult), 1 = rel + x (TransE)
 };
 
-// One workgroup of 16 waves (64 lane groups) per (sample, span, listed row): group G takes the row's in-edges G, G + 64, ...
-// -- a hub row of thousands of edges (the positives of a batch are degree-biased) is a few dozen rounds, not a thousand.
+// One workgroup of 16 waves (64 lane groups) per (sample, span, listed row): group G takes the row's in-edges G, G + 64, ...,
+// four at a time -- a hub row of thousands of edges (the positives of a batch are degree-biased) is a few dozen rounds.
 constexpr int ROWS_GROUPS = 64;
 template <bool BACKWARD>
 __global__ void __launch_bounds__(1024) rspmm_rows_kernel(const RowsParams p) {
@@ -54,21 +54,34 @@ __global__ void __launch_bounds__(1024) rspmm_rows_kernel(const RowsParams p) {
     float *cell = p.agg + ((long long)o * p.n_list + j) * p.row_len + d0;
     if (!BACKWARD) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int e0 = beg + G; e0 < end; e0 += 2 * ROWS_GROUPS) {          // two edges in flight per group
-            const int e1 = e0 + ROWS_GROUPS;
-            const bool two = e1 < end;
-            const int c0 = p.col[e0], t0 = p.type[e0], c1 = two ? p.col[e1] : c0, t1 = two ? p.type[e1] : t0;
-            const float w0 = p.w ? p.w[p.perm[e0]] : 1.f, w1 = (p.w && two) ? p.w[p.perm[e1]] : 1.f;
-            const float4 x0 = *reinterpret_cast<const float4 *>(xb + (long long)c0 * p.x.stride_row);
-            const float4 r0 = *reinterpret_cast<const float4 *>(rb + (long long)t0 * p.rel.stride_row);
-            const float4 x1 = *reinterpret_cast<const float4 *>(xb + (long long)c1 * p.x.stride_row);
-            const float4 r1 = *reinterpret_cast<const float4 *>(rb + (long long)t1 * p.rel.stride_row);
-            if (p.mul_add) {
-                acc.x += w0 * (r0.x + x0.x), acc.y += w0 * (r0.y + x0.y), acc.z += w0 * (r0.z + x0.z), acc.w += w0 * (r0.w + x0.w);
-                if (two) acc.x += w1 * (r1.x + x1.x), acc.y += w1 * (r1.y + x1.y), acc.z += w1 * (r1.z + x1.z), acc.w += w1 * (r1.w + x1.w);
-            } else {
-                acc.x += w0 * (r0.x * x0.x), acc.y += w0 * (r0.y * x0.y), acc.z += w0 * (r0.z * x0.z), acc.w += w0 * (r0.w * x0.w);
-                if (two) acc.x += w1 * (r1.x * x1.x), acc.y += w1 * (r1.y * x1.y), acc.z += w1 * (r1.z * x1.z), acc.w += w1 * (r1.w * x1.w);
+        // four edges in flight per group (a hub row of 16 k in-edges is 64 rounds of the workgroup's 256 instead of 128 of 128)
+        for (int e0 = beg + G; e0 < end; e0 += 4 * ROWS_GROUPS) {
+            int c[4], t[4];
+            float w[4];
+            bool live[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * ROWS_GROUPS;
+                live[u] = e < end;
+                const int ec = live[u] ? e : e0;
+                c[u] = p.col[ec], t[u] = p.type[ec];
+                w[u] = (p.w && live[u]) ? p.w[p.perm[ec]] : 1.f;
+            }
+            float4 xv[4], rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xv[u] = *reinterpret_cast<const float4 *>(xb + (long long)c[u] * p.x.stride_row);
+                rv[u] = *reinterpret_cast<const float4 *>(rb + (long long)t[u] * p.rel.stride_row);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!live[u]) continue;
+                if (p.mul_add)
+                    acc.x += w[u] * (rv[u].x + xv[u].x), acc.y += w[u] * (rv[u].y + xv[u].y), acc.z += w[u] * (rv[u].z + xv[u].z),
+                        acc.w += w[u] * (rv[u].w + xv[u].w);
+                else
+                    acc.x += w[u] * (rv[u].x * xv[u].x), acc.y += w[u] * (rv[u].y * xv[u].y), acc.z += w[u] * (rv[u].z * xv[u].z),
+                        acc.w += w[u] * (rv[u].w * xv[u].w);
             }
         }
         // a wave's four groups: 0 + 1, 2 + 3, then the two halves; the sixteen waves through LDS, in wave order
