@@ -53,6 +53,8 @@ def _tie_band(ref_score, pos, mask, band):
 @pytest.mark.parametrize("name,ckpt,shape,bs,aggr,n_batch", CONFIGS, ids=[c[0] for c in CONFIGS])
 def test_scores_and_rankings_at_baseline_size(dev, name, ckpt, shape, bs, aggr, n_batch):
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    # (ULTRA_PARITY_BATCHES=n: that many batches instead -- one-off long runs, profiles/r6_experiments.txt)
+    n_batch = int(os.environ.get("ULTRA_PARITY_BATCHES", n_batch))
     data = synthetic.make_kg(**synthetic.SHAPES[shape], seed=1234)
     cfg = synthetic.default_model_cfg(aggregate_func=aggr)
     state = torch.load(os.path.join(GOLDEN, ckpt + "_model.pt"))
