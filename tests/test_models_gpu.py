@@ -1,6 +1,8 @@
 """Model-level parity on the GPU: Ultra.forward through the HIP engine vs (a) golden scores recorded
 from the reference and (b) the CPU oracle model on a larger seeded graph.  Tolerance: fp32 scores
 within 1e-4 (BASELINE north_star), rankings / metrics identical."""
+import os
+
 import pytest
 import torch
 
@@ -90,6 +92,11 @@ def test_training_step_gradients_match_cpu_autograd(dev):
     batch = data.target_triples[:4]
     torch.manual_seed(0)
     neg = tasks.negative_sampling(data, batch, 8, strict=True)
+    if os.environ.get("ULTRA_GRAD_PARITY_SHAPE"):
+        # one-off long run (profiles/r6_experiments.txt): a BASELINE-sized graph, one query with 256 strict negatives -- ~ 5 GB of
+        # saved fp64 messages on the CPU side
+        data = synthetic.make_kg(**synthetic.SHAPES[os.environ["ULTRA_GRAD_PARITY_SHAPE"]], seed=1234)
+        neg = tasks.negative_sampling(data, data.target_triples[:1], 256, strict=True)
 
     def torch_rspmm(edge_index, edge_type, edge_weight, relation, input, sum="add", mul="mul"):
         msg = relation[edge_type] * input[edge_index[1]] if mul == "mul" else relation[edge_type] + input[edge_index[1]]
