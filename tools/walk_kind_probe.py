@@ -39,6 +39,7 @@ for shape in sys.argv[1:] or ["fb15k237", "yago310"]:
     rel = torch.randn(bs, R, 64, generator=g).to(dev)
     x = torch.randn(bs, N, 64, generator=g).to(dev)
     keep = (torch.rand(data.num_edges, generator=g) > 0.001).float().to(dev)
+    keep = rspmm.tag_edge_weight(keep)      # (as the training step does: brought into a plan's edge order once, not once per call)
     out = torch.empty_like(x)
     res = {}
     for kind, exact in (("re-associating", False), ("reference order", True)):
