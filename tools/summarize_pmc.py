@@ -5,7 +5,7 @@ import sys
 
 NAMES = (("true, 3>(ultra::OrderParams)", "entity layer, 1 launch"), ("true, 1>(ultra::OrderParams)", "entity layer, tail form"), ("rspmm_order_kernel", "entity rspmm"), ("rspmm_fwd_kernel", "entity rspmm (r1)"), ("conv_update_kernel", "entity update"),
          ("dense_order_layer_kernel", "relation layer"), ("dense_layer_kernel", "relation layer (r1)"), ("readout_kernel", "readout"),
-         ("rspmm_fixup_kernel", "fix-up"))
+         ("rspmm_fixup_kernel", "fix-up"), ("conv_update_bwd_fused_kernel", "update backward"), ("conv_update_bwd_reduce_kernel", "update bwd reduce"))
 out = []
 for path in sys.argv[1:]:
     agg = collections.OrderedDict()
